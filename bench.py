@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py -- BSDF Gsamples/s of the batched closure hot path on MI355X.
+
+Default workload = BASELINE.json configs[1]: rlGgx reflect + refract visible-normal sampling over
+2^26 SoA shading points per GPU, fp32, mixed per-point parameters.  One
+"step" is one pass of the fused kernel (`rls_ggx_reflect_refract`) over the batch = 2 samples per
+point (a reflect sample->eval->pdf triple and a refract sample->weight).  Inputs are generated on
+the device before the timed region; nothing crosses PCIe inside it.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.  For N > 1
+it runs under `python -m torch.distributed.run --nproc-per-node N ...` (one rank per GPU); the
+batch shards by index range with no collective on the data path (weak scaling: every GPU gets its
+own 2^26 points), the only communication being the barrier and the max-over-ranks of the time.
+
+`roofline`: algorithmic bytes per launch / average kernel duration (HIP events on the launch
+stream) against the 8 TB/s HBM3E peak.  `cpu_baseline`: the CPU oracle (a port of the reference's
+scalar closure code) timed on this host's cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+SEED = 1234               # throughput seed, SURVEY.md 8(d)
+
+# stream ids (shared with oracle/rls_oracle.h)
+S_ROUGH, S_IOR = 5, 6
+S_KS = 8
+S_XI0 = 11
+S_PARAM0 = 32
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2-points", type=int, default=26, help="points per GPU = 2^this (config: 26)")
+    ap.add_argument("--workload", default="ggx_reflect_refract",
+                    choices=["ggx_reflect_refract", "ggx_reflect", "disney_integrate", "sss_probe", "skin"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target seconds of CPU-baseline work")
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------
+class Workload:
+    """name, samples per point, algorithmic bytes per point, a launch() closure"""
+
+    def __init__(self, name, samples_per_point, bytes_per_point, launch, kernel, desc):
+        self.name, self.samples_per_point, self.bytes_per_point = name, samples_per_point, bytes_per_point
+        self.launch, self.kernel, self.desc = launch, kernel, desc
+
+
+def make_workload(R, ctx, name: str, n: int, first: int):
+    import torch
+    u = lambda stream, lo=0.0, hi=1.0: R.gen_uniform(ctx, SEED, first, n, stream, lo, hi)
+    u3 = lambda stream, lo=0.0, hi=1.0: torch.stack([u(stream + j, lo, hi) for j in range(3)])
+    wo, N, T = R.gen_frame(ctx, SEED, first, n)
+    if name in ("ggx_reflect_refract", "ggx_reflect"):
+        g = R.GgxSampler(ctx, wo, N, T, specColor=u3(S_KS), ior=u(S_IOR, 1.05, 2.55),
+                         roughness=u(S_ROUGH, 0.05, 1.0), anisotropic=R.gen_aniso(ctx, SEED, first, n))
+        xi = [u(S_XI0 + j) for j in range(4)]
+        if name == "ggx_reflect_refract":
+            out = (ctx.empty(3, n), ctx.empty(3, n), ctx.empty(n), ctx.empty(n), ctx.empty(3, n), ctx.empty(n))
+            # in: wo3 N3 T3 Ks3 rough ior aniso xi4 = 19 f; out: wi3 f3 pdf F wt3 weight = 12 f
+            return Workload(name, 2, (19 + 12) * 4, lambda: g.reflectRefract(xi[0], xi[1], xi[2], xi[3], out=out),
+                            "ggx_kernel<OP_REFLECT_REFRACT>",
+                            "rlGgx reflect+refract VNDF sampling, mixed params (SURVEY 8d config 2)")
+        out = (ctx.empty(3, n), ctx.empty(3, n), ctx.empty(n), ctx.empty(n))
+        return Workload(name, 1, (17 + 8) * 4, lambda: g.sampleEvalPdf(xi[0], xi[1], out=out),
+                        "ggx_kernel<OP_FUSED>", "rlGgx reflect triple, mixed params")
+    if name == "disney_integrate":
+        sc = {k: u(S_PARAM0 + j) for j, k in enumerate(R._capi.DISNEY_SCALARS)}
+        d = R.DisneySampler(ctx, wo, N, T, base_color=u3(S_KS), **sc)
+        out = {"diffuse_sum": ctx.empty(3, n), "diffuse_count": ctx.empty(n),
+               "specular_sum": ctx.empty(3, n), "specular_count": ctx.empty(n)}
+        return Workload(name, 128, (22 + 8) * 4, lambda: d.integrate(8, SEED, out=out),
+                        "disney_integrate_kernel<1>",
+                        "rlDisney both lobes x 64 spp, reduced mode (SURVEY 8d config 3, mode R; VALU-bound)")
+    if name == "sss_probe":
+        s = R.SssSampler(ctx, N, T, albedo=u3(S_KS), dist=u3(S_PARAM0, 0.1, 2.1))
+        xi = [u(S_XI0 + j) for j in range(2)]
+        out = {"r": ctx.empty(n), "origin": ctx.empty(3, n), "dir": ctx.empty(3, n), "maxdist": ctx.empty(n),
+               "pdf": ctx.empty(n), "profile": ctx.empty(3, n)}
+        return Workload(name, 1, (14 + 12) * 4, lambda: s.getProbeRay(xi[0], xi[1], out=out),
+                        "sss_kernel<OP_PROBE>", "rlSss ND probe ray + pdf + profile (SURVEY 8d config 4)")
+    if name == "skin":
+        p = dict(sss_color=u3(S_PARAM0), sss_weight=u(S_PARAM0 + 3), sss_dist_multiplier=u(S_PARAM0 + 4, 0.5, 1.5),
+                 sss_scatter_dist=u3(S_PARAM0 + 5, 0.1, 2.1),
+                 specular_color=u3(S_PARAM0 + 8), specular_weight=u(S_PARAM0 + 11),
+                 specular_roughness=u(S_PARAM0 + 12, 0.05, 1.0), specular_ior=u(S_PARAM0 + 13, 1.05, 2.55),
+                 sheen_color=u3(S_PARAM0 + 14), sheen_weight=u(S_PARAM0 + 17),
+                 sheen_roughness=u(S_PARAM0 + 18, 0.05, 1.0), sheen_ior=u(S_PARAM0 + 19, 1.05, 2.55))
+        sk = R.SkinShader(ctx, wo, N, T, **p)
+        xi = torch.stack([u(S_XI0 + j) for j in range(6)])
+        out = sk.alloc_out()
+        return Workload(name, 3, (35 + 24) * 4, lambda: sk.sampleEvalPdf(xi, out=out),
+                        "skin_kernel", "rlSkin sheen GGX + specular GGX + SSS (SURVEY 8d config 5)")
+    raise ValueError(name)
+
+
+# ------------------------------------------------------------------------------------------------
+def cpu_baseline(workload: str, target_seconds: float) -> dict | None:
+    """The CPU oracle on a bounded sample of the same synthetic workload, all host cores."""
+    if workload != "ggx_reflect_refract":
+        return None
+    import numpy as np
+    import oracle_lib as O
+    import cases
+    threads = O.hardware_threads()
+
+    def run(n):
+        c = cases.ggx_mixed(SEED, n)
+        x = cases.xi(SEED, n, 4)
+        g = O.Ggx(c["wo"], c["N"], c["T"], KsColor=c["KsColor"], ior=c["ior"], roughness=c["roughness"],
+                  anisotropic=c["anisotropic"], nthreads=threads)
+        out = g.reflect_refract(x[0], x[1], x[2], x[3])          # touch pages
+        best = float("inf")
+        for _ in range(3):
+            t0 = time.perf_counter()
+            g.reflect_refract(x[0], x[1], x[2], x[3], out=out)
+            best = min(best, time.perf_counter() - t0)
+        return best
+
+    n0 = 1 << 18
+    t = run(n0)
+    # size the sample so three timed passes + the page-touch pass take about target_seconds
+    n = int(min(1 << 24, max(n0, n0 * (target_seconds / 4.0) / max(t, 1e-6))))
+    n = 1 << (n.bit_length() - 1)
+    best = run(n) if n > n0 else t
+    return {"value": round(2 * n / best / 1e9, 6), "unit": "Gsamples/s", "cores": threads, "kind": "port",
+            "sample": f"{n} points (2 samples each) of the same seeded workload, best of 3, "
+                      f"oracle/rls_oracle.c orc_batch_ggx_reflect_refract on {threads} threads"}
+
+
+def traffic_bytes(workload: str):
+    """HBM bytes per launch from committed PMC profiles (profiles/*_traffic.json), or None."""
+    best = None
+    for p in sorted((ROOT / "profiles").glob("*_traffic.json")):
+        try:
+            d = json.loads(p.read_text())
+        except Exception:
+            continue
+        if d.get("workload") == workload and d.get("hbm_bytes_per_launch"):
+            best = d
+    return best
+
+
+# ------------------------------------------------------------------------------------------------
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        # launched bare: start one rank per GPU as child processes and return their exit code
+        port = 29500 + (os.getpid() % 2000)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()),
+               *sys.argv[1:]]
+        sys.exit(subprocess.call(cmd))
+
+    import torch
+    import rlshaders_amd as R
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no GPU visible; the closures only run on the HIP path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    ctx = R.Context(local_rank)
+    n = 1 << args.log2_points
+    wl = make_workload(R, ctx, args.workload, n, first=rank * n)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        wl.launch()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for _ in range(args.steps):
+        wl.launch()
+    ctx.timer_stop()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ctx.timer_elapsed_ms() / max(args.steps, 1)
+
+    if dist is not None:
+        tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(tt[0]), float(tt[1])
+
+    if rank == 0:
+        samples = world * n * wl.samples_per_point * args.steps
+        value = samples / elapsed / 1e9
+        bytes_per_launch = n * wl.bytes_per_point
+        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        tr = traffic_bytes(args.workload)
+        line = {
+            "metric": "BSDF Gsamples/sec (eval+sample+pdf)",
+            "value": round(value, 4),
+            "unit": "Gsamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": wl.desc, "name": wl.name, "points_per_gpu": n,
+                       "samples_per_point": wl.samples_per_point, "sharding": f"index-range x{world}, no collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": tr["hbm_bytes_per_launch"] if tr else None,
+                         "kernel": wl.kernel, "kernel_ms": round(kernel_ms, 5),
+                         "algorithmic_bytes_per_point": wl.bytes_per_point,
+                         "algorithmic_bytes_per_launch": bytes_per_launch},
+        }
+        if tr:
+            line["roofline"]["traffic_source"] = tr.get("source")
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(args.workload, args.cpu_seconds)
+            if cb:
+                line["cpu_baseline"] = cb
+        print(json.dumps(line), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

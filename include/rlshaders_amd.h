@@ -1,0 +1,272 @@
+/*
+ * rlshaders_amd.h -- C ABI of the MI355X-native batched BSDF evaluator / importance sampler.
+ *
+ * This is the drop-in boundary for the closure layer of shihchinw/rlShaders: the per-shading-point
+ * (sample, eval, pdf) callback triple that the reference hands to Arnold
+ *     static AtVector evalSample(const void *brdf, float rx, float ry);
+ *     static AtColor  evalBrdf  (const void *brdf, const AtVector *indir);
+ *     static float    evalPdf   (const void *brdf, const AtVector *indir);
+ * (src/rlGgx.h:97,110,121; src/rlDisney.cpp:109,120,139 -- paths relative to the reference
+ * repository), turned into batch calls over planar SoA device arrays, one entry per shading point.
+ * The closure object the reference builds on the stack per point (`brdf`) becomes a struct of
+ * device pointers named after the reference's node parameters (src/rlShaders.mtd,
+ * node_parameters in src/rlGgx.cpp:170-198, src/rlDisney.cpp:604-638, src/rlSkin.cpp:107-139);
+ * construction (src/rlGgx.h:130-156, src/rlDisney.cpp:155-192, src/rlSss.cpp:20-34) happens
+ * in registers inside the kernels.
+ *
+ * Conventions (all kept from the reference):
+ *   - eval returns BRDF x signed cosine (src/rlGgx.h:164, src/rlDisney.cpp:133,136);
+ *   - an invalid sample is the zero vector; eval of a zero vector is black, pdf of it is 0
+ *     (src/rlDisney.cpp:124-127,141-144,385-387; src/rlGgx.h:112-115);
+ *   - the GGX pdf is floored at 1e-4 (src/rlGgx.h:79), the Disney diffuse pdf too
+ *     (src/rlDisney.cpp:517);
+ *   - no exceptions cross this ABI; every entry point returns an rls_status.
+ *
+ * Geometry inputs per point: wo = -sg->Rd, N = sg->Nf (face-forward), T = the tangent U that
+ * AiBuildLocalFramePolar(&U,&V,&N) returns (closed Arnold code, so an input; V = N x T).
+ * All pointers are DEVICE pointers owned by the caller; a plane holds n floats; planes of a
+ * vec3/rgb need not be adjacent.  The library allocates nothing per call.
+ * All arithmetic is fp32.  Launches go to the context's stream and are asynchronous.
+ */
+#ifndef RLSHADERS_AMD_H
+#define RLSHADERS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RLS_VERSION_MAJOR 0
+#define RLS_VERSION_MINOR 1
+
+typedef int rls_status;
+enum {
+    RLS_OK = 0,
+    RLS_ERR_INVALID_ARGUMENT = 1,   /* NULL required pointer, n < 0, bad enum          */
+    RLS_ERR_NO_DEVICE = 2,          /* no HIP device / bad ordinal                      */
+    RLS_ERR_HIP = 3,                /* a HIP runtime call failed; see rls_last_error()  */
+    RLS_ERR_OUT_OF_MEMORY = 4,
+    RLS_ERR_UNSUPPORTED = 5
+};
+
+typedef struct rls_context rls_context;
+
+/* planar vec3 / rgb views (device pointers) */
+typedef struct { const float *x, *y, *z; } rls_cvec3;
+typedef struct { float *x, *y, *z; } rls_vec3;
+typedef struct { const float *r, *g, *b; } rls_crgb;
+typedef struct { float *r, *g, *b; } rls_rgb;
+
+/* A node parameter: per-point stream (v != NULL, n floats) or one uniform value (v == NULL).
+ * Arnold parameters are constants unless a texture is linked; uniform ones cost no bandwidth. */
+typedef struct { const float *v; float u; } rls_param;
+typedef struct { const float *r, *g, *b; float ur, ug, ub; } rls_param_rgb;
+
+/* Arnold ray-type tags selecting the rlDisney lobe (DisneySampler::mSampleType,
+ * src/rlDisney.cpp:112,132,147,194-197) */
+#define RLS_RAY_DIFFUSE 0x08
+#define RLS_RAY_GLOSSY  0x10
+
+/* microfacet-normal sampling kernels of rlGgx (src/rlGgx.h:24-89; the reference selects VNDF,
+ * src/rlGgx.h:375) */
+#define RLS_KERNEL_VNDF 0
+#define RLS_KERNEL_NDF  1
+
+/* ------------------------------------------------------------------------------------------
+ * Context, memory, timing
+ * ---------------------------------------------------------------------------------------- */
+rls_status  rls_context_create(int device_ordinal, rls_context **out);
+void        rls_context_destroy(rls_context *ctx);
+/* Use an existing hipStream_t (e.g. the framework's current stream); NULL -> the context's own. */
+rls_status  rls_context_set_stream(rls_context *ctx, void *hip_stream);
+void       *rls_context_get_stream(rls_context *ctx);
+rls_status  rls_context_synchronize(rls_context *ctx);
+int         rls_context_device(const rls_context *ctx);
+/* Thread-local text of the most recent failure in the calling thread ("" if none). */
+const char *rls_last_error(void);
+const char *rls_status_string(rls_status s);
+int         rls_version(void);                 /* major*1000 + minor */
+/* Device properties the host side sizes shards with. */
+rls_status  rls_device_info(rls_context *ctx, int *compute_units, size_t *hbm_bytes_total,
+                            size_t *hbm_bytes_free, char *arch_name, size_t arch_name_len);
+
+rls_status  rls_device_alloc(rls_context *ctx, size_t bytes, void **out);
+rls_status  rls_device_free(rls_context *ctx, void *p);
+rls_status  rls_copy_to_device(rls_context *ctx, void *dst, const void *src_host, size_t bytes);
+rls_status  rls_copy_to_host(rls_context *ctx, void *dst_host, const void *src, size_t bytes);
+
+/* HIP-event stopwatch on the context's stream (what bench.py times kernels with). */
+rls_status  rls_timer_start(rls_context *ctx);
+rls_status  rls_timer_stop(rls_context *ctx);
+rls_status  rls_timer_elapsed_ms(rls_context *ctx, float *ms);   /* synchronises on the stop event */
+
+/* ------------------------------------------------------------------------------------------
+ * rlGgx closure: rls::GgxSamplerT<VNDFKernel>  (src/rlGgx.h:92-373, src/rlGgx.cpp:14-99)
+ * Parameter names: src/rlGgx.cpp:172-186 (KsColor, specularRoughness, ior, anisotropic).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct rls_ggx_closure {
+    rls_cvec3      wo, N, T;
+    const uint8_t *exiting;            /* optional; 1 where !(dot(sg->N, sg->Rd) < 1e-4): swaps
+                                          the IORs as src/rlGgx.h:137-142 does                 */
+    rls_param_rgb  KsColor;            /* specColor                                            */
+    rls_param      specularRoughness;  /* roughness; alpha = roughness^2 (src/rlGgx.h:149)     */
+    rls_param      ior;
+    rls_param      anisotropic;
+} rls_ggx_closure;
+
+/* evalSample (src/rlGgx.h:97-107): wi = reflect(wo, VNDF microfacet).  fresnel (optional)
+ * receives the Fresnel term the reference accumulates into mReflectWeight for this sample. */
+rls_status rls_ggx_sample(rls_context *ctx, int64_t n, const rls_ggx_closure *c,
+                          const float *rx, const float *ry, rls_vec3 wi, float *fresnel);
+/* evalBrdf (src/rlGgx.h:110-119,158-165,304-313) */
+rls_status rls_ggx_eval(rls_context *ctx, int64_t n, const rls_ggx_closure *c, rls_cvec3 wi, rls_rgb f);
+/* evalPdf (src/rlGgx.h:121-127,72-80) */
+rls_status rls_ggx_pdf(rls_context *ctx, int64_t n, const rls_ggx_closure *c, rls_cvec3 wi, float *pdf);
+/* the triple fused in the reference's call order: sample -> eval(wi) -> pdf(wi) */
+rls_status rls_ggx_sample_eval_pdf(rls_context *ctx, int64_t n, const rls_ggx_closure *c,
+                                   const float *rx, const float *ry,
+                                   rls_vec3 wi, rls_rgb f, float *pdf, float *fresnel);
+/* per-sample body of integrateRefract (src/rlGgx.h:228-242): microfacet sample, Snell refraction
+ * about it (mirror on total internal reflection), weight = getSampleWeight (src/rlGgx.h:294-301).
+ * refracted (optional) gets 1 / 0 (TIR). */
+rls_status rls_ggx_refract_sample(rls_context *ctx, int64_t n, const rls_ggx_closure *c,
+                                  const float *rx, const float *ry,
+                                  rls_vec3 wt, float *weight, uint8_t *refracted);
+/* reflect triple with (rx,ry) + refract sample with (rx2,ry2) over the same closure, one pass */
+rls_status rls_ggx_reflect_refract(rls_context *ctx, int64_t n, const rls_ggx_closure *c,
+                                   const float *rx, const float *ry, const float *rx2, const float *ry2,
+                                   rls_vec3 wi, rls_rgb f, float *pdf, float *fresnel,
+                                   rls_vec3 wt, float *weight);
+/* microfacet normal only: kernel = RLS_KERNEL_VNDF (src/rlGgx.cpp:63-99) or RLS_KERNEL_NDF
+ * (src/rlGgx.h:33-41) */
+rls_status rls_ggx_microfacet(rls_context *ctx, int64_t n, const rls_ggx_closure *c, int kernel,
+                              const float *rx, const float *ry, rls_vec3 m);
+/* NDFKernel::evalPdf (src/rlGgx.h:45-50), the alternate pdf */
+rls_status rls_ggx_ndf_pdf(rls_context *ctx, int64_t n, const rls_ggx_closure *c, rls_cvec3 wi, float *pdf);
+/* spp_n^2 stratified samples per point drawn in-kernel (stand-in for AiSampler(spp_n, 2),
+ * src/rlGgx.cpp:148): sum_f_over_pdf = sum over samples of eval/pdf (what AiBRDFIntegrate
+ * accumulates before radiance), avg_reflect_weight = getAvgReflectWeight (src/rlGgx.h:181-184).
+ * One wavefront per point group, lanes = strata, wave-shuffle reduction. */
+rls_status rls_ggx_integrate(rls_context *ctx, int64_t n, const rls_ggx_closure *c,
+                             int spp_n, uint32_t seed,
+                             rls_rgb sum_f_over_pdf, float *avg_reflect_weight);
+
+/* ------------------------------------------------------------------------------------------
+ * rlDisney closure: DisneySampler (src/rlDisney.cpp:105-602)
+ * Parameter names: src/rlDisney.cpp:606-610.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct rls_disney_closure {
+    rls_cvec3     wo, N, T;
+    rls_param_rgb base_color;
+    rls_param     subsurface, metallic, specular, specular_tint, roughness, anisotropic,
+                  sheen, sheen_tint, clearcoat, clearcoat_gloss;
+} rls_disney_closure;
+
+/* lobe = RLS_RAY_DIFFUSE or RLS_RAY_GLOSSY (what setSampleType selects) */
+rls_status rls_disney_sample(rls_context *ctx, int64_t n, const rls_disney_closure *c, int lobe,
+                             const float *rx, const float *ry, rls_vec3 wi);
+rls_status rls_disney_eval(rls_context *ctx, int64_t n, const rls_disney_closure *c, int lobe,
+                           rls_cvec3 wi, rls_rgb f);
+rls_status rls_disney_pdf(rls_context *ctx, int64_t n, const rls_disney_closure *c, int lobe,
+                          rls_cvec3 wi, float *pdf);
+rls_status rls_disney_sample_eval_pdf(rls_context *ctx, int64_t n, const rls_disney_closure *c, int lobe,
+                                      const float *rx, const float *ry,
+                                      rls_vec3 wi, rls_rgb f, float *pdf);
+/* spp_n^2 stratified samples per point and lobe, drawn in-kernel, both lobes.
+ * Reduced mode: per point and lobe the sum of eval/pdf over valid samples and the valid count
+ * (pdf > 1e-4 and wi != 0, as src/rlDisney.cpp:309).  Streamed mode (any of s_* non-NULL):
+ * additionally every sample's (wi, f, pdf) at index  lobe*n*spp + s*n + i  (sample-major planes). */
+typedef struct rls_disney_stream_out { rls_vec3 wi; rls_rgb f; float *pdf; } rls_disney_stream_out;
+rls_status rls_disney_integrate(rls_context *ctx, int64_t n, const rls_disney_closure *c,
+                                int spp_n, uint32_t seed,
+                                rls_rgb diffuse_sum, float *diffuse_count,
+                                rls_rgb specular_sum, float *specular_count,
+                                const rls_disney_stream_out *stream /* optional */);
+
+/* ------------------------------------------------------------------------------------------
+ * rlSss: NDProfile + SssSampler<NDProfile> hot parts (src/rlSss.h:27-61,143-167,246-266,
+ * 401-413,487-545; src/rlSss.cpp:20-106).  Parameter names: src/rlSkin.cpp:109-115.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct rls_sss_closure {
+    rls_param_rgb sss_color;            /* albedo (does not shape the profile: src/rlSss.cpp:23)  */
+    rls_param     sss_dist_multiplier;  /* scatterDist = sss_scatter_dist * multiplier            */
+    rls_param     sss_scatter_dist[3];  /* VEC parameter: x, y, z                                 */
+    rls_cvec3     N;                    /* sg->Ns; may be all-NULL for the profile-only calls     */
+    rls_cvec3     T;                    /* sg->dPdu (has_dPdu) or the polar-frame tangent         */
+    int           has_dPdu;             /* 1: Gram-Schmidt frame from dPdu (src/rlSss.h:151-154)  */
+} rls_sss_closure;
+
+/* getRadius(rx) -> r, getPdf(r), evalProfile(r) in one pass (src/rlSss.cpp:36-106) */
+rls_status rls_nd_sample(rls_context *ctx, int64_t n, const rls_sss_closure *c, const float *rx,
+                         float *r, float *pdf, rls_rgb profile);
+rls_status rls_nd_pdf(rls_context *ctx, int64_t n, const rls_sss_closure *c, const float *r, float *pdf);
+rls_status rls_nd_eval(rls_context *ctx, int64_t n, const rls_sss_closure *c, const float *r, rls_rgb profile);
+/* getProbeRay (src/rlSss.h:487-533): offset = ray.origin - sg->P, dir, maxdist, r; plus pdf(r)
+ * and profile(r).  P (optional, all three planes or none) is added to the offset. */
+rls_status rls_sss_probe_ray(rls_context *ctx, int64_t n, const rls_sss_closure *c,
+                             const float *rx, const float *ry, rls_cvec3 P,
+                             float *r, rls_vec3 origin, rls_vec3 dir, float *maxdist,
+                             float *pdf, rls_rgb profile);
+/* 3-axis MIS pdf of a probe hit (src/rlSss.h:246-266).  literal_matrix: 0 = projection onto the
+ * frame axes (intent), 1 = literal row-vector product ("closed Arnold services"). */
+rls_status rls_sss_mis_pdf(rls_context *ctx, int64_t n, const rls_sss_closure *c,
+                           rls_cvec3 disp, rls_cvec3 sampleN, int literal_matrix, float *pdf);
+/* cavity fade (src/rlSss.h:401-413); r = |disp| (src/rlSss.h:382) */
+rls_status rls_sss_cavity_fade(rls_context *ctx, int64_t n, rls_cvec3 disp, rls_cvec3 sampleN,
+                               rls_cvec3 No, float *fade);
+/* cosine-hemisphere direction about an arbitrary normal (src/rlSss.h:536-545) */
+rls_status rls_sss_sample_diffuse_direction(rls_context *ctx, int64_t n, rls_cvec3 normal, rls_cvec3 T,
+                                            const float *rx, const float *ry, rls_vec3 wi);
+
+/* ------------------------------------------------------------------------------------------
+ * rlSkin composite: sheen GGX + specular GGX + NDProfile SSS with the layer-weight arithmetic
+ * of shader_evaluate (src/rlSkin.cpp:174-246).  Parameter names: src/rlSkin.cpp:109-128.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct rls_skin_closure {
+    rls_cvec3     wo, N, T;             /* T doubles as sg->dPdu for the SSS frame              */
+    rls_param_rgb sss_color;
+    rls_param     sss_weight, sss_dist_multiplier;
+    rls_param     sss_scatter_dist[3];
+    rls_param_rgb specular_color;
+    rls_param     specular_weight, specular_roughness, specular_ior;
+    rls_param_rgb sheen_color;
+    rls_param     sheen_weight, sheen_roughness, sheen_ior;
+} rls_skin_closure;
+
+typedef struct rls_skin_out {
+    rls_vec3 sheen_wi;  rls_rgb sheen_f;  float *sheen_pdf;  float *sheen_fresnel;
+    rls_vec3 spec_wi;   rls_rgb spec_f;   float *spec_pdf;   float *spec_fresnel;
+    float   *r, *r_pdf; rls_rgb profile;
+    float   *sheenFresnel, *specularFresnel, *sssWeight;   /* src/rlSkin.cpp:204,228,238 */
+} rls_skin_out;
+
+/* xi: six planes {sheen rx, ry, specular rx, ry, sss rx, ry} */
+rls_status rls_skin_sample_eval_pdf(rls_context *ctx, int64_t n, const rls_skin_closure *c,
+                                    const float *const xi[6], const rls_skin_out *out);
+
+/* ------------------------------------------------------------------------------------------
+ * rlUtil closures (src/rlUtil.h:21-29, src/rlUtil.cpp:3-27), batch form for parity checks:
+ * spherical = sphericalDirection(2a-1, 2*pi*b), disk = concentricDiskSample(a, b) (z = 0).
+ * ---------------------------------------------------------------------------------------- */
+rls_status rls_util_directions(rls_context *ctx, int64_t n, const float *a, const float *b,
+                               rls_vec3 spherical, rls_vec3 disk);
+
+/* ------------------------------------------------------------------------------------------
+ * Synthetic shading-point generator (bench / tests): counter-based, value = f(seed, index,
+ * stream); integer hashing and + - * / sqrt only, so the CPU oracle's generator matches bit
+ * for bit.  Distributions: DESIGN.md "Synthetic inputs".
+ * ---------------------------------------------------------------------------------------- */
+rls_status rls_gen_frame(rls_context *ctx, uint32_t seed, uint64_t first_index, int64_t n,
+                         rls_vec3 wo, rls_vec3 N, rls_vec3 T);
+rls_status rls_gen_uniform(rls_context *ctx, uint32_t seed, uint64_t first_index, int64_t n,
+                           uint32_t stream, float lo, float hi, float *out);
+rls_status rls_gen_aniso(rls_context *ctx, uint32_t seed, uint64_t first_index, int64_t n, float *out);
+/* order-independent 64-bit checksum of n floats (sum of per-element hashes of the bit patterns) */
+rls_status rls_checksum(rls_context *ctx, int64_t n, const float *data, uint64_t *out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RLSHADERS_AMD_H */

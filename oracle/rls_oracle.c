@@ -1,0 +1,1503 @@
+/*
+ * rls_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).  See rls_oracle.h for
+ * the parity status ("parity unpinned" + SURVEY.md 8(c) KATs) and the substitution table for
+ * closed Arnold services.  Every function cites the reference lines it restates (paths are
+ * relative to /root/reference).  Scalar fp32, literal operation order, no FMA contraction.
+ */
+#define _GNU_SOURCE
+#include "rls_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+/* ---- Arnold constants / helpers (public 4.x definitions) ---------- */
+#define AI_PI        3.14159265f
+#define AI_PITIMES2  6.28318530f
+#define AI_PIOVER2   1.57079632f
+#define AI_ONEOVERPI 0.31830988f
+#define AI_EPSILON   1e-4f
+
+static inline float SQRf(float a) { return a * a; }
+static inline float ABSf(float a) { return a < 0.0f ? -a : a; }
+static inline float MAXf(float a, float b) { return a > b ? a : b; }
+static inline float MINf(float a, float b) { return a < b ? a : b; }
+static inline float CLAMPf(float v, float lo, float hi) { return MAXf(lo, MINf(v, hi)); }
+static inline float LERPf(float t, float a, float b) { return ((1.0f - t) * a) + (b * t); }
+static inline float LINEARSTEPf(float lo, float hi, float t) { return CLAMPf((t - lo) / (hi - lo), 0.0f, 1.0f); }
+static inline int   SGNf(float a) { return a < 0.0f ? -1 : 1; }
+
+static inline orc_v3 v3(float x, float y, float z) { orc_v3 r = { x, y, z }; return r; }
+static inline orc_v3 v3add(orc_v3 a, orc_v3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline orc_v3 v3sub(orc_v3 a, orc_v3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline orc_v3 v3scale(orc_v3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+static inline orc_v3 v3neg(orc_v3 a) { return v3(-a.x, -a.y, -a.z); }
+static inline float  v3dot(orc_v3 a, orc_v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline orc_v3 v3cross(orc_v3 a, orc_v3 b)
+{
+    return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static inline float  v3length(orc_v3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+/* AiV3Normalize: multiply by the reciprocal length, zero-safe */
+static inline orc_v3 v3normalize(orc_v3 a)
+{
+    float tmp = v3length(a);
+    if (tmp != 0.0f) tmp = 1.0f / tmp;
+    return v3(a.x * tmp, a.y * tmp, a.z * tmp);
+}
+/* AiV3RotateToFrame(a,u,v,w): a = a.x*u + a.y*v + a.z*w */
+static inline orc_v3 v3rotate_to_frame(orc_v3 a, orc_v3 u, orc_v3 v, orc_v3 w)
+{
+    return v3(a.x * u.x + a.y * v.x + a.z * w.x,
+              a.x * u.y + a.y * v.y + a.z * w.y,
+              a.x * u.z + a.y * v.z + a.z * w.z);
+}
+static inline int v3iszero(orc_v3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
+static inline int v3exists(orc_v3 a) { return isfinite(a.x) && isfinite(a.y) && isfinite(a.z); }
+
+static inline orc_rgb rgb(float r, float g, float b) { orc_rgb c = { r, g, b }; return c; }
+static inline orc_rgb rgbscale(orc_rgb c, float s) { return rgb(c.r * s, c.g * s, c.b * s); }
+static inline orc_rgb rgblerp(float t, orc_rgb a, orc_rgb b)
+{
+    return rgb(LERPf(t, a.r, b.r), LERPf(t, a.g, b.g), LERPf(t, a.b, b.b));
+}
+static const orc_rgb RGB_BLACK = { 0.0f, 0.0f, 0.0f };
+static const orc_rgb RGB_WHITE = { 1.0f, 1.0f, 1.0f };
+static inline int rgb_is_small(orc_rgb c)
+{
+    return ABSf(c.r) < AI_EPSILON && ABSf(c.g) < AI_EPSILON && ABSf(c.b) < AI_EPSILON;
+}
+
+/* ===================================== rlUtil ========================================== */
+
+/* src/rlUtil.h:21-29 */
+orc_v3 orc_spherical_direction(float cosTheta, float phi)
+{
+    orc_v3 omega;
+    omega.z = cosTheta;
+    float r = sqrtf(1.0f - SQRf(omega.z));
+    omega.x = r * cosf(phi);
+    omega.y = r * sinf(phi);
+    return omega;
+}
+
+/* src/rlUtil.h:31-34 */
+orc_v3 orc_reflect_direction(orc_v3 i, orc_v3 n)
+{
+    return v3sub(v3scale(n, 2.0f * ABSf(v3dot(i, n))), i);
+}
+
+/* src/rlUtil.h:36-39 */
+float orc_color_to_luminance(orc_rgb c)
+{
+    return c.r * 0.212671f + c.g * 0.715160f + c.b * 0.072169f;
+}
+
+/* src/rlUtil.cpp:3-27 (z is left unset by the reference; returned as a 2-vector here) */
+orc_v2 orc_concentric_disk_sample(float rx, float ry)
+{
+    orc_v2 result;
+    rx = rx * 2.0f - 1.0f;
+    ry = ry * 2.0f - 1.0f;
+    if (rx == 0.0f && ry == 0.0f) {
+        result.x = result.y = 0.0f;
+        return result;
+    }
+    float r, phi;
+    if (ABSf(rx) > ABSf(ry)) {
+        r = rx;
+        phi = AI_PIOVER2 * 0.5f * ry / rx;
+    } else {
+        r = ry;
+        phi = AI_PIOVER2 * (1.0f - 0.5f * rx / ry);
+    }
+    result.x = r * cosf(phi);
+    result.y = r * sinf(phi);
+    return result;
+}
+
+/* ====================================== rlGgx ========================================== */
+
+/* src/rlGgx.h:130-156.  Boundary: wo = -sg->Rd, Nf = sg->Nf, T = tangent returned by the
+ * closed AiBuildLocalFramePolar (input), exiting = !(dot(sg->N, sg->Rd) < AI_EPSILON). */
+void orc_ggx_init(orc_ggx *g, orc_v3 wo, orc_v3 Nf, orc_v3 T, int exiting,
+                  orc_rgb specColor, float ior, float roughness, float anisotropic)
+{
+    g->specColor = specColor;
+    g->reflectWeight = 0.0f;
+    g->misSampleCount = 0.0f;
+    g->iorIn = 1.0f;
+    g->iorOut = MAXf(ior, 1e-4f);
+    if (exiting) {
+        float t = g->iorIn; g->iorIn = g->iorOut; g->iorOut = t;
+    }
+    g->viewDir = wo;
+    g->N = g->axisN = Nf;
+    g->U = T;
+    g->V = v3cross(Nf, T);
+
+    float aspect = sqrtf(1.0f - anisotropic * 0.9f);
+    g->alphaX = MAXf(1e-4f, SQRf(roughness) / aspect);
+    g->alphaY = MAXf(1e-4f, SQRf(roughness) * aspect);
+    g->roughness = MAXf(1e-5f, SQRf(roughness));
+}
+
+/* src/rlGgx.cpp:14-61 (identical code duplicated at src/rlDisney.cpp:416-463) */
+static orc_v2 uniform_slope(float rx, float ry)
+{
+    orc_v2 slope;
+    float r = sqrtf(rx / (1.0f - rx));
+    float phi = AI_PITIMES2 * ry;
+    slope.x = r * cosf(phi);
+    slope.y = r * sinf(phi);
+    return slope;
+}
+
+orc_v2 orc_vndf_sample_slope(float theta, float rx, float ry)
+{
+    orc_v2 slope;
+    if (theta < AI_EPSILON) {
+        return uniform_slope(rx, ry);
+    }
+    float B = tanf(theta);
+    float B2 = SQRf(B);
+    float G1 = 2.0f / (1.0f + sqrtf(1.0f + B2));
+
+    float A = 2.0f * rx / G1 - 1.0f;
+    float A2 = SQRf(A);
+    if (ABSf(A2 - 1.0f) < AI_EPSILON) {
+        return uniform_slope(rx, ry);
+    }
+    float tmp = 1.0f / (A2 - 1.0f);
+    float D = sqrtf(MAXf(0.0f, B2 * SQRf(tmp) - (A2 - B2) * tmp));
+    float slopeX1 = B * tmp - D;
+    float slopeX2 = B * tmp + D;
+    slope.x = (A < 0.0f || slopeX2 > 1.0f / B) ? slopeX1 : slopeX2;
+
+    float sign = 1.0f;
+    if (ry > 0.5f) {
+        ry = 2.0f * (ry - 0.5f);
+    } else {
+        sign = -1.0f;
+        ry = 2.0f * (0.5f - ry);
+    }
+    float z = (ry * (ry * (ry * 0.27385f - 0.73369f) + 0.46341f))
+            / (ry * (ry * (ry * 0.093073f + 0.309420f) - 1.0f) + 0.597999f);
+    slope.y = sign * z * sqrtf(1.0f + SQRf(slope.x));
+    return slope;
+}
+
+/* Shared body of VNDFKernel::evalSample (src/rlGgx.cpp:63-99) and
+ * DisneySampler::sampleGTR2AnisoDirectionFromSlope (src/rlDisney.cpp:467-502). */
+static orc_v3 vndf_microfacet(orc_v3 view, orc_v3 U, orc_v3 Vb, orc_v3 N, float ax, float ay,
+                              float rx, float ry)
+{
+    orc_v3 V = view;
+    float cosThetaV = CLAMPf(v3dot(N, V), -1.0f, 1.0f);
+    float phiV = atan2f(v3dot(Vb, V), v3dot(U, V));
+    V = orc_spherical_direction(cosThetaV, phiV);
+
+    V.x *= ax;
+    V.y *= ay;
+    V = v3normalize(V);
+
+    float theta = 0.0f;
+    float phi = 0.0f;
+    if (V.z < (1.0f - AI_EPSILON)) {
+        theta = acosf(V.z);
+        phi = atan2f(V.y, V.x);
+    }
+
+    orc_v2 slope = orc_vndf_sample_slope(theta, rx, ry);
+
+    float cosPhi = cosf(phi);
+    float sinPhi = sinf(phi);
+    orc_v3 omega;
+    omega.x = -(cosPhi * slope.x - sinPhi * slope.y) * ax;
+    omega.y = -(sinPhi * slope.x + cosPhi * slope.y) * ay;
+    omega.z = 1.0f;
+
+    omega = v3rotate_to_frame(omega, U, Vb, N);
+    return v3normalize(omega);
+}
+
+orc_v3 orc_vndf_sample(const orc_ggx *g, float rx, float ry)
+{
+    return vndf_microfacet(g->viewDir, g->U, g->V, g->N, g->alphaX, g->alphaY, rx, ry);
+}
+
+/* NDFKernel::evalSample, src/rlGgx.h:33-41 (alternate kernel, not selected: src/rlGgx.h:375) */
+orc_v3 orc_ndf_sample(const orc_ggx *g, float rx, float ry)
+{
+    float gg = sqrtf(rx / (1.0f - rx));
+    float phi = AI_PITIMES2 * ry;
+    orc_v3 omega = v3(gg * g->alphaX * cosf(phi), gg * g->alphaY * sinf(phi), 1.0f);
+    omega = v3rotate_to_frame(omega, g->U, g->V, g->N);
+    return v3normalize(omega);
+}
+
+/* src/rlGgx.h:249-270 */
+float orc_ggx_fresnel(const orc_ggx *g, orc_v3 i, orc_v3 m)
+{
+    float c = ABSf(v3dot(i, m));
+    float gSqr = SQRf(g->iorOut / g->iorIn) - 1.0f + c * c;
+    if (gSqr < 0.0f) {
+        return 1.0f;
+    }
+    float gg = sqrtf(gSqr);
+    float gmc = gg - c;
+    float gpc = gg + c;
+    return 0.5f * SQRf(gmc / gpc) * (1.0f + SQRf((c * gpc - 1.0f) / (c * gmc + 1.0f)));
+}
+
+/* src/rlGgx.h:332-340 */
+float orc_ggx_D(const orc_ggx *g, orc_v3 m)
+{
+    float MdotU = v3dot(m, g->U);
+    float MdotV = v3dot(m, g->V);
+    float MdotN2 = SQRf(v3dot(g->axisN, m));
+    float denominator = g->alphaX * g->alphaY
+        * SQRf(SQRf(MdotU / g->alphaX) + SQRf(MdotV / g->alphaY) + MdotN2);
+    return AI_ONEOVERPI / denominator;
+}
+
+/* src/rlGgx.h:343-357 (uses the isotropic mRoughness even when alphaX != alphaY) */
+float orc_ggx_G1(const orc_ggx *g, orc_v3 v, orc_v3 m, orc_v3 n)
+{
+    float VdotM = v3dot(v, m);
+    float VdotN = v3dot(v, n);
+    if (VdotM * VdotN < 0.0f) {
+        return 0.0f;
+    }
+    float cosSqr = SQRf(VdotN);
+    float tanSqr = 1.0f / cosSqr - 1.0f;
+    float denominator = 1.0f + sqrtf(1.0f + SQRf(g->roughness) * tanSqr);
+    return 2.0f / denominator;
+}
+
+/* src/rlGgx.h:272-275 */
+float orc_ggx_G(const orc_ggx *g, orc_v3 i, orc_v3 o, orc_v3 m, orc_v3 n)
+{
+    return orc_ggx_G1(g, i, m, n) * orc_ggx_G1(g, o, m, n);
+}
+
+/* src/rlGgx.h:304-313 */
+float orc_ggx_reflection(const orc_ggx *g, orc_v3 i, orc_v3 o, orc_v3 n)
+{
+    orc_v3 hr = v3scale(v3normalize(v3add(o, i)), (float)SGNf(v3dot(i, n)));
+    float reflectWeight = orc_ggx_fresnel(g, i, hr);
+    float LdotN = ABSf(v3dot(o, n));
+    float VdotN = ABSf(v3dot(i, n));
+    return reflectWeight * orc_ggx_G(g, i, o, hr, n) * orc_ggx_D(g, hr) * 0.25f / (LdotN * VdotN);
+}
+
+/* src/rlGgx.h:316-328 (dead code in the reference; restated for the "next" rows) */
+float orc_ggx_refraction(const orc_ggx *g, orc_v3 i, orc_v3 o, orc_v3 n)
+{
+    orc_v3 ht = v3neg(v3normalize(v3add(v3scale(i, g->iorIn), v3scale(o, g->iorOut))));
+    float refractWeight = 1.0f - orc_ggx_fresnel(g, i, ht);
+    float OdotN = ABSf(v3dot(o, n));
+    float IdotN = ABSf(v3dot(i, n));
+    float OdotH = v3dot(o, ht);
+    float IdotH = v3dot(i, ht);
+    float denominator = OdotN * IdotN * SQRf(g->iorIn * IdotH + g->iorOut * OdotH);
+    return ABSf(OdotH * IdotH) * SQRf(g->iorOut) * refractWeight
+         * orc_ggx_G(g, i, o, ht, n) * orc_ggx_D(g, ht) / denominator;
+}
+
+/* src/rlGgx.h:294-301 */
+float orc_ggx_sample_weight(const orc_ggx *g, orc_v3 i, orc_v3 o, orc_v3 m)
+{
+    float IdotH = v3dot(i, m);
+    float MdotN = ABSf(v3dot(m, g->axisN));
+    float IdotN = ABSf(v3dot(i, g->axisN));
+    return orc_ggx_G(g, i, o, m, g->axisN) * ABSf(IdotH / (IdotN * MdotN));
+}
+
+/* VNDFKernel::evalPdf, src/rlGgx.h:72-80 */
+float orc_vndf_pdf(const orc_ggx *g, orc_v3 i, orc_v3 m)
+{
+    float IdotN = ABSf(v3dot(i, g->N));
+    float pdf = orc_ggx_D(g, m) * orc_ggx_G1(g, i, m, g->N) / IdotN * 0.25f;
+    return MAXf(pdf, AI_EPSILON);
+}
+
+/* NDFKernel::evalPdf, src/rlGgx.h:45-50 */
+float orc_ndf_pdf(const orc_ggx *g, orc_v3 i, orc_v3 m)
+{
+    float IdotM = ABSf(v3dot(i, m));
+    float MdotN = ABSf(v3dot(m, g->N));
+    return orc_ggx_D(g, m) * MdotN * 0.25f / IdotM;
+}
+
+/* src/rlGgx.h:97-107 */
+orc_v3 orc_ggx_eval_sample(orc_ggx *g, float rx, float ry)
+{
+    orc_v3 M = orc_vndf_sample(g, rx, ry);
+    orc_v3 L = orc_reflect_direction(g->viewDir, M);
+    g->reflectWeight += orc_ggx_fresnel(g, L, M);
+    g->misSampleCount += 1.0f;
+    return L;
+}
+
+/* src/rlGgx.h:110-119 + evalReflectance 158-165 */
+orc_rgb orc_ggx_eval_brdf(const orc_ggx *g, orc_v3 indir)
+{
+    if (v3iszero(indir)) {
+        return RGB_BLACK;
+    }
+    if (rgb_is_small(g->specColor)) {
+        return RGB_BLACK;
+    }
+    float refl = orc_ggx_reflection(g, g->viewDir, indir, g->axisN);
+    float LdotN = v3dot(indir, g->axisN);
+    return rgb(g->specColor.r * refl * LdotN, g->specColor.g * refl * LdotN, g->specColor.b * refl * LdotN);
+}
+
+/* src/rlGgx.h:121-127 */
+float orc_ggx_eval_pdf(const orc_ggx *g, orc_v3 indir)
+{
+    orc_v3 V = g->viewDir;
+    orc_v3 H = v3normalize(v3add(V, indir));
+    return orc_vndf_pdf(g, V, H);
+}
+
+/* src/rlGgx.h:181-184 */
+float orc_ggx_avg_reflect_weight(const orc_ggx *g)
+{
+    return g->misSampleCount > 0.0f ? g->reflectWeight / g->misSampleCount : 1.0f;
+}
+
+/* Per-sample body of integrateRefract, src/rlGgx.h:228-242.  AiRefractRay / AiReflectRay are
+ * closed: replaced by Snell's law about m (Walter et al. EGSR'07 eq. 40, eta = iorIn/iorOut,
+ * incident = sg->Rd = -viewDir) and by the mirror of sg->Rd about m on total internal
+ * reflection.  PARITY UNPINNED for the direction; the weight is src/rlGgx.h:294-301. */
+int orc_ggx_refract_sample(const orc_ggx *g, float rx, float ry, orc_v3 *dir, float *weight)
+{
+    orc_v3 m = orc_vndf_sample(g, rx, ry);
+    orc_v3 i = g->viewDir;
+    float eta = g->iorIn / g->iorOut;
+    float c = v3dot(i, m);
+    float cosThetaTSqr = 1.0f - eta * eta * (1.0f - c * c);
+    int refracted = !(cosThetaTSqr < 0.0f);
+    if (refracted) {
+        float sign = (float)SGNf(v3dot(i, g->axisN));
+        float k = eta * c - sign * sqrtf(cosThetaTSqr);
+        *dir = v3sub(v3scale(m, k), v3scale(i, eta));
+    } else {
+        *dir = v3sub(v3scale(m, 2.0f * c), i);
+    }
+    *weight = orc_ggx_sample_weight(g, i, *dir, m);
+    return refracted;
+}
+
+/* ===================================== rlDisney ======================================== */
+
+/* src/rlDisney.cpp:155-192 */
+void orc_disney_init(orc_disney *d, orc_v3 wo, orc_v3 Nf, orc_v3 T, orc_rgb base_color,
+                     const float s[10])
+{
+    d->baseColor = base_color;
+    d->subsurface = s[0];
+    d->metallic = s[1];
+    d->specular = s[2] * 0.08f;
+    d->specularTint = s[3];
+    d->roughness = s[4];
+    d->anisotropic = s[5];
+    d->sheen = s[6];
+    d->sheenTint = s[7];
+    d->clearcoat = s[8] * 0.25f;
+    d->clearcoatGloss = s[9];
+
+    d->viewDir = wo;
+    d->axisN = Nf;
+    d->axisU = T;
+    d->axisV = v3cross(Nf, T);
+
+    float aspect = sqrtf(1.0f - d->anisotropic * 0.9f);
+    d->alphaX = MAXf(1e-2f, SQRf(d->roughness) / aspect);
+    d->alphaY = MAXf(1e-2f, SQRf(d->roughness) * aspect);
+    d->specularRoughness = SQRf(d->roughness);
+
+    float luminance = orc_color_to_luminance(d->baseColor);
+    orc_rgb tintColor = luminance > 0.0f
+        ? rgb(d->baseColor.r / luminance, d->baseColor.g / luminance, d->baseColor.b / luminance)
+        : RGB_WHITE;
+    orc_rgb metallicColor = rgbscale(rgblerp(d->specularTint, RGB_WHITE, tintColor), d->specular);
+    d->specularF0 = rgblerp(d->metallic, metallicColor, d->baseColor);
+    d->sheenColor = rgbscale(rgblerp(d->sheenTint, RGB_WHITE, tintColor), d->sheen);
+    d->sampleFromVisibleNormal = 1;
+    d->sampleType = ORC_RAY_GLOSSY;
+}
+
+/* src/rlDisney.cpp:570-577 */
+static float smithG_GGX(float NdotV, float alphaG)
+{
+    float a = alphaG * alphaG;
+    float b = NdotV * NdotV;
+    return 1.0f / (NdotV + sqrtf(a + b - a * b));
+}
+
+/* src/rlDisney.cpp:545-551 */
+static float D_GTR1(const orc_disney *d, float MdotN2)
+{
+    float alpha = LERPf(d->clearcoatGloss, 0.1f, 0.001f);
+    float a2 = SQRf(alpha);
+    float denominator = logf(a2) * (1.0f + (a2 - 1.0f) * MdotN2);
+    return (a2 - 1.0f) * AI_ONEOVERPI / denominator;
+}
+
+/* src/rlDisney.cpp:561-568 */
+static float D_GTR2Aniso(const orc_disney *d, orc_v3 m, float MdotN2)
+{
+    float HdotU = v3dot(m, d->axisU);
+    float HdotV = v3dot(m, d->axisV);
+    float denominator = d->alphaX * d->alphaY
+        * SQRf(SQRf(HdotU / d->alphaX) + SQRf(HdotV / d->alphaY) + MdotN2);
+    return AI_ONEOVERPI / denominator;
+}
+
+/* src/rlDisney.cpp:199-236 */
+orc_rgb orc_disney_eval_diffuse(const orc_disney *d, orc_v3 L)
+{
+    float LdotN = v3dot(L, d->axisN);
+    float VdotN = v3dot(d->viewDir, d->axisN);
+    if (LdotN < AI_EPSILON || VdotN < AI_EPSILON) {
+        return RGB_BLACK;
+    }
+    orc_v3 H = v3normalize(v3add(L, d->viewDir));
+    float LdotH = v3dot(L, H);
+    float NdotH = v3dot(d->viewDir, H);     /* named NdotH in the reference, is V.H (line 210) */
+    if (NdotH < AI_EPSILON || LdotH < AI_EPSILON) {
+        return RGB_BLACK;
+    }
+    float LdotH2 = SQRf(LdotH);
+
+    float FL = powf(CLAMPf(1.0f - LdotN, 0.0f, 1.0f), 5.0f);
+    float FV = powf(CLAMPf(1.0f - VdotN, 0.0f, 1.0f), 5.0f);
+    float F90 = 0.5f + 2.0f * d->roughness * LdotH2;
+    float diffuseFactor = LERPf(FL, 1.0f, F90) * LERPf(FV, 1.0f, F90);
+
+    float Fss90 = d->roughness * LdotH2;
+    float Fss = LERPf(FL, 1.0f, Fss90) * LERPf(FV, 1.0f, Fss90);
+    float ssFactor = 1.25f * (Fss * (1.0f / (LdotN + VdotN) - 0.5f) + 0.5f);
+
+    float mix = LERPf(d->subsurface, diffuseFactor, ssFactor);
+    float om = 1.0f - d->metallic;
+    return rgb(d->baseColor.r * AI_ONEOVERPI * mix * om,
+               d->baseColor.g * AI_ONEOVERPI * mix * om,
+               d->baseColor.b * AI_ONEOVERPI * mix * om);
+}
+
+/* src/rlDisney.cpp:318-356 */
+orc_rgb orc_disney_eval_specular(const orc_disney *d, orc_v3 L)
+{
+    float LdotN = v3dot(L, d->axisN);
+    float VdotN = v3dot(d->viewDir, d->axisN);
+    if (LdotN < AI_EPSILON || VdotN < AI_EPSILON) {
+        return RGB_BLACK;
+    }
+    orc_v3 M = v3normalize(v3add(L, d->viewDir));
+    float LdotM = v3dot(L, M);
+    float NdotM = v3dot(d->axisN, M);
+    if (NdotM < AI_EPSILON || LdotM < AI_EPSILON) {
+        return RGB_BLACK;
+    }
+    float NdotM2 = SQRf(v3dot(d->axisN, M));
+
+    float Ds = D_GTR2Aniso(d, M, NdotM2);
+    float FH = powf(CLAMPf(1.0f - LdotM, 0.0f, 1.0f), 5.0f);
+    orc_rgb Fs = rgblerp(FH, d->specularF0, RGB_WHITE);
+    float Gs = smithG_GGX(LdotN, d->specularRoughness) * smithG_GGX(VdotN, d->specularRoughness);
+
+    const float clearcoatF0 = 0.04f;
+    const float clearcoatRoughness = 0.25f;
+    float Dr = D_GTR1(d, NdotM2);
+    float Fr = LERPf(FH, clearcoatF0, 1.0f);
+    float Gr = smithG_GGX(LdotN, clearcoatRoughness) * smithG_GGX(VdotN, clearcoatRoughness);
+
+    float om = 1.0f - d->metallic;
+    orc_rgb Fsheen = rgb(FH * d->sheenColor.r * om, FH * d->sheenColor.g * om, FH * d->sheenColor.b * om);
+    float cc = d->clearcoat * Dr * Fr * Gr;
+    return rgb((Ds * Fs.r * Gs + cc) + Fsheen.r,
+               (Ds * Fs.g * Gs + cc) + Fsheen.g,
+               (Ds * Fs.b * Gs + cc) + Fsheen.b);
+}
+
+/* src/rlDisney.cpp:359-365 */
+orc_v3 orc_disney_sample_diffuse(const orc_disney *d, float rx, float ry)
+{
+    orc_v2 dk = orc_concentric_disk_sample(rx, ry);
+    orc_v3 omega = v3(dk.x, dk.y, 0.0f);
+    omega.z = sqrtf(MAXf(0.0f, 1.0f - SQRf(omega.x) - SQRf(omega.y)));
+    return v3rotate_to_frame(omega, d->axisU, d->axisV, d->axisN);
+}
+
+/* src/rlDisney.cpp:393-404 (a2 = roughness^2, not the clearcoat-gloss alpha of D_GTR1) */
+static orc_v3 disney_sample_gtr1(const orc_disney *d, float rx, float ry)
+{
+    float phiH = AI_PITIMES2 * rx;
+    float a2 = SQRf(d->roughness);
+    float cosThetaH = a2 == 1.0f
+        ? sqrtf(1.0f - ry)
+        : sqrtf((1.0f - powf(a2, 1.0f - ry)) / (1.0f - a2));
+    orc_v3 omega = orc_spherical_direction(cosThetaH, phiH);
+    omega = v3rotate_to_frame(omega, d->axisU, d->axisV, d->axisN);
+    return v3normalize(omega);
+}
+
+/* src/rlDisney.cpp:406-414 (dead: mSampleFromVisibleNormal = true) */
+static orc_v3 disney_sample_gtr2_aniso(const orc_disney *d, float rx, float ry)
+{
+    float gg = sqrtf(ry / (1.0f - ry));
+    float phi = AI_PITIMES2 * rx;
+    orc_v3 omega = v3(gg * d->alphaX * cosf(phi), gg * d->alphaY * sinf(phi), 1.0f);
+    omega = v3rotate_to_frame(omega, d->axisU, d->axisV, d->axisN);
+    return v3normalize(omega);
+}
+
+/* src/rlDisney.cpp:367-390 */
+orc_v3 orc_disney_sample_specular(const orc_disney *d, float rx, float ry)
+{
+    orc_v3 M;
+    float gtr2Weight = 1.0f / (d->clearcoat + 1.0f);
+    if (rx < gtr2Weight) {
+        rx /= gtr2Weight;
+        M = d->sampleFromVisibleNormal
+            ? vndf_microfacet(d->viewDir, d->axisU, d->axisV, d->axisN, d->alphaX, d->alphaY, rx, ry)
+            : disney_sample_gtr2_aniso(d, rx, ry);
+    } else {
+        rx = (rx - gtr2Weight) / (1.0f - gtr2Weight);
+        M = disney_sample_gtr1(d, rx, ry);
+    }
+    if (v3dot(d->axisN, M) < 0.0f) {
+        return v3(0.0f, 0.0f, 0.0f);
+    }
+    return orc_reflect_direction(d->viewDir, M);
+}
+
+/* src/rlDisney.cpp:515-518 */
+float orc_disney_diffuse_pdf(const orc_disney *d, orc_v3 i)
+{
+    return MAXf(1e-4f, v3dot(i, d->axisN) * AI_ONEOVERPI);
+}
+
+/* src/rlDisney.cpp:520-543 */
+float orc_disney_specular_pdf(const orc_disney *d, orc_v3 i)
+{
+    orc_v3 m = v3normalize(v3add(i, d->viewDir));
+    float IdotM = ABSf(v3dot(i, m));
+    float MdotN = v3dot(m, d->axisN);
+    if (MdotN < 0.0f) {
+        return 0.0f;
+    }
+    float MdotN2 = SQRf(MdotN);
+    float clearcoatWeight = d->clearcoat / (d->clearcoat + 1.0f);
+    if (d->sampleFromVisibleNormal) {
+        float VdotN = MAXf(1e-4f, v3dot(d->viewDir, d->axisN));
+        float Dw = smithG_GGX(IdotM, d->specularRoughness) * D_GTR2Aniso(d, m, MdotN2) * 2.0f * IdotM / VdotN;
+        float D = LERPf(clearcoatWeight, Dw, D_GTR1(d, MdotN2) * ABSf(MdotN) / IdotM);
+        return D * 0.25f;
+    }
+    float D = LERPf(clearcoatWeight, D_GTR2Aniso(d, m, MdotN2), D_GTR1(d, MdotN2));
+    return D * ABSf(MdotN) * 0.25f / IdotM;
+}
+
+/* the static triple, src/rlDisney.cpp:109-152 */
+orc_v3 orc_disney_eval_sample(const orc_disney *d, float rx, float ry)
+{
+    if (d->sampleType == ORC_RAY_DIFFUSE) {
+        return orc_disney_sample_diffuse(d, rx, ry);
+    }
+    return orc_disney_sample_specular(d, rx, ry);
+}
+
+orc_rgb orc_disney_eval_brdf(const orc_disney *d, orc_v3 L)
+{
+    if (v3iszero(L)) {
+        return RGB_BLACK;
+    }
+    float NdotL = v3dot(d->axisN, L);
+    orc_rgb f = d->sampleType == ORC_RAY_DIFFUSE ? orc_disney_eval_diffuse(d, L) : orc_disney_eval_specular(d, L);
+    return rgbscale(f, NdotL);
+}
+
+float orc_disney_eval_pdf(const orc_disney *d, orc_v3 indir)
+{
+    if (v3iszero(indir)) {
+        return 0.0f;
+    }
+    if (d->sampleType == ORC_RAY_DIFFUSE) {
+        return orc_disney_diffuse_pdf(d, indir);
+    }
+    return orc_disney_specular_pdf(d, indir);
+}
+
+/* =================================== rlSss: NDProfile ================================== */
+
+/* src/rlSss.cpp:20-34 (the albedo-derived `s` at line 23 is computed and never used) */
+void orc_nd_set_distance(orc_nd *p, orc_v3 dist, orc_rgb albedo)
+{
+    (void)albedo;
+    p->distance[0] = dist.x; p->distance[1] = dist.y; p->distance[2] = dist.z;
+    p->maxRadius = MAXf(dist.x, MAXf(dist.y, dist.z)) * 3.0f;
+    for (int i = 0; i < 3; i++) {
+        float d = p->distance[i];
+        p->c1[i] = 1.0f - expf(-p->maxRadius / d);
+        p->c2[i] = 1.0f - expf(-p->maxRadius / d / 3.0f);
+    }
+}
+
+/* src/rlSss.h:30-42 */
+int orc_nd_select_dist_lobe(float *x)
+{
+    if (*x < 0.3333f) {
+        *x = LINEARSTEPf(0.0f, 0.3333f, *x);
+        return 0;
+    } else if (*x > 0.6666f) {
+        *x = LINEARSTEPf(0.6666f, 1.0f, *x);
+        return 2;
+    }
+    *x = LINEARSTEPf(0.3333f, 0.6666f, *x);
+    return 1;
+}
+
+/* src/rlSss.cpp:36-66 */
+float orc_nd_get_radius(const orc_nd *p, float rx)
+{
+    if (p->maxRadius < AI_EPSILON) {
+        return 0.0f;
+    }
+    int distIdx = orc_nd_select_dist_lobe(&rx);
+    float d = p->distance[distIdx];
+    if (d < AI_EPSILON) {
+        return 0.0f;
+    }
+    float w1 = p->c1[distIdx];
+    float w2 = p->c2[distIdx];
+    float w = w1 / (w1 + w2 * 3.0f);
+    float r = 1.0f;
+    if (rx > w) {
+        rx = LINEARSTEPf(w, 1.0f, rx);
+        r = logf(1.0f - rx * w2) * (-d * 3.0f);
+    } else {
+        rx = LINEARSTEPf(0.0f, w, rx);
+        r = logf(1.0f - rx * w1) * (-d);
+    }
+    return r;
+}
+
+/* src/rlSss.cpp:68-84 */
+float orc_nd_get_pdf(const orc_nd *p, float r)
+{
+    if (p->maxRadius < AI_EPSILON) {
+        return 1.0f;
+    }
+    float pdf = 0.0f;
+    for (unsigned i = 0u; i < 3; i++) {
+        float d = MAXf(p->distance[i], AI_EPSILON);
+        float p1 = expf(-r / d);
+        float p2 = expf(-r / d / 3.0f);
+        pdf += (p1 + p2) / d / (p->c1[i] + p->c2[i] * 3.0f);
+    }
+    return pdf / (AI_PITIMES2 * r * 3.0f);
+}
+
+/* src/rlSss.cpp:86-106 */
+orc_rgb orc_nd_eval_profile(const orc_nd *p, float r)
+{
+    if (p->maxRadius < AI_EPSILON) {
+        return RGB_BLACK;
+    } else if (r < AI_EPSILON) {
+        return RGB_WHITE;
+    }
+    float denom = 8.0f * AI_PI * r;
+    float out[3];
+    for (unsigned i = 0u; i < 3; i++) {
+        float d = p->distance[i];
+        out[i] = d < AI_EPSILON ? 1.0f
+            : (expf(-r / d) + expf(-r / (3.0f * d))) / (denom * d);
+    }
+    return rgb(out[0], out[1], out[2]);
+}
+
+/* =================================== rlSss: SssSampler ================================= */
+
+/* src/rlSss.h:143-167 */
+void orc_sss_init(orc_sss *s, orc_v3 Ns, orc_v3 dPdu_or_T, int has_dPdu, orc_rgb albedo, orc_v3 dist)
+{
+    s->baseColor = albedo;
+    orc_nd_set_distance(&s->profile, dist, albedo);
+    s->axisN = Ns;
+    if (has_dPdu && !v3iszero(dPdu_or_T) && v3exists(dPdu_or_T)) {
+        orc_v3 U = v3normalize(dPdu_or_T);
+        s->axisV = v3normalize(v3cross(s->axisN, U));
+        s->axisU = v3cross(s->axisV, s->axisN);
+    } else {
+        s->axisU = dPdu_or_T;
+        s->axisV = v3cross(Ns, dPdu_or_T);
+    }
+}
+
+/* src/rlSss.h:487-533.  `(idx & 0x04)` is always 0 in the reference -> always +U / +V. */
+float orc_sss_get_probe_ray(const orc_sss *s, float rx, float ry,
+                            orc_v3 *out_offset, orc_v3 *out_dir, float *out_maxdist)
+{
+    int idx = 0;
+    if (rx < 0.5f) {
+        idx = 0;
+        rx = LINEARSTEPf(0.0f, 0.5f, rx);
+    } else if (rx < 0.75f) {
+        idx = 2;
+        rx = LINEARSTEPf(0.5f, 0.75f, rx);
+    } else {
+        idx = 3;
+        rx = LINEARSTEPf(0.75f, 1.0f, rx);
+    }
+    float r = orc_nd_get_radius(&s->profile, rx);
+    float rmax = s->profile.maxRadius;
+    float phi = AI_PITIMES2 * ry;
+
+    orc_v3 offset;
+    offset.x = cosf(phi) * r;
+    offset.z = sinf(phi) * r;
+    offset.y = sqrtf(rmax * rmax - r * r);
+    *out_maxdist = offset.y * 2.0f;
+
+    orc_v3 dir;
+    if ((idx & 0x03) < 2) {
+        dir = v3neg(s->axisN);
+        offset = v3rotate_to_frame(offset, s->axisU, v3neg(dir), s->axisV);
+    } else if ((idx & 0x03) == 2) {
+        dir = s->axisU;
+        offset = v3rotate_to_frame(offset, s->axisV, v3neg(dir), s->axisN);
+    } else {
+        dir = s->axisV;
+        offset = v3rotate_to_frame(offset, s->axisN, v3neg(dir), s->axisU);
+    }
+    *out_offset = offset;
+    *out_dir = dir;
+    return r;
+}
+
+/* src/rlSss.h:246-266.  AiM4Frame/AiM4VectorByMatrixMult are closed: PARITY UNPINNED. */
+float orc_sss_mis_pdf(const orc_sss *s, orc_v3 disp, orc_v3 sampleN, int literal_matrix)
+{
+    orc_v3 offset;
+    if (literal_matrix) {
+        offset = v3rotate_to_frame(disp, s->axisU, s->axisV, s->axisN);
+    } else {
+        offset = v3(v3dot(disp, s->axisU), v3dot(disp, s->axisV), v3dot(disp, s->axisN));
+    }
+    offset = v3(offset.x * offset.x, offset.y * offset.y, offset.z * offset.z);
+    float rr[3];
+    rr[0] = sqrtf(offset.y + offset.z);
+    rr[1] = sqrtf(offset.x + offset.z);
+    rr[2] = sqrtf(offset.x + offset.y);
+    float pdf = orc_nd_get_pdf(&s->profile, rr[0]) * ABSf(v3dot(s->axisU, sampleN)) * 0.25f
+              + orc_nd_get_pdf(&s->profile, rr[1]) * ABSf(v3dot(s->axisV, sampleN)) * 0.25f
+              + orc_nd_get_pdf(&s->profile, rr[2]) * ABSf(v3dot(s->axisN, sampleN)) * 0.5f;
+    return pdf;
+}
+
+/* src/rlSss.h:401-413 */
+float orc_sss_cavity_fade(orc_v3 disp, float r, orc_v3 sampleN, orc_v3 No)
+{
+    orc_v3 dispDir = v3(disp.x / r, disp.y / r, disp.z / r);
+    float cavityFade;
+    if (v3dot(No, dispDir) < 0.0f) {
+        float cosCavityAngle = ABSf(v3dot(sampleN, No));
+        cavityFade = sqrtf((1.0f + cosCavityAngle) * 0.5f);
+    } else {
+        float cosCavityAngle = CLAMPf(v3dot(sampleN, No), -1.0f, 1.0f);
+        cavityFade = sqrtf((1.0f + cosCavityAngle) * 0.5f);
+    }
+    return cavityFade;
+}
+
+/* src/rlSss.h:536-545 (polar frame closed -> tangent input, v = normal x T) */
+orc_v3 orc_sss_sample_diffuse_direction(float rx, float ry, orc_v3 normal, orc_v3 T)
+{
+    orc_v2 dk = orc_concentric_disk_sample(rx, ry);
+    orc_v3 omega = v3(dk.x, dk.y, 0.0f);
+    omega.z = sqrtf(MAXf(0.0f, 1.0f - SQRf(omega.x) - SQRf(omega.y)));
+    orc_v3 v = v3cross(normal, T);
+    return v3rotate_to_frame(omega, T, v, normal);
+}
+
+/* ====================================== rlSkin ========================================= */
+
+/* Layer arithmetic of shader_evaluate, src/rlSkin.cpp:174-246, with ONE (sample, eval, pdf)
+ * triple per GGX lobe standing in for Arnold's light loop / AiBRDFIntegrate. */
+void orc_skin_eval(const orc_skin_params *p, orc_v3 wo, orc_v3 Nf, orc_v3 T,
+                   const float xi[6], orc_skin_out *o)
+{
+    memset(o, 0, sizeof(*o));
+    float sheenFresnel = 0.0f;
+    float specularFresnel = 0.0f;
+
+    if (p->sheen_weight > AI_EPSILON) {                                  /* line 191 */
+        orc_ggx g;
+        orc_ggx_init(&g, wo, Nf, T, 0, p->sheen_color, p->sheen_ior, p->sheen_roughness, 0.0f);
+        o->sheen_wi = orc_ggx_eval_sample(&g, xi[0], xi[1]);
+        o->sheen_f = orc_ggx_eval_brdf(&g, o->sheen_wi);
+        o->sheen_pdf = orc_ggx_eval_pdf(&g, o->sheen_wi);
+        o->sheen_fresnel = g.reflectWeight;
+        sheenFresnel = orc_ggx_avg_reflect_weight(&g) * p->sheen_weight; /* line 204 */
+    }
+    if (p->specular_weight > AI_EPSILON) {                               /* line 214 */
+        orc_ggx g;
+        orc_ggx_init(&g, wo, Nf, T, 0, p->specular_color, p->specular_ior, p->specular_roughness, 0.0f);
+        o->spec_wi = orc_ggx_eval_sample(&g, xi[2], xi[3]);
+        o->spec_f = orc_ggx_eval_brdf(&g, o->spec_wi);
+        o->spec_pdf = orc_ggx_eval_pdf(&g, o->spec_wi);
+        o->spec_fresnel = g.reflectWeight;
+        specularFresnel = orc_ggx_avg_reflect_weight(&g) * p->specular_weight; /* line 228 */
+    }
+    o->specScale = p->specular_weight * (1.0f - sheenFresnel);          /* line 231 */
+    o->sheenFresnel = sheenFresnel;
+    o->specularFresnel = specularFresnel;
+
+    orc_v3 scatterDist = v3scale(p->sss_scatter_dist, p->sss_dist_multiplier);   /* line 236 */
+    float sssWeight = p->sss_weight;
+    sssWeight *= 1.0f - specularFresnel * (1.0f - sheenFresnel);        /* line 238 */
+    o->sssWeight = sssWeight;
+
+    orc_sss s;
+    orc_sss_init(&s, Nf, T, 1, p->sss_color, scatterDist);               /* line 241 */
+    if (!(sssWeight < AI_EPSILON)) {                                     /* line 244 */
+        orc_v3 off, dir; float maxdist;
+        o->r = orc_sss_get_probe_ray(&s, xi[4], xi[5], &off, &dir, &maxdist);
+        o->r_pdf = orc_nd_get_pdf(&s.profile, o->r);
+        o->profile = orc_nd_eval_profile(&s.profile, o->r);
+    }
+}
+
+/* ==================================== threading ======================================== */
+
+typedef void (*range_fn)(int64_t lo, int64_t hi, void *ctx);
+typedef struct { range_fn fn; void *ctx; int64_t lo, hi; } range_job;
+
+static void *range_thread(void *arg)
+{
+    range_job *j = (range_job *)arg;
+    j->fn(j->lo, j->hi, j->ctx);
+    return NULL;
+}
+
+static void parallel_for(int64_t n, int nthreads, range_fn fn, void *ctx)
+{
+    if (nthreads <= 1 || n < 4096) {
+        fn(0, n, ctx);
+        return;
+    }
+    if (nthreads > 256) nthreads = 256;
+    pthread_t th[256];
+    range_job jobs[256];
+    int64_t chunk = (n + nthreads - 1) / nthreads;
+    int started = 0;
+    for (int t = 0; t < nthreads; t++) {
+        int64_t lo = (int64_t)t * chunk;
+        int64_t hi = lo + chunk > n ? n : lo + chunk;
+        if (lo >= hi) break;
+        jobs[t].fn = fn; jobs[t].ctx = ctx; jobs[t].lo = lo; jobs[t].hi = hi;
+        pthread_create(&th[t], NULL, range_thread, &jobs[t]);
+        started++;
+    }
+    for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+}
+
+int orc_hardware_threads(void)
+{
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+        int c = CPU_COUNT(&set);
+        if (c > 0) return c;
+    }
+    long n = sysconf(_SC_NPROCESSORS_ONLN);
+    return n > 0 ? (int)n : 1;
+}
+
+static inline orc_v3 ld3(orc_cv3p p, int64_t i) { return v3(p.x[i], p.y[i], p.z[i]); }
+static inline orc_rgb ldc(orc_cv3p p, int64_t i) { return rgb(p.x[i], p.y[i], p.z[i]); }
+static inline void st3(orc_v3p p, int64_t i, orc_v3 v) { p.x[i] = v.x; p.y[i] = v.y; p.z[i] = v.z; }
+static inline void stc(orc_v3p p, int64_t i, orc_rgb c) { p.x[i] = c.r; p.y[i] = c.g; p.z[i] = c.b; }
+
+/* ------------------------------------ GGX batches -------------------------------------- */
+
+static inline void ggx_load(const orc_ggx_soa *in, int64_t i, orc_ggx *g)
+{
+    orc_ggx_init(g, ld3(in->wo, i), ld3(in->N, i), ld3(in->T, i),
+                 in->exiting ? in->exiting[i] : 0, ldc(in->KsColor, i), in->ior[i],
+                 in->specularRoughness[i], in->anisotropic ? in->anisotropic[i] : 0.0f);
+}
+
+typedef struct {
+    const orc_ggx_soa *in; const float *rx, *ry; orc_cv3p cwi;
+    orc_v3p wi, f; float *pdf, *fresnel; float *weight; uint8_t *flag; int mode; int alt;
+} ggx_job;
+
+enum { GGX_FUSED, GGX_SAMPLE, GGX_EVAL, GGX_PDF, GGX_REFRACT, GGX_MICRO, GGX_NDFPDF };
+
+static void ggx_range(int64_t lo, int64_t hi, void *ctx)
+{
+    ggx_job *j = (ggx_job *)ctx;
+    for (int64_t i = lo; i < hi; i++) {
+        orc_ggx g;
+        ggx_load(j->in, i, &g);
+        switch (j->mode) {
+        case GGX_FUSED: {
+            /* the reference's call order: evalSample -> evalBrdf -> evalPdf */
+            orc_v3 L = orc_ggx_eval_sample(&g, j->rx[i], j->ry[i]);
+            orc_rgb f = orc_ggx_eval_brdf(&g, L);
+            float pdf = orc_ggx_eval_pdf(&g, L);
+            st3(j->wi, i, L); stc(j->f, i, f); j->pdf[i] = pdf;
+            if (j->fresnel) j->fresnel[i] = g.reflectWeight;
+        } break;
+        case GGX_SAMPLE: {
+            orc_v3 L = orc_ggx_eval_sample(&g, j->rx[i], j->ry[i]);
+            st3(j->wi, i, L);
+            if (j->fresnel) j->fresnel[i] = g.reflectWeight;
+        } break;
+        case GGX_EVAL:
+            stc(j->f, i, orc_ggx_eval_brdf(&g, ld3(j->cwi, i)));
+            break;
+        case GGX_PDF:
+            j->pdf[i] = orc_ggx_eval_pdf(&g, ld3(j->cwi, i));
+            break;
+        case GGX_REFRACT: {
+            orc_v3 d; float w;
+            int ok = orc_ggx_refract_sample(&g, j->rx[i], j->ry[i], &d, &w);
+            st3(j->wi, i, d); j->weight[i] = w;
+            if (j->flag) j->flag[i] = (uint8_t)ok;
+        } break;
+        case GGX_MICRO:
+            st3(j->wi, i, j->alt ? orc_ndf_sample(&g, j->rx[i], j->ry[i])
+                                 : orc_vndf_sample(&g, j->rx[i], j->ry[i]));
+            break;
+        case GGX_NDFPDF: {
+            orc_v3 H = v3normalize(v3add(g.viewDir, ld3(j->cwi, i)));
+            j->pdf[i] = orc_ndf_pdf(&g, g.viewDir, H);
+        } break;
+        }
+    }
+}
+
+void orc_batch_ggx_sample_eval_pdf(int64_t n, const orc_ggx_soa *in, const float *rx, const float *ry,
+                                   orc_v3p wi, orc_v3p f, float *pdf, float *fresnel, int nthreads)
+{
+    ggx_job j = { .in = in, .rx = rx, .ry = ry, .wi = wi, .f = f, .pdf = pdf, .fresnel = fresnel, .mode = GGX_FUSED };
+    parallel_for(n, nthreads, ggx_range, &j);
+}
+
+void orc_batch_ggx_sample(int64_t n, const orc_ggx_soa *in, const float *rx, const float *ry,
+                          orc_v3p wi, float *fresnel, int nthreads)
+{
+    ggx_job j = { .in = in, .rx = rx, .ry = ry, .wi = wi, .fresnel = fresnel, .mode = GGX_SAMPLE };
+    parallel_for(n, nthreads, ggx_range, &j);
+}
+
+void orc_batch_ggx_eval(int64_t n, const orc_ggx_soa *in, orc_cv3p wi, orc_v3p f, int nthreads)
+{
+    ggx_job j = { .in = in, .cwi = wi, .f = f, .mode = GGX_EVAL };
+    parallel_for(n, nthreads, ggx_range, &j);
+}
+
+void orc_batch_ggx_pdf(int64_t n, const orc_ggx_soa *in, orc_cv3p wi, float *pdf, int nthreads)
+{
+    ggx_job j = { .in = in, .cwi = wi, .pdf = pdf, .mode = GGX_PDF };
+    parallel_for(n, nthreads, ggx_range, &j);
+}
+
+void orc_batch_ggx_refract(int64_t n, const orc_ggx_soa *in, const float *rx, const float *ry,
+                           orc_v3p wt, float *weight, uint8_t *refracted, int nthreads)
+{
+    ggx_job j = { .in = in, .rx = rx, .ry = ry, .wi = wt, .weight = weight, .flag = refracted, .mode = GGX_REFRACT };
+    parallel_for(n, nthreads, ggx_range, &j);
+}
+
+typedef struct {
+    const orc_ggx_soa *in; const float *rx, *ry, *rx2, *ry2;
+    orc_v3p wi, f, wt; float *pdf, *fresnel, *weight;
+} ggx_rr_job;
+
+static void ggx_rr_range(int64_t lo, int64_t hi, void *ctx)
+{
+    ggx_rr_job *j = (ggx_rr_job *)ctx;
+    for (int64_t i = lo; i < hi; i++) {
+        orc_ggx g;
+        ggx_load(j->in, i, &g);
+        orc_v3 L = orc_ggx_eval_sample(&g, j->rx[i], j->ry[i]);
+        orc_rgb f = orc_ggx_eval_brdf(&g, L);
+        float pdf = orc_ggx_eval_pdf(&g, L);
+        orc_v3 d; float w;
+        orc_ggx_refract_sample(&g, j->rx2[i], j->ry2[i], &d, &w);
+        st3(j->wi, i, L); stc(j->f, i, f); j->pdf[i] = pdf; j->fresnel[i] = g.reflectWeight;
+        st3(j->wt, i, d); j->weight[i] = w;
+    }
+}
+
+void orc_batch_ggx_reflect_refract(int64_t n, const orc_ggx_soa *in, const float *rx, const float *ry,
+                                   const float *rx2, const float *ry2,
+                                   orc_v3p wi, orc_v3p f, float *pdf, float *fresnel,
+                                   orc_v3p wt, float *weight, int nthreads)
+{
+    ggx_rr_job j = { in, rx, ry, rx2, ry2, wi, f, wt, pdf, fresnel, weight };
+    parallel_for(n, nthreads, ggx_rr_range, &j);
+}
+
+void orc_batch_ggx_microfacet(int64_t n, const orc_ggx_soa *in, const float *rx, const float *ry,
+                              orc_v3p m, int use_ndf_kernel, int nthreads)
+{
+    ggx_job j = { .in = in, .rx = rx, .ry = ry, .wi = m, .mode = GGX_MICRO, .alt = use_ndf_kernel };
+    parallel_for(n, nthreads, ggx_range, &j);
+}
+
+void orc_batch_ggx_ndf_pdf(int64_t n, const orc_ggx_soa *in, orc_cv3p wi, float *pdf, int nthreads)
+{
+    ggx_job j = { .in = in, .cwi = wi, .pdf = pdf, .mode = GGX_NDFPDF };
+    parallel_for(n, nthreads, ggx_range, &j);
+}
+
+/* ----------------------------------- Disney batches ------------------------------------ */
+
+typedef struct {
+    const orc_disney_soa *in; int lobe; const float *rx, *ry; orc_cv3p cwi;
+    orc_v3p wi, f; float *pdf; int mode;
+} disney_job;
+
+enum { DIS_SAMPLE, DIS_EVAL, DIS_PDF, DIS_FUSED };
+
+static void disney_range(int64_t lo, int64_t hi, void *ctx)
+{
+    disney_job *j = (disney_job *)ctx;
+    for (int64_t i = lo; i < hi; i++) {
+        orc_disney d;
+        float s[10];
+        for (int k = 0; k < 10; k++) s[k] = j->in->scalars[k][i];
+        orc_disney_init(&d, ld3(j->in->wo, i), ld3(j->in->N, i), ld3(j->in->T, i), ldc(j->in->base_color, i), s);
+        d.sampleType = j->lobe;
+        switch (j->mode) {
+        case DIS_SAMPLE:
+            st3(j->wi, i, orc_disney_eval_sample(&d, j->rx[i], j->ry[i]));
+            break;
+        case DIS_EVAL:
+            stc(j->f, i, orc_disney_eval_brdf(&d, ld3(j->cwi, i)));
+            break;
+        case DIS_PDF:
+            j->pdf[i] = orc_disney_eval_pdf(&d, ld3(j->cwi, i));
+            break;
+        case DIS_FUSED: {
+            orc_v3 L = orc_disney_eval_sample(&d, j->rx[i], j->ry[i]);
+            st3(j->wi, i, L);
+            stc(j->f, i, orc_disney_eval_brdf(&d, L));
+            j->pdf[i] = orc_disney_eval_pdf(&d, L);
+        } break;
+        }
+    }
+}
+
+void orc_batch_disney_sample(int64_t n, const orc_disney_soa *in, int lobe, const float *rx, const float *ry,
+                             orc_v3p wi, int nthreads)
+{
+    disney_job j = { .in = in, .lobe = lobe, .rx = rx, .ry = ry, .wi = wi, .mode = DIS_SAMPLE };
+    parallel_for(n, nthreads, disney_range, &j);
+}
+
+void orc_batch_disney_eval(int64_t n, const orc_disney_soa *in, int lobe, orc_cv3p wi, orc_v3p f, int nthreads)
+{
+    disney_job j = { .in = in, .lobe = lobe, .cwi = wi, .f = f, .mode = DIS_EVAL };
+    parallel_for(n, nthreads, disney_range, &j);
+}
+
+void orc_batch_disney_pdf(int64_t n, const orc_disney_soa *in, int lobe, orc_cv3p wi, float *pdf, int nthreads)
+{
+    disney_job j = { .in = in, .lobe = lobe, .cwi = wi, .pdf = pdf, .mode = DIS_PDF };
+    parallel_for(n, nthreads, disney_range, &j);
+}
+
+void orc_batch_disney_sample_eval_pdf(int64_t n, const orc_disney_soa *in, int lobe,
+                                      const float *rx, const float *ry,
+                                      orc_v3p wi, orc_v3p f, float *pdf, int nthreads)
+{
+    disney_job j = { .in = in, .lobe = lobe, .rx = rx, .ry = ry, .wi = wi, .f = f, .pdf = pdf, .mode = DIS_FUSED };
+    parallel_for(n, nthreads, disney_range, &j);
+}
+
+/* ------------------------------------- SSS batches ------------------------------------- */
+
+typedef struct {
+    const orc_sss_soa *in; int has_dPdu; const float *rx, *ry; const float *rin;
+    orc_cv3p disp, sampleN, No; int literal;
+    float *r; orc_v3p offset, dir; float *maxdist, *pdf; orc_v3p profile; int mode;
+} sss_job;
+
+enum { SSS_ND, SSS_NDPDF, SSS_NDPROFILE, SSS_PROBE, SSS_MIS };
+
+static inline orc_v3 sss_dist(const orc_sss_soa *in, int64_t i)
+{
+    orc_v3 d = ld3(in->sss_scatter_dist, i);
+    if (in->sss_dist_multiplier) d = v3scale(d, in->sss_dist_multiplier[i]);   /* src/rlSkin.cpp:236 */
+    return d;
+}
+
+static void sss_range(int64_t lo, int64_t hi, void *ctx)
+{
+    sss_job *j = (sss_job *)ctx;
+    for (int64_t i = lo; i < hi; i++) {
+        orc_rgb albedo = j->in->sss_color.x ? ldc(j->in->sss_color, i) : RGB_WHITE;
+        orc_v3 dist = sss_dist(j->in, i);
+        switch (j->mode) {
+        case SSS_ND: {
+            orc_nd p; orc_nd_set_distance(&p, dist, albedo);
+            float r = orc_nd_get_radius(&p, j->rx[i]);
+            j->r[i] = r; j->pdf[i] = orc_nd_get_pdf(&p, r); stc(j->profile, i, orc_nd_eval_profile(&p, r));
+        } break;
+        case SSS_NDPDF: {
+            orc_nd p; orc_nd_set_distance(&p, dist, albedo);
+            j->pdf[i] = orc_nd_get_pdf(&p, j->rin[i]);
+        } break;
+        case SSS_NDPROFILE: {
+            orc_nd p; orc_nd_set_distance(&p, dist, albedo);
+            stc(j->profile, i, orc_nd_eval_profile(&p, j->rin[i]));
+        } break;
+        case SSS_PROBE: {
+            orc_sss s; orc_sss_init(&s, ld3(j->in->N, i), ld3(j->in->T, i), j->has_dPdu, albedo, dist);
+            orc_v3 off, dir; float md;
+            float r = orc_sss_get_probe_ray(&s, j->rx[i], j->ry[i], &off, &dir, &md);
+            j->r[i] = r; st3(j->offset, i, off); st3(j->dir, i, dir); j->maxdist[i] = md;
+            j->pdf[i] = orc_nd_get_pdf(&s.profile, r);
+            stc(j->profile, i, orc_nd_eval_profile(&s.profile, r));
+        } break;
+        case SSS_MIS: {
+            orc_sss s; orc_sss_init(&s, ld3(j->in->N, i), ld3(j->in->T, i), j->has_dPdu, albedo, dist);
+            j->pdf[i] = orc_sss_mis_pdf(&s, ld3(j->disp, i), ld3(j->sampleN, i), j->literal);
+        } break;
+        }
+    }
+}
+
+void orc_batch_nd_sample_pdf_profile(int64_t n, const orc_sss_soa *in, const float *rx,
+                                     float *r, float *pdf, orc_v3p profile, int nthreads)
+{
+    sss_job j = { .in = in, .rx = rx, .r = r, .pdf = pdf, .profile = profile, .mode = SSS_ND };
+    parallel_for(n, nthreads, sss_range, &j);
+}
+
+void orc_batch_nd_pdf(int64_t n, const orc_sss_soa *in, const float *r, float *pdf, int nthreads)
+{
+    sss_job j = { .in = in, .rin = r, .pdf = pdf, .mode = SSS_NDPDF };
+    parallel_for(n, nthreads, sss_range, &j);
+}
+
+void orc_batch_nd_profile(int64_t n, const orc_sss_soa *in, const float *r, orc_v3p profile, int nthreads)
+{
+    sss_job j = { .in = in, .rin = r, .profile = profile, .mode = SSS_NDPROFILE };
+    parallel_for(n, nthreads, sss_range, &j);
+}
+
+void orc_batch_sss_probe(int64_t n, const orc_sss_soa *in, int has_dPdu, const float *rx, const float *ry,
+                         float *r, orc_v3p offset, orc_v3p dir, float *maxdist,
+                         float *pdf, orc_v3p profile, int nthreads)
+{
+    sss_job j = { .in = in, .has_dPdu = has_dPdu, .rx = rx, .ry = ry, .r = r, .offset = offset, .dir = dir,
+                  .maxdist = maxdist, .pdf = pdf, .profile = profile, .mode = SSS_PROBE };
+    parallel_for(n, nthreads, sss_range, &j);
+}
+
+void orc_batch_sss_mis_pdf(int64_t n, const orc_sss_soa *in, int has_dPdu, orc_cv3p disp, orc_cv3p sampleN,
+                           int literal_matrix, float *pdf, int nthreads)
+{
+    sss_job j = { .in = in, .has_dPdu = has_dPdu, .disp = disp, .sampleN = sampleN, .literal = literal_matrix,
+                  .pdf = pdf, .mode = SSS_MIS };
+    parallel_for(n, nthreads, sss_range, &j);
+}
+
+typedef struct { orc_cv3p a, b, c; const float *rx, *ry; float *out; orc_v3p wi; int mode; } misc_job;
+
+static void misc_range(int64_t lo, int64_t hi, void *ctx)
+{
+    misc_job *j = (misc_job *)ctx;
+    for (int64_t i = lo; i < hi; i++) {
+        if (j->mode == 0) {
+            orc_v3 disp = ld3(j->a, i);
+            j->out[i] = orc_sss_cavity_fade(disp, v3length(disp), ld3(j->b, i), ld3(j->c, i));   /* r: src/rlSss.h:382 */
+        } else {
+            st3(j->wi, i, orc_sss_sample_diffuse_direction(j->rx[i], j->ry[i], ld3(j->a, i), ld3(j->b, i)));
+        }
+    }
+}
+
+void orc_batch_sss_cavity_fade(int64_t n, orc_cv3p disp, orc_cv3p sampleN, orc_cv3p No, float *fade, int nthreads)
+{
+    misc_job j = { .a = disp, .b = sampleN, .c = No, .out = fade, .mode = 0 };
+    parallel_for(n, nthreads, misc_range, &j);
+}
+
+void orc_batch_sss_sample_diffuse(int64_t n, orc_cv3p normal, orc_cv3p T, const float *rx, const float *ry,
+                                  orc_v3p wi, int nthreads)
+{
+    misc_job j = { .a = normal, .b = T, .rx = rx, .ry = ry, .wi = wi, .mode = 1 };
+    parallel_for(n, nthreads, misc_range, &j);
+}
+
+/* ------------------------------------- skin batch -------------------------------------- */
+
+typedef struct { const orc_skin_soa *in; const orc_skin_out_soa *out; } skin_job;
+
+static void skin_range(int64_t lo, int64_t hi, void *ctx)
+{
+    skin_job *j = (skin_job *)ctx;
+    const orc_skin_soa *in = j->in;
+    const orc_skin_out_soa *o = j->out;
+    for (int64_t i = lo; i < hi; i++) {
+        orc_skin_params p;
+        p.sss_color = ldc(in->sss_color, i);
+        p.sss_weight = in->sss_weight[i];
+        p.sss_dist_multiplier = in->sss_dist_multiplier[i];
+        p.sss_scatter_dist = ld3(in->sss_scatter_dist, i);
+        p.specular_color = ldc(in->specular_color, i);
+        p.specular_weight = in->specular_weight[i];
+        p.specular_roughness = in->specular_roughness[i];
+        p.specular_ior = in->specular_ior[i];
+        p.sheen_color = ldc(in->sheen_color, i);
+        p.sheen_weight = in->sheen_weight[i];
+        p.sheen_roughness = in->sheen_roughness[i];
+        p.sheen_ior = in->sheen_ior[i];
+        float xi[6];
+        for (int k = 0; k < 6; k++) xi[k] = in->xi[k][i];
+        orc_skin_out r;
+        orc_skin_eval(&p, ld3(in->wo, i), ld3(in->N, i), ld3(in->T, i), xi, &r);
+        st3(o->sheen_wi, i, r.sheen_wi); stc(o->sheen_f, i, r.sheen_f);
+        o->sheen_pdf[i] = r.sheen_pdf; o->sheen_fresnel[i] = r.sheen_fresnel;
+        st3(o->spec_wi, i, r.spec_wi); stc(o->spec_f, i, r.spec_f);
+        o->spec_pdf[i] = r.spec_pdf; o->spec_fresnel[i] = r.spec_fresnel;
+        o->r[i] = r.r; o->r_pdf[i] = r.r_pdf; stc(o->profile, i, r.profile);
+        o->sheenFresnel[i] = r.sheenFresnel; o->specularFresnel[i] = r.specularFresnel;
+        o->sssWeight[i] = r.sssWeight;
+    }
+}
+
+void orc_batch_skin(int64_t n, const orc_skin_soa *in, const orc_skin_out_soa *out, int nthreads)
+{
+    skin_job j = { in, out };
+    parallel_for(n, nthreads, skin_range, &j);
+}
+
+/* ----------------------------------- integrators --------------------------------------- */
+
+static inline uint32_t brev32(uint32_t x)
+{
+    x = (x >> 16) | (x << 16);
+    x = ((x & 0xFF00FF00U) >> 8) | ((x & 0x00FF00FFU) << 8);
+    x = ((x & 0xF0F0F0F0U) >> 4) | ((x & 0x0F0F0F0FU) << 4);
+    x = ((x & 0xCCCCCCCCU) >> 2) | ((x & 0x33333333U) << 2);
+    x = ((x & 0xAAAAAAAAU) >> 1) | ((x & 0x55555555U) << 1);
+    return x;
+}
+
+static inline uint32_t sobol2(uint32_t s)
+{
+    uint32_t r = 0;
+    for (uint32_t v = 1U << 31; s != 0; s >>= 1, v ^= v >> 1) {
+        if (s & 1U) r ^= v;
+    }
+    return r;
+}
+
+/* sample s of the scrambled (0,2)-sequence of point `index`, dimension pair `dim_pair` */
+void orc_sample_02(uint32_t seed, uint64_t index, uint32_t dim_pair, uint32_t s, float *rx, float *ry)
+{
+    uint32_t sx = orc_hash_u32(seed, index, ORC_S_SCRAMBLE + 2 * dim_pair);
+    uint32_t sy = orc_hash_u32(seed, index, ORC_S_SCRAMBLE + 2 * dim_pair + 1);
+    *rx = (float)((brev32(s) ^ sx) >> 8) * (1.0f / 16777216.0f);
+    *ry = (float)((sobol2(s) ^ sy) >> 8) * (1.0f / 16777216.0f);
+}
+
+typedef struct {
+    const orc_ggx_soa *gin; const orc_disney_soa *din; int spp; uint32_t seed; int64_t n;
+    orc_v3p sum, sum2; float *avg, *cnt, *cnt2; orc_v3p s_wi, s_f; float *s_pdf;
+} int_job;
+
+static void ggx_int_range(int64_t lo, int64_t hi, void *ctx)
+{
+    int_job *j = (int_job *)ctx;
+    for (int64_t i = lo; i < hi; i++) {
+        orc_ggx g;
+        ggx_load(j->gin, i, &g);
+        float aR = 0.0f, aG = 0.0f, aB = 0.0f;
+        for (int s = 0; s < j->spp; s++) {
+            float rx, ry;
+            orc_sample_02(j->seed, (uint64_t)i, 0, (uint32_t)s, &rx, &ry);
+            orc_v3 L = orc_ggx_eval_sample(&g, rx, ry);
+            orc_rgb f = orc_ggx_eval_brdf(&g, L);
+            float pdf = orc_ggx_eval_pdf(&g, L);
+            aR += f.r / pdf; aG += f.g / pdf; aB += f.b / pdf;
+        }
+        stc(j->sum, i, rgb(aR, aG, aB));
+        j->avg[i] = orc_ggx_avg_reflect_weight(&g);
+    }
+}
+
+void orc_batch_ggx_integrate(int64_t n, const orc_ggx_soa *in, int spp_n, uint32_t seed,
+                             orc_v3p sum_f_over_pdf, float *avg_reflect_weight, int nthreads)
+{
+    int_job j = { .gin = in, .spp = spp_n * spp_n, .seed = seed, .n = n, .sum = sum_f_over_pdf, .avg = avg_reflect_weight };
+    parallel_for(n, nthreads, ggx_int_range, &j);
+}
+
+static void disney_int_range(int64_t lo, int64_t hi, void *ctx)
+{
+    int_job *j = (int_job *)ctx;
+    for (int64_t i = lo; i < hi; i++) {
+        orc_disney d;
+        float sc[10];
+        for (int k = 0; k < 10; k++) sc[k] = j->din->scalars[k][i];
+        orc_disney_init(&d, ld3(j->din->wo, i), ld3(j->din->N, i), ld3(j->din->T, i), ldc(j->din->base_color, i), sc);
+        float acc[2][4] = { { 0 } };
+        for (int s = 0; s < j->spp; s++) {
+            for (int lobe = 0; lobe < 2; lobe++) {
+                d.sampleType = lobe == 0 ? ORC_RAY_DIFFUSE : ORC_RAY_GLOSSY;
+                float rx, ry;
+                orc_sample_02(j->seed, (uint64_t)i, (uint32_t)lobe, (uint32_t)s, &rx, &ry);
+                orc_v3 L = orc_disney_eval_sample(&d, rx, ry);
+                orc_rgb f = orc_disney_eval_brdf(&d, L);
+                float pdf = orc_disney_eval_pdf(&d, L);
+                if (pdf > AI_EPSILON) {                            /* src/rlDisney.cpp:309 */
+                    acc[lobe][0] += f.r / pdf; acc[lobe][1] += f.g / pdf; acc[lobe][2] += f.b / pdf;
+                    acc[lobe][3] += 1.0f;
+                }
+                if (j->s_pdf) {
+                    int64_t o = ((int64_t)lobe * j->spp + s) * j->n + i;
+                    st3(j->s_wi, o, L); stc(j->s_f, o, f); j->s_pdf[o] = pdf;
+                }
+            }
+        }
+        stc(j->sum, i, rgb(acc[0][0], acc[0][1], acc[0][2])); j->cnt[i] = acc[0][3];
+        stc(j->sum2, i, rgb(acc[1][0], acc[1][1], acc[1][2])); j->cnt2[i] = acc[1][3];
+    }
+}
+
+void orc_batch_disney_integrate(int64_t n, const orc_disney_soa *in, int spp_n, uint32_t seed,
+                                orc_v3p dsum, float *dcount, orc_v3p ssum, float *scount,
+                                orc_v3p s_wi, orc_v3p s_f, float *s_pdf, int nthreads)
+{
+    int_job j = { .din = in, .spp = spp_n * spp_n, .seed = seed, .n = n, .sum = dsum, .cnt = dcount,
+                  .sum2 = ssum, .cnt2 = scount, .s_wi = s_wi, .s_f = s_f, .s_pdf = s_pdf };
+    parallel_for(n, nthreads, disney_int_range, &j);
+}
+
+/* ------------------------------------- util batch -------------------------------------- */
+
+typedef struct { const float *a, *b; orc_v3p sph, disk; } util_job;
+
+static void util_range(int64_t lo, int64_t hi, void *ctx)
+{
+    util_job *j = (util_job *)ctx;
+    for (int64_t i = lo; i < hi; i++) {
+        /* a in [0,1) -> cosTheta = 2a-1, phi = 2*pi*b */
+        st3(j->sph, i, orc_spherical_direction(2.0f * j->a[i] - 1.0f, AI_PITIMES2 * j->b[i]));
+        orc_v2 d = orc_concentric_disk_sample(j->a[i], j->b[i]);
+        st3(j->disk, i, v3(d.x, d.y, 0.0f));
+    }
+}
+
+void orc_batch_util(int64_t n, const float *a, const float *b, orc_v3p spherical, orc_v3p disk, int nthreads)
+{
+    util_job j = { a, b, spherical, disk };
+    parallel_for(n, nthreads, util_range, &j);
+}
+
+/* ================================ synthetic generator ================================== */
+/* Counter-based: value = f(seed, point index, stream id).  Integer hashing plus + - * / sqrt
+ * only, so the device generator (rlshaders_amd/csrc/gen.hip) reproduces it bit for bit. */
+
+static inline uint32_t mix32(uint32_t h)
+{
+    h ^= h >> 16; h *= 0x7feb352dU; h ^= h >> 15; h *= 0x846ca68bU; h ^= h >> 16;
+    return h;
+}
+
+uint32_t orc_hash_u32(uint32_t seed, uint64_t index, uint32_t stream)
+{
+    uint32_t h = mix32(seed ^ (0x9E3779B9U * (stream + 1U)));
+    h = mix32(h ^ (uint32_t)(index & 0xFFFFFFFFULL));
+    h = mix32(h + (uint32_t)(index >> 32) * 0x85EBCA6BU + 0xC2B2AE35U);
+    return h;
+}
+
+float orc_hash_u01(uint32_t seed, uint64_t index, uint32_t stream)
+{
+    return (float)(orc_hash_u32(seed, index, stream) >> 8) * (1.0f / 16777216.0f);
+}
+
+/* unit-circle point from u in [0,1): "diamond angle" (no trig), exact quadrant symmetry */
+static inline void circle_point(float u, float *c, float *s)
+{
+    float t = 4.0f * u;
+    int q = (int)t;
+    float f = t - (float)q;
+    float a = 1.0f - f, b = f;
+    float l = sqrtf(a * a + b * b);
+    a = a / l; b = b / l;
+    switch (q & 3) {
+    case 0: *c = a;  *s = b;  break;
+    case 1: *c = -b; *s = a;  break;
+    case 2: *c = -a; *s = -b; break;
+    default: *c = b; *s = -a; break;
+    }
+}
+
+static inline orc_v3 v3normalize_div(orc_v3 a)
+{
+    float l = v3length(a);
+    return v3(a.x / l, a.y / l, a.z / l);
+}
+
+void orc_gen_frame(uint32_t seed, uint64_t first, int64_t n, orc_v3p wo, orc_v3p N, orc_v3p T)
+{
+    for (int64_t k = 0; k < n; k++) {
+        uint64_t i = first + (uint64_t)k;
+        float u0 = orc_hash_u01(seed, i, ORC_S_N0);
+        float z = 1.0f - 2.0f * u0;
+        float rr = sqrtf(MAXf(0.0f, 1.0f - z * z));
+        float c, s;
+        circle_point(orc_hash_u01(seed, i, ORC_S_N1), &c, &s);
+        orc_v3 Nn = v3normalize_div(v3(rr * c, rr * s, z));
+
+        orc_v3 e = ABSf(Nn.x) < 0.57735f ? v3(1.0f, 0.0f, 0.0f) : v3(0.0f, 1.0f, 0.0f);
+        orc_v3 T0 = v3normalize_div(v3cross(e, Nn));
+        orc_v3 B0 = v3cross(Nn, T0);
+        circle_point(orc_hash_u01(seed, i, ORC_S_T), &c, &s);
+        orc_v3 Tt = v3add(v3scale(T0, c), v3scale(B0, s));
+        Tt = v3sub(Tt, v3scale(Nn, v3dot(Tt, Nn)));
+        Tt = v3normalize_div(Tt);
+        orc_v3 Bt = v3cross(Nn, Tt);
+
+        float ct = 0.02f + 0.98f * orc_hash_u01(seed, i, ORC_S_WO0);
+        float st = sqrtf(MAXf(0.0f, 1.0f - ct * ct));
+        circle_point(orc_hash_u01(seed, i, ORC_S_WO1), &c, &s);
+        orc_v3 w = v3add(v3scale(v3add(v3scale(Tt, c), v3scale(Bt, s)), st), v3scale(Nn, ct));
+        w = v3normalize_div(w);
+
+        st3(N, k, Nn); st3(T, k, Tt); st3(wo, k, w);
+    }
+}
+
+void orc_gen_uniform(uint32_t seed, uint64_t first, int64_t n, uint32_t stream, float lo, float hi, float *out)
+{
+    float span = hi - lo;
+    for (int64_t k = 0; k < n; k++) {
+        out[k] = lo + span * orc_hash_u01(seed, first + (uint64_t)k, stream);
+    }
+}
+
+void orc_gen_aniso(uint32_t seed, uint64_t first, int64_t n, float *out)
+{
+    for (int64_t k = 0; k < n; k++) {
+        uint64_t i = first + (uint64_t)k;
+        out[k] = (i & 1ULL) ? orc_hash_u01(seed, i, ORC_S_ANISO) : 0.0f;
+    }
+}

@@ -1,0 +1,16 @@
+"""rlshaders_amd -- MI355X-native batched BSDF evaluator / importance sampler.
+
+A drop-in for the closure layer (sample / eval / pdf) of shihchinw/rlShaders' rlGgx, rlDisney and
+rlSss/rlSkin shaders: hand-written HIP kernels for gfx950 behind the C ABI in
+``include/rlshaders_amd.h``.  This package is the host-side mirror of the reference's closure
+classes; it fails loudly when the HIP library is missing -- there is no CPU path.
+"""
+from ._capi import (RLS_KERNEL_NDF, RLS_KERNEL_VNDF, RLS_RAY_DIFFUSE, RLS_RAY_GLOSSY, RlsError, load)
+from .closures import (Context, DisneySampler, GgxSampler, NDProfile, SkinShader, SssSampler, checksum,
+                       gen_aniso, gen_frame, gen_uniform, util_directions)
+
+__all__ = [
+    "Context", "GgxSampler", "DisneySampler", "NDProfile", "SssSampler", "SkinShader",
+    "RLS_RAY_DIFFUSE", "RLS_RAY_GLOSSY", "RLS_KERNEL_VNDF", "RLS_KERNEL_NDF",
+    "RlsError", "load", "gen_frame", "gen_uniform", "gen_aniso", "checksum", "util_directions",
+]

@@ -1,0 +1,206 @@
+"""ctypes binding of the C ABI declared in ``include/rlshaders_amd.h``.
+
+The shared library is the product: there is no Python / CPU fallback.  If it is missing or fails
+to load this module raises, loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "lib" / "librlshaders_amd.so"
+
+RLS_OK = 0
+RLS_RAY_DIFFUSE = 0x08
+RLS_RAY_GLOSSY = 0x10
+RLS_KERNEL_VNDF = 0
+RLS_KERNEL_NDF = 1
+
+c_float_p = C.POINTER(C.c_float)
+c_u8_p = C.POINTER(C.c_uint8)
+
+
+class CVec3(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("z", C.c_void_p)]
+
+
+class Vec3(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("z", C.c_void_p)]
+
+
+class CRgb(C.Structure):
+    _fields_ = [("r", C.c_void_p), ("g", C.c_void_p), ("b", C.c_void_p)]
+
+
+class Rgb(C.Structure):
+    _fields_ = [("r", C.c_void_p), ("g", C.c_void_p), ("b", C.c_void_p)]
+
+
+class Param(C.Structure):
+    _fields_ = [("v", C.c_void_p), ("u", C.c_float)]
+
+
+class ParamRgb(C.Structure):
+    _fields_ = [("r", C.c_void_p), ("g", C.c_void_p), ("b", C.c_void_p),
+                ("ur", C.c_float), ("ug", C.c_float), ("ub", C.c_float)]
+
+
+class GgxClosure(C.Structure):
+    _fields_ = [("wo", CVec3), ("N", CVec3), ("T", CVec3),
+                ("exiting", C.c_void_p),
+                ("KsColor", ParamRgb),
+                ("specularRoughness", Param), ("ior", Param), ("anisotropic", Param)]
+
+
+class DisneyClosure(C.Structure):
+    _fields_ = [("wo", CVec3), ("N", CVec3), ("T", CVec3),
+                ("base_color", ParamRgb),
+                ("subsurface", Param), ("metallic", Param), ("specular", Param),
+                ("specular_tint", Param), ("roughness", Param), ("anisotropic", Param),
+                ("sheen", Param), ("sheen_tint", Param), ("clearcoat", Param),
+                ("clearcoat_gloss", Param)]
+
+
+DISNEY_SCALARS = ("subsurface", "metallic", "specular", "specular_tint", "roughness", "anisotropic",
+                  "sheen", "sheen_tint", "clearcoat", "clearcoat_gloss")
+
+
+class DisneyStreamOut(C.Structure):
+    _fields_ = [("wi", Vec3), ("f", Rgb), ("pdf", C.c_void_p)]
+
+
+class SssClosure(C.Structure):
+    _fields_ = [("sss_color", ParamRgb),
+                ("sss_dist_multiplier", Param),
+                ("sss_scatter_dist", Param * 3),
+                ("N", CVec3), ("T", CVec3),
+                ("has_dPdu", C.c_int)]
+
+
+class SkinClosure(C.Structure):
+    _fields_ = [("wo", CVec3), ("N", CVec3), ("T", CVec3),
+                ("sss_color", ParamRgb),
+                ("sss_weight", Param), ("sss_dist_multiplier", Param),
+                ("sss_scatter_dist", Param * 3),
+                ("specular_color", ParamRgb),
+                ("specular_weight", Param), ("specular_roughness", Param), ("specular_ior", Param),
+                ("sheen_color", ParamRgb),
+                ("sheen_weight", Param), ("sheen_roughness", Param), ("sheen_ior", Param)]
+
+
+class SkinOut(C.Structure):
+    _fields_ = [("sheen_wi", Vec3), ("sheen_f", Rgb), ("sheen_pdf", C.c_void_p), ("sheen_fresnel", C.c_void_p),
+                ("spec_wi", Vec3), ("spec_f", Rgb), ("spec_pdf", C.c_void_p), ("spec_fresnel", C.c_void_p),
+                ("r", C.c_void_p), ("r_pdf", C.c_void_p), ("profile", Rgb),
+                ("sheenFresnel", C.c_void_p), ("specularFresnel", C.c_void_p), ("sssWeight", C.c_void_p)]
+
+
+_ctx = C.c_void_p
+_i64 = C.c_int64
+_vp = C.c_void_p
+
+# name -> (restype, argtypes).  Every symbol include/rlshaders_amd.h declares is listed here;
+# tests/test_capi_symbols.py checks the two stay in step.
+PROTOTYPES = {
+    "rls_context_create": (C.c_int, [C.c_int, C.POINTER(_ctx)]),
+    "rls_context_destroy": (None, [_ctx]),
+    "rls_context_set_stream": (C.c_int, [_ctx, _vp]),
+    "rls_context_get_stream": (_vp, [_ctx]),
+    "rls_context_synchronize": (C.c_int, [_ctx]),
+    "rls_context_device": (C.c_int, [_ctx]),
+    "rls_last_error": (C.c_char_p, []),
+    "rls_status_string": (C.c_char_p, [C.c_int]),
+    "rls_version": (C.c_int, []),
+    "rls_device_info": (C.c_int, [_ctx, C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
+                                  C.c_char_p, C.c_size_t]),
+    "rls_device_alloc": (C.c_int, [_ctx, C.c_size_t, C.POINTER(_vp)]),
+    "rls_device_free": (C.c_int, [_ctx, _vp]),
+    "rls_copy_to_device": (C.c_int, [_ctx, _vp, _vp, C.c_size_t]),
+    "rls_copy_to_host": (C.c_int, [_ctx, _vp, _vp, C.c_size_t]),
+    "rls_timer_start": (C.c_int, [_ctx]),
+    "rls_timer_stop": (C.c_int, [_ctx]),
+    "rls_timer_elapsed_ms": (C.c_int, [_ctx, C.POINTER(C.c_float)]),
+    # rlGgx
+    "rls_ggx_sample": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), _vp, _vp, Vec3, _vp]),
+    "rls_ggx_eval": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), CVec3, Rgb]),
+    "rls_ggx_pdf": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), CVec3, _vp]),
+    "rls_ggx_sample_eval_pdf": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), _vp, _vp, Vec3, Rgb, _vp, _vp]),
+    "rls_ggx_refract_sample": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), _vp, _vp, Vec3, _vp, _vp]),
+    "rls_ggx_reflect_refract": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), _vp, _vp, _vp, _vp,
+                                          Vec3, Rgb, _vp, _vp, Vec3, _vp]),
+    "rls_ggx_microfacet": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), C.c_int, _vp, _vp, Vec3]),
+    "rls_ggx_ndf_pdf": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), CVec3, _vp]),
+    "rls_ggx_integrate": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), C.c_int, C.c_uint32, Rgb, _vp]),
+    # rlDisney
+    "rls_disney_sample": (C.c_int, [_ctx, _i64, C.POINTER(DisneyClosure), C.c_int, _vp, _vp, Vec3]),
+    "rls_disney_eval": (C.c_int, [_ctx, _i64, C.POINTER(DisneyClosure), C.c_int, CVec3, Rgb]),
+    "rls_disney_pdf": (C.c_int, [_ctx, _i64, C.POINTER(DisneyClosure), C.c_int, CVec3, _vp]),
+    "rls_disney_sample_eval_pdf": (C.c_int, [_ctx, _i64, C.POINTER(DisneyClosure), C.c_int, _vp, _vp,
+                                             Vec3, Rgb, _vp]),
+    "rls_disney_integrate": (C.c_int, [_ctx, _i64, C.POINTER(DisneyClosure), C.c_int, C.c_uint32,
+                                       Rgb, _vp, Rgb, _vp, C.POINTER(DisneyStreamOut)]),
+    # rlSss
+    "rls_nd_sample": (C.c_int, [_ctx, _i64, C.POINTER(SssClosure), _vp, _vp, _vp, Rgb]),
+    "rls_nd_pdf": (C.c_int, [_ctx, _i64, C.POINTER(SssClosure), _vp, _vp]),
+    "rls_nd_eval": (C.c_int, [_ctx, _i64, C.POINTER(SssClosure), _vp, Rgb]),
+    "rls_sss_probe_ray": (C.c_int, [_ctx, _i64, C.POINTER(SssClosure), _vp, _vp, CVec3,
+                                    _vp, Vec3, Vec3, _vp, _vp, Rgb]),
+    "rls_sss_mis_pdf": (C.c_int, [_ctx, _i64, C.POINTER(SssClosure), CVec3, CVec3, C.c_int, _vp]),
+    "rls_sss_cavity_fade": (C.c_int, [_ctx, _i64, CVec3, CVec3, CVec3, _vp]),
+    "rls_sss_sample_diffuse_direction": (C.c_int, [_ctx, _i64, CVec3, CVec3, _vp, _vp, Vec3]),
+    # rlSkin
+    "rls_skin_sample_eval_pdf": (C.c_int, [_ctx, _i64, C.POINTER(SkinClosure), C.POINTER(_vp), C.POINTER(SkinOut)]),
+    # rlUtil, generator, checksum
+    "rls_util_directions": (C.c_int, [_ctx, _i64, _vp, _vp, Vec3, Vec3]),
+    "rls_gen_frame": (C.c_int, [_ctx, C.c_uint32, C.c_uint64, _i64, Vec3, Vec3, Vec3]),
+    "rls_gen_uniform": (C.c_int, [_ctx, C.c_uint32, C.c_uint64, _i64, C.c_uint32, C.c_float, C.c_float, _vp]),
+    "rls_gen_aniso": (C.c_int, [_ctx, C.c_uint32, C.c_uint64, _i64, _vp]),
+    "rls_checksum": (C.c_int, [_ctx, _i64, _vp, C.POINTER(C.c_uint64)]),
+}
+
+_lib = None
+
+
+class RlsError(RuntimeError):
+    """A C-ABI call returned a non-zero rls_status."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"rlshaders_amd: status {status}: {message}")
+        self.status = status
+
+
+def load() -> C.CDLL:
+    """Load (once) and prototype the HIP library.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("RLSHADERS_AMD_LIB", str(LIB_PATH)))
+    if not path.exists():
+        raise RuntimeError(
+            f"rlshaders_amd: HIP library not found at {path}. Build it with "
+            f"`python -m rlshaders_amd.build` (needs hipcc); there is no CPU fallback.")
+    lib = C.CDLL(str(path), mode=C.RTLD_GLOBAL)
+    missing = []
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if missing:
+        raise RuntimeError(f"rlshaders_amd: {path} lacks C-ABI symbols: {missing}")
+    _lib = lib
+    return lib
+
+
+def check(status: int) -> None:
+    if status != RLS_OK:
+        lib = load()
+        msg = lib.rls_last_error().decode("utf-8", "replace")
+        if not msg:
+            msg = lib.rls_status_string(status).decode()
+        raise RlsError(status, msg)

@@ -1,0 +1,511 @@
+"""Host-side mirror of the reference's closure classes over the C ABI.
+
+Each class keeps the reference's name and verbs -- ``GgxSampler.evalSample / evalBrdf / evalPdf``
+(src/rlGgx.h:97-127), ``DisneySampler`` + ``setSampleType`` (src/rlDisney.cpp:109-152,194-197),
+``NDProfile.getRadius / getPdf / evalProfile`` (src/rlSss.h:49-55), ``SssSampler.getProbeRay``
+(src/rlSss.h:487) -- but works on a *batch* of shading points: every argument that was one
+``AtVector`` / ``AtColor`` / ``float`` per call in the reference is a planar SoA torch tensor on
+the GPU (``[3, n]`` / ``[n]`` float32), or a Python float / 3-tuple for a parameter that is
+uniform over the batch.  torch is plumbing only (device memory and streams); every number is
+computed by the hand-written HIP kernels behind ``include/rlshaders_amd.h``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Union
+
+import torch
+
+from . import _capi as capi
+from ._capi import (RLS_KERNEL_NDF, RLS_KERNEL_VNDF, RLS_RAY_DIFFUSE, RLS_RAY_GLOSSY, check)
+
+Scalar = Union[float, torch.Tensor]
+Color = Union[Sequence[float], torch.Tensor]
+
+
+class Context:
+    """One rls_context: a device plus the stream launches go to (torch's current stream by default)."""
+
+    def __init__(self, device: Optional[int] = None, use_torch_stream: bool = True):
+        self.lib = capi.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("rlshaders_amd.Context: no HIP device visible to torch; the closures run on the GPU only")
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        h = C.c_void_p()
+        check(self.lib.rls_context_create(self.device, C.byref(h)))
+        self.handle = h
+        self.torch_device = torch.device("cuda", self.device)
+        if use_torch_stream:
+            self.use_stream(torch.cuda.current_stream(self.torch_device))
+
+    def use_stream(self, stream: Optional["torch.cuda.Stream"]) -> None:
+        ptr = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p()
+        check(self.lib.rls_context_set_stream(self.handle, ptr))
+
+    def synchronize(self) -> None:
+        check(self.lib.rls_context_synchronize(self.handle))
+
+    def timer_start(self) -> None:
+        check(self.lib.rls_timer_start(self.handle))
+
+    def timer_stop(self) -> None:
+        check(self.lib.rls_timer_stop(self.handle))
+
+    def timer_elapsed_ms(self) -> float:
+        ms = C.c_float()
+        check(self.lib.rls_timer_elapsed_ms(self.handle, C.byref(ms)))
+        return float(ms.value)
+
+    def device_info(self) -> dict:
+        cus = C.c_int()
+        total = C.c_size_t()
+        free = C.c_size_t()
+        name = C.create_string_buffer(64)
+        check(self.lib.rls_device_info(self.handle, C.byref(cus), C.byref(total), C.byref(free), name, 64))
+        return {"compute_units": cus.value, "hbm_total": total.value, "hbm_free": free.value,
+                "arch": name.value.decode()}
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.rls_context_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers --------------------------------------------------------------------------------
+    def empty(self, *shape) -> torch.Tensor:
+        return torch.empty(*shape, dtype=torch.float32, device=self.torch_device)
+
+
+def _chk(t: torch.Tensor, n: Optional[int], rows: Optional[int], what: str) -> None:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{what}: expected a torch tensor, got {type(t).__name__}")
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise TypeError(f"{what}: expected a float32 CUDA tensor, got {t.dtype} on {t.device}")
+    if rows is None:
+        if t.dim() != 1 or not t.is_contiguous():
+            raise ValueError(f"{what}: expected a contiguous [n] tensor, got shape {tuple(t.shape)}")
+    else:
+        if t.dim() != 2 or t.shape[0] != rows or t.stride(1) != 1:
+            raise ValueError(f"{what}: expected a [{rows}, n] tensor with unit inner stride, got {tuple(t.shape)}")
+    if n is not None and t.shape[-1] != n:
+        raise ValueError(f"{what}: batch size {t.shape[-1]} != {n}")
+
+
+def cvec3(t: torch.Tensor, n: int, what: str) -> capi.CVec3:
+    _chk(t, n, 3, what)
+    return capi.CVec3(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr())
+
+
+def vec3(t: torch.Tensor, n: int, what: str) -> capi.Vec3:
+    _chk(t, n, 3, what)
+    return capi.Vec3(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr())
+
+
+def rgb(t: torch.Tensor, n: int, what: str) -> capi.Rgb:
+    _chk(t, n, 3, what)
+    return capi.Rgb(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr())
+
+
+def plane(t: torch.Tensor, n: int, what: str) -> int:
+    _chk(t, n, None, what)
+    return t.data_ptr()
+
+
+def param(v: Scalar, n: int, what: str) -> capi.Param:
+    if isinstance(v, torch.Tensor):
+        return capi.Param(plane(v, n, what), 0.0)
+    return capi.Param(None, float(v))
+
+
+def param_rgb(v: Color, n: int, what: str) -> capi.ParamRgb:
+    if isinstance(v, torch.Tensor):
+        _chk(v, n, 3, what)
+        return capi.ParamRgb(v[0].data_ptr(), v[1].data_ptr(), v[2].data_ptr(), 0.0, 0.0, 0.0)
+    r, g, b = (float(x) for x in v)
+    return capi.ParamRgb(None, None, None, r, g, b)
+
+
+# ================================================================================================
+class GgxSampler:
+    """Batched ``rls::GgxSampler`` (= ``GgxSamplerT<VNDFKernel>``, src/rlGgx.h:92-375).
+
+    Constructor arguments follow src/rlGgx.h:130-131: ``(sg, specColor, ior, roughness,
+    anisotropic=0)`` where ``sg`` contributes ``wo = -sg->Rd``, ``N = sg->Nf`` and the tangent ``T``
+    of the local frame; ``exiting`` (uint8 [n], optional) marks points where
+    ``dot(sg->N, sg->Rd) >= AI_EPSILON`` (src/rlGgx.h:137).
+    """
+
+    def __init__(self, ctx: Context, wo, N, T, specColor: Color = (1.0, 1.0, 1.0), ior: Scalar = 1.0,
+                 roughness: Scalar = 0.0, anisotropic: Scalar = 0.0, exiting: Optional[torch.Tensor] = None):
+        self.ctx = ctx
+        self.n = int(wo.shape[-1])
+        n = self.n
+        self._keep = (wo, N, T, specColor, ior, roughness, anisotropic, exiting)
+        c = capi.GgxClosure()
+        c.wo, c.N, c.T = cvec3(wo, n, "wo"), cvec3(N, n, "N"), cvec3(T, n, "T")
+        if exiting is not None:
+            if exiting.dtype != torch.uint8 or exiting.shape != (n,) or not exiting.is_cuda:
+                raise TypeError("exiting: expected a uint8 CUDA tensor of shape [n]")
+            c.exiting = exiting.data_ptr()
+        c.KsColor = param_rgb(specColor, n, "specColor")
+        c.ior = param(ior, n, "ior")
+        c.specularRoughness = param(roughness, n, "roughness")
+        c.anisotropic = param(anisotropic, n, "anisotropic")
+        self.c = c
+
+    # -- the callback triple ---------------------------------------------------------------------
+    def evalSample(self, rx, ry, out_wi=None, out_fresnel=None):
+        """src/rlGgx.h:97-107 -> (wi [3,n], fresnel [n])."""
+        n, ctx = self.n, self.ctx
+        wi = ctx.empty(3, n) if out_wi is None else out_wi
+        F = ctx.empty(n) if out_fresnel is None else out_fresnel
+        check(ctx.lib.rls_ggx_sample(ctx.handle, n, C.byref(self.c), plane(rx, n, "rx"), plane(ry, n, "ry"),
+                                     vec3(wi, n, "wi"), plane(F, n, "fresnel")))
+        return wi, F
+
+    def evalBrdf(self, indir, out=None):
+        """src/rlGgx.h:110-119 -> f [3,n] (BRDF x signed cosine)."""
+        n, ctx = self.n, self.ctx
+        f = ctx.empty(3, n) if out is None else out
+        check(ctx.lib.rls_ggx_eval(ctx.handle, n, C.byref(self.c), cvec3(indir, n, "indir"), rgb(f, n, "f")))
+        return f
+
+    def evalPdf(self, indir, out=None):
+        """src/rlGgx.h:121-127 -> pdf [n]."""
+        n, ctx = self.n, self.ctx
+        pdf = ctx.empty(n) if out is None else out
+        check(ctx.lib.rls_ggx_pdf(ctx.handle, n, C.byref(self.c), cvec3(indir, n, "indir"), plane(pdf, n, "pdf")))
+        return pdf
+
+    def sampleEvalPdf(self, rx, ry, out=None):
+        """The triple fused in one pass -> (wi, f, pdf, fresnel)."""
+        n, ctx = self.n, self.ctx
+        wi, f, pdf, F = out if out is not None else (ctx.empty(3, n), ctx.empty(3, n), ctx.empty(n), ctx.empty(n))
+        check(ctx.lib.rls_ggx_sample_eval_pdf(ctx.handle, n, C.byref(self.c), plane(rx, n, "rx"), plane(ry, n, "ry"),
+                                              vec3(wi, n, "wi"), rgb(f, n, "f"), plane(pdf, n, "pdf"),
+                                              plane(F, n, "fresnel")))
+        return wi, f, pdf, F
+
+    def refractSample(self, rx, ry):
+        """Per-sample body of integrateRefract (src/rlGgx.h:228-242) -> (wt, weight, refracted)."""
+        n, ctx = self.n, self.ctx
+        wt, w = ctx.empty(3, n), ctx.empty(n)
+        flag = torch.empty(n, dtype=torch.uint8, device=ctx.torch_device)
+        check(ctx.lib.rls_ggx_refract_sample(ctx.handle, n, C.byref(self.c), plane(rx, n, "rx"), plane(ry, n, "ry"),
+                                             vec3(wt, n, "wt"), plane(w, n, "weight"), flag.data_ptr()))
+        return wt, w, flag
+
+    def reflectRefract(self, rx, ry, rx2, ry2, out=None):
+        """Reflect triple + refract sample in one pass -> (wi, f, pdf, fresnel, wt, weight)."""
+        n, ctx = self.n, self.ctx
+        if out is None:
+            out = (ctx.empty(3, n), ctx.empty(3, n), ctx.empty(n), ctx.empty(n), ctx.empty(3, n), ctx.empty(n))
+        wi, f, pdf, F, wt, w = out
+        check(ctx.lib.rls_ggx_reflect_refract(
+            ctx.handle, n, C.byref(self.c), plane(rx, n, "rx"), plane(ry, n, "ry"), plane(rx2, n, "rx2"),
+            plane(ry2, n, "ry2"), vec3(wi, n, "wi"), rgb(f, n, "f"), plane(pdf, n, "pdf"), plane(F, n, "fresnel"),
+            vec3(wt, n, "wt"), plane(w, n, "weight")))
+        return out
+
+    def microfacet(self, rx, ry, kernel: int = RLS_KERNEL_VNDF):
+        """VNDFKernel::evalSample (src/rlGgx.cpp:63-99) or NDFKernel::evalSample (src/rlGgx.h:33-41)."""
+        n, ctx = self.n, self.ctx
+        m = ctx.empty(3, n)
+        check(ctx.lib.rls_ggx_microfacet(ctx.handle, n, C.byref(self.c), kernel, plane(rx, n, "rx"),
+                                         plane(ry, n, "ry"), vec3(m, n, "m")))
+        return m
+
+    def ndfPdf(self, indir):
+        n, ctx = self.n, self.ctx
+        pdf = ctx.empty(n)
+        check(ctx.lib.rls_ggx_ndf_pdf(ctx.handle, n, C.byref(self.c), cvec3(indir, n, "indir"), plane(pdf, n, "pdf")))
+        return pdf
+
+    def integrate(self, spp_n: int, seed: int, out=None):
+        """spp_n^2 in-kernel samples -> (sum of f/pdf [3,n], getAvgReflectWeight [n]) (src/rlGgx.h:181-184)."""
+        n, ctx = self.n, self.ctx
+        s, a = out if out is not None else (ctx.empty(3, n), ctx.empty(n))
+        check(ctx.lib.rls_ggx_integrate(ctx.handle, n, C.byref(self.c), int(spp_n), int(seed) & 0xFFFFFFFF,
+                                        rgb(s, n, "sum"), plane(a, n, "avg")))
+        return s, a
+
+
+# ================================================================================================
+class DisneySampler:
+    """Batched ``DisneySampler`` (src/rlDisney.cpp:105-602); parameter names from
+    src/rlDisney.cpp:606-610.  ``setSampleType`` picks the lobe the triple acts on."""
+
+    def __init__(self, ctx: Context, wo, N, T, base_color: Color = (1.0, 1.0, 1.0), **scalars: Scalar):
+        self.ctx = ctx
+        self.n = int(wo.shape[-1])
+        n = self.n
+        unknown = set(scalars) - set(capi.DISNEY_SCALARS)
+        if unknown:
+            raise TypeError(f"unknown rlDisney parameters: {sorted(unknown)}")
+        self._keep = (wo, N, T, base_color, scalars)
+        c = capi.DisneyClosure()
+        c.wo, c.N, c.T = cvec3(wo, n, "wo"), cvec3(N, n, "N"), cvec3(T, n, "T")
+        c.base_color = param_rgb(base_color, n, "base_color")
+        for name in capi.DISNEY_SCALARS:
+            setattr(c, name, param(scalars.get(name, 0.0), n, name))
+        self.c = c
+        self.mSampleType = RLS_RAY_GLOSSY
+
+    def setSampleType(self, ray_type: int) -> None:
+        if ray_type not in (RLS_RAY_DIFFUSE, RLS_RAY_GLOSSY):
+            raise ValueError("ray_type must be RLS_RAY_DIFFUSE or RLS_RAY_GLOSSY")
+        self.mSampleType = ray_type
+
+    def evalSample(self, rx, ry):
+        n, ctx = self.n, self.ctx
+        wi = ctx.empty(3, n)
+        check(ctx.lib.rls_disney_sample(ctx.handle, n, C.byref(self.c), self.mSampleType, plane(rx, n, "rx"),
+                                        plane(ry, n, "ry"), vec3(wi, n, "wi")))
+        return wi
+
+    def evalBrdf(self, indir):
+        n, ctx = self.n, self.ctx
+        f = ctx.empty(3, n)
+        check(ctx.lib.rls_disney_eval(ctx.handle, n, C.byref(self.c), self.mSampleType, cvec3(indir, n, "indir"),
+                                      rgb(f, n, "f")))
+        return f
+
+    def evalPdf(self, indir):
+        n, ctx = self.n, self.ctx
+        pdf = ctx.empty(n)
+        check(ctx.lib.rls_disney_pdf(ctx.handle, n, C.byref(self.c), self.mSampleType, cvec3(indir, n, "indir"),
+                                     plane(pdf, n, "pdf")))
+        return pdf
+
+    def sampleEvalPdf(self, rx, ry, out=None):
+        n, ctx = self.n, self.ctx
+        wi, f, pdf = out if out is not None else (ctx.empty(3, n), ctx.empty(3, n), ctx.empty(n))
+        check(ctx.lib.rls_disney_sample_eval_pdf(ctx.handle, n, C.byref(self.c), self.mSampleType,
+                                                 plane(rx, n, "rx"), plane(ry, n, "ry"), vec3(wi, n, "wi"),
+                                                 rgb(f, n, "f"), plane(pdf, n, "pdf")))
+        return wi, f, pdf
+
+    def integrate(self, spp_n: int, seed: int, streamed: bool = False, out=None):
+        """Both lobes, spp_n^2 samples each -> dict(diffuse_sum, diffuse_count, specular_sum,
+        specular_count[, wi, f, pdf as [3, 2*spp*n] / [2*spp*n] sample-major planes])."""
+        n, ctx = self.n, self.ctx
+        if out is None:
+            out = {"diffuse_sum": ctx.empty(3, n), "diffuse_count": ctx.empty(n),
+                   "specular_sum": ctx.empty(3, n), "specular_count": ctx.empty(n)}
+            if streamed:
+                m = 2 * spp_n * spp_n * n
+                out.update(wi=ctx.empty(3, m), f=ctx.empty(3, m), pdf=ctx.empty(m))
+        so = None
+        if streamed:
+            m = 2 * spp_n * spp_n * n
+            so = capi.DisneyStreamOut(vec3(out["wi"], m, "wi"), rgb(out["f"], m, "f"), plane(out["pdf"], m, "pdf"))
+        check(ctx.lib.rls_disney_integrate(
+            ctx.handle, n, C.byref(self.c), int(spp_n), int(seed) & 0xFFFFFFFF,
+            rgb(out["diffuse_sum"], n, "diffuse_sum"), plane(out["diffuse_count"], n, "diffuse_count"),
+            rgb(out["specular_sum"], n, "specular_sum"), plane(out["specular_count"], n, "specular_count"),
+            C.byref(so) if so is not None else None))
+        return out
+
+
+# ================================================================================================
+def _sss_closure(n, sss_scatter_dist, sss_dist_multiplier, sss_color, N, T, has_dPdu) -> capi.SssClosure:
+    c = capi.SssClosure()
+    c.sss_color = param_rgb(sss_color, n, "sss_color")
+    c.sss_dist_multiplier = param(sss_dist_multiplier, n, "sss_dist_multiplier")
+    if isinstance(sss_scatter_dist, torch.Tensor):
+        _chk(sss_scatter_dist, n, 3, "sss_scatter_dist")
+        for k in range(3):
+            c.sss_scatter_dist[k] = capi.Param(sss_scatter_dist[k].data_ptr(), 0.0)
+    else:
+        for k in range(3):
+            c.sss_scatter_dist[k] = capi.Param(None, float(sss_scatter_dist[k]))
+    if N is not None:
+        c.N = cvec3(N, n, "N")
+        c.T = cvec3(T, n, "T")
+    c.has_dPdu = 1 if has_dPdu else 0
+    return c
+
+
+class NDProfile:
+    """Batched ``rls::NDProfile`` (src/rlSss.h:27-61, src/rlSss.cpp:20-106).  ``setDistance(dist,
+    albedo)`` happens in the constructor; n must be given when every parameter is uniform."""
+
+    def __init__(self, ctx: Context, n: int, dist, albedo: Color = (1.0, 1.0, 1.0), multiplier: Scalar = 1.0):
+        self.ctx, self.n = ctx, int(n)
+        self._keep = (dist, albedo, multiplier)
+        self.c = _sss_closure(self.n, dist, multiplier, albedo, None, None, False)
+
+    def sample(self, rx):
+        """getRadius(rx), getPdf(r), evalProfile(r) in one pass -> (r, pdf, profile)."""
+        n, ctx = self.n, self.ctx
+        r, pdf, prof = ctx.empty(n), ctx.empty(n), ctx.empty(3, n)
+        check(ctx.lib.rls_nd_sample(ctx.handle, n, C.byref(self.c), plane(rx, n, "rx"), plane(r, n, "r"),
+                                    plane(pdf, n, "pdf"), rgb(prof, n, "profile")))
+        return r, pdf, prof
+
+    def getRadius(self, rx):
+        return self.sample(rx)[0]
+
+    def getPdf(self, r):
+        n, ctx = self.n, self.ctx
+        pdf = ctx.empty(n)
+        check(ctx.lib.rls_nd_pdf(ctx.handle, n, C.byref(self.c), plane(r, n, "r"), plane(pdf, n, "pdf")))
+        return pdf
+
+    def evalProfile(self, r):
+        n, ctx = self.n, self.ctx
+        prof = ctx.empty(3, n)
+        check(ctx.lib.rls_nd_eval(ctx.handle, n, C.byref(self.c), plane(r, n, "r"), rgb(prof, n, "profile")))
+        return prof
+
+
+class SssSampler:
+    """Batched hot parts of ``rls::SssSampler<NDProfile>`` (src/rlSss.h:143-167,246-266,401-413,
+    487-545).  ``Ns`` = sg->Ns, ``dPdu`` = sg->dPdu (Gram-Schmidt frame) or, with
+    ``has_dPdu=False``, the polar-frame tangent."""
+
+    def __init__(self, ctx: Context, Ns, dPdu, albedo: Color, dist, multiplier: Scalar = 1.0, has_dPdu: bool = True):
+        self.ctx, self.n = ctx, int(Ns.shape[-1])
+        self._keep = (Ns, dPdu, albedo, dist, multiplier)
+        self.c = _sss_closure(self.n, dist, multiplier, albedo, Ns, dPdu, has_dPdu)
+
+    def getProbeRay(self, rx, ry, P=None, out=None):
+        """src/rlSss.h:487-533 -> dict(r, origin, dir, maxdist, pdf, profile)."""
+        n, ctx = self.n, self.ctx
+        if out is None:
+            out = {"r": ctx.empty(n), "origin": ctx.empty(3, n), "dir": ctx.empty(3, n), "maxdist": ctx.empty(n),
+                   "pdf": ctx.empty(n), "profile": ctx.empty(3, n)}
+        Pv = cvec3(P, n, "P") if P is not None else capi.CVec3(None, None, None)
+        check(ctx.lib.rls_sss_probe_ray(
+            ctx.handle, n, C.byref(self.c), plane(rx, n, "rx"), plane(ry, n, "ry"), Pv, plane(out["r"], n, "r"),
+            vec3(out["origin"], n, "origin"), vec3(out["dir"], n, "dir"), plane(out["maxdist"], n, "maxdist"),
+            plane(out["pdf"], n, "pdf"), rgb(out["profile"], n, "profile")))
+        return out
+
+    def misPdf(self, disp, sampleN, literal_matrix: bool = False):
+        """3-axis MIS pdf of a probe hit (src/rlSss.h:246-266)."""
+        n, ctx = self.n, self.ctx
+        pdf = ctx.empty(n)
+        check(ctx.lib.rls_sss_mis_pdf(ctx.handle, n, C.byref(self.c), cvec3(disp, n, "disp"),
+                                      cvec3(sampleN, n, "sampleN"), 1 if literal_matrix else 0, plane(pdf, n, "pdf")))
+        return pdf
+
+    @staticmethod
+    def cavityFade(ctx: Context, disp, sampleN, No):
+        """src/rlSss.h:401-413."""
+        n = int(disp.shape[-1])
+        fade = ctx.empty(n)
+        check(ctx.lib.rls_sss_cavity_fade(ctx.handle, n, cvec3(disp, n, "disp"), cvec3(sampleN, n, "sampleN"),
+                                          cvec3(No, n, "No"), plane(fade, n, "fade")))
+        return fade
+
+    @staticmethod
+    def sampleDiffuseDirection(ctx: Context, rx, ry, normal, T):
+        """src/rlSss.h:536-545."""
+        n = int(normal.shape[-1])
+        wi = ctx.empty(3, n)
+        check(ctx.lib.rls_sss_sample_diffuse_direction(ctx.handle, n, cvec3(normal, n, "normal"), cvec3(T, n, "T"),
+                                                       plane(rx, n, "rx"), plane(ry, n, "ry"), vec3(wi, n, "wi")))
+        return wi
+
+
+# ================================================================================================
+SKIN_OUT_VEC = ("sheen_wi", "sheen_f", "spec_wi", "spec_f", "profile")
+SKIN_OUT_SCALAR = ("sheen_pdf", "sheen_fresnel", "spec_pdf", "spec_fresnel", "r", "r_pdf",
+                   "sheenFresnel", "specularFresnel", "sssWeight")
+
+
+class SkinShader:
+    """Batched lobe composition of rlSkin's shader_evaluate (src/rlSkin.cpp:174-246); parameter
+    names and defaults from src/rlSkin.cpp:109-128."""
+
+    DEFAULTS = dict(sss_color=(1.0, 1.0, 1.0), sss_weight=1.0, sss_dist_multiplier=1.0,
+                    sss_scatter_dist=(1.0, 1.0, 1.0),
+                    specular_color=(1.0, 1.0, 1.0), specular_weight=0.6, specular_roughness=0.5, specular_ior=1.44,
+                    sheen_color=(1.0, 1.0, 1.0), sheen_weight=0.0, sheen_roughness=0.35, sheen_ior=1.44)
+
+    def __init__(self, ctx: Context, wo, N, T, **params):
+        self.ctx, self.n = ctx, int(wo.shape[-1])
+        n = self.n
+        unknown = set(params) - set(self.DEFAULTS)
+        if unknown:
+            raise TypeError(f"unknown rlSkin parameters: {sorted(unknown)}")
+        p = dict(self.DEFAULTS)
+        p.update(params)
+        self._keep = (wo, N, T, p)
+        c = capi.SkinClosure()
+        c.wo, c.N, c.T = cvec3(wo, n, "wo"), cvec3(N, n, "N"), cvec3(T, n, "T")
+        for name in ("sss_color", "specular_color", "sheen_color"):
+            setattr(c, name, param_rgb(p[name], n, name))
+        for name in ("sss_weight", "sss_dist_multiplier", "specular_weight", "specular_roughness", "specular_ior",
+                     "sheen_weight", "sheen_roughness", "sheen_ior"):
+            setattr(c, name, param(p[name], n, name))
+        d = p["sss_scatter_dist"]
+        for k in range(3):
+            if isinstance(d, torch.Tensor):
+                _chk(d, n, 3, "sss_scatter_dist")
+                c.sss_scatter_dist[k] = capi.Param(d[k].data_ptr(), 0.0)
+            else:
+                c.sss_scatter_dist[k] = capi.Param(None, float(d[k]))
+        self.c = c
+
+    def alloc_out(self) -> dict:
+        n, ctx = self.n, self.ctx
+        out = {k: ctx.empty(3, n) for k in SKIN_OUT_VEC}
+        out.update({k: ctx.empty(n) for k in SKIN_OUT_SCALAR})
+        return out
+
+    def sampleEvalPdf(self, xi, out=None) -> dict:
+        """xi: [6, n] (sheen rx, ry, specular rx, ry, sss rx, ry) -> dict of output planes."""
+        n, ctx = self.n, self.ctx
+        _chk(xi, n, 6, "xi")
+        out = self.alloc_out() if out is None else out
+        o = capi.SkinOut()
+        for k in SKIN_OUT_VEC:
+            setattr(o, k, (rgb if k.endswith("_f") or k == "profile" else vec3)(out[k], n, k))
+        for k in SKIN_OUT_SCALAR:
+            setattr(o, k, plane(out[k], n, k))
+        xs = (C.c_void_p * 6)(*[xi[k].data_ptr() for k in range(6)])
+        check(ctx.lib.rls_skin_sample_eval_pdf(ctx.handle, n, C.byref(self.c), xs, C.byref(o)))
+        return out
+
+
+# ================================================================================================
+def gen_frame(ctx: Context, seed: int, first: int, n: int):
+    """Synthetic (wo, N, T) planes (DESIGN.md "Synthetic inputs")."""
+    wo, N, T = ctx.empty(3, n), ctx.empty(3, n), ctx.empty(3, n)
+    check(ctx.lib.rls_gen_frame(ctx.handle, seed, first, n, vec3(wo, n, "wo"), vec3(N, n, "N"), vec3(T, n, "T")))
+    return wo, N, T
+
+
+def gen_uniform(ctx: Context, seed: int, first: int, n: int, stream: int, lo: float = 0.0, hi: float = 1.0,
+                out: Optional[torch.Tensor] = None):
+    out = ctx.empty(n) if out is None else out
+    check(ctx.lib.rls_gen_uniform(ctx.handle, seed, first, n, stream, lo, hi, plane(out, n, "out")))
+    return out
+
+
+def gen_aniso(ctx: Context, seed: int, first: int, n: int):
+    out = ctx.empty(n)
+    check(ctx.lib.rls_gen_aniso(ctx.handle, seed, first, n, plane(out, n, "out")))
+    return out
+
+
+def checksum(ctx: Context, t: torch.Tensor) -> int:
+    flat = t.reshape(-1)
+    v = C.c_uint64()
+    check(ctx.lib.rls_checksum(ctx.handle, flat.numel(), plane(flat, flat.numel(), "data"), C.byref(v)))
+    return int(v.value)
+
+
+def util_directions(ctx: Context, a, b):
+    n = int(a.shape[0])
+    sph, disk = ctx.empty(3, n), ctx.empty(3, n)
+    check(ctx.lib.rls_util_directions(ctx.handle, n, plane(a, n, "a"), plane(b, n, "b"), vec3(sph, n, "spherical"),
+                                      vec3(disk, n, "disk")))
+    return sph, disk

@@ -1,0 +1,359 @@
+// context.hip -- context, memory, timing, synthetic generator and checksum entry points of the
+// C ABI (include/rlshaders_amd.h).  gfx950 only.
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "rls_internal.hpp"
+
+namespace {
+thread_local char g_error[512] = "";
+}
+
+namespace rlsh {
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+}
+
+rls_status hip_fail(hipError_t e, const char *what)
+{
+    set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    return e == hipErrorOutOfMemory ? RLS_ERR_OUT_OF_MEMORY : RLS_ERR_HIP;
+}
+
+} // namespace rlsh
+
+using namespace rlsd;
+
+extern "C" {
+
+const char *rls_last_error(void) { return g_error; }
+
+const char *rls_status_string(rls_status s)
+{
+    switch (s) {
+    case RLS_OK: return "ok";
+    case RLS_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case RLS_ERR_NO_DEVICE: return "no HIP device";
+    case RLS_ERR_HIP: return "HIP runtime error";
+    case RLS_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case RLS_ERR_UNSUPPORTED: return "unsupported";
+    default: return "unknown status";
+    }
+}
+
+int rls_version(void) { return RLS_VERSION_MAJOR * 1000 + RLS_VERSION_MINOR; }
+
+rls_status rls_context_create(int device_ordinal, rls_context **out)
+{
+    RLS_REQUIRE(out != nullptr, "out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        rlsh::set_error("rls_context_create: no HIP device visible (%s)",
+                        e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+        return RLS_ERR_NO_DEVICE;
+    }
+    if (device_ordinal < 0 || device_ordinal >= count) {
+        rlsh::set_error("rls_context_create: device %d out of range [0, %d)", device_ordinal, count);
+        return RLS_ERR_NO_DEVICE;
+    }
+    RLS_HIP_TRY(hipSetDevice(device_ordinal));
+    hipDeviceProp_t prop;
+    RLS_HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
+
+    rls_context *ctx = (rls_context *)calloc(1, sizeof(rls_context));
+    if (!ctx) { rlsh::set_error("rls_context_create: host allocation failed"); return RLS_ERR_OUT_OF_MEMORY; }
+    ctx->device = device_ordinal;
+    ctx->compute_units = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ctx->blocks_per_cu = 8;
+    if (const char *s = getenv("RLS_BLOCKS_PER_CU")) {
+        int v = atoi(s);
+        if (v >= 1 && v <= 4096) ctx->blocks_per_cu = v;
+    }
+    hipError_t e1 = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    hipError_t e2 = e1 == hipSuccess ? hipEventCreate(&ctx->ev_start) : e1;
+    hipError_t e3 = e2 == hipSuccess ? hipEventCreate(&ctx->ev_stop) : e2;
+    hipError_t e4 = e3 == hipSuccess ? hipMalloc((void **)&ctx->scratch_u64, sizeof(unsigned long long)) : e3;
+    if (e4 != hipSuccess) {
+        rls_status st = rlsh::hip_fail(e4, "rls_context_create");
+        rls_context_destroy(ctx);
+        return st;
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return RLS_OK;
+}
+
+void rls_context_destroy(rls_context *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->scratch_u64) (void)hipFree(ctx->scratch_u64);
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    free(ctx);
+}
+
+rls_status rls_context_set_stream(rls_context *ctx, void *hip_stream)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return RLS_OK;
+}
+
+void *rls_context_get_stream(rls_context *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int rls_context_device(const rls_context *ctx) { return ctx ? ctx->device : -1; }
+
+rls_status rls_context_synchronize(rls_context *ctx)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RLS_OK;
+}
+
+rls_status rls_device_info(rls_context *ctx, int *compute_units, size_t *hbm_total, size_t *hbm_free,
+                           char *arch_name, size_t arch_name_len)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_HIP_TRY(hipSetDevice(ctx->device));
+    if (compute_units) *compute_units = ctx->compute_units;
+    if (hbm_total || hbm_free) {
+        size_t f = 0, t = 0;
+        RLS_HIP_TRY(hipMemGetInfo(&f, &t));
+        if (hbm_total) *hbm_total = t;
+        if (hbm_free) *hbm_free = f;
+    }
+    if (arch_name && arch_name_len > 0) {
+        hipDeviceProp_t prop;
+        RLS_HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+        strncpy(arch_name, prop.gcnArchName, arch_name_len - 1);
+        arch_name[arch_name_len - 1] = '\0';
+    }
+    return RLS_OK;
+}
+
+rls_status rls_device_alloc(rls_context *ctx, size_t bytes, void **out)
+{
+    RLS_REQUIRE(ctx != nullptr && out != nullptr, "NULL argument");
+    *out = nullptr;
+    if (bytes == 0) return RLS_OK;
+    RLS_HIP_TRY(hipSetDevice(ctx->device));
+    RLS_HIP_TRY(hipMalloc(out, bytes));
+    return RLS_OK;
+}
+
+rls_status rls_device_free(rls_context *ctx, void *p)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    if (!p) return RLS_OK;
+    RLS_HIP_TRY(hipSetDevice(ctx->device));
+    RLS_HIP_TRY(hipFree(p));
+    return RLS_OK;
+}
+
+rls_status rls_copy_to_device(rls_context *ctx, void *dst, const void *src_host, size_t bytes)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    if (bytes == 0) return RLS_OK;
+    RLS_REQUIRE(dst != nullptr && src_host != nullptr, "NULL buffer");
+    RLS_HIP_TRY(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    RLS_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RLS_OK;
+}
+
+rls_status rls_copy_to_host(rls_context *ctx, void *dst_host, const void *src, size_t bytes)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    if (bytes == 0) return RLS_OK;
+    RLS_REQUIRE(dst_host != nullptr && src != nullptr, "NULL buffer");
+    RLS_HIP_TRY(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RLS_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RLS_OK;
+}
+
+rls_status rls_timer_start(rls_context *ctx)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
+    return RLS_OK;
+}
+
+rls_status rls_timer_stop(rls_context *ctx)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
+    return RLS_OK;
+}
+
+rls_status rls_timer_elapsed_ms(rls_context *ctx, float *ms)
+{
+    RLS_REQUIRE(ctx != nullptr && ms != nullptr, "NULL argument");
+    RLS_HIP_TRY(hipEventSynchronize(ctx->ev_stop));
+    RLS_HIP_TRY(hipEventElapsedTime(ms, ctx->ev_start, ctx->ev_stop));
+    return RLS_OK;
+}
+
+} // extern "C"
+
+// ---- generator kernels -----------------------------------------------------------------------
+namespace {
+
+// stream ids shared with oracle/rls_oracle.h
+enum { S_N0 = 0, S_N1, S_T, S_WO0, S_WO1, S_ROUGH, S_IOR, S_ANISO };
+
+__device__ __forceinline__ void circle_point(float u, float &c, float &s)
+{
+    float t = 4.0f * u;
+    int q = (int)t;
+    float f = t - (float)q;
+    float a = 1.0f - f, b = f;
+    float l = sqrtf(a * a + b * b);
+    a = a / l; b = b / l;
+    switch (q & 3) {
+    case 0: c = a;  s = b;  break;
+    case 1: c = -b; s = a;  break;
+    case 2: c = -a; s = -b; break;
+    default: c = b; s = -a; break;
+    }
+}
+
+__device__ __forceinline__ V3 normalize_div(V3 a)
+{
+    float l = length(a);
+    return mk(a.x / l, a.y / l, a.z / l);
+}
+
+__global__ __launch_bounds__(rlsh::kBlock) void gen_frame_kernel(uint32_t seed, uint64_t first, int64_t n,
+                                                                 rls_vec3 wo, rls_vec3 N, rls_vec3 T)
+{
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        uint64_t i = first + (uint64_t)k;
+        float u0 = hash_u01(seed, i, S_N0);
+        float z = 1.0f - 2.0f * u0;
+        float rr = sqrtf(maxf(0.0f, 1.0f - z * z));
+        float c, s;
+        circle_point(hash_u01(seed, i, S_N1), c, s);
+        V3 Nn = normalize_div(mk(rr * c, rr * s, z));
+
+        V3 e = absf(Nn.x) < 0.57735f ? mk(1.0f, 0.0f, 0.0f) : mk(0.0f, 1.0f, 0.0f);
+        V3 T0 = normalize_div(cross(e, Nn));
+        V3 B0 = cross(Nn, T0);
+        circle_point(hash_u01(seed, i, S_T), c, s);
+        V3 Tt = T0 * c + B0 * s;
+        Tt = Tt - Nn * dot(Tt, Nn);
+        Tt = normalize_div(Tt);
+        V3 Bt = cross(Nn, Tt);
+
+        float ct = 0.02f + 0.98f * hash_u01(seed, i, S_WO0);
+        float st = sqrtf(maxf(0.0f, 1.0f - ct * ct));
+        circle_point(hash_u01(seed, i, S_WO1), c, s);
+        V3 w = (Tt * c + Bt * s) * st + Nn * ct;
+        w = normalize_div(w);
+
+        N.x[k] = Nn.x; N.y[k] = Nn.y; N.z[k] = Nn.z;
+        T.x[k] = Tt.x; T.y[k] = Tt.y; T.z[k] = Tt.z;
+        wo.x[k] = w.x; wo.y[k] = w.y; wo.z[k] = w.z;
+    }
+}
+
+__global__ __launch_bounds__(rlsh::kBlock) void gen_uniform_kernel(uint32_t seed, uint64_t first, int64_t n,
+                                                                   uint32_t stream, float lo, float span, float *out)
+{
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        out[k] = lo + span * hash_u01(seed, first + (uint64_t)k, stream);
+    }
+}
+
+__global__ __launch_bounds__(rlsh::kBlock) void gen_aniso_kernel(uint32_t seed, uint64_t first, int64_t n, float *out)
+{
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        uint64_t i = first + (uint64_t)k;
+        out[k] = (i & 1ULL) ? hash_u01(seed, i, S_ANISO) : 0.0f;
+    }
+}
+
+// Order-independent checksum: sum over elements of a 64-bit hash of (bit pattern, low index bits
+// are NOT mixed in, so the same multiset of values gives the same sum in any order).
+__global__ __launch_bounds__(rlsh::kBlock) void checksum_kernel(int64_t n, const float *data, unsigned long long *acc)
+{
+    unsigned long long local = 0;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t b = __float_as_uint(data[k]);
+        uint64_t h = ((uint64_t)mix32(b ^ 0x68bc21ebU) << 32) | (uint64_t)mix32(b + 0x02e5be93U);
+        local += h;
+    }
+    // wave64 butterfly, then one atomic per wavefront
+    for (int off = 32; off > 0; off >>= 1) {
+        local += __shfl_xor(local, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) atomicAdd(acc, local);
+}
+
+} // namespace
+
+extern "C" {
+
+rls_status rls_gen_frame(rls_context *ctx, uint32_t seed, uint64_t first_index, int64_t n,
+                         rls_vec3 wo, rls_vec3 N, rls_vec3 T)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return RLS_OK;
+    RLS_REQUIRE(rlsh::has3(wo) && rlsh::has3(N) && rlsh::has3(T), "NULL output plane");
+    hipLaunchKernelGGL(gen_frame_kernel, rlsh::grid_for(ctx, n), dim3(rlsh::kBlock), 0, ctx->stream,
+                       seed, first_index, n, wo, N, T);
+    return rlsh::check_launch("gen_frame_kernel");
+}
+
+rls_status rls_gen_uniform(rls_context *ctx, uint32_t seed, uint64_t first_index, int64_t n,
+                           uint32_t stream, float lo, float hi, float *out)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return RLS_OK;
+    RLS_REQUIRE(out != nullptr, "out is NULL");
+    hipLaunchKernelGGL(gen_uniform_kernel, rlsh::grid_for(ctx, n), dim3(rlsh::kBlock), 0, ctx->stream,
+                       seed, first_index, n, stream, lo, hi - lo, out);
+    return rlsh::check_launch("gen_uniform_kernel");
+}
+
+rls_status rls_gen_aniso(rls_context *ctx, uint32_t seed, uint64_t first_index, int64_t n, float *out)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return RLS_OK;
+    RLS_REQUIRE(out != nullptr, "out is NULL");
+    hipLaunchKernelGGL(gen_aniso_kernel, rlsh::grid_for(ctx, n), dim3(rlsh::kBlock), 0, ctx->stream,
+                       seed, first_index, n, out);
+    return rlsh::check_launch("gen_aniso_kernel");
+}
+
+rls_status rls_checksum(rls_context *ctx, int64_t n, const float *data, uint64_t *out_host)
+{
+    RLS_REQUIRE(ctx != nullptr && out_host != nullptr, "NULL argument");
+    RLS_REQUIRE(n >= 0, "n < 0");
+    *out_host = 0;
+    if (n == 0) return RLS_OK;
+    RLS_REQUIRE(data != nullptr, "data is NULL");
+    RLS_HIP_TRY(hipMemsetAsync(ctx->scratch_u64, 0, sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(checksum_kernel, rlsh::grid_for(ctx, n), dim3(rlsh::kBlock), 0, ctx->stream,
+                       n, data, ctx->scratch_u64);
+    rls_status st = rlsh::check_launch("checksum_kernel");
+    if (st != RLS_OK) return st;
+    unsigned long long v = 0;
+    RLS_HIP_TRY(hipMemcpyAsync(&v, ctx->scratch_u64, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+    RLS_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *out_host = (uint64_t)v;
+    return RLS_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,146 @@
+// disney.hip -- rlDisney closure kernels (DisneySampler, src/rlDisney.cpp:105-602 of the
+// reference) and their C-ABI entry points.  gfx950, wave64, one shading point per lane.
+//
+// Roofline: HBM for the 1-sample calls.  Algorithmic bytes per point with every parameter
+// streamed: 88 B of closure (wo3 N3 T3 base3 + 10 scalars) + 8 B xi in, 28 B out (wi3 f3 pdf).
+#include "rls_internal.hpp"
+
+using namespace rlsd;
+
+namespace {
+
+enum DisneyOp { OP_SAMPLE, OP_EVAL, OP_PDF, OP_FUSED };
+
+struct DisneyIO {
+    rls_disney_closure c;
+    const float *rx, *ry;
+    rls_cvec3 cwi;
+    rls_vec3 wi;
+    rls_rgb f;
+    float *pdf;
+    int64_t n;
+};
+
+__device__ __forceinline__ Disney load_closure(const rls_disney_closure &c, int64_t i)
+{
+    V3 wo = ld3(c.wo, i), N = ld3(c.N, i), T = ld3(c.T, i);
+    float br, bg, bb;
+    ldrgb(c.base_color, i, br, bg, bb);
+    float s[10];
+    s[0] = ldp(c.subsurface, i);
+    s[1] = ldp(c.metallic, i);
+    s[2] = ldp(c.specular, i);
+    s[3] = ldp(c.specular_tint, i);
+    s[4] = ldp(c.roughness, i);
+    s[5] = ldp(c.anisotropic, i);
+    s[6] = ldp(c.sheen, i);
+    s[7] = ldp(c.sheen_tint, i);
+    s[8] = ldp(c.clearcoat, i);
+    s[9] = ldp(c.clearcoat_gloss, i);
+    return disney_make(wo, N, T, br, bg, bb, s);
+}
+
+template <int OP, bool DIFFUSE>
+__global__ __launch_bounds__(rlsh::kBlock) void disney_kernel(DisneyIO a)
+{
+    const int64_t stride = (int64_t)gridDim.x * rlsh::kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * rlsh::kBlock + threadIdx.x; i < a.n; i += stride) {
+        Disney d = load_closure(a.c, i);
+        V3 L;
+        if (OP == OP_SAMPLE || OP == OP_FUSED) {
+            float rx = ldg(a.rx, i), ry = ldg(a.ry, i);
+            if (DIFFUSE) {
+                L = cosine_hemisphere(d.fr, rx, ry);                  // src/rlDisney.cpp:359-365
+            } else {
+                VndfView w = vndf_view(d.view, d.fr, d.ax, d.ay);
+                L = disney_sample_specular(d, w, rx, ry);             // src/rlDisney.cpp:367-390
+            }
+            st3(a.wi, i, L);
+        } else {
+            L = ld3(a.cwi, i);
+        }
+        if (OP == OP_EVAL || OP == OP_FUSED) {
+            float r, g, b;
+            disney_eval<DIFFUSE>(d, L, r, g, b);
+            strgb(a.f, i, r, g, b);
+        }
+        if (OP == OP_PDF || OP == OP_FUSED) {
+            stg(a.pdf, i, disney_pdf<DIFFUSE>(d, L));
+        }
+    }
+}
+
+rls_status check_closure(const rls_disney_closure *c, int lobe)
+{
+    RLS_REQUIRE(c != nullptr, "closure is NULL");
+    RLS_REQUIRE(lobe == RLS_RAY_DIFFUSE || lobe == RLS_RAY_GLOSSY, "lobe must be RLS_RAY_DIFFUSE or RLS_RAY_GLOSSY");
+    RLS_REQUIRE(rlsh::has3(c->wo) && rlsh::has3(c->N) && rlsh::has3(c->T), "wo/N/T plane is NULL");
+    RLS_REQUIRE(rlsh::ok_rgb(c->base_color), "base_color planes must be all set or all NULL");
+    return RLS_OK;
+}
+
+template <int OP>
+rls_status launch(rls_context *ctx, int lobe, const DisneyIO &io, const char *name)
+{
+    dim3 grid = rlsh::grid_for(ctx, io.n);
+    if (lobe == RLS_RAY_DIFFUSE)
+        hipLaunchKernelGGL((disney_kernel<OP, true>), grid, dim3(rlsh::kBlock), 0, ctx->stream, io);
+    else
+        hipLaunchKernelGGL((disney_kernel<OP, false>), grid, dim3(rlsh::kBlock), 0, ctx->stream, io);
+    return rlsh::check_launch(name);
+}
+
+} // namespace
+
+#define RLS_PROLOGUE()                                   \
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");          \
+    RLS_REQUIRE(n >= 0, "n < 0");                        \
+    if (n == 0) return RLS_OK;                           \
+    { rls_status _s = check_closure(c, lobe); if (_s != RLS_OK) return _s; }
+
+extern "C" {
+
+rls_status rls_disney_sample(rls_context *ctx, int64_t n, const rls_disney_closure *c, int lobe,
+                             const float *rx, const float *ry, rls_vec3 wi)
+{
+    RLS_PROLOGUE();
+    RLS_REQUIRE(rx && ry, "rx/ry is NULL");
+    RLS_REQUIRE(rlsh::has3(wi), "wi plane is NULL");
+    DisneyIO io = {};
+    io.c = *c; io.rx = rx; io.ry = ry; io.wi = wi; io.n = n;
+    return launch<OP_SAMPLE>(ctx, lobe, io, "rls_disney_sample");
+}
+
+rls_status rls_disney_eval(rls_context *ctx, int64_t n, const rls_disney_closure *c, int lobe,
+                           rls_cvec3 wi, rls_rgb f)
+{
+    RLS_PROLOGUE();
+    RLS_REQUIRE(rlsh::has3(wi) && rlsh::has3(f), "wi/f plane is NULL");
+    DisneyIO io = {};
+    io.c = *c; io.cwi = wi; io.f = f; io.n = n;
+    return launch<OP_EVAL>(ctx, lobe, io, "rls_disney_eval");
+}
+
+rls_status rls_disney_pdf(rls_context *ctx, int64_t n, const rls_disney_closure *c, int lobe,
+                          rls_cvec3 wi, float *pdf)
+{
+    RLS_PROLOGUE();
+    RLS_REQUIRE(rlsh::has3(wi) && pdf, "wi/pdf is NULL");
+    DisneyIO io = {};
+    io.c = *c; io.cwi = wi; io.pdf = pdf; io.n = n;
+    return launch<OP_PDF>(ctx, lobe, io, "rls_disney_pdf");
+}
+
+rls_status rls_disney_sample_eval_pdf(rls_context *ctx, int64_t n, const rls_disney_closure *c, int lobe,
+                                      const float *rx, const float *ry,
+                                      rls_vec3 wi, rls_rgb f, float *pdf)
+{
+    RLS_PROLOGUE();
+    RLS_REQUIRE(rx && ry, "rx/ry is NULL");
+    RLS_REQUIRE(rlsh::has3(wi) && rlsh::has3(f) && pdf, "wi/f/pdf is NULL");
+    DisneyIO io = {};
+    io.c = *c; io.rx = rx; io.ry = ry; io.wi = wi; io.f = f; io.pdf = pdf; io.n = n;
+    return launch<OP_FUSED>(ctx, lobe, io, "rls_disney_sample_eval_pdf");
+}
+
+} // extern "C"

@@ -1,0 +1,219 @@
+// ggx.hip -- rlGgx closure kernels (rls::GgxSamplerT<VNDFKernel>, src/rlGgx.h:92-373 and
+// src/rlGgx.cpp:14-99 of the reference) and their C-ABI entry points.  gfx950, wave64, one
+// shading point per lane, planar SoA streams, grid-stride over the batch.
+//
+// Roofline: HBM.  Algorithmic bytes per point (all planes streamed): reflect triple 64 B in
+// (wo3 N3 T3 Ks3 rough ior xi2) + 32 B out (wi3 f3 pdf F) = 96 B; reflect+refract 72 B in +
+// 48 B out = 120 B; +4 B when `anisotropic` is a stream.
+#include "rls_internal.hpp"
+
+using namespace rlsd;
+
+namespace {
+
+enum GgxOp { OP_SAMPLE, OP_EVAL, OP_PDF, OP_FUSED, OP_REFRACT, OP_REFLECT_REFRACT, OP_MICROFACET, OP_NDF_PDF };
+
+struct GgxIO {
+    rls_ggx_closure c;
+    const float *rx, *ry, *rx2, *ry2;
+    rls_cvec3 cwi;
+    rls_vec3 wi;
+    rls_rgb f;
+    float *pdf, *fresnel;
+    rls_vec3 wt;
+    float *weight;
+    uint8_t *refracted;
+    int64_t n;
+    int kernel;
+};
+
+__device__ __forceinline__ Ggx load_closure(const rls_ggx_closure &c, int64_t i)
+{
+    V3 wo = ld3(c.wo, i), N = ld3(c.N, i), T = ld3(c.T, i);
+    float kr, kg, kb;
+    ldrgb(c.KsColor, i, kr, kg, kb);
+    float rough = ldp(c.specularRoughness, i);
+    float ior = ldp(c.ior, i);
+    float aniso = ldp(c.anisotropic, i);
+    bool exiting = c.exiting ? (c.exiting[i] != 0) : false;
+    return ggx_make(wo, N, T, exiting, kr, kg, kb, ior, rough, aniso);
+}
+
+template <int OP>
+__global__ __launch_bounds__(rlsh::kBlock) void ggx_kernel(GgxIO a)
+{
+    const int64_t stride = (int64_t)gridDim.x * rlsh::kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * rlsh::kBlock + threadIdx.x; i < a.n; i += stride) {
+        Ggx g = load_closure(a.c, i);
+
+        if (OP == OP_SAMPLE || OP == OP_FUSED || OP == OP_REFLECT_REFRACT) {
+            float rx = ldg(a.rx, i), ry = ldg(a.ry, i);
+            VndfView w = vndf_view(g.view, g.fr, g.ax, g.ay);
+            // evalSample: src/rlGgx.h:97-107
+            V3 M = vndf_microfacet(w, g.fr, rx, ry);
+            V3 L = reflect_direction(g.view, M);
+            float F = ggx_fresnel(g, L, M);
+            st3(a.wi, i, L);
+            if (a.fresnel) stg(a.fresnel, i, F);
+            if (OP != OP_SAMPLE) {
+                float fr, fg, fb;
+                ggx_eval(g, L, fr, fg, fb);
+                strgb(a.f, i, fr, fg, fb);
+                stg(a.pdf, i, ggx_pdf(g, L));
+            }
+            if (OP == OP_REFLECT_REFRACT) {
+                // second sample on the same closure: the view analysis is reused
+                float rx2 = ldg(a.rx2, i), ry2 = ldg(a.ry2, i);
+                V3 M2 = vndf_microfacet(w, g.fr, rx2, ry2);
+                V3 dir;
+                ggx_refract(g, M2, dir);
+                st3(a.wt, i, dir);
+                stg(a.weight, i, ggx_sample_weight(g, g.view, dir, M2));
+            }
+        } else if (OP == OP_EVAL) {
+            float fr, fg, fb;
+            ggx_eval(g, ld3(a.cwi, i), fr, fg, fb);
+            strgb(a.f, i, fr, fg, fb);
+        } else if (OP == OP_PDF) {
+            stg(a.pdf, i, ggx_pdf(g, ld3(a.cwi, i)));
+        } else if (OP == OP_REFRACT) {
+            float rx = ldg(a.rx, i), ry = ldg(a.ry, i);
+            VndfView w = vndf_view(g.view, g.fr, g.ax, g.ay);
+            V3 M = vndf_microfacet(w, g.fr, rx, ry);
+            V3 dir;
+            bool ok = ggx_refract(g, M, dir);
+            st3(a.wt, i, dir);
+            stg(a.weight, i, ggx_sample_weight(g, g.view, dir, M));
+            if (a.refracted) a.refracted[i] = ok ? 1 : 0;
+        } else if (OP == OP_MICROFACET) {
+            float rx = ldg(a.rx, i), ry = ldg(a.ry, i);
+            V3 M;
+            if (a.kernel == RLS_KERNEL_NDF) {
+                M = ndf_microfacet(g, rx, ry);
+            } else {
+                VndfView w = vndf_view(g.view, g.fr, g.ax, g.ay);
+                M = vndf_microfacet(w, g.fr, rx, ry);
+            }
+            st3(a.wi, i, M);
+        } else if (OP == OP_NDF_PDF) {
+            V3 H = normalize(g.view + ld3(a.cwi, i));
+            stg(a.pdf, i, ndf_pdf(g, g.view, H));
+        }
+    }
+}
+
+rls_status check_closure(const rls_ggx_closure *c)
+{
+    RLS_REQUIRE(c != nullptr, "closure is NULL");
+    RLS_REQUIRE(rlsh::has3(c->wo) && rlsh::has3(c->N) && rlsh::has3(c->T), "wo/N/T plane is NULL");
+    RLS_REQUIRE(rlsh::ok_rgb(c->KsColor), "KsColor planes must be all set or all NULL");
+    return RLS_OK;
+}
+
+template <int OP>
+rls_status launch(rls_context *ctx, const GgxIO &io, const char *name)
+{
+    hipLaunchKernelGGL(ggx_kernel<OP>, rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
+    return rlsh::check_launch(name);
+}
+
+} // namespace
+
+#define RLS_PROLOGUE()                                   \
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");          \
+    RLS_REQUIRE(n >= 0, "n < 0");                        \
+    if (n == 0) return RLS_OK;                           \
+    { rls_status _s = check_closure(c); if (_s != RLS_OK) return _s; }
+
+extern "C" {
+
+rls_status rls_ggx_sample(rls_context *ctx, int64_t n, const rls_ggx_closure *c,
+                          const float *rx, const float *ry, rls_vec3 wi, float *fresnel)
+{
+    RLS_PROLOGUE();
+    RLS_REQUIRE(rx && ry, "rx/ry is NULL");
+    RLS_REQUIRE(rlsh::has3(wi), "wi plane is NULL");
+    GgxIO io = {};
+    io.c = *c; io.rx = rx; io.ry = ry; io.wi = wi; io.fresnel = fresnel; io.n = n;
+    return launch<OP_SAMPLE>(ctx, io, "rls_ggx_sample");
+}
+
+rls_status rls_ggx_eval(rls_context *ctx, int64_t n, const rls_ggx_closure *c, rls_cvec3 wi, rls_rgb f)
+{
+    RLS_PROLOGUE();
+    RLS_REQUIRE(rlsh::has3(wi) && rlsh::has3(f), "wi/f plane is NULL");
+    GgxIO io = {};
+    io.c = *c; io.cwi = wi; io.f = f; io.n = n;
+    return launch<OP_EVAL>(ctx, io, "rls_ggx_eval");
+}
+
+rls_status rls_ggx_pdf(rls_context *ctx, int64_t n, const rls_ggx_closure *c, rls_cvec3 wi, float *pdf)
+{
+    RLS_PROLOGUE();
+    RLS_REQUIRE(rlsh::has3(wi) && pdf, "wi/pdf is NULL");
+    GgxIO io = {};
+    io.c = *c; io.cwi = wi; io.pdf = pdf; io.n = n;
+    return launch<OP_PDF>(ctx, io, "rls_ggx_pdf");
+}
+
+rls_status rls_ggx_sample_eval_pdf(rls_context *ctx, int64_t n, const rls_ggx_closure *c,
+                                   const float *rx, const float *ry,
+                                   rls_vec3 wi, rls_rgb f, float *pdf, float *fresnel)
+{
+    RLS_PROLOGUE();
+    RLS_REQUIRE(rx && ry, "rx/ry is NULL");
+    RLS_REQUIRE(rlsh::has3(wi) && rlsh::has3(f) && pdf, "wi/f/pdf is NULL");
+    GgxIO io = {};
+    io.c = *c; io.rx = rx; io.ry = ry; io.wi = wi; io.f = f; io.pdf = pdf; io.fresnel = fresnel; io.n = n;
+    return launch<OP_FUSED>(ctx, io, "rls_ggx_sample_eval_pdf");
+}
+
+rls_status rls_ggx_refract_sample(rls_context *ctx, int64_t n, const rls_ggx_closure *c,
+                                  const float *rx, const float *ry,
+                                  rls_vec3 wt, float *weight, uint8_t *refracted)
+{
+    RLS_PROLOGUE();
+    RLS_REQUIRE(rx && ry, "rx/ry is NULL");
+    RLS_REQUIRE(rlsh::has3(wt) && weight, "wt/weight is NULL");
+    GgxIO io = {};
+    io.c = *c; io.rx = rx; io.ry = ry; io.wt = wt; io.weight = weight; io.refracted = refracted; io.n = n;
+    return launch<OP_REFRACT>(ctx, io, "rls_ggx_refract_sample");
+}
+
+rls_status rls_ggx_reflect_refract(rls_context *ctx, int64_t n, const rls_ggx_closure *c,
+                                   const float *rx, const float *ry, const float *rx2, const float *ry2,
+                                   rls_vec3 wi, rls_rgb f, float *pdf, float *fresnel,
+                                   rls_vec3 wt, float *weight)
+{
+    RLS_PROLOGUE();
+    RLS_REQUIRE(rx && ry && rx2 && ry2, "random-number plane is NULL");
+    RLS_REQUIRE(rlsh::has3(wi) && rlsh::has3(f) && pdf, "wi/f/pdf is NULL");
+    RLS_REQUIRE(rlsh::has3(wt) && weight, "wt/weight is NULL");
+    GgxIO io = {};
+    io.c = *c; io.rx = rx; io.ry = ry; io.rx2 = rx2; io.ry2 = ry2;
+    io.wi = wi; io.f = f; io.pdf = pdf; io.fresnel = fresnel; io.wt = wt; io.weight = weight; io.n = n;
+    return launch<OP_REFLECT_REFRACT>(ctx, io, "rls_ggx_reflect_refract");
+}
+
+rls_status rls_ggx_microfacet(rls_context *ctx, int64_t n, const rls_ggx_closure *c, int kernel,
+                              const float *rx, const float *ry, rls_vec3 m)
+{
+    RLS_PROLOGUE();
+    RLS_REQUIRE(kernel == RLS_KERNEL_VNDF || kernel == RLS_KERNEL_NDF, "unknown sampling kernel");
+    RLS_REQUIRE(rx && ry, "rx/ry is NULL");
+    RLS_REQUIRE(rlsh::has3(m), "m plane is NULL");
+    GgxIO io = {};
+    io.c = *c; io.rx = rx; io.ry = ry; io.wi = m; io.kernel = kernel; io.n = n;
+    return launch<OP_MICROFACET>(ctx, io, "rls_ggx_microfacet");
+}
+
+rls_status rls_ggx_ndf_pdf(rls_context *ctx, int64_t n, const rls_ggx_closure *c, rls_cvec3 wi, float *pdf)
+{
+    RLS_PROLOGUE();
+    RLS_REQUIRE(rlsh::has3(wi) && pdf, "wi/pdf is NULL");
+    GgxIO io = {};
+    io.c = *c; io.cwi = wi; io.pdf = pdf; io.n = n;
+    return launch<OP_NDF_PDF>(ctx, io, "rls_ggx_ndf_pdf");
+}
+
+} // extern "C"

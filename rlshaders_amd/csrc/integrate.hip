@@ -1,0 +1,276 @@
+// integrate.hip -- n^2-samples-per-point integrators for rlGgx and rlDisney: the per-sample loop
+// arithmetic of the reference's glossy / diffuse integration (the loops Arnold's AiBRDFIntegrate
+// runs over the callback triple, src/rlGgx.h:172-179, src/rlDisney.cpp:240-315; explicit form at
+// src/rlDisney.cpp:299-312) with the random numbers drawn in-kernel.
+//
+// Sampler: stand-in for the closed AiSampler(n, 2) (src/rlGgx.cpp:148, src/rlDisney.cpp:68,72):
+// a per-point XOR-scrambled (0,2)-sequence -- sample s has x = bitreverse(s) ^ scr_x,
+// y = sobol2(s) ^ scr_y -- which is stratified on every elementary interval of the n^2 samples.
+// The unscrambled table (2 x spp words) is staged in LDS once per workgroup; scrambles come from
+// the counter hash of (seed, point index).
+//
+// Mapping: G lanes cooperate on one shading point (G = 1, 4, 16 or 64, chosen on the host from
+// the batch size so that small batches still fill 256 CUs).  Lane `sub` of a group takes samples
+// sub, sub+G, ...; the closure setup (frame, alphas, stretched-view analysis) is done once per
+// lane and the partial sums are combined with wave64 butterfly shuffles.  G = 1 adds samples in
+// ascending order, exactly like the reference's `result +=` loop.
+//
+// Roofline: fp32 VALU (not HBM) in reduced mode -- 88 B of parameters in and 32 B out per point
+// against 2*n^2 triples of arithmetic (SURVEY.md section 8(d), config 3 mode R).  Streamed mode
+// writes 28 B per triple and is HBM-bound.
+#include <stdlib.h>
+
+#include "rls_internal.hpp"
+
+using namespace rlsd;
+
+namespace {
+
+constexpr int kMaxSpp = 256;   // spp_n <= 16
+
+// stream ids of the per-point scrambles (oracle/rls_oracle.h: ORC_S_SCRAMBLE)
+constexpr uint32_t kScrambleStream = 64;
+
+__device__ __forceinline__ uint32_t sobol2(uint32_t s)
+{
+    uint32_t r = 0;
+    for (uint32_t v = 1u << 31; s != 0; s >>= 1, v ^= v >> 1) {
+        if (s & 1u) r ^= v;
+    }
+    return r;
+}
+
+__device__ __forceinline__ float bits_u01(uint32_t b) { return (float)(b >> 8) * (1.0f / 16777216.0f); }
+
+__device__ __forceinline__ void stage_table(uint32_t (*tab)[kMaxSpp], int spp)
+{
+    for (int t = threadIdx.x; t < spp; t += rlsh::kBlock) {
+        tab[0][t] = __brev((uint32_t)t);
+        tab[1][t] = sobol2((uint32_t)t);
+    }
+    __syncthreads();
+}
+
+template <int G>
+__device__ __forceinline__ float group_sum(float v)
+{
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+struct GgxIntIO {
+    rls_ggx_closure c;
+    rls_rgb sum;
+    float *avgF;
+    int64_t n;
+    int spp;
+    uint32_t seed;
+};
+
+template <int G>
+__global__ __launch_bounds__(rlsh::kBlock) void ggx_integrate_kernel(GgxIntIO a)
+{
+    __shared__ uint32_t tab[2][kMaxSpp];
+    stage_table(tab, a.spp);
+    const int sub = threadIdx.x % G;
+    const int64_t groups_per_block = rlsh::kBlock / G;
+    const int64_t stride = (int64_t)gridDim.x * groups_per_block;
+    // all lanes of a wave iterate the same number of times (shuffles need every lane live)
+    const int64_t rounds = (a.n + stride - 1) / stride;
+    int64_t i = (int64_t)blockIdx.x * groups_per_block + threadIdx.x / G;
+    for (int64_t it = 0; it < rounds; it++, i += stride) {
+        const bool live = i < a.n;
+        const int64_t ii = live ? i : a.n - 1;
+        const rls_ggx_closure &c = a.c;
+        V3 wo = ld3(c.wo, ii), N = ld3(c.N, ii), T = ld3(c.T, ii);
+        float kr, kg, kb;
+        ldrgb(c.KsColor, ii, kr, kg, kb);
+        bool exiting = c.exiting ? (c.exiting[ii] != 0) : false;
+        Ggx g = ggx_make(wo, N, T, exiting, kr, kg, kb, ldp(c.ior, ii), ldp(c.specularRoughness, ii),
+                         ldp(c.anisotropic, ii));
+        VndfView w = vndf_view(g.view, g.fr, g.ax, g.ay);
+        const uint32_t sx = hash_u32(a.seed, (uint64_t)ii, kScrambleStream);
+        const uint32_t sy = hash_u32(a.seed, (uint64_t)ii, kScrambleStream + 1);
+
+        float accR = 0.0f, accG = 0.0f, accB = 0.0f, accF = 0.0f;
+        for (int s = sub; s < a.spp; s += G) {
+            float rx = bits_u01(tab[0][s] ^ sx);
+            float ry = bits_u01(tab[1][s] ^ sy);
+            V3 M = vndf_microfacet(w, g.fr, rx, ry);
+            V3 L = reflect_direction(g.view, M);
+            accF += ggx_fresnel(g, L, M);                   // mReflectWeight, src/rlGgx.h:103
+            float fr, fg, fb;
+            ggx_eval(g, L, fr, fg, fb);
+            float pdf = ggx_pdf(g, L);
+            accR += fr / pdf; accG += fg / pdf; accB += fb / pdf;
+        }
+        if (G > 1) {
+            accR = group_sum<G>(accR); accG = group_sum<G>(accG);
+            accB = group_sum<G>(accB); accF = group_sum<G>(accF);
+        }
+        if (live && sub == 0) {
+            strgb(a.sum, i, accR, accG, accB);
+            // getAvgReflectWeight, src/rlGgx.h:181-184
+            stg(a.avgF, i, a.spp > 0 ? accF / (float)a.spp : 1.0f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct DisneyIntIO {
+    rls_disney_closure c;
+    rls_rgb dsum, ssum;
+    float *dcount, *scount;
+    rls_disney_stream_out st;
+    int streamed;
+    int64_t n;
+    int spp;
+    uint32_t seed;
+};
+
+template <int G>
+__global__ __launch_bounds__(rlsh::kBlock) void disney_integrate_kernel(DisneyIntIO a)
+{
+    __shared__ uint32_t tab[2][kMaxSpp];
+    stage_table(tab, a.spp);
+    const int sub = threadIdx.x % G;
+    const int64_t groups_per_block = rlsh::kBlock / G;
+    const int64_t stride = (int64_t)gridDim.x * groups_per_block;
+    const int64_t rounds = (a.n + stride - 1) / stride;
+    int64_t i = (int64_t)blockIdx.x * groups_per_block + threadIdx.x / G;
+    for (int64_t it = 0; it < rounds; it++, i += stride) {
+        const bool live = i < a.n;
+        const int64_t ii = live ? i : a.n - 1;
+        const rls_disney_closure &c = a.c;
+        V3 wo = ld3(c.wo, ii), N = ld3(c.N, ii), T = ld3(c.T, ii);
+        float br, bg, bb;
+        ldrgb(c.base_color, ii, br, bg, bb);
+        float sc[10];
+        sc[0] = ldp(c.subsurface, ii); sc[1] = ldp(c.metallic, ii); sc[2] = ldp(c.specular, ii);
+        sc[3] = ldp(c.specular_tint, ii); sc[4] = ldp(c.roughness, ii); sc[5] = ldp(c.anisotropic, ii);
+        sc[6] = ldp(c.sheen, ii); sc[7] = ldp(c.sheen_tint, ii); sc[8] = ldp(c.clearcoat, ii);
+        sc[9] = ldp(c.clearcoat_gloss, ii);
+        Disney d = disney_make(wo, N, T, br, bg, bb, sc);
+        VndfView w = vndf_view(d.view, d.fr, d.ax, d.ay);
+        const uint32_t dx = hash_u32(a.seed, (uint64_t)ii, kScrambleStream);
+        const uint32_t dy = hash_u32(a.seed, (uint64_t)ii, kScrambleStream + 1);
+        const uint32_t sx = hash_u32(a.seed, (uint64_t)ii, kScrambleStream + 2);
+        const uint32_t sy = hash_u32(a.seed, (uint64_t)ii, kScrambleStream + 3);
+
+        float dR = 0.0f, dG = 0.0f, dB = 0.0f, dC = 0.0f;
+        float sR = 0.0f, sG = 0.0f, sB = 0.0f, sC = 0.0f;
+        for (int s = sub; s < a.spp; s += G) {
+            // diffuse lobe (setSampleType(AI_RAY_DIFFUSE), src/rlDisney.cpp:242)
+            {
+                float rx = bits_u01(tab[0][s] ^ dx), ry = bits_u01(tab[1][s] ^ dy);
+                V3 L = cosine_hemisphere(d.fr, rx, ry);
+                float r, g, b;
+                disney_eval<true>(d, L, r, g, b);
+                float pdf = disney_pdf<true>(d, L);
+                if (pdf > kEps) { dR += r / pdf; dG += g / pdf; dB += b / pdf; dC += 1.0f; }
+                if (a.streamed && live) {
+                    int64_t o = (int64_t)s * a.n + i;
+                    st3(a.st.wi, o, L); strgb(a.st.f, o, r, g, b); stg(a.st.pdf, o, pdf);
+                }
+            }
+            // specular lobe (setSampleType(AI_RAY_GLOSSY), src/rlDisney.cpp:281,289)
+            {
+                float rx = bits_u01(tab[0][s] ^ sx), ry = bits_u01(tab[1][s] ^ sy);
+                V3 L = disney_sample_specular(d, w, rx, ry);
+                float r, g, b;
+                disney_eval<false>(d, L, r, g, b);
+                float pdf = disney_pdf<false>(d, L);
+                if (pdf > kEps) { sR += r / pdf; sG += g / pdf; sB += b / pdf; sC += 1.0f; }   // :309
+                if (a.streamed && live) {
+                    int64_t o = ((int64_t)a.spp + s) * a.n + i;
+                    st3(a.st.wi, o, L); strgb(a.st.f, o, r, g, b); stg(a.st.pdf, o, pdf);
+                }
+            }
+        }
+        if (G > 1) {
+            dR = group_sum<G>(dR); dG = group_sum<G>(dG); dB = group_sum<G>(dB); dC = group_sum<G>(dC);
+            sR = group_sum<G>(sR); sG = group_sum<G>(sG); sB = group_sum<G>(sB); sC = group_sum<G>(sC);
+        }
+        if (live && sub == 0) {
+            strgb(a.dsum, i, dR, dG, dB); stg(a.dcount, i, dC);
+            strgb(a.ssum, i, sR, sG, sB); stg(a.scount, i, sC);
+        }
+    }
+}
+
+// lanes per point: fill >= ~4 waves per SIMD on every CU when the batch is small
+int pick_group(const rls_context *ctx, int64_t n, int spp)
+{
+    if (const char *s = getenv("RLS_INTEGRATE_GROUP")) {
+        int g = atoi(s);
+        if (g == 1 || g == 4 || g == 16 || g == 64) return g;
+    }
+    const int64_t want_lanes = (int64_t)ctx->compute_units * 4 * 4 * 64;
+    int g = 1;
+    while (g < 64 && n * g < want_lanes && g * 4 <= spp) g *= 4;
+    return g;
+}
+
+template <typename K, typename IO>
+rls_status launch_g(rls_context *ctx, K k1, K k4, K k16, K k64, int g, const IO &io, const char *name)
+{
+    K k = g == 1 ? k1 : g == 4 ? k4 : g == 16 ? k16 : k64;
+    dim3 grid = rlsh::grid_for(ctx, io.n, rlsh::kBlock / g);
+    hipLaunchKernelGGL(k, grid, dim3(rlsh::kBlock), 0, ctx->stream, io);
+    return rlsh::check_launch(name);
+}
+
+} // namespace
+
+extern "C" {
+
+rls_status rls_ggx_integrate(rls_context *ctx, int64_t n, const rls_ggx_closure *c,
+                             int spp_n, uint32_t seed, rls_rgb sum_f_over_pdf, float *avg_reflect_weight)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_REQUIRE(n >= 0, "n < 0");
+    RLS_REQUIRE(spp_n >= 1 && spp_n * spp_n <= kMaxSpp, "spp_n must be in [1, 16]");
+    if (n == 0) return RLS_OK;
+    RLS_REQUIRE(c != nullptr, "closure is NULL");
+    RLS_REQUIRE(rlsh::has3(c->wo) && rlsh::has3(c->N) && rlsh::has3(c->T), "wo/N/T plane is NULL");
+    RLS_REQUIRE(rlsh::ok_rgb(c->KsColor), "KsColor planes must be all set or all NULL");
+    RLS_REQUIRE(rlsh::has3(sum_f_over_pdf) && avg_reflect_weight, "NULL output plane");
+    GgxIntIO io = {};
+    io.c = *c; io.sum = sum_f_over_pdf; io.avgF = avg_reflect_weight; io.n = n; io.spp = spp_n * spp_n; io.seed = seed;
+    int g = pick_group(ctx, n, io.spp);
+    return launch_g(ctx, ggx_integrate_kernel<1>, ggx_integrate_kernel<4>, ggx_integrate_kernel<16>,
+                    ggx_integrate_kernel<64>, g, io, "rls_ggx_integrate");
+}
+
+rls_status rls_disney_integrate(rls_context *ctx, int64_t n, const rls_disney_closure *c,
+                                int spp_n, uint32_t seed,
+                                rls_rgb diffuse_sum, float *diffuse_count,
+                                rls_rgb specular_sum, float *specular_count,
+                                const rls_disney_stream_out *stream)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_REQUIRE(n >= 0, "n < 0");
+    RLS_REQUIRE(spp_n >= 1 && spp_n * spp_n <= kMaxSpp, "spp_n must be in [1, 16]");
+    if (n == 0) return RLS_OK;
+    RLS_REQUIRE(c != nullptr, "closure is NULL");
+    RLS_REQUIRE(rlsh::has3(c->wo) && rlsh::has3(c->N) && rlsh::has3(c->T), "wo/N/T plane is NULL");
+    RLS_REQUIRE(rlsh::ok_rgb(c->base_color), "base_color planes must be all set or all NULL");
+    RLS_REQUIRE(rlsh::has3(diffuse_sum) && diffuse_count && rlsh::has3(specular_sum) && specular_count,
+                "NULL output plane");
+    DisneyIntIO io = {};
+    io.c = *c; io.dsum = diffuse_sum; io.dcount = diffuse_count; io.ssum = specular_sum; io.scount = specular_count;
+    io.n = n; io.spp = spp_n * spp_n; io.seed = seed;
+    if (stream) {
+        RLS_REQUIRE(rlsh::has3(stream->wi) && rlsh::has3(stream->f) && stream->pdf, "NULL streamed-output plane");
+        io.st = *stream;
+        io.streamed = 1;
+    }
+    // streamed planes are sample-major: one lane per point keeps every store coalesced
+    int g = io.streamed ? 1 : pick_group(ctx, n, io.spp);
+    return launch_g(ctx, disney_integrate_kernel<1>, disney_integrate_kernel<4>, disney_integrate_kernel<16>,
+                    disney_integrate_kernel<64>, g, io, "rls_disney_integrate");
+}
+
+} // extern "C"

@@ -1,0 +1,720 @@
+// rls_device.hpp -- device-side closure arithmetic for gfx950 (CDNA4), fp32, one shading point
+// per lane.  Hand-written for this library; the reference lines each routine reproduces are
+// cited (paths relative to the reference repository).  Build with -ffp-contract=off and without
+// fast-math: results must match the reference's CPU closures to <= 1e-5 relative.
+//
+// Structure (differs from the reference on purpose): every closure is split into
+//   * a per-point *setup* that holds everything independent of the random numbers -- frame,
+//     alphas, and for visible-normal sampling the whole stretched-view analysis with its
+//     atan2f/acosf/tanf/sincosf calls -- and
+//   * a per-sample part that is only mul/add/div/sqrt.
+// Kernels that draw several samples per point (reflect+refract, rlSkin's two GGX lobes on one
+// frame, the n^2-spp integrators) run the setup once.  The split hoists work; it never changes
+// the order of floating-point operations inside an expression.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rlsd {
+
+// ---- Arnold constants as the reference sees them (public SDK 4.x values) --------------------
+constexpr float kPi = 3.14159265f;
+constexpr float kTwoPi = 6.28318530f;
+constexpr float kHalfPi = 1.57079632f;
+constexpr float kInvPi = 0.31830988f;
+constexpr float kEps = 1e-4f;   // AI_EPSILON
+
+struct V3 { float x, y, z; };
+struct V2 { float x, y; };
+
+#define RLS_DEV __device__ __forceinline__
+
+RLS_DEV float sqr(float a) { return a * a; }
+RLS_DEV float absf(float a) { return a < 0.0f ? -a : a; }
+RLS_DEV float maxf(float a, float b) { return a > b ? a : b; }
+RLS_DEV float minf(float a, float b) { return a < b ? a : b; }
+RLS_DEV float clampf(float v, float lo, float hi) { return maxf(lo, minf(v, hi)); }
+// LERP(t, a, b) = (1 - t) * a + b * t
+RLS_DEV float lerpf(float t, float a, float b) { return ((1.0f - t) * a) + (b * t); }
+RLS_DEV float linearstep(float lo, float hi, float t) { return clampf((t - lo) / (hi - lo), 0.0f, 1.0f); }
+RLS_DEV float sgnf(float a) { return a < 0.0f ? -1.0f : 1.0f; }
+
+RLS_DEV V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+RLS_DEV V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+RLS_DEV V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+RLS_DEV V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+RLS_DEV V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+RLS_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RLS_DEV V3 cross(V3 a, V3 b)
+{
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+RLS_DEV float length(V3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+// AiV3Normalize: scale by the reciprocal length, zero vector stays zero
+RLS_DEV V3 normalize(V3 a)
+{
+    float t = length(a);
+    if (t != 0.0f) t = 1.0f / t;
+    return mk(a.x * t, a.y * t, a.z * t);
+}
+// AiV3RotateToFrame(a, u, v, w) = a.x*u + a.y*v + a.z*w
+RLS_DEV V3 to_frame(V3 a, V3 u, V3 v, V3 w)
+{
+    return mk(a.x * u.x + a.y * v.x + a.z * w.x,
+              a.x * u.y + a.y * v.y + a.z * w.y,
+              a.x * u.z + a.y * v.z + a.z * w.z);
+}
+RLS_DEV bool is_zero(V3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
+RLS_DEV bool is_finite3(V3 a) { return isfinite(a.x) && isfinite(a.y) && isfinite(a.z); }
+
+struct Frame { V3 U, V, N; };
+
+// ---- rlUtil ----------------------------------------------------------------------------------
+// src/rlUtil.h:21-29
+RLS_DEV V3 spherical_direction(float cosTheta, float phi)
+{
+    float r = sqrtf(1.0f - sqr(cosTheta));
+    float s, c;
+    sincosf(phi, &s, &c);
+    return mk(r * c, r * s, cosTheta);
+}
+// src/rlUtil.h:31-34
+RLS_DEV V3 reflect_direction(V3 i, V3 n) { return n * (2.0f * absf(dot(i, n))) - i; }
+// src/rlUtil.h:36-39
+RLS_DEV float luminance(float r, float g, float b) { return r * 0.212671f + g * 0.715160f + b * 0.072169f; }
+// src/rlUtil.cpp:3-27
+RLS_DEV V2 concentric_disk(float rx, float ry)
+{
+    rx = rx * 2.0f - 1.0f;
+    ry = ry * 2.0f - 1.0f;
+    V2 out;
+    if (rx == 0.0f && ry == 0.0f) {
+        out.x = 0.0f; out.y = 0.0f;
+        return out;
+    }
+    float r, phi;
+    if (absf(rx) > absf(ry)) {
+        r = rx;
+        phi = kHalfPi * 0.5f * ry / rx;
+    } else {
+        r = ry;
+        phi = kHalfPi * (1.0f - 0.5f * rx / ry);
+    }
+    float s, c;
+    sincosf(phi, &s, &c);
+    out.x = r * c;
+    out.y = r * s;
+    return out;
+}
+// cosine hemisphere in a frame: src/rlDisney.cpp:359-365, src/rlSss.h:536-545
+RLS_DEV V3 cosine_hemisphere(const Frame &fr, float rx, float ry)
+{
+    V2 d = concentric_disk(rx, ry);
+    float z = sqrtf(maxf(0.0f, 1.0f - sqr(d.x) - sqr(d.y)));
+    return to_frame(mk(d.x, d.y, z), fr.U, fr.V, fr.N);
+}
+
+// ---- visible-normal sampling (Heitz & d'Eon), src/rlGgx.cpp:14-99 == src/rlDisney.cpp:416-502
+// Per-point part: everything up to (and inside sampleSlope, everything before) the first use of
+// the random numbers.
+struct VndfView {
+    float ax, ay;
+    float cosPhi, sinPhi;   // of the stretched view azimuth
+    float B, B2, G1, invB;  // tanf(theta) terms (valid when !nearNormal)
+    bool nearNormal;        // theta < AI_EPSILON -> uniform slope sample
+};
+
+RLS_DEV VndfView vndf_view(V3 view, const Frame &fr, float ax, float ay)
+{
+    VndfView w;
+    w.ax = ax; w.ay = ay;
+    float cosThetaV = clampf(dot(fr.N, view), -1.0f, 1.0f);
+    float phiV = atan2f(dot(fr.V, view), dot(fr.U, view));
+    V3 v = spherical_direction(cosThetaV, phiV);
+    v.x *= ax;
+    v.y *= ay;
+    v = normalize(v);
+
+    float theta = 0.0f, phi = 0.0f;
+    if (v.z < (1.0f - kEps)) {
+        theta = acosf(v.z);
+        phi = atan2f(v.y, v.x);
+    }
+    sincosf(phi, &w.sinPhi, &w.cosPhi);
+    w.nearNormal = theta < kEps;
+    float B = tanf(theta);
+    w.B = B;
+    w.B2 = sqr(B);
+    w.G1 = 2.0f / (1.0f + sqrtf(1.0f + w.B2));
+    w.invB = 1.0f / B;
+    return w;
+}
+
+// uniformSample lambda, src/rlGgx.cpp:18-25
+RLS_DEV V2 uniform_slope(float rx, float ry)
+{
+    float r = sqrtf(rx / (1.0f - rx));
+    float phi = kTwoPi * ry;
+    float s, c;
+    sincosf(phi, &s, &c);
+    V2 slope;
+    slope.x = r * c;
+    slope.y = r * s;
+    return slope;
+}
+
+// Per-sample part of sampleSlope + evalSample: src/rlGgx.cpp:36-60, 89-98
+RLS_DEV V3 vndf_microfacet(const VndfView &w, const Frame &fr, float rx, float ry)
+{
+    V2 slope;
+    float A = 2.0f * rx / w.G1 - 1.0f;
+    float A2 = sqr(A);
+    if (w.nearNormal || absf(A2 - 1.0f) < kEps) {
+        slope = uniform_slope(rx, ry);
+    } else {
+        float tmp = 1.0f / (A2 - 1.0f);
+        float D = sqrtf(maxf(0.0f, w.B2 * sqr(tmp) - (A2 - w.B2) * tmp));
+        float slopeX1 = w.B * tmp - D;
+        float slopeX2 = w.B * tmp + D;
+        slope.x = (A < 0.0f || slopeX2 > w.invB) ? slopeX1 : slopeX2;
+
+        float sign = 1.0f;
+        float u;
+        if (ry > 0.5f) {
+            u = 2.0f * (ry - 0.5f);
+        } else {
+            sign = -1.0f;
+            u = 2.0f * (0.5f - ry);
+        }
+        float z = (u * (u * (u * 0.27385f - 0.73369f) + 0.46341f))
+                / (u * (u * (u * 0.093073f + 0.309420f) - 1.0f) + 0.597999f);
+        slope.y = sign * z * sqrtf(1.0f + sqr(slope.x));
+    }
+    V3 omega;
+    omega.x = -(w.cosPhi * slope.x - w.sinPhi * slope.y) * w.ax;
+    omega.y = -(w.sinPhi * slope.x + w.cosPhi * slope.y) * w.ay;
+    omega.z = 1.0f;
+    return normalize(to_frame(omega, fr.U, fr.V, fr.N));
+}
+
+// ---- rlGgx closure state, src/rlGgx.h:130-156 ---------------------------------------------------
+struct Ggx {
+    Frame fr;
+    V3 view;
+    float ksR, ksG, ksB;
+    float rough;          // mRoughness = max(1e-5, r^2)
+    float ax, ay;
+    float iorIn, iorOut;
+};
+
+RLS_DEV Ggx ggx_make(V3 wo, V3 N, V3 T, bool exiting, float ksR, float ksG, float ksB,
+                     float ior, float roughness, float anisotropic)
+{
+    Ggx g;
+    g.ksR = ksR; g.ksG = ksG; g.ksB = ksB;
+    float in = 1.0f, out = maxf(ior, 1e-4f);
+    g.iorIn = exiting ? out : in;
+    g.iorOut = exiting ? in : out;
+    g.view = wo;
+    g.fr.N = N;
+    g.fr.U = T;
+    g.fr.V = cross(N, T);
+    float aspect = sqrtf(1.0f - anisotropic * 0.9f);
+    g.ax = maxf(1e-4f, sqr(roughness) / aspect);
+    g.ay = maxf(1e-4f, sqr(roughness) * aspect);
+    g.rough = maxf(1e-5f, sqr(roughness));
+    return g;
+}
+
+// src/rlGgx.h:249-270
+RLS_DEV float ggx_fresnel(const Ggx &g, V3 i, V3 m)
+{
+    float c = absf(dot(i, m));
+    float gSqr = sqr(g.iorOut / g.iorIn) - 1.0f + c * c;
+    if (gSqr < 0.0f) return 1.0f;
+    float gg = sqrtf(gSqr);
+    float gmc = gg - c;
+    float gpc = gg + c;
+    return 0.5f * sqr(gmc / gpc) * (1.0f + sqr((c * gpc - 1.0f) / (c * gmc + 1.0f)));
+}
+
+// src/rlGgx.h:332-340
+RLS_DEV float ggx_D(const Ggx &g, V3 m)
+{
+    float mu = dot(m, g.fr.U);
+    float mv = dot(m, g.fr.V);
+    float mn2 = sqr(dot(g.fr.N, m));
+    float den = g.ax * g.ay * sqr(sqr(mu / g.ax) + sqr(mv / g.ay) + mn2);
+    return kInvPi / den;
+}
+
+// src/rlGgx.h:343-357
+RLS_DEV float ggx_G1(const Ggx &g, V3 v, V3 m, V3 n)
+{
+    float vm = dot(v, m);
+    float vn = dot(v, n);
+    if (vm * vn < 0.0f) return 0.0f;
+    float cosSqr = sqr(vn);
+    float tanSqr = 1.0f / cosSqr - 1.0f;
+    float den = 1.0f + sqrtf(1.0f + sqr(g.rough) * tanSqr);
+    return 2.0f / den;
+}
+
+// src/rlGgx.h:272-275
+RLS_DEV float ggx_G(const Ggx &g, V3 i, V3 o, V3 m, V3 n) { return ggx_G1(g, i, m, n) * ggx_G1(g, o, m, n); }
+
+// reflection(), src/rlGgx.h:304-313
+RLS_DEV float ggx_reflection(const Ggx &g, V3 i, V3 o, V3 n)
+{
+    V3 hr = normalize(o + i) * sgnf(dot(i, n));
+    float rw = ggx_fresnel(g, i, hr);
+    float ln = absf(dot(o, n));
+    float vn = absf(dot(i, n));
+    return rw * ggx_G(g, i, o, hr, n) * ggx_D(g, hr) * 0.25f / (ln * vn);
+}
+
+// evalBrdf + evalReflectance, src/rlGgx.h:110-119,158-165
+RLS_DEV void ggx_eval(const Ggx &g, V3 L, float &fr, float &fg, float &fb)
+{
+    bool small = absf(g.ksR) < kEps && absf(g.ksG) < kEps && absf(g.ksB) < kEps;
+    if (is_zero(L) || small) {
+        fr = 0.0f; fg = 0.0f; fb = 0.0f;
+        return;
+    }
+    float refl = ggx_reflection(g, g.view, L, g.fr.N);
+    float ln = dot(L, g.fr.N);
+    fr = g.ksR * refl * ln;
+    fg = g.ksG * refl * ln;
+    fb = g.ksB * refl * ln;
+}
+
+// VNDFKernel::evalPdf, src/rlGgx.h:72-80
+RLS_DEV float vndf_pdf(const Ggx &g, V3 i, V3 m)
+{
+    float in = absf(dot(i, g.fr.N));
+    float pdf = ggx_D(g, m) * ggx_G1(g, i, m, g.fr.N) / in * 0.25f;
+    return maxf(pdf, kEps);
+}
+
+// evalPdf, src/rlGgx.h:121-127
+RLS_DEV float ggx_pdf(const Ggx &g, V3 L) { return vndf_pdf(g, g.view, normalize(g.view + L)); }
+
+// NDFKernel, src/rlGgx.h:33-50 (alternate, not selected by the reference)
+RLS_DEV V3 ndf_microfacet(const Ggx &g, float rx, float ry)
+{
+    float gg = sqrtf(rx / (1.0f - rx));
+    float phi = kTwoPi * ry;
+    float s, c;
+    sincosf(phi, &s, &c);
+    V3 omega = mk(gg * g.ax * c, gg * g.ay * s, 1.0f);
+    return normalize(to_frame(omega, g.fr.U, g.fr.V, g.fr.N));
+}
+RLS_DEV float ndf_pdf(const Ggx &g, V3 i, V3 m)
+{
+    float im = absf(dot(i, m));
+    float mn = absf(dot(m, g.fr.N));
+    return ggx_D(g, m) * mn * 0.25f / im;
+}
+
+// getSampleWeight, src/rlGgx.h:294-301
+RLS_DEV float ggx_sample_weight(const Ggx &g, V3 i, V3 o, V3 m)
+{
+    float ih = dot(i, m);
+    float mn = absf(dot(m, g.fr.N));
+    float in = absf(dot(i, g.fr.N));
+    return ggx_G(g, i, o, m, g.fr.N) * absf(ih / (in * mn));
+}
+
+// Refraction of sg->Rd = -view about the microfacet m, eta = iorIn/iorOut (Walter et al. EGSR'07
+// eq. 40); mirror on total internal reflection.  Stands in for the closed AiRefractRay /
+// AiReflectRay the reference calls at src/rlGgx.h:230-236.
+RLS_DEV bool ggx_refract(const Ggx &g, V3 m, V3 &dir)
+{
+    V3 i = g.view;
+    float eta = g.iorIn / g.iorOut;
+    float c = dot(i, m);
+    float k = 1.0f - eta * eta * (1.0f - c * c);
+    bool refracted = !(k < 0.0f);
+    if (refracted) {
+        float s = sgnf(dot(i, g.fr.N));
+        float t = eta * c - s * sqrtf(k);
+        dir = m * t - i * eta;
+    } else {
+        dir = m * (2.0f * c) - i;
+    }
+    return refracted;
+}
+
+// ---- rlDisney closure state, src/rlDisney.cpp:155-192 -------------------------------------------
+struct Disney {
+    Frame fr;
+    V3 view;
+    float f0R, f0G, f0B;          // mSpecularF0
+    float shR, shG, shB;          // mSheenColor
+    float baseR, baseG, baseB;
+    float roughness, subsurface, metallic, clearcoat, clearcoatGloss;
+    float specRough;              // mSpecularRoughness
+    float ax, ay;
+};
+
+// s: subsurface, metallic, specular, specular_tint, roughness, anisotropic, sheen, sheen_tint,
+//    clearcoat, clearcoat_gloss
+RLS_DEV Disney disney_make(V3 wo, V3 N, V3 T, float bR, float bG, float bB, const float (&s)[10])
+{
+    Disney d;
+    d.baseR = bR; d.baseG = bG; d.baseB = bB;
+    d.subsurface = s[0];
+    d.metallic = s[1];
+    float specular = s[2] * 0.08f;
+    float specularTint = s[3];
+    d.roughness = s[4];
+    float anisotropic = s[5];
+    float sheen = s[6];
+    float sheenTint = s[7];
+    d.clearcoat = s[8] * 0.25f;
+    d.clearcoatGloss = s[9];
+    d.view = wo;
+    d.fr.N = N;
+    d.fr.U = T;
+    d.fr.V = cross(N, T);
+
+    float aspect = sqrtf(1.0f - anisotropic * 0.9f);
+    d.ax = maxf(1e-2f, sqr(d.roughness) / aspect);
+    d.ay = maxf(1e-2f, sqr(d.roughness) * aspect);
+    d.specRough = sqr(d.roughness);
+
+    float lum = luminance(bR, bG, bB);
+    float tR = 1.0f, tG = 1.0f, tB = 1.0f;
+    if (lum > 0.0f) { tR = bR / lum; tG = bG / lum; tB = bB / lum; }
+    float mR = lerpf(specularTint, 1.0f, tR) * specular;
+    float mG = lerpf(specularTint, 1.0f, tG) * specular;
+    float mB = lerpf(specularTint, 1.0f, tB) * specular;
+    d.f0R = lerpf(d.metallic, mR, bR);
+    d.f0G = lerpf(d.metallic, mG, bG);
+    d.f0B = lerpf(d.metallic, mB, bB);
+    d.shR = lerpf(sheenTint, 1.0f, tR) * sheen;
+    d.shG = lerpf(sheenTint, 1.0f, tG) * sheen;
+    d.shB = lerpf(sheenTint, 1.0f, tB) * sheen;
+    return d;
+}
+
+// src/rlDisney.cpp:570-577
+RLS_DEV float smithG_GGX(float ndv, float alphaG)
+{
+    float a = alphaG * alphaG;
+    float b = ndv * ndv;
+    return 1.0f / (ndv + sqrtf(a + b - a * b));
+}
+// src/rlDisney.cpp:545-551
+RLS_DEV float D_GTR1(const Disney &d, float mn2)
+{
+    float alpha = lerpf(d.clearcoatGloss, 0.1f, 0.001f);
+    float a2 = sqr(alpha);
+    float den = logf(a2) * (1.0f + (a2 - 1.0f) * mn2);
+    return (a2 - 1.0f) * kInvPi / den;
+}
+// src/rlDisney.cpp:561-568
+RLS_DEV float D_GTR2Aniso(const Disney &d, V3 m, float mn2)
+{
+    float hu = dot(m, d.fr.U);
+    float hv = dot(m, d.fr.V);
+    float den = d.ax * d.ay * sqr(sqr(hu / d.ax) + sqr(hv / d.ay) + mn2);
+    return kInvPi / den;
+}
+
+// evalDiffuse, src/rlDisney.cpp:199-236 (BRDF without the cosine)
+RLS_DEV void disney_eval_diffuse(const Disney &d, V3 L, float &r, float &g, float &b)
+{
+    r = 0.0f; g = 0.0f; b = 0.0f;
+    float ln = dot(L, d.fr.N);
+    float vn = dot(d.view, d.fr.N);
+    if (ln < kEps || vn < kEps) return;
+    V3 H = normalize(L + d.view);
+    float lh = dot(L, H);
+    float vh = dot(d.view, H);     // the reference's "NdotH" (line 210)
+    if (vh < kEps || lh < kEps) return;
+    float lh2 = sqr(lh);
+    float FL = powf(clampf(1.0f - ln, 0.0f, 1.0f), 5.0f);
+    float FV = powf(clampf(1.0f - vn, 0.0f, 1.0f), 5.0f);
+    float F90 = 0.5f + 2.0f * d.roughness * lh2;
+    float diffuseFactor = lerpf(FL, 1.0f, F90) * lerpf(FV, 1.0f, F90);
+    float Fss90 = d.roughness * lh2;
+    float Fss = lerpf(FL, 1.0f, Fss90) * lerpf(FV, 1.0f, Fss90);
+    float ssFactor = 1.25f * (Fss * (1.0f / (ln + vn) - 0.5f) + 0.5f);
+    float mix = lerpf(d.subsurface, diffuseFactor, ssFactor);
+    float om = 1.0f - d.metallic;
+    r = d.baseR * kInvPi * mix * om;
+    g = d.baseG * kInvPi * mix * om;
+    b = d.baseB * kInvPi * mix * om;
+}
+
+// evalSpecular, src/rlDisney.cpp:318-356
+RLS_DEV void disney_eval_specular(const Disney &d, V3 L, float &r, float &g, float &b)
+{
+    r = 0.0f; g = 0.0f; b = 0.0f;
+    float ln = dot(L, d.fr.N);
+    float vn = dot(d.view, d.fr.N);
+    if (ln < kEps || vn < kEps) return;
+    V3 M = normalize(L + d.view);
+    float lm = dot(L, M);
+    float nm = dot(d.fr.N, M);
+    if (nm < kEps || lm < kEps) return;
+    float nm2 = sqr(nm);
+    float Ds = D_GTR2Aniso(d, M, nm2);
+    float FH = powf(clampf(1.0f - lm, 0.0f, 1.0f), 5.0f);
+    float FsR = lerpf(FH, d.f0R, 1.0f);
+    float FsG = lerpf(FH, d.f0G, 1.0f);
+    float FsB = lerpf(FH, d.f0B, 1.0f);
+    float Gs = smithG_GGX(ln, d.specRough) * smithG_GGX(vn, d.specRough);
+    float Dr = D_GTR1(d, nm2);
+    float Fr = lerpf(FH, 0.04f, 1.0f);
+    float Gr = smithG_GGX(ln, 0.25f) * smithG_GGX(vn, 0.25f);
+    float om = 1.0f - d.metallic;
+    float cc = d.clearcoat * Dr * Fr * Gr;
+    r = (Ds * FsR * Gs + cc) + FH * d.shR * om;
+    g = (Ds * FsG * Gs + cc) + FH * d.shG * om;
+    b = (Ds * FsB * Gs + cc) + FH * d.shB * om;
+}
+
+// sampleGTR1Direction, src/rlDisney.cpp:393-404
+RLS_DEV V3 disney_gtr1_microfacet(const Disney &d, float rx, float ry)
+{
+    float phiH = kTwoPi * rx;
+    float a2 = sqr(d.roughness);
+    float cosThetaH = a2 == 1.0f
+        ? sqrtf(1.0f - ry)
+        : sqrtf((1.0f - powf(a2, 1.0f - ry)) / (1.0f - a2));
+    V3 omega = spherical_direction(cosThetaH, phiH);
+    return normalize(to_frame(omega, d.fr.U, d.fr.V, d.fr.N));
+}
+
+// sampleSpecularDirection, src/rlDisney.cpp:367-390 (visible-normal branch; 191: always true)
+RLS_DEV V3 disney_sample_specular(const Disney &d, const VndfView &w, float rx, float ry)
+{
+    V3 M;
+    float gtr2Weight = 1.0f / (d.clearcoat + 1.0f);
+    if (rx < gtr2Weight) {
+        rx /= gtr2Weight;
+        M = vndf_microfacet(w, d.fr, rx, ry);
+    } else {
+        rx = (rx - gtr2Weight) / (1.0f - gtr2Weight);
+        M = disney_gtr1_microfacet(d, rx, ry);
+    }
+    if (dot(d.fr.N, M) < 0.0f) return mk(0.0f, 0.0f, 0.0f);
+    return reflect_direction(d.view, M);
+}
+
+// evalDiffusePdf, src/rlDisney.cpp:515-518
+RLS_DEV float disney_diffuse_pdf(const Disney &d, V3 i) { return maxf(1e-4f, dot(i, d.fr.N) * kInvPi); }
+
+// evalSpecularPdf, src/rlDisney.cpp:520-543 (visible-normal branch)
+RLS_DEV float disney_specular_pdf(const Disney &d, V3 i)
+{
+    V3 m = normalize(i + d.view);
+    float im = absf(dot(i, m));
+    float mn = dot(m, d.fr.N);
+    if (mn < 0.0f) return 0.0f;
+    float mn2 = sqr(mn);
+    float ccw = d.clearcoat / (d.clearcoat + 1.0f);
+    float vn = maxf(1e-4f, dot(d.view, d.fr.N));
+    float Dw = smithG_GGX(im, d.specRough) * D_GTR2Aniso(d, m, mn2) * 2.0f * im / vn;
+    float D = lerpf(ccw, Dw, D_GTR1(d, mn2) * absf(mn) / im);
+    return D * 0.25f;
+}
+
+// static triple dispatch, src/rlDisney.cpp:120-152
+template <bool DIFFUSE>
+RLS_DEV void disney_eval(const Disney &d, V3 L, float &r, float &g, float &b)
+{
+    if (is_zero(L)) { r = 0.0f; g = 0.0f; b = 0.0f; return; }
+    float nl = dot(d.fr.N, L);
+    if (DIFFUSE) disney_eval_diffuse(d, L, r, g, b);
+    else disney_eval_specular(d, L, r, g, b);
+    r *= nl; g *= nl; b *= nl;
+}
+template <bool DIFFUSE>
+RLS_DEV float disney_pdf(const Disney &d, V3 L)
+{
+    if (is_zero(L)) return 0.0f;
+    return DIFFUSE ? disney_diffuse_pdf(d, L) : disney_specular_pdf(d, L);
+}
+
+// ---- rlSss: NDProfile, src/rlSss.h:27-61, src/rlSss.cpp:20-106 ---------------------------------
+struct NdProfile {
+    float d[3], c1[3], c2[3];
+    float maxR;
+};
+
+RLS_DEV NdProfile nd_make(float dx, float dy, float dz)
+{
+    NdProfile p;
+    p.d[0] = dx; p.d[1] = dy; p.d[2] = dz;
+    p.maxR = maxf(dx, maxf(dy, dz)) * 3.0f;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        p.c1[i] = 1.0f - expf(-p.maxR / p.d[i]);
+        p.c2[i] = 1.0f - expf(-p.maxR / p.d[i] / 3.0f);
+    }
+    return p;
+}
+
+// selectDistLobe + getRadius, src/rlSss.h:30-42, src/rlSss.cpp:36-66
+RLS_DEV float nd_radius(const NdProfile &p, float rx)
+{
+    if (p.maxR < kEps) return 0.0f;
+    float d, w1, w2;
+    if (rx < 0.3333f) {
+        rx = linearstep(0.0f, 0.3333f, rx);
+        d = p.d[0]; w1 = p.c1[0]; w2 = p.c2[0];
+    } else if (rx > 0.6666f) {
+        rx = linearstep(0.6666f, 1.0f, rx);
+        d = p.d[2]; w1 = p.c1[2]; w2 = p.c2[2];
+    } else {
+        rx = linearstep(0.3333f, 0.6666f, rx);
+        d = p.d[1]; w1 = p.c1[1]; w2 = p.c2[1];
+    }
+    if (d < kEps) return 0.0f;
+    float w = w1 / (w1 + w2 * 3.0f);
+    float r;
+    if (rx > w) {
+        rx = linearstep(w, 1.0f, rx);
+        r = logf(1.0f - rx * w2) * (-d * 3.0f);
+    } else {
+        rx = linearstep(0.0f, w, rx);
+        r = logf(1.0f - rx * w1) * (-d);
+    }
+    return r;
+}
+
+// getPdf, src/rlSss.cpp:68-84
+RLS_DEV float nd_pdf(const NdProfile &p, float r)
+{
+    if (p.maxR < kEps) return 1.0f;
+    float pdf = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        float d = maxf(p.d[i], kEps);
+        float p1 = expf(-r / d);
+        float p2 = expf(-r / d / 3.0f);
+        pdf += (p1 + p2) / d / (p.c1[i] + p.c2[i] * 3.0f);
+    }
+    return pdf / (kTwoPi * r * 3.0f);
+}
+
+// evalProfile, src/rlSss.cpp:86-106
+RLS_DEV void nd_profile(const NdProfile &p, float r, float &R, float &G, float &B)
+{
+    if (p.maxR < kEps) { R = 0.0f; G = 0.0f; B = 0.0f; return; }
+    if (r < kEps) { R = 1.0f; G = 1.0f; B = 1.0f; return; }
+    float denom = 8.0f * kPi * r;
+    float out[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        float d = p.d[i];
+        out[i] = d < kEps ? 1.0f : (expf(-r / d) + expf(-r / (3.0f * d))) / (denom * d);
+    }
+    R = out[0]; G = out[1]; B = out[2];
+}
+
+// SssSampler frame, src/rlSss.h:149-158
+RLS_DEV Frame sss_frame(V3 Ns, V3 t, bool has_dPdu)
+{
+    Frame fr;
+    fr.N = Ns;
+    if (has_dPdu && !is_zero(t) && is_finite3(t)) {
+        V3 U = normalize(t);
+        fr.V = normalize(cross(Ns, U));
+        fr.U = cross(fr.V, Ns);
+    } else {
+        fr.U = t;
+        fr.V = cross(Ns, t);
+    }
+    return fr;
+}
+
+// getProbeRay, src/rlSss.h:487-533
+RLS_DEV float sss_probe_ray(const NdProfile &p, const Frame &fr, float rx, float ry,
+                            V3 &offset, V3 &dir, float &maxdist)
+{
+    int idx;
+    if (rx < 0.5f) {
+        idx = 0;
+        rx = linearstep(0.0f, 0.5f, rx);
+    } else if (rx < 0.75f) {
+        idx = 2;
+        rx = linearstep(0.5f, 0.75f, rx);
+    } else {
+        idx = 3;
+        rx = linearstep(0.75f, 1.0f, rx);
+    }
+    float r = nd_radius(p, rx);
+    float rmax = p.maxR;
+    float phi = kTwoPi * ry;
+    float s, c;
+    sincosf(phi, &s, &c);
+    V3 o;
+    o.x = c * r;
+    o.z = s * r;
+    o.y = sqrtf(rmax * rmax - r * r);
+    maxdist = o.y * 2.0f;
+    if (idx < 2) {
+        dir = -fr.N;
+        offset = to_frame(o, fr.U, -dir, fr.V);
+    } else if (idx == 2) {
+        dir = fr.U;
+        offset = to_frame(o, fr.V, -dir, fr.N);
+    } else {
+        dir = fr.V;
+        offset = to_frame(o, fr.N, -dir, fr.U);
+    }
+    return r;
+}
+
+// 3-axis MIS pdf, src/rlSss.h:246-266
+RLS_DEV float sss_mis_pdf(const NdProfile &p, const Frame &fr, V3 disp, V3 sN, bool literal)
+{
+    V3 o = literal ? to_frame(disp, fr.U, fr.V, fr.N)
+                   : mk(dot(disp, fr.U), dot(disp, fr.V), dot(disp, fr.N));
+    o = mk(o.x * o.x, o.y * o.y, o.z * o.z);
+    float rr0 = sqrtf(o.y + o.z);
+    float rr1 = sqrtf(o.x + o.z);
+    float rr2 = sqrtf(o.x + o.y);
+    return nd_pdf(p, rr0) * absf(dot(fr.U, sN)) * 0.25f
+         + nd_pdf(p, rr1) * absf(dot(fr.V, sN)) * 0.25f
+         + nd_pdf(p, rr2) * absf(dot(fr.N, sN)) * 0.5f;
+}
+
+// cavity fade, src/rlSss.h:401-413
+RLS_DEV float sss_cavity_fade(V3 disp, float r, V3 sN, V3 No)
+{
+    V3 dd = mk(disp.x / r, disp.y / r, disp.z / r);
+    float c = dot(No, dd) < 0.0f ? absf(dot(sN, No)) : clampf(dot(sN, No), -1.0f, 1.0f);
+    return sqrtf((1.0f + c) * 0.5f);
+}
+
+// ---- counter-based generator (mirrors oracle/rls_oracle.c: hash + exactly rounded ops) ---------
+RLS_DEV uint32_t mix32(uint32_t h)
+{
+    h ^= h >> 16; h *= 0x7feb352dU; h ^= h >> 15; h *= 0x846ca68bU; h ^= h >> 16;
+    return h;
+}
+RLS_DEV uint32_t hash_u32(uint32_t seed, uint64_t index, uint32_t stream)
+{
+    uint32_t h = mix32(seed ^ (0x9E3779B9U * (stream + 1U)));
+    h = mix32(h ^ (uint32_t)(index & 0xFFFFFFFFULL));
+    h = mix32(h + (uint32_t)(index >> 32) * 0x85EBCA6BU + 0xC2B2AE35U);
+    return h;
+}
+RLS_DEV float hash_u01(uint32_t seed, uint64_t index, uint32_t stream)
+{
+    return (float)(hash_u32(seed, index, stream) >> 8) * (1.0f / 16777216.0f);
+}
+
+// ---- streaming loads / stores -------------------------------------------------------------------
+// Every plane is read or written exactly once per launch: non-temporal so the streams do not
+// evict each other from L2 / Infinity Cache.
+RLS_DEV float ldg(const float *p, int64_t i) { return __builtin_nontemporal_load(p + i); }
+RLS_DEV void stg(float *p, int64_t i, float v) { __builtin_nontemporal_store(v, p + i); }
+
+} // namespace rlsd

@@ -1,0 +1,130 @@
+// skin.hip -- rlSkin composite kernel: sheen GGX lobe + specular GGX lobe + NDProfile SSS sample
+// with the layer-weight arithmetic of shader_evaluate (src/rlSkin.cpp:174-246 of the reference).
+// One (sample, eval, pdf) triple per GGX lobe stands in for Arnold's light loop/AiBRDFIntegrate;
+// the Fresnel average the reference hands down between layers (src/rlSkin.cpp:204,228) is the
+// Fresnel term of that sample.  gfx950, one shading point per lane.
+//
+// Roofline: HBM.  Algorithmic bytes per point (every parameter streamed): 140 B in (wo3 N3 T3,
+// sss_color3 dist3 mult w_sss, spec col3 w rough ior, sheen col3 w rough ior, xi6) + 96 B out
+// (2 x [wi3 f3 pdf F] + [r pdf R3] + [sheenFresnel specularFresnel sssWeight]) = 236 B = 3 samples
+// (SURVEY.md section 8(d), config 5).
+#include "rls_internal.hpp"
+
+using namespace rlsd;
+
+namespace {
+
+struct SkinIO {
+    rls_skin_closure c;
+    const float *xi[6];
+    rls_skin_out o;
+    int64_t n;
+};
+
+struct LobeOut { V3 wi; float fr, fg, fb, pdf, F; };
+
+// One isotropic GGX lobe of rlSkin (src/rlSkin.cpp:192,215: anisotropic defaulted to 0).
+__device__ __forceinline__ LobeOut ggx_lobe(V3 wo, V3 N, V3 T, float cr, float cg, float cb,
+                                            float ior, float rough, float rx, float ry)
+{
+    LobeOut o;
+    Ggx g = ggx_make(wo, N, T, false, cr, cg, cb, ior, rough, 0.0f);
+    VndfView w = vndf_view(g.view, g.fr, g.ax, g.ay);
+    V3 M = vndf_microfacet(w, g.fr, rx, ry);
+    o.wi = reflect_direction(g.view, M);
+    o.F = ggx_fresnel(g, o.wi, M);
+    ggx_eval(g, o.wi, o.fr, o.fg, o.fb);
+    o.pdf = ggx_pdf(g, o.wi);
+    return o;
+}
+
+__global__ __launch_bounds__(rlsh::kBlock) void skin_kernel(SkinIO a)
+{
+    const int64_t stride = (int64_t)gridDim.x * rlsh::kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * rlsh::kBlock + threadIdx.x; i < a.n; i += stride) {
+        const rls_skin_closure &c = a.c;
+        V3 wo = ld3(c.wo, i), N = ld3(c.N, i), T = ld3(c.T, i);
+
+        float sheenFresnel = 0.0f, specularFresnel = 0.0f;
+        LobeOut sh = {}, sp = {};
+
+        float sheenWeight = ldp(c.sheen_weight, i);
+        float shr, shg, shb;
+        ldrgb(c.sheen_color, i, shr, shg, shb);
+        float sheenIor = ldp(c.sheen_ior, i), sheenRough = ldp(c.sheen_roughness, i);
+        float rx0 = ldg(a.xi[0], i), ry0 = ldg(a.xi[1], i);
+        if (sheenWeight > kEps) {                                           // src/rlSkin.cpp:191
+            sh = ggx_lobe(wo, N, T, shr, shg, shb, sheenIor, sheenRough, rx0, ry0);
+            sheenFresnel = sh.F * sheenWeight;                              // :204 (one sample)
+        }
+
+        float specWeight = ldp(c.specular_weight, i);
+        float spr, spg, spb;
+        ldrgb(c.specular_color, i, spr, spg, spb);
+        float specIor = ldp(c.specular_ior, i), specRough = ldp(c.specular_roughness, i);
+        float rx1 = ldg(a.xi[2], i), ry1 = ldg(a.xi[3], i);
+        if (specWeight > kEps) {                                            // :214
+            sp = ggx_lobe(wo, N, T, spr, spg, spb, specIor, specRough, rx1, ry1);
+            specularFresnel = sp.F * specWeight;                            // :228
+        }
+
+        float mult = ldp(c.sss_dist_multiplier, i);                         // :235-236
+        float dx = ldp(c.sss_scatter_dist[0], i) * mult;
+        float dy = ldp(c.sss_scatter_dist[1], i) * mult;
+        float dz = ldp(c.sss_scatter_dist[2], i) * mult;
+        float sssWeight = ldp(c.sss_weight, i);
+        sssWeight *= 1.0f - specularFresnel * (1.0f - sheenFresnel);        // :238
+        float rx2 = ldg(a.xi[4], i), ry2 = ldg(a.xi[5], i);
+
+        float r = 0.0f, rpdf = 0.0f, R = 0.0f, G = 0.0f, B = 0.0f;
+        if (!(sssWeight < kEps)) {                                          // :244
+            NdProfile p = nd_make(dx, dy, dz);
+            Frame fr = sss_frame(N, T, true);                               // src/rlSss.h:151-154
+            V3 off, dir;
+            float maxdist;
+            r = sss_probe_ray(p, fr, rx2, ry2, off, dir, maxdist);
+            rpdf = nd_pdf(p, r);
+            nd_profile(p, r, R, G, B);
+        }
+
+        const rls_skin_out &o = a.o;
+        st3(o.sheen_wi, i, sh.wi); strgb(o.sheen_f, i, sh.fr, sh.fg, sh.fb);
+        stg(o.sheen_pdf, i, sh.pdf); stg(o.sheen_fresnel, i, sh.F);
+        st3(o.spec_wi, i, sp.wi); strgb(o.spec_f, i, sp.fr, sp.fg, sp.fb);
+        stg(o.spec_pdf, i, sp.pdf); stg(o.spec_fresnel, i, sp.F);
+        stg(o.r, i, r); stg(o.r_pdf, i, rpdf); strgb(o.profile, i, R, G, B);
+        stg(o.sheenFresnel, i, sheenFresnel);
+        stg(o.specularFresnel, i, specularFresnel);
+        stg(o.sssWeight, i, sssWeight);
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+rls_status rls_skin_sample_eval_pdf(rls_context *ctx, int64_t n, const rls_skin_closure *c,
+                                    const float *const xi[6], const rls_skin_out *out)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return RLS_OK;
+    RLS_REQUIRE(c != nullptr && xi != nullptr && out != nullptr, "NULL argument");
+    RLS_REQUIRE(rlsh::has3(c->wo) && rlsh::has3(c->N) && rlsh::has3(c->T), "wo/N/T plane is NULL");
+    RLS_REQUIRE(rlsh::ok_rgb(c->sss_color) && rlsh::ok_rgb(c->specular_color) && rlsh::ok_rgb(c->sheen_color),
+                "colour planes must be all set or all NULL");
+    for (int k = 0; k < 6; k++) RLS_REQUIRE(xi[k] != nullptr, "xi plane is NULL");
+    RLS_REQUIRE(rlsh::has3(out->sheen_wi) && rlsh::has3(out->sheen_f) && out->sheen_pdf && out->sheen_fresnel &&
+                rlsh::has3(out->spec_wi) && rlsh::has3(out->spec_f) && out->spec_pdf && out->spec_fresnel &&
+                out->r && out->r_pdf && rlsh::has3(out->profile) &&
+                out->sheenFresnel && out->specularFresnel && out->sssWeight, "NULL output plane");
+    SkinIO io = {};
+    io.c = *c;
+    for (int k = 0; k < 6; k++) io.xi[k] = xi[k];
+    io.o = *out;
+    io.n = n;
+    hipLaunchKernelGGL(skin_kernel, rlsh::grid_for(ctx, n), dim3(rlsh::kBlock), 0, ctx->stream, io);
+    return rlsh::check_launch("rls_skin_sample_eval_pdf");
+}
+
+} // extern "C"

@@ -1,0 +1,232 @@
+// sss.hip -- rlSss kernels: NDProfile (src/rlSss.h:27-61, src/rlSss.cpp:20-106 of the reference)
+// and the hot parts of SssSampler<NDProfile> (src/rlSss.h:143-167,246-266,401-413,487-545), plus
+// the rlUtil direction helpers, with their C-ABI entry points.  gfx950, one point per lane.
+//
+// Roofline: HBM.  Algorithmic bytes per sample: probe ray 56 B in (dist3 albedo3 N3 T3 xi2) +
+// 48 B out (r, origin3, dir3, maxdist, pdf, R3) = 104 B; profile-only 32 B in + 20 B out = 52 B
+// (SURVEY.md section 8(d), config 4).
+#include "rls_internal.hpp"
+
+using namespace rlsd;
+
+namespace {
+
+enum SssOp { OP_ND, OP_ND_PDF, OP_ND_EVAL, OP_PROBE, OP_MIS };
+
+struct SssIO {
+    rls_sss_closure c;
+    const float *rx, *ry, *rin;
+    rls_cvec3 P, disp, sampleN;
+    int literal;
+    float *r;
+    rls_vec3 origin, dir;
+    float *maxdist, *pdf;
+    rls_rgb profile;
+    int64_t n;
+};
+
+__device__ __forceinline__ NdProfile load_profile(const rls_sss_closure &c, int64_t i)
+{
+    // scatterDist = sss_scatter_dist * sss_dist_multiplier (src/rlSkin.cpp:235-236)
+    float m = ldp(c.sss_dist_multiplier, i);
+    float dx = ldp(c.sss_scatter_dist[0], i) * m;
+    float dy = ldp(c.sss_scatter_dist[1], i) * m;
+    float dz = ldp(c.sss_scatter_dist[2], i) * m;
+    return nd_make(dx, dy, dz);
+}
+
+template <int OP>
+__global__ __launch_bounds__(rlsh::kBlock) void sss_kernel(SssIO a)
+{
+    const int64_t stride = (int64_t)gridDim.x * rlsh::kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * rlsh::kBlock + threadIdx.x; i < a.n; i += stride) {
+        NdProfile p = load_profile(a.c, i);
+        if (OP == OP_ND) {
+            float r = nd_radius(p, ldg(a.rx, i));
+            float R, G, B;
+            nd_profile(p, r, R, G, B);
+            stg(a.r, i, r);
+            stg(a.pdf, i, nd_pdf(p, r));
+            strgb(a.profile, i, R, G, B);
+        } else if (OP == OP_ND_PDF) {
+            stg(a.pdf, i, nd_pdf(p, ldg(a.rin, i)));
+        } else if (OP == OP_ND_EVAL) {
+            float R, G, B;
+            nd_profile(p, ldg(a.rin, i), R, G, B);
+            strgb(a.profile, i, R, G, B);
+        } else if (OP == OP_PROBE) {
+            Frame fr = sss_frame(ld3(a.c.N, i), ld3(a.c.T, i), a.c.has_dPdu != 0);
+            V3 off, dir;
+            float maxdist;
+            float r = sss_probe_ray(p, fr, ldg(a.rx, i), ldg(a.ry, i), off, dir, maxdist);
+            if (a.P.x) off = ld3(a.P, i) + off;                       // ray.origin = origin + offset
+            float R, G, B;
+            nd_profile(p, r, R, G, B);
+            stg(a.r, i, r);
+            st3(a.origin, i, off);
+            st3(a.dir, i, dir);
+            stg(a.maxdist, i, maxdist);
+            stg(a.pdf, i, nd_pdf(p, r));
+            strgb(a.profile, i, R, G, B);
+        } else if (OP == OP_MIS) {
+            Frame fr = sss_frame(ld3(a.c.N, i), ld3(a.c.T, i), a.c.has_dPdu != 0);
+            stg(a.pdf, i, sss_mis_pdf(p, fr, ld3(a.disp, i), ld3(a.sampleN, i), a.literal != 0));
+        }
+    }
+}
+
+struct MiscIO {
+    rls_cvec3 a, b, c;
+    const float *rx, *ry;
+    float *out;
+    rls_vec3 v0, v1;
+    int64_t n;
+};
+
+enum MiscOp { OP_CAVITY, OP_DIFFUSE_DIR, OP_UTIL };
+
+template <int OP>
+__global__ __launch_bounds__(rlsh::kBlock) void misc_kernel(MiscIO a)
+{
+    const int64_t stride = (int64_t)gridDim.x * rlsh::kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * rlsh::kBlock + threadIdx.x; i < a.n; i += stride) {
+        if (OP == OP_CAVITY) {
+            V3 disp = ld3(a.a, i);
+            stg(a.out, i, sss_cavity_fade(disp, length(disp), ld3(a.b, i), ld3(a.c, i)));
+        } else if (OP == OP_DIFFUSE_DIR) {
+            Frame fr;
+            fr.N = ld3(a.a, i);
+            fr.U = ld3(a.b, i);
+            fr.V = cross(fr.N, fr.U);
+            st3(a.v0, i, cosine_hemisphere(fr, ldg(a.rx, i), ldg(a.ry, i)));
+        } else {
+            float u = ldg(a.rx, i), v = ldg(a.ry, i);
+            st3(a.v0, i, spherical_direction(2.0f * u - 1.0f, kTwoPi * v));
+            V2 d = concentric_disk(u, v);
+            st3(a.v1, i, mk(d.x, d.y, 0.0f));
+        }
+    }
+}
+
+rls_status check_closure(const rls_sss_closure *c, bool need_frame)
+{
+    RLS_REQUIRE(c != nullptr, "closure is NULL");
+    RLS_REQUIRE(rlsh::ok_rgb(c->sss_color), "sss_color planes must be all set or all NULL");
+    if (need_frame) RLS_REQUIRE(rlsh::has3(c->N) && rlsh::has3(c->T), "N/T plane is NULL");
+    return RLS_OK;
+}
+
+template <int OP>
+rls_status launch(rls_context *ctx, const SssIO &io, const char *name)
+{
+    hipLaunchKernelGGL(sss_kernel<OP>, rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
+    return rlsh::check_launch(name);
+}
+
+template <int OP>
+rls_status launch_misc(rls_context *ctx, const MiscIO &io, const char *name)
+{
+    hipLaunchKernelGGL(misc_kernel<OP>, rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
+    return rlsh::check_launch(name);
+}
+
+} // namespace
+
+#define RLS_PROLOGUE(frame)                              \
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");          \
+    RLS_REQUIRE(n >= 0, "n < 0");                        \
+    if (n == 0) return RLS_OK;                           \
+    { rls_status _s = check_closure(c, frame); if (_s != RLS_OK) return _s; }
+
+extern "C" {
+
+rls_status rls_nd_sample(rls_context *ctx, int64_t n, const rls_sss_closure *c, const float *rx,
+                         float *r, float *pdf, rls_rgb profile)
+{
+    RLS_PROLOGUE(false);
+    RLS_REQUIRE(rx && r && pdf && rlsh::has3(profile), "NULL plane");
+    SssIO io = {};
+    io.c = *c; io.rx = rx; io.r = r; io.pdf = pdf; io.profile = profile; io.n = n;
+    return launch<OP_ND>(ctx, io, "rls_nd_sample");
+}
+
+rls_status rls_nd_pdf(rls_context *ctx, int64_t n, const rls_sss_closure *c, const float *r, float *pdf)
+{
+    RLS_PROLOGUE(false);
+    RLS_REQUIRE(r && pdf, "NULL plane");
+    SssIO io = {};
+    io.c = *c; io.rin = r; io.pdf = pdf; io.n = n;
+    return launch<OP_ND_PDF>(ctx, io, "rls_nd_pdf");
+}
+
+rls_status rls_nd_eval(rls_context *ctx, int64_t n, const rls_sss_closure *c, const float *r, rls_rgb profile)
+{
+    RLS_PROLOGUE(false);
+    RLS_REQUIRE(r && rlsh::has3(profile), "NULL plane");
+    SssIO io = {};
+    io.c = *c; io.rin = r; io.profile = profile; io.n = n;
+    return launch<OP_ND_EVAL>(ctx, io, "rls_nd_eval");
+}
+
+rls_status rls_sss_probe_ray(rls_context *ctx, int64_t n, const rls_sss_closure *c,
+                             const float *rx, const float *ry, rls_cvec3 P,
+                             float *r, rls_vec3 origin, rls_vec3 dir, float *maxdist,
+                             float *pdf, rls_rgb profile)
+{
+    RLS_PROLOGUE(true);
+    RLS_REQUIRE(rx && ry, "rx/ry is NULL");
+    RLS_REQUIRE(rlsh::has3(P) || rlsh::none3(P), "P planes must be all set or all NULL");
+    RLS_REQUIRE(r && rlsh::has3(origin) && rlsh::has3(dir) && maxdist && pdf && rlsh::has3(profile), "NULL output plane");
+    SssIO io = {};
+    io.c = *c; io.rx = rx; io.ry = ry; io.P = P; io.r = r; io.origin = origin; io.dir = dir;
+    io.maxdist = maxdist; io.pdf = pdf; io.profile = profile; io.n = n;
+    return launch<OP_PROBE>(ctx, io, "rls_sss_probe_ray");
+}
+
+rls_status rls_sss_mis_pdf(rls_context *ctx, int64_t n, const rls_sss_closure *c,
+                           rls_cvec3 disp, rls_cvec3 sampleN, int literal_matrix, float *pdf)
+{
+    RLS_PROLOGUE(true);
+    RLS_REQUIRE(rlsh::has3(disp) && rlsh::has3(sampleN) && pdf, "NULL plane");
+    SssIO io = {};
+    io.c = *c; io.disp = disp; io.sampleN = sampleN; io.literal = literal_matrix; io.pdf = pdf; io.n = n;
+    return launch<OP_MIS>(ctx, io, "rls_sss_mis_pdf");
+}
+
+rls_status rls_sss_cavity_fade(rls_context *ctx, int64_t n, rls_cvec3 disp, rls_cvec3 sampleN,
+                               rls_cvec3 No, float *fade)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return RLS_OK;
+    RLS_REQUIRE(rlsh::has3(disp) && rlsh::has3(sampleN) && rlsh::has3(No) && fade, "NULL plane");
+    MiscIO io = {};
+    io.a = disp; io.b = sampleN; io.c = No; io.out = fade; io.n = n;
+    return launch_misc<OP_CAVITY>(ctx, io, "rls_sss_cavity_fade");
+}
+
+rls_status rls_sss_sample_diffuse_direction(rls_context *ctx, int64_t n, rls_cvec3 normal, rls_cvec3 T,
+                                            const float *rx, const float *ry, rls_vec3 wi)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return RLS_OK;
+    RLS_REQUIRE(rlsh::has3(normal) && rlsh::has3(T) && rx && ry && rlsh::has3(wi), "NULL plane");
+    MiscIO io = {};
+    io.a = normal; io.b = T; io.rx = rx; io.ry = ry; io.v0 = wi; io.n = n;
+    return launch_misc<OP_DIFFUSE_DIR>(ctx, io, "rls_sss_sample_diffuse_direction");
+}
+
+rls_status rls_util_directions(rls_context *ctx, int64_t n, const float *a, const float *b,
+                               rls_vec3 spherical, rls_vec3 disk)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return RLS_OK;
+    RLS_REQUIRE(a && b && rlsh::has3(spherical) && rlsh::has3(disk), "NULL plane");
+    MiscIO io = {};
+    io.rx = a; io.ry = b; io.v0 = spherical; io.v1 = disk; io.n = n;
+    return launch_misc<OP_UTIL>(ctx, io, "rls_util_directions");
+}
+
+} // extern "C"

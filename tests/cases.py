@@ -1,0 +1,176 @@
+"""Seeded synthetic shading-point sets shared by the parity tests, the golden-fixture generator and
+bench.py's CPU leg.  Distributions follow SURVEY.md section 8(d); the ten named presets are the
+shader parameter blocks of the reference's own regression scenes (testsuite/mtoa/0001..0010/data/*.ass,
+first line of each README).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+import oracle_lib as O
+
+SEED_THROUGHPUT = 1234
+SEED_PARITY = 99
+SEED_EDGE = 7
+
+
+def frame(seed: int, n: int, first: int = 0):
+    return O.gen_frame(seed, first, n)
+
+
+def xi(seed: int, n: int, k: int, first: int = 0) -> np.ndarray:
+    """k planes of U[0,1) random numbers -> [k, n]"""
+    return np.stack([O.gen_uniform(seed, first, n, O.S_XI0 + j) for j in range(k)])
+
+
+def ggx_mixed(seed: int, n: int, first: int = 0) -> dict:
+    """roughness U[.05,1], ior U[1.05,2.55], anisotropic 0 (even index) / U[0,1) (odd), Ks U[0,1)^3"""
+    wo, N, T = frame(seed, n, first)
+    return dict(wo=wo, N=N, T=T,
+                KsColor=np.stack([O.gen_uniform(seed, first, n, O.S_KS_R + j) for j in range(3)]),
+                roughness=O.gen_uniform(seed, first, n, O.S_ROUGH, 0.05, 1.0),
+                ior=O.gen_uniform(seed, first, n, O.S_IOR, 1.05, 2.55),
+                anisotropic=O.gen_aniso(seed, first, n))
+
+
+def ggx_alpha03(seed: int, n: int) -> dict:
+    """BASELINE config 1: alpha = 0.3 (roughness = sqrt(0.3)), ior 1.5, Ks = 1, isotropic"""
+    wo, N, T = frame(seed, n)
+    return dict(wo=wo, N=N, T=T, KsColor=(1.0, 1.0, 1.0), roughness=float(np.sqrt(np.float32(0.3))), ior=1.5,
+                anisotropic=0.0)
+
+
+# rlGgx presets: testsuite/mtoa/0001/data/ggx_teflon.ass:9-29, 0002/data/ggx_gold.ass:9-29,
+# 0003/data/ggx_anisotropic.ass:116-136
+GGX_PRESETS = {
+    "0001_teflon": dict(KsColor=(1.0, 1.0, 1.0), roughness=0.35, ior=1.35, anisotropic=0.0),
+    "0002_gold": dict(KsColor=(1.0, 1.0, 1.0), roughness=0.35, ior=0.47, anisotropic=0.0),
+    "0003_anisotropic": dict(KsColor=(1.0, 1.0, 1.0), roughness=0.3, ior=0.47, anisotropic=1.0),
+}
+
+# rlDisney presets: 0004 default, 0005 subsurface=1, 0006 rough metallic, 0007 specular=1,
+# 0008 anisotropic (testsuite/mtoa/0004..0008/data/*.ass)
+_GOLD = (0.850000024, 0.704699695, 0.205699995)
+DISNEY_PRESETS = {
+    "0004_default": dict(base_color=_GOLD),
+    "0005_subsurface": dict(base_color=_GOLD, subsurface=1.0),
+    "0006_rough_metallic": dict(base_color=_GOLD, metallic=1.0, roughness=0.3),
+    "0007_specular": dict(base_color=_GOLD, specular=1.0),
+    "0008_anisotropic": dict(base_color=(1.0, 1.0, 1.0), metallic=1.0, roughness=0.2, anisotropic=1.0),
+}
+
+# rlSkin: node defaults (src/rlSkin.cpp:109-128) and the two scene blocks -- 0009 probe sampling
+# (cavity fade on) and 0010 diffusion decay (cavity fade off); both scenes set specular_weight 0
+# (testsuite/mtoa/0009/data/skin_probe_sampling.ass:154-175, 0010/data/skin_diffusion.ass:125-146)
+SKIN_DEFAULTS = dict(sss_color=(1.0, 1.0, 1.0), sss_weight=1.0, sss_dist_multiplier=1.0,
+                     sss_scatter_dist=(1.0, 1.0, 1.0),
+                     specular_color=(1.0, 1.0, 1.0), specular_weight=0.6, specular_roughness=0.5, specular_ior=1.44,
+                     sheen_color=(1.0, 1.0, 1.0), sheen_weight=0.0, sheen_roughness=0.35, sheen_ior=1.44)
+_SKIN_SCENE = dict(SKIN_DEFAULTS, sss_color=(1.0, 0.842350006, 0.5), specular_weight=0.0)
+SKIN_PRESETS = {
+    "node_defaults": dict(SKIN_DEFAULTS),
+    "0009_probe_sampling": dict(_SKIN_SCENE),
+    "0010_diffusion": dict(_SKIN_SCENE),
+}
+
+
+def disney_mixed(seed: int, n: int, first: int = 0) -> dict:
+    """every rlDisney scalar U[0,1), base_color U[0,1)^3"""
+    wo, N, T = frame(seed, n, first)
+    d = dict(wo=wo, N=N, T=T,
+             base_color=np.stack([O.gen_uniform(seed, first, n, O.S_KS_R + j) for j in range(3)]))
+    for k, name in enumerate(O.DISNEY_SCALARS):
+        d[name] = O.gen_uniform(seed, first, n, O.S_PARAM0 + k)
+    return d
+
+
+def sss_mixed(seed: int, n: int, first: int = 0) -> dict:
+    """scatter distances U[.1,2.1)^3, multiplier 1, albedo U[0,1)^3"""
+    _, N, T = frame(seed, n, first)
+    return dict(N=N, T=T,
+                dist=np.stack([O.gen_uniform(seed, first, n, O.S_PARAM0 + j, 0.1, 2.1) for j in range(3)]),
+                albedo=np.stack([O.gen_uniform(seed, first, n, O.S_KS_R + j) for j in range(3)]))
+
+
+def skin_mixed(seed: int, n: int, first: int = 0) -> dict:
+    """weights U[0,1), roughness U[.05,1), ior U[1.05,2.55), colours U[0,1)^3, dist U[.1,2.1)^3"""
+    wo, N, T = frame(seed, n, first)
+    u = lambda k, lo=0.0, hi=1.0: O.gen_uniform(seed, first, n, O.S_PARAM0 + k, lo, hi)
+    u3 = lambda k, lo=0.0, hi=1.0: np.stack([u(k + j, lo, hi) for j in range(3)])
+    p = dict(sss_color=u3(0), sss_weight=u(3), sss_dist_multiplier=u(4, 0.5, 1.5), sss_scatter_dist=u3(5, 0.1, 2.1),
+             specular_color=u3(8), specular_weight=u(11), specular_roughness=u(12, 0.05, 1.0),
+             specular_ior=u(13, 1.05, 2.55),
+             sheen_color=u3(14), sheen_weight=u(17), sheen_roughness=u(18, 0.05, 1.0), sheen_ior=u(19, 1.05, 2.55))
+    return dict(wo=wo, N=N, T=T, params=p)
+
+
+def ggx_edge(seed: int, n: int) -> dict:
+    """Edge regimes interleaved by index (mod 8): grazing wo, normal incidence, roughness floors,
+    ior < 1 (TIR on refraction), ior == 1, xi at {0, 0.5, ->1}, strong anisotropy, black Ks."""
+    d = ggx_mixed(seed, n)
+    wo, N, T = d["wo"], d["N"], d["T"]
+    B = np.cross(N.T, T.T).T.astype(np.float32)
+    k = np.arange(n) % 8
+    # 0: grazing view, cos in [.02, .1]
+    ct = (0.02 + 0.08 * O.gen_uniform(seed, 0, n, 40)).astype(np.float32)
+    st = np.sqrt(np.maximum(0, 1 - ct * ct)).astype(np.float32)
+    graz = (st * T + ct * N).astype(np.float32)
+    graz /= np.linalg.norm(graz, axis=0, keepdims=True).astype(np.float32)
+    wo = np.where(k == 0, graz, wo)
+    # 1: (near-)normal incidence
+    tilt = (1e-5 * O.gen_uniform(seed, 0, n, 41)).astype(np.float32)
+    nrm = (N + tilt * B).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=0, keepdims=True).astype(np.float32)
+    wo = np.where(k == 1, nrm, wo)
+    d["wo"] = np.ascontiguousarray(wo.astype(np.float32))
+    rough = d["roughness"]
+    rough = np.where(k == 2, np.float32(0.0), rough)             # alpha floor 1e-4 / roughness floor 1e-5
+    rough = np.where(k == 3, np.float32(0.005), rough)
+    d["roughness"] = rough.astype(np.float32)
+    ior = d["ior"]
+    ior = np.where(k == 4, (0.3 + 0.6 * O.gen_uniform(seed, 0, n, 42)).astype(np.float32), ior)   # ior < 1
+    ior = np.where(k == 5, np.float32(1.0), ior)
+    d["ior"] = ior.astype(np.float32)
+    d["anisotropic"] = np.where(k == 6, np.float32(1.0), d["anisotropic"]).astype(np.float32)
+    Ks = d["KsColor"].copy()
+    Ks[:, k == 7] = np.float32(5e-5)                               # AiColorIsSmall -> black
+    d["KsColor"] = Ks
+    return d
+
+
+def xi_edge(seed: int, n: int) -> np.ndarray:
+    """[2, n]: xi planes with the special values 0, 0.5 and the largest float below 1 mixed in"""
+    x = xi(seed, n, 2)
+    j = (np.arange(n) // 8) % 6
+    one = np.nextafter(np.float32(1.0), np.float32(0.0))
+    x[0] = np.where(j == 0, np.float32(0.0), x[0])
+    x[0] = np.where(j == 1, one, x[0])
+    x[1] = np.where(j == 2, np.float32(0.5), x[1])
+    x[1] = np.where(j == 3, np.float32(0.0), x[1])
+    x[1] = np.where(j == 4, one, x[1])
+    return np.ascontiguousarray(x.astype(np.float32))
+
+
+# ------------------------------------------------------------------------------------------------
+def rel_err(a: np.ndarray, b: np.ndarray, floor: float = 1e-30) -> np.ndarray:
+    """per-point relative error; [3, n] inputs are compared as vectors (|a-b| / |b|)"""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    if a.ndim == 2:
+        num = np.linalg.norm(a - b, axis=0)
+        den = np.linalg.norm(b, axis=0)
+    else:
+        num = np.abs(a - b)
+        den = np.abs(b)
+    out = num / np.maximum(den, floor)
+    out[(num == 0)] = 0.0
+    return out
+
+
+def summarize(err: np.ndarray) -> dict:
+    err = np.asarray(err)
+    fin = np.isfinite(err)
+    e = np.where(fin, err, np.inf)
+    return dict(n=int(err.size), median=float(np.median(e)), p99=float(np.quantile(e, 0.99)),
+                p999=float(np.quantile(e, 0.999)), max=float(e.max()), frac_gt_1e5=float((e > 1e-5).mean()),
+                nonfinite=int((~fin).sum()))

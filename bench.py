@@ -120,28 +120,32 @@ def cpu_baseline(workload: str, target_seconds: float) -> dict | None:
     import cases
     threads = O.hardware_threads()
 
-    def run(n):
+    def run(n, seconds):
         c = cases.ggx_mixed(SEED, n)
         x = cases.xi(SEED, n, 4)
         g = O.Ggx(c["wo"], c["N"], c["T"], KsColor=c["KsColor"], ior=c["ior"], roughness=c["roughness"],
                   anisotropic=c["anisotropic"], nthreads=threads)
         out = g.reflect_refract(x[0], x[1], x[2], x[3])          # touch pages
-        best = float("inf")
-        for _ in range(3):
+        times = []
+        t_end = time.perf_counter() + seconds
+        while len(times) < 3 or time.perf_counter() < t_end:
             t0 = time.perf_counter()
             g.reflect_refract(x[0], x[1], x[2], x[3], out=out)
-            best = min(best, time.perf_counter() - t0)
-        return best
+            times.append(time.perf_counter() - t0)
+        return times
 
     n0 = 1 << 18
-    t = run(n0)
-    # size the sample so three timed passes + the page-touch pass take about target_seconds
-    n = int(min(1 << 24, max(n0, n0 * (target_seconds / 4.0) / max(t, 1e-6))))
+    t = min(run(n0, 0.0))
+    # one pass of about a second (bounded by 2^24 points = 2 GB of planes), repeated for target_seconds
+    n = int(min(1 << 24, max(n0, n0 * 1.0 / max(t, 1e-6))))
     n = 1 << (n.bit_length() - 1)
-    best = run(n) if n > n0 else t
+    times = run(n, target_seconds)
+    best, mean = min(times), sum(times) / len(times)
     return {"value": round(2 * n / best / 1e9, 6), "unit": "Gsamples/s", "cores": threads, "kind": "port",
-            "sample": f"{n} points (2 samples each) of the same seeded workload, best of 3, "
-                      f"oracle/rls_oracle.c orc_batch_ggx_reflect_refract on {threads} threads"}
+            "mean_value": round(2 * n / mean / 1e9, 6),
+            "sample": f"{n} points (2 samples each) of the same seeded workload, best of {len(times)} passes "
+                      f"({sum(times):.1f} s of CPU work), oracle/rls_oracle.c orc_batch_ggx_reflect_refract "
+                      f"on {threads} threads"}
 
 
 def traffic_bytes(workload: str):

@@ -79,8 +79,11 @@ typedef struct { const float *r, *g, *b; float ur, ug, ub; } rls_param_rgb;
  * ---------------------------------------------------------------------------------------- */
 rls_status  rls_context_create(int device_ordinal, rls_context **out);
 void        rls_context_destroy(rls_context *ctx);
-/* Use an existing hipStream_t (e.g. the framework's current stream); NULL -> the context's own. */
+/* Launch on an existing hipStream_t (e.g. the framework's current stream).  The handle is taken
+ * literally: NULL is HIP's default (null) stream.  A new context launches on a private
+ * non-blocking stream until this is called; rls_context_use_own_stream() goes back to it. */
 rls_status  rls_context_set_stream(rls_context *ctx, void *hip_stream);
+rls_status  rls_context_use_own_stream(rls_context *ctx);
 void       *rls_context_get_stream(rls_context *ctx);
 rls_status  rls_context_synchronize(rls_context *ctx);
 int         rls_context_device(const rls_context *ctx);

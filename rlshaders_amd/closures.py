@@ -39,8 +39,12 @@ class Context:
             self.use_stream(torch.cuda.current_stream(self.torch_device))
 
     def use_stream(self, stream: Optional["torch.cuda.Stream"]) -> None:
-        ptr = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p()
-        check(self.lib.rls_context_set_stream(self.handle, ptr))
+        """stream = a torch.cuda.Stream (its handle may be 0 = the null stream), or None for the
+        context's private stream"""
+        if stream is None:
+            check(self.lib.rls_context_use_own_stream(self.handle))
+        else:
+            check(self.lib.rls_context_set_stream(self.handle, C.c_void_p(stream.cuda_stream)))
 
     def synchronize(self) -> None:
         check(self.lib.rls_context_synchronize(self.handle))

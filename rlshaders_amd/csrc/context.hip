@@ -105,7 +105,14 @@ void rls_context_destroy(rls_context *ctx)
 rls_status rls_context_set_stream(rls_context *ctx, void *hip_stream)
 {
     RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = (hipStream_t)hip_stream;
+    return RLS_OK;
+}
+
+rls_status rls_context_use_own_stream(rls_context *ctx)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    ctx->stream = ctx->own_stream;
     return RLS_OK;
 }
 
@@ -207,7 +214,7 @@ rls_status rls_timer_elapsed_ms(rls_context *ctx, float *ms)
 // ---- generator kernels -----------------------------------------------------------------------
 namespace {
 
-// stream ids shared with oracle/rls_oracle.h
+// hash stream ids (DESIGN.md "Synthetic inputs")
 enum { S_N0 = 0, S_N1, S_T, S_WO0, S_WO1, S_ROUGH, S_IOR, S_ANISO };
 
 __device__ __forceinline__ void circle_point(float u, float &c, float &s)

@@ -28,7 +28,7 @@ namespace {
 
 constexpr int kMaxSpp = 256;   // spp_n <= 16
 
-// stream ids of the per-point scrambles (oracle/rls_oracle.h: ORC_S_SCRAMBLE)
+// hash stream ids of the per-point scrambles (DESIGN.md "Synthetic inputs": streams 64..67)
 constexpr uint32_t kScrambleStream = 64;
 
 __device__ __forceinline__ uint32_t sobol2(uint32_t s)

@@ -693,7 +693,7 @@ RLS_DEV float sss_cavity_fade(V3 disp, float r, V3 sN, V3 No)
     return sqrtf((1.0f + c) * 0.5f);
 }
 
-// ---- counter-based generator (mirrors oracle/rls_oracle.c: hash + exactly rounded ops) ---------
+// ---- counter-based generator: integer hash + exactly rounded ops only (reproducible on a CPU) ----
 RLS_DEV uint32_t mix32(uint32_t h)
 {
     h ^= h >> 16; h *= 0x7feb352dU; h ^= h >> 15; h *= 0x846ca68bU; h ^= h >> 16;

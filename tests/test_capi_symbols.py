@@ -1,0 +1,84 @@
+"""CPU: the C-ABI library builds, loads, exports every symbol include/rlshaders_amd.h declares, and
+fails loudly (status + message, no fallback) when there is no GPU."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def declared_symbols():
+    text = (ROOT / "include" / "rlshaders_amd.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rls_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound():
+    from rlshaders_amd import _capi as capi, build
+    build.build_library()
+    lib = capi.load()
+    names = declared_symbols()
+    assert len(names) >= 40
+    for nm in names:
+        assert hasattr(lib, nm), f"{nm} declared in the header but not exported"
+        assert nm in capi.PROTOTYPES, f"{nm} has no ctypes prototype"
+    extra = set(capi.PROTOTYPES) - set(names)
+    assert not extra, f"prototypes without a header declaration: {extra}"
+
+
+def test_header_compiles_as_c_and_cxx(tmp_path):
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "rlshaders_amd.h"\nint main(void){ rls_ggx_closure c; (void)c; return rls_version() ? 0 : 0; }\n')
+    for cc, std in (("gcc", "-std=c99"), ("g++", "-std=c++14")):
+        p = subprocess.run([cc, std, "-Wall", "-Werror", "-pedantic", "-fsyntax-only", f"-I{ROOT / 'include'}",
+                            "-x", "c" if cc == "gcc" else "c++", str(src)], capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import rlshaders_amd as R
+    lib = R.load()
+    h = C.c_void_p()
+    st = lib.rls_context_create(0, C.byref(h))
+    assert st == 2 and not h.value
+    assert b"no HIP device" in lib.rls_last_error()
+    with pytest.raises(RuntimeError):
+        R.Context(0)
+
+
+def test_struct_layouts_match_header():
+    """sizeof of every ABI struct as the C compiler sees it == the ctypes mirror"""
+    import subprocess
+    import tempfile
+    from rlshaders_amd import _capi as capi
+    pairs = [("rls_cvec3", capi.CVec3), ("rls_vec3", capi.Vec3), ("rls_rgb", capi.Rgb), ("rls_param", capi.Param),
+             ("rls_param_rgb", capi.ParamRgb), ("rls_ggx_closure", capi.GgxClosure),
+             ("rls_disney_closure", capi.DisneyClosure), ("rls_disney_stream_out", capi.DisneyStreamOut),
+             ("rls_sss_closure", capi.SssClosure), ("rls_skin_closure", capi.SkinClosure),
+             ("rls_skin_out", capi.SkinOut)]
+    body = "".join(f'printf("%zu\\n", sizeof({c}));' for c, _ in pairs)
+    with tempfile.TemporaryDirectory() as d:
+        src = Path(d) / "s.c"
+        src.write_text(f'#include <stdio.h>\n#include "rlshaders_amd.h"\nint main(void){{{body} return 0;}}\n')
+        exe = Path(d) / "s"
+        subprocess.run(["gcc", f"-I{ROOT / 'include'}", str(src), "-o", str(exe)], check=True)
+        sizes = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    for (cname, ct), sz in zip(pairs, sizes):
+        assert C.sizeof(ct) == sz, (cname, C.sizeof(ct), sz)
+
+
+def test_product_never_touches_oracle():
+    """the product path must not import, link or call anything under oracle/"""
+    import subprocess
+    pkg = ROOT / "rlshaders_amd"
+    for p in list(pkg.rglob("*.py")) + list(pkg.rglob("*.hip")) + list(pkg.rglob("*.hpp")) + list(pkg.rglob("*.cpp")):
+        t = p.read_text()
+        assert "oracle_lib" not in t and "librls_oracle" not in t and "rls_oracle.h" not in t, p
+    out = subprocess.run(["ldd", str(pkg / "lib" / "librlshaders_amd.so")], capture_output=True, text=True).stdout
+    assert "rls_oracle" not in out

@@ -1,0 +1,153 @@
+"""GPU parity of the rlSss (NDProfile, SssSampler hot parts) and rlSkin kernels against the oracle."""
+import numpy as np
+import pytest
+
+import cases
+import rlshaders_amd as R
+from gpu_util import dev, host
+
+pytestmark = pytest.mark.gpu
+
+N = 1 << 16
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def mixed(oracle):
+    return cases.sss_mixed(cases.SEED_PARITY, N), cases.xi(cases.SEED_PARITY, N, 2)
+
+
+def test_nd_profile_sample_pdf_eval(gpu, oracle, mixed):
+    c, x = mixed
+    o = oracle.Sss(N, c["dist"], c["albedo"])
+    r_ref, pdf_ref, prof_ref = o.nd_sample(x[0])
+    p = R.NDProfile(gpu, N, dev(c["dist"]), dev(c["albedo"]))
+    r, pdf, prof = (host(t) for t in p.sample(dev(x[0])))
+    for nm, a, b in (("r", r, r_ref), ("pdf", pdf, pdf_ref), ("profile", prof, prof_ref)):
+        st = cases.summarize(cases.rel_err(a, b))
+        print("nd", nm, st)
+        assert st["nonfinite"] == 0 and st["frac_gt_1e5"] <= 3e-2, (nm, st)
+        assert st["median"] <= 2e-6
+    # decoupled on the oracle's r: only expf differs between the two libms
+    st = cases.summarize(cases.rel_err(host(p.getPdf(dev(r_ref))), o.nd_pdf(r_ref)))
+    sp = cases.summarize(cases.rel_err(host(p.evalProfile(dev(r_ref))), o.nd_profile(r_ref)))
+    print("nd pdf decoupled", st)
+    print("nd profile decoupled", sp)
+    assert st["max"] <= TOL and sp["max"] <= TOL
+
+
+def test_nd_uniform_kat(gpu, oracle):
+    """the SURVEY 8(c) probe configuration: d = (1, .5, .25), uniform over the batch"""
+    n = 4096
+    rx = np.linspace(0, 1, n, endpoint=False).astype(np.float32)
+    o = oracle.Sss(n, (1.0, 0.5, 0.25), (1.0, 0.84235, 0.5))
+    p = R.NDProfile(gpu, n, (1.0, 0.5, 0.25), (1.0, 0.84235, 0.5))
+    ref = o.nd_sample(rx)
+    got = [host(t) for t in p.sample(dev(rx))]
+    for a, b in zip(got, ref):
+        fin = np.isfinite(b) if b.ndim == 1 else np.isfinite(b).all(axis=0)
+        assert cases.summarize(cases.rel_err(a[..., fin], b[..., fin]))["p99"] <= 1e-5
+
+
+def test_nd_degenerate_distances(gpu, oracle):
+    """maxRadius < 1e-4 -> r = 0, pdf = 1, black profile; one tiny channel -> that channel 1, r = 0
+    when it is selected (src/rlSss.cpp:38,46,70,88-91,101)"""
+    n = 4096
+    rx = cases.xi(cases.SEED_EDGE, n, 1)[0]
+    for dist in ((0.0, 0.0, 0.0), (1e-5, 1e-5, 1e-5), (1.0, 1e-5, 0.5)):
+        o = oracle.Sss(n, dist)
+        ref = o.nd_sample(rx)
+        got = [host(t) for t in R.NDProfile(gpu, n, dist).sample(dev(rx))]
+        for a, b in zip(got, ref):
+            both = np.isfinite(a) & np.isfinite(b)
+            assert (np.isfinite(a) == np.isfinite(b)).all()
+            assert cases.summarize(cases.rel_err(a[both], b[both]))["p99"] <= 1e-5, dist
+
+
+@pytest.mark.parametrize("has_dPdu", [True, False])
+def test_probe_ray(gpu, oracle, mixed, has_dPdu):
+    c, x = mixed
+    # dPdu: scaled, not orthogonal to N -> exercises the Gram-Schmidt frame (src/rlSss.h:151-154)
+    T = (c["T"] * 2.5 + 0.3 * c["N"]).astype(np.float32) if has_dPdu else c["T"]
+    o = oracle.Sss(N, c["dist"], c["albedo"], N=c["N"], T=T, has_dPdu=has_dPdu)
+    ref = o.probe(x[0], x[1])
+    s = R.SssSampler(gpu, dev(c["N"]), dev(T), dev(c["albedo"]), dev(c["dist"]), has_dPdu=has_dPdu)
+    got = {k: host(v) for k, v in s.getProbeRay(dev(x[0]), dev(x[1])).items()}
+    for k in ("r", "origin", "dir", "maxdist", "pdf", "profile"):
+        st = cases.summarize(cases.rel_err(got[k], ref[k]))
+        print("probe", has_dPdu, k, st)
+        assert st["nonfinite"] == 0 and st["frac_gt_1e5"] <= 3e-2, (k, st)
+    assert np.array_equal(got["dir"], ref["dir"]) or cases.rel_err(got["dir"], ref["dir"]).max() <= 1e-6
+    # with P the origin is P + offset
+    P = cases.xi(cases.SEED_EDGE, N, 3)
+    got2 = host(s.getProbeRay(dev(x[0]), dev(x[1]), P=dev(P))["origin"])
+    assert np.allclose(got2, P + got["origin"], rtol=0, atol=1e-6)
+
+
+def test_mis_pdf_and_cavity_fade(gpu, oracle, mixed):
+    c, x = mixed
+    o = oracle.Sss(N, c["dist"], c["albedo"], N=c["N"], T=c["T"], has_dPdu=True)
+    s = R.SssSampler(gpu, dev(c["N"]), dev(c["T"]), dev(c["albedo"]), dev(c["dist"]))
+    # displacement of a probe hit: a point near the surface within maxR; normal of the hit
+    disp = (cases.xi(cases.SEED_EDGE, N, 3) - 0.5).astype(np.float32)
+    sN, _, _ = cases.frame(cases.SEED_EDGE, N)
+    for literal in (False, True):
+        st = cases.summarize(cases.rel_err(host(s.misPdf(dev(disp), dev(sN), literal)), o.mis_pdf(disp, sN, literal)))
+        print("mis pdf literal" if literal else "mis pdf projection", st)
+        assert st["frac_gt_1e5"] <= 1e-3 and st["median"] <= 2e-6
+    fade = host(R.SssSampler.cavityFade(gpu, dev(disp), dev(sN), dev(c["N"])))
+    assert cases.summarize(cases.rel_err(fade, oracle.cavity_fade(disp, sN, c["N"])))["max"] <= TOL
+    wi = host(R.SssSampler.sampleDiffuseDirection(gpu, dev(x[0]), dev(x[1]), dev(c["N"]), dev(c["T"])))
+    st = cases.summarize(cases.rel_err(wi, oracle.sample_diffuse_direction(c["N"], c["T"], x[0], x[1])))
+    print("sss diffuse direction", st)
+    assert st["frac_gt_1e5"] <= 1e-3
+
+
+def test_util_directions(gpu, oracle, mixed):
+    _, x = mixed
+    sph, disk = (host(t) for t in R.util_directions(gpu, dev(x[0]), dev(x[1])))
+    rs, rd = oracle.util_directions(x[0], x[1])
+    assert cases.summarize(cases.rel_err(sph, rs))["frac_gt_1e5"] <= 1e-3
+    assert cases.summarize(cases.rel_err(disk, rd))["frac_gt_1e5"] <= 1e-3
+    # the degenerate centre of the square maps to the centre of the disk
+    h = dev(np.full(64, 0.5, np.float32))
+    assert np.all(host(R.util_directions(gpu, h, h)[1]) == 0)
+
+
+SKIN_KEYS = ("sheen_wi", "sheen_f", "sheen_pdf", "sheen_fresnel", "spec_wi", "spec_f", "spec_pdf", "spec_fresnel",
+             "r", "r_pdf", "profile", "sheenFresnel", "specularFresnel", "sssWeight")
+
+
+def _skin_check(gpu, oracle, wo, N, T, params, xi, tag, frac=2e-2):
+    ref = oracle.skin(wo, N, T, params, xi, nthreads=4)
+    sk = R.SkinShader(gpu, dev(wo), dev(N), dev(T), **{k: dev(v) for k, v in params.items()})
+    got = {k: host(v) for k, v in sk.sampleEvalPdf(dev(xi)).items()}
+    for k in SKIN_KEYS:
+        st = cases.summarize(cases.rel_err(got[k], ref[k]))
+        print("skin", tag, k, st)
+        assert st["nonfinite"] == 0 and st["frac_gt_1e5"] <= frac, (tag, k, st)
+    return got, ref
+
+
+def test_skin_mixed(gpu, oracle):
+    c = cases.skin_mixed(cases.SEED_PARITY, N)
+    xi = cases.xi(cases.SEED_PARITY, N, 6)
+    got, ref = _skin_check(gpu, oracle, c["wo"], c["N"], c["T"], c["params"], xi, "mixed")
+    # layer weights are exact functions of the sampled Fresnel terms (src/rlSkin.cpp:204,228,238)
+    p = c["params"]
+    sf = np.where(p["sheen_weight"] > 1e-4, got["sheen_fresnel"] * p["sheen_weight"], 0).astype(np.float32)
+    assert np.array_equal(sf, got["sheenFresnel"])
+
+
+@pytest.mark.parametrize("preset", sorted(cases.SKIN_PRESETS))
+def test_skin_presets(gpu, oracle, preset):
+    n = 1 << 14
+    wo, N, T = cases.frame(cases.SEED_PARITY, n)
+    xi = cases.xi(cases.SEED_PARITY, n, 6)
+    p = cases.SKIN_PRESETS[preset]
+    got, ref = _skin_check(gpu, oracle, wo, N, T, p, xi, preset)
+    if p["sheen_weight"] <= 1e-4:      # lobe skipped: zero outputs (src/rlSkin.cpp:191)
+        assert np.all(got["sheen_wi"] == 0) and np.all(got["sheen_pdf"] == 0) and np.all(got["sheenFresnel"] == 0)
+    if p["specular_weight"] <= 1e-4:
+        assert np.all(got["spec_f"] == 0) and np.all(got["specularFresnel"] == 0)
+        assert np.array_equal(got["sssWeight"], np.full(n, p["sss_weight"], np.float32))

@@ -23,7 +23,8 @@ LIB = LIBDIR / "librlshaders_amd.so"
 ARCH = "gfx950"
 
 SOURCES = ["context.hip", "ggx.hip", "disney.hip", "sss.hip", "skin.hip", "integrate.hip"]
-HEADERS = [CSRC / "rls_device.hpp", CSRC / "rls_internal.hpp", PKG.parent / "include" / "rlshaders_amd.h"]
+HEADERS = [CSRC / "rls_device.hpp", CSRC / "rls_libm.hpp", CSRC / "rls_internal.hpp",
+           PKG.parent / "include" / "rlshaders_amd.h"]
 
 HIPCC_FLAGS = [
     f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
@@ -51,19 +52,24 @@ def sources():
     return [CSRC / s for s in SOURCES if (CSRC / s).exists()]
 
 
-def build_library(force: bool = False, verbose: bool = False) -> Path:
-    """Compile every HIP TU for gfx950 and link the C-ABI shared library.  Returns its path."""
+def build_library(force: bool = False, verbose: bool = False, variant: str = "", defines=()) -> Path:
+    """Compile every HIP TU for gfx950 and link the C-ABI shared library.  Returns its path.
+
+    ``variant`` / ``defines`` build an experiment flavour next to the product library
+    (``librlshaders_amd_<variant>.so``, selected at run time with RLSHADERS_AMD_LIB)."""
     hipcc = _hipcc()
     LIBDIR.mkdir(exist_ok=True)
-    OBJDIR.mkdir(exist_ok=True)
+    objdir = OBJDIR if not variant else PKG / f"build_{variant}"
+    lib = LIB if not variant else LIBDIR / f"librlshaders_amd_{variant}.so"
+    objdir.mkdir(exist_ok=True)
     srcs = sources()
     jobs = []
     objs = []
     for src in srcs:
-        obj = OBJDIR / (src.stem + ".o")
+        obj = objdir / (src.stem + ".o")
         objs.append(obj)
         if force or _stale(obj, [src, *HEADERS, Path(__file__)]):
-            jobs.append([hipcc, *HIPCC_FLAGS, "-c", str(src), "-o", str(obj)])
+            jobs.append([hipcc, *HIPCC_FLAGS, *[f"-D{d}" for d in defines], "-c", str(src), "-o", str(obj)])
 
     def run(cmd):
         if verbose:
@@ -76,9 +82,9 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
-        run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)])
-    return LIB
+    if force or jobs or _stale(lib, objs):
+        run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(lib), *map(str, objs)])
+    return lib
 
 
 def build_host_examples(verbose: bool = False) -> Path:
@@ -102,5 +108,8 @@ def build_host_examples(verbose: bool = False) -> Path:
 
 
 if __name__ == "__main__":
-    lib = build_library(force="--force" in sys.argv, verbose=True)
-    print(lib)
+    # python -m rlshaders_amd.build [--force] [--variant NAME -DFOO=1 ...]
+    args = sys.argv[1:]
+    variant = args[args.index("--variant") + 1] if "--variant" in args else ""
+    defines = [a[2:] for a in args if a.startswith("-D")]
+    print(build_library(force="--force" in args, verbose=True, variant=variant, defines=defines))

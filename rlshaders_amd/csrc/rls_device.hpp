@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "rls_libm.hpp"
+
 namespace rlsd {
 
 // ---- Arnold constants as the reference sees them (public SDK 4.x values) --------------------
@@ -70,13 +72,31 @@ RLS_DEV bool is_finite3(V3 a) { return isfinite(a.x) && isfinite(a.y) && isfinit
 
 struct Frame { V3 U, V, N; };
 
+// ---- angle functions ----------------------------------------------------------------------------
+// RLS_HOST_LIBM = 1 (default): the host-libm-faithful routines of rls_libm.hpp, so sampled
+// directions agree with the CPU closures bit for bit; 0: ROCm's ocml (differs in the last ulp).
+#ifndef RLS_HOST_LIBM
+#define RLS_HOST_LIBM 1
+#endif
+#if RLS_HOST_LIBM
+RLS_DEV void t_sincos(float x, float *s, float *c) { rlm::sincos32(x, s, c); }
+RLS_DEV float t_atan2(float y, float x) { return rlm::atan2_32(y, x); }
+RLS_DEV float t_acos(float x) { return rlm::acos32(x); }
+RLS_DEV float t_tan(float x) { return rlm::tan32(x); }
+#else
+RLS_DEV void t_sincos(float x, float *s, float *c) { sincosf(x, s, c); }
+RLS_DEV float t_atan2(float y, float x) { return atan2f(y, x); }
+RLS_DEV float t_acos(float x) { return acosf(x); }
+RLS_DEV float t_tan(float x) { return tanf(x); }
+#endif
+
 // ---- rlUtil ----------------------------------------------------------------------------------
 // src/rlUtil.h:21-29
 RLS_DEV V3 spherical_direction(float cosTheta, float phi)
 {
     float r = sqrtf(1.0f - sqr(cosTheta));
     float s, c;
-    sincosf(phi, &s, &c);
+    t_sincos(phi, &s, &c);
     return mk(r * c, r * s, cosTheta);
 }
 // src/rlUtil.h:31-34
@@ -102,7 +122,7 @@ RLS_DEV V2 concentric_disk(float rx, float ry)
         phi = kHalfPi * (1.0f - 0.5f * rx / ry);
     }
     float s, c;
-    sincosf(phi, &s, &c);
+    t_sincos(phi, &s, &c);
     out.x = r * c;
     out.y = r * s;
     return out;
@@ -130,7 +150,7 @@ RLS_DEV VndfView vndf_view(V3 view, const Frame &fr, float ax, float ay)
     VndfView w;
     w.ax = ax; w.ay = ay;
     float cosThetaV = clampf(dot(fr.N, view), -1.0f, 1.0f);
-    float phiV = atan2f(dot(fr.V, view), dot(fr.U, view));
+    float phiV = t_atan2(dot(fr.V, view), dot(fr.U, view));
     V3 v = spherical_direction(cosThetaV, phiV);
     v.x *= ax;
     v.y *= ay;
@@ -138,12 +158,12 @@ RLS_DEV VndfView vndf_view(V3 view, const Frame &fr, float ax, float ay)
 
     float theta = 0.0f, phi = 0.0f;
     if (v.z < (1.0f - kEps)) {
-        theta = acosf(v.z);
-        phi = atan2f(v.y, v.x);
+        theta = t_acos(v.z);
+        phi = t_atan2(v.y, v.x);
     }
-    sincosf(phi, &w.sinPhi, &w.cosPhi);
+    t_sincos(phi, &w.sinPhi, &w.cosPhi);
     w.nearNormal = theta < kEps;
-    float B = tanf(theta);
+    float B = t_tan(theta);
     w.B = B;
     w.B2 = sqr(B);
     w.G1 = 2.0f / (1.0f + sqrtf(1.0f + w.B2));
@@ -157,7 +177,7 @@ RLS_DEV V2 uniform_slope(float rx, float ry)
     float r = sqrtf(rx / (1.0f - rx));
     float phi = kTwoPi * ry;
     float s, c;
-    sincosf(phi, &s, &c);
+    t_sincos(phi, &s, &c);
     V2 slope;
     slope.x = r * c;
     slope.y = r * s;
@@ -306,7 +326,7 @@ RLS_DEV V3 ndf_microfacet(const Ggx &g, float rx, float ry)
     float gg = sqrtf(rx / (1.0f - rx));
     float phi = kTwoPi * ry;
     float s, c;
-    sincosf(phi, &s, &c);
+    t_sincos(phi, &s, &c);
     V3 omega = mk(gg * g.ax * c, gg * g.ay * s, 1.0f);
     return normalize(to_frame(omega, g.fr.U, g.fr.V, g.fr.N));
 }
@@ -652,7 +672,7 @@ RLS_DEV float sss_probe_ray(const NdProfile &p, const Frame &fr, float rx, float
     float rmax = p.maxR;
     float phi = kTwoPi * ry;
     float s, c;
-    sincosf(phi, &s, &c);
+    t_sincos(phi, &s, &c);
     V3 o;
     o.x = c * r;
     o.z = s * r;

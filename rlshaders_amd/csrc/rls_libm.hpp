@@ -1,0 +1,317 @@
+// rls_libm.hpp -- fp32 elementary functions that reproduce the HOST libm bit for bit.
+//
+// Why: the reference's closures call atan2f / acosf / tanf / sinf / cosf (src/rlGgx.cpp:71-91,
+// src/rlDisney.cpp:474-494 of the reference) and feed the results into the ill-conditioned slope
+// equations of visible-normal sampling, where a 1-ulp change of an angle moves 0.1-0.5 % of the
+// outputs by more than 1e-5.  ROCm's device libm (ocml) rounds these
+// functions differently from the libm the reference's CPU build links (glibc on Linux), so the
+// only way to make the GPU closures agree with the CPU closures on every point -- not just on
+// the well-conditioned ones -- is to compute the angles with the same algorithms:
+//   * atanf / atan2f / acosf / tanf: the fdlibm single-precision algorithms (Sun Microsystems,
+//     1993; "Permission to use, copy, modify, and distribute this software is freely granted,
+//     provided that this notice is preserved") that glibc <= 2.40 ships in
+//     sysdeps/ieee754/flt-32/{s_atanf,e_atan2f,e_acosf,s_tanf,k_tanf,e_rem_pio2f}.c -- pure
+//     fp32 + - * / sqrt sequences, reproducible exactly with FMA contraction off;
+//   * sinf / cosf: the double-precision polynomial scheme of glibc >= 2.28 (s_sincosf.h, from
+//     ARM's optimized-routines): reduce by pi/2 in fp64, degree-7/8 polynomials in fp64, round
+//     once to fp32.  (glibc's FMA-multiarch build may contract the fp64 steps; the final fp32
+//     rounding hides that on all but ~1e-8 of arguments.)
+// Restated here from the published algorithms for the argument ranges the closures produce
+// (|x| <= 2*pi for sin/cos, [0, pi/2] for tan, [-1, 1] for acos); outside them the routines
+// still return a correct value but fall back to simple forms.
+//
+// The header compiles for the host too (tests/test_libm_faithful.py builds it with g++ and
+// compares every routine against the host libm over millions of arguments, bit for bit).
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RLM_FN __host__ __device__ __forceinline__
+#else
+#define RLM_FN static inline
+#endif
+
+namespace rlm {
+
+RLM_FN uint32_t f2u(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __float_as_uint(x);
+#else
+    uint32_t u; memcpy(&u, &x, 4); return u;
+#endif
+}
+RLM_FN float u2f(uint32_t u)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    float x; memcpy(&x, &u, 4); return x;
+#endif
+}
+RLM_FN float fabs32(float x) { return u2f(f2u(x) & 0x7fffffffu); }
+
+// ---- atanf: fdlibm s_atanf.c ---------------------------------------------------------------------
+RLM_FN float atan32(float x)
+{
+    const float atanhi0 = u2f(0x3eed6338u), atanhi1 = u2f(0x3f490fdau), atanhi2 = u2f(0x3f7b985eu),
+                atanhi3 = u2f(0x3fc90fdau);
+    const float atanlo0 = u2f(0x31ac3769u), atanlo1 = u2f(0x33222168u), atanlo2 = u2f(0x33140fb4u),
+                atanlo3 = u2f(0x33a22168u);
+    const float aT0 = u2f(0x3eaaaaabu), aT1 = u2f(0xbe4ccccdu), aT2 = u2f(0x3e124925u), aT3 = u2f(0xbde38e38u),
+                aT4 = u2f(0x3dba2e6eu), aT5 = u2f(0xbd9d8795u), aT6 = u2f(0x3d886b35u), aT7 = u2f(0xbd6ef16bu),
+                aT8 = u2f(0x3d4bda59u), aT9 = u2f(0xbd15a221u), aT10 = u2f(0x3c8569d7u);
+    const int32_t hx = (int32_t)f2u(x);
+    const int32_t ix = hx & 0x7fffffff;
+    if (ix >= 0x4c000000) {                       // |x| >= 2^25
+        if (ix > 0x7f800000) return x + x;        // NaN
+        return hx > 0 ? atanhi3 + atanlo3 : -atanhi3 - atanlo3;
+    }
+    int id;
+    float hi = 0.0f, lo = 0.0f;
+    if (ix < 0x3ee00000) {                        // |x| < 0.4375
+        if (ix < 0x31000000) return x;            // |x| < 2^-29
+        id = -1;
+    } else {
+        x = fabs32(x);
+        if (ix < 0x3f980000) {                    // |x| < 1.1875
+            if (ix < 0x3f300000) {                // 7/16 <= |x| < 11/16
+                id = 0; hi = atanhi0; lo = atanlo0;
+                x = (2.0f * x - 1.0f) / (2.0f + x);
+            } else {                              // 11/16 <= |x| < 19/16
+                id = 1; hi = atanhi1; lo = atanlo1;
+                x = (x - 1.0f) / (x + 1.0f);
+            }
+        } else {
+            if (ix < 0x401c0000) {                // |x| < 2.4375
+                id = 2; hi = atanhi2; lo = atanlo2;
+                x = (x - 1.5f) / (1.0f + 1.5f * x);
+            } else {                              // 2.4375 <= |x| < 2^25
+                id = 3; hi = atanhi3; lo = atanlo3;
+                x = -1.0f / x;
+            }
+        }
+    }
+    const float z = x * x;
+    const float w = z * z;
+    const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    if (id < 0) return x - x * (s1 + s2);
+    const float r = hi - ((x * (s1 + s2) - lo) - x);
+    return hx < 0 ? -r : r;
+}
+
+// ---- atan2f: fdlibm e_atan2f.c ---------------------------------------------------------------------
+RLM_FN float atan2_32(float y, float x)
+{
+    const float tiny = 1.0e-30f;
+    const float pi_o_4 = u2f(0x3f490fdbu), pi_o_2 = u2f(0x3fc90fdbu), pi = u2f(0x40490fdbu), pi_lo = u2f(0xb3bbbd2eu);
+    const int32_t hx = (int32_t)f2u(x), hy = (int32_t)f2u(y);
+    const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;              // NaN
+    if (hx == 0x3f800000) return atan32(y);                               // x == 1
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);                    // 2*sign(x) + sign(y)
+    if (iy == 0) {
+        switch (m) {
+        case 0:
+        case 1: return y;
+        case 2: return pi + tiny;
+        default: return -pi - tiny;
+        }
+    }
+    if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000) {
+            switch (m) {
+            case 0: return pi_o_4 + tiny;
+            case 1: return -pi_o_4 - tiny;
+            case 2: return 3.0f * pi_o_4 + tiny;
+            default: return -3.0f * pi_o_4 - tiny;
+            }
+        }
+        switch (m) {
+        case 0: return 0.0f;
+        case 1: return -0.0f;
+        case 2: return pi + tiny;
+        default: return -pi - tiny;
+        }
+    }
+    if (iy == 0x7f800000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    const int32_t k = (iy - ix) >> 23;
+    float z;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;                                // |y/x| > 2^60
+    else if (hx < 0 && k < -60) z = 0.0f;                                 // |y|/x < -2^60
+    else z = atan32(fabs32(y / x));
+    switch (m) {
+    case 0: return z;
+    case 1: return u2f(f2u(z) ^ 0x80000000u);
+    case 2: return pi - (z - pi_lo);
+    default: return (z - pi_lo) - pi;
+    }
+}
+
+// ---- acosf: fdlibm e_acosf.c ----------------------------------------------------------------------
+RLM_FN float acos32(float x)
+{
+    const float pi = u2f(0x40490fdau), pio2_hi = u2f(0x3fc90fdau), pio2_lo = u2f(0x33a22168u);
+    const float pS0 = u2f(0x3e2aaaabu), pS1 = u2f(0xbea6b090u), pS2 = u2f(0x3e4e0aa8u), pS3 = u2f(0xbd241146u),
+                pS4 = u2f(0x3a4f7f04u), pS5 = u2f(0x3811ef08u);
+    const float qS1 = u2f(0xc019d139u), qS2 = u2f(0x4001572du), qS3 = u2f(0xbf303361u), qS4 = u2f(0x3d9dc62eu);
+    const int32_t hx = (int32_t)f2u(x);
+    const int32_t ix = hx & 0x7fffffff;
+    if (ix == 0x3f800000) return hx > 0 ? 0.0f : pi + 2.0f * pio2_lo;    // |x| == 1
+    if (ix > 0x3f800000) return (x - x) / (x - x);                        // |x| > 1: NaN
+    if (ix < 0x3f000000) {                                                // |x| < 0.5
+        if (ix <= 0x23000000) return pio2_hi + pio2_lo;                   // |x| < 2^-57
+        const float z = x * x;
+        const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        const float r = p / q;
+        return pio2_hi - (x - (pio2_lo - x * r));
+    }
+    if (hx < 0) {                                                         // x < -0.5
+        const float z = (1.0f + x) * 0.5f;
+        const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        const float s = sqrtf(z);
+        const float r = p / q;
+        const float w = r * s - pio2_lo;
+        return pi - 2.0f * (s + w);
+    }
+    const float z = (1.0f - x) * 0.5f;                                    // x > 0.5
+    const float s = sqrtf(z);
+    const float df = u2f(f2u(s) & 0xfffff000u);
+    const float c = (z - df * df) / (s + df);
+    const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const float r = p / q;
+    const float w = r * s + c;
+    return 2.0f * (df + w);
+}
+
+// ---- tanf: fdlibm s_tanf.c + k_tanf.c; argument reduction as glibc >= 2.27 e_rem_pio2f.c (fp64) -----
+RLM_FN float kernel_tan32(float x, float y, int iy)
+{
+    const float pio4 = u2f(0x3f490fdau), pio4lo = u2f(0x33222168u);
+    const float T0 = u2f(0x3eaaaaabu), T1 = u2f(0x3e088889u), T2 = u2f(0x3d5d0dd1u), T3 = u2f(0x3cb327a4u),
+                T4 = u2f(0x3c11371fu), T5 = u2f(0x3b6b6916u), T6 = u2f(0x3abede48u), T7 = u2f(0x3a1a26c8u),
+                T8 = u2f(0x398137b9u), T9 = u2f(0x38a3f445u), T10 = u2f(0x3895c07au), T11 = u2f(0xb79bae5fu),
+                T12 = u2f(0x37d95384u);
+    const int32_t hx = (int32_t)f2u(x);
+    const int32_t ix = hx & 0x7fffffff;
+    if (ix < 0x39000000) {                                                // |x| < 2^-13
+        if ((int)x == 0) {
+            if ((ix | (iy + 1)) == 0) return 1.0f / fabs32(x);
+            if (iy == 1) return x;
+            return -1.0f / x;
+        }
+    }
+    if (ix >= 0x3f2ca140) {                                               // |x| >= 0.6744
+        if (hx < 0) { x = -x; y = -y; }
+        const float zz = pio4 - x;
+        const float ww = pio4lo - y;
+        x = zz + ww;
+        y = 0.0f;
+        if (fabs32(x) < 0x1p-13f) return (float)(1 - ((hx >> 30) & 2)) * (float)iy * (1.0f - 2.0f * (float)iy * x);
+    }
+    float z = x * x;
+    float w = z * z;
+    float r = T1 + w * (T3 + w * (T5 + w * (T7 + w * (T9 + w * T11))));
+    float v = z * (T2 + w * (T4 + w * (T6 + w * (T8 + w * (T10 + w * T12)))));
+    float s = z * x;
+    r = y + z * (s * (r + v) + y);
+    r += T0 * s;
+    w = x + r;
+    if (ix >= 0x3f2ca140) {
+        v = (float)iy;
+        return (float)(1 - ((hx >> 30) & 2)) * (v - 2.0f * (x - (w * w / (w + v) - r)));
+    }
+    if (iy == 1) return w;
+    // -1/(x+r) computed accurately
+    z = u2f(f2u(w) & 0xfffff000u);
+    v = r - (z - x);
+    const float a = -1.0f / w;
+    const float t = u2f(f2u(a) & 0xfffff000u);
+    s = 1.0f + t * z;
+    return t + a * (s + t * v);
+}
+
+
+// ---- sinf / cosf: glibc >= 2.28 s_sincosf.h ----------------------------------------------------------
+// Returns both values; each equals what sinf(x) / cosf(x) return separately.
+RLM_FN void sincos32(float y, float *sinp, float *cosp)
+{
+    const double hpi_inv = 0x1.45F306DC9C883p+23;   // 2/pi * 2^24
+    const double hpi = 0x1.921FB54442D18p0;
+    const double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5, C3 = -0x1.6c087e89a359dp-10,
+                 C4 = 0x1.99343027bf8c3p-16;
+    const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
+    const uint32_t top = (f2u(y) >> 20) & 0x7ffu;
+    double x = (double)y;
+    int n = 0;
+    bool tiny = false;
+    if (top < 0x3f4u) {                                                   // abstop12(y) < abstop12(pi/4)
+        tiny = top < 0x398u;                                              // |y| < 2^-12: sin = y, cos = 1
+    } else if (top < 0x42fu) {                                            // |y| < 120
+        const double r = x * hpi_inv;
+        n = ((int32_t)r + 0x800000) >> 24;
+        x = x - (double)n * hpi;
+    } else {
+        // huge or non-finite argument: not produced by the closures
+        *sinp = (float)sin(x);
+        *cosp = (float)cos(x);
+        return;
+    }
+    // quadrant handling of sinf/cosf: sign[n&3] applied to x, second table (negated cosine) if n&2
+    const double sgn = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+    const double cs = (n & 2) ? -1.0 : 1.0;
+    const double xs = x * sgn;
+    const double x2 = x * x;
+    // sine polynomial in xs
+    const double x3 = xs * x2;
+    const double s1 = S2 + x2 * S3;
+    const double x7 = x3 * x2;
+    const double sv = xs + x3 * S1;
+    const double sres = sv + x7 * s1;
+    // cosine polynomial (table[1] negates every coefficient)
+    const double x4 = x2 * x2;
+    const double c2 = (cs * C3) + x2 * (cs * C4);
+    const double c1 = (cs * C0) + x2 * (cs * C1);
+    const double x6 = x4 * x2;
+    const double cv = c1 + x4 * (cs * C2);
+    const double cres = cv + x6 * c2;
+    // sinf(y): quadrant n -> sine poly if n even else cosine poly; cosf(y): uses n ^ 1
+    // Note the sign conventions of s_sinf.c / s_cosf.c: both multiply x by sign[n & 3] and select
+    // the second table on n & 2; the polynomial is chosen by the parity of n (sin) or n ^ 1 (cos).
+    float sf, cf;
+    if ((n & 1) == 0) { sf = (float)sres; cf = (float)cres; }
+    else              { sf = (float)cres; cf = (float)sres; }
+    if (tiny) { sf = y; cf = 1.0f; }
+    *sinp = sf;
+    *cosp = cf;
+}
+
+RLM_FN float tan32(float x)
+{
+    const int32_t hx = (int32_t)f2u(x);
+    const int32_t ix = hx & 0x7fffffff;
+    if (ix <= 0x3f490fda) return kernel_tan32(x, 0.0f, 1);                // |x| <= pi/4
+    if (ix < 0x42f00000) {                                                // |x| < 120
+        // __ieee754_rem_pio2f of glibc >= 2.27: the fp64 reduction of s_sincosf.h, split into
+        // a high and a low fp32 part
+        const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+        const double r = (double)x * hpi_inv;
+        const int n = ((int32_t)r + 0x800000) >> 24;
+        const double dx = (double)x - (double)n * hpi;
+        const float y0 = (float)dx;
+        const float y1 = (float)(dx - (double)y0);
+        return kernel_tan32(y0, y1, 1 - ((n & 1) << 1));
+    }
+    return (float)tan((double)x);                                         // never reached by the closures
+}
+
+} // namespace rlm

@@ -56,10 +56,10 @@ __global__ __launch_bounds__(rlsh::kBlock) void ggx_kernel(GgxIO a)
             st3(a.wi, i, L);
             if (a.fresnel) stg(a.fresnel, i, F);
             if (OP != OP_SAMPLE) {
-                float fr, fg, fb;
-                ggx_eval(g, L, fr, fg, fb);
+                float fr, fg, fb, pdf;
+                ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pdf);
                 strgb(a.f, i, fr, fg, fb);
-                stg(a.pdf, i, ggx_pdf(g, L));
+                stg(a.pdf, i, pdf);
             }
             if (OP == OP_REFLECT_REFRACT) {
                 // second sample on the same closure: the view analysis is reused

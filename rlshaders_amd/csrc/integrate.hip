@@ -101,9 +101,8 @@ __global__ __launch_bounds__(rlsh::kBlock) void ggx_integrate_kernel(GgxIntIO a)
             V3 M = vndf_microfacet(w, g.fr, rx, ry);
             V3 L = reflect_direction(g.view, M);
             accF += ggx_fresnel(g, L, M);                   // mReflectWeight, src/rlGgx.h:103
-            float fr, fg, fb;
-            ggx_eval(g, L, fr, fg, fb);
-            float pdf = ggx_pdf(g, L);
+            float fr, fg, fb, pdf;
+            ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pdf);
             accR += fr / pdf; accG += fg / pdf; accB += fb / pdf;
         }
         if (G > 1) {

@@ -79,10 +79,10 @@ struct Frame { V3 U, V, N; };
 #define RLS_HOST_LIBM 1
 #endif
 #if RLS_HOST_LIBM
-RLS_DEV void t_sincos(float x, float *s, float *c) { rlm::sincos32(x, s, c); }
-RLS_DEV float t_atan2(float y, float x) { return rlm::atan2_32(y, x); }
-RLS_DEV float t_acos(float x) { return rlm::acos32(x); }
-RLS_DEV float t_tan(float x) { return rlm::tan32(x); }
+RLS_DEV void t_sincos(float x, float *s, float *c) { rlm::sincos32_v(x, s, c); }
+RLS_DEV float t_atan2(float y, float x) { return rlm::atan2_32_v(y, x); }
+RLS_DEV float t_acos(float x) { return rlm::acos32_v(x); }
+RLS_DEV float t_tan(float x) { return rlm::tan32_v(x); }
 #else
 RLS_DEV void t_sincos(float x, float *s, float *c) { sincosf(x, s, c); }
 RLS_DEV float t_atan2(float y, float x) { return atan2f(y, x); }
@@ -226,6 +226,10 @@ struct Ggx {
     float rough;          // mRoughness = max(1e-5, r^2)
     float ax, ay;
     float iorIn, iorOut;
+    // values the reference recomputes in every call, hoisted (same expressions, same bits):
+    float eta2;           // SQR(mIorOut / mIorIn), src/rlGgx.h:258
+    float vn;             // dot(mViewDir, mAxisN)
+    float g1v;            // G1(mViewDir, m, n) where it is not zero, src/rlGgx.h:353-356
 };
 
 RLS_DEV Ggx ggx_make(V3 wo, V3 N, V3 T, bool exiting, float ksR, float ksG, float ksB,
@@ -244,6 +248,13 @@ RLS_DEV Ggx ggx_make(V3 wo, V3 N, V3 T, bool exiting, float ksR, float ksG, floa
     g.ax = maxf(1e-4f, sqr(roughness) / aspect);
     g.ay = maxf(1e-4f, sqr(roughness) * aspect);
     g.rough = maxf(1e-5f, sqr(roughness));
+    g.eta2 = sqr(g.iorOut / g.iorIn);
+    g.vn = dot(wo, N);
+    {
+        float cosSqr = sqr(g.vn);
+        float tanSqr = 1.0f / cosSqr - 1.0f;
+        g.g1v = 2.0f / (1.0f + sqrtf(1.0f + sqr(g.rough) * tanSqr));
+    }
     return g;
 }
 
@@ -251,7 +262,7 @@ RLS_DEV Ggx ggx_make(V3 wo, V3 N, V3 T, bool exiting, float ksR, float ksG, floa
 RLS_DEV float ggx_fresnel(const Ggx &g, V3 i, V3 m)
 {
     float c = absf(dot(i, m));
-    float gSqr = sqr(g.iorOut / g.iorIn) - 1.0f + c * c;
+    float gSqr = g.eta2 - 1.0f + c * c;
     if (gSqr < 0.0f) return 1.0f;
     float gg = sqrtf(gSqr);
     float gmc = gg - c;
@@ -281,44 +292,54 @@ RLS_DEV float ggx_G1(const Ggx &g, V3 v, V3 m, V3 n)
     return 2.0f / den;
 }
 
-// src/rlGgx.h:272-275
-RLS_DEV float ggx_G(const Ggx &g, V3 i, V3 o, V3 m, V3 n) { return ggx_G1(g, i, m, n) * ggx_G1(g, o, m, n); }
+// G1(mViewDir, m, mAxisN): the value depends on the view only, the zero test on m
+RLS_DEV float ggx_G1_view(const Ggx &g, V3 m) { return dot(g.view, m) * g.vn < 0.0f ? 0.0f : g.g1v; }
 
-// reflection(), src/rlGgx.h:304-313
-RLS_DEV float ggx_reflection(const Ggx &g, V3 i, V3 o, V3 n)
+// src/rlGgx.h:272-275 (i is always mViewDir at the reference's call sites: 300,312)
+RLS_DEV float ggx_G(const Ggx &g, V3 o, V3 m) { return ggx_G1_view(g, m) * ggx_G1(g, o, m, g.fr.N); }
+
+// evalBrdf (src/rlGgx.h:110-119,158-165) with reflection() (304-313), and evalPdf (121-127) with
+// VNDFKernel::evalPdf (72-80), sharing what both compute: the half vector (normalize(L + V) and
+// normalize(V + L) are the same bits; hr = sgn * H only flips signs) and D (even in m).
+template <bool WANT_F, bool WANT_PDF>
+RLS_DEV void ggx_eval_pdf(const Ggx &g, V3 L, float &fr, float &fg, float &fb, float &pdf)
 {
-    V3 hr = normalize(o + i) * sgnf(dot(i, n));
-    float rw = ggx_fresnel(g, i, hr);
-    float ln = absf(dot(o, n));
-    float vn = absf(dot(i, n));
-    return rw * ggx_G(g, i, o, hr, n) * ggx_D(g, hr) * 0.25f / (ln * vn);
+    V3 H = normalize(L + g.view);
+    float d = ggx_D(g, H);
+    if (WANT_PDF) {
+        float p = d * ggx_G1_view(g, H) / absf(g.vn) * 0.25f;
+        pdf = maxf(p, kEps);
+    }
+    if (WANT_F) {
+        bool small = absf(g.ksR) < kEps && absf(g.ksG) < kEps && absf(g.ksB) < kEps;
+        if (is_zero(L) || small) {
+            fr = 0.0f; fg = 0.0f; fb = 0.0f;
+            return;
+        }
+        V3 hr = H * sgnf(g.vn);
+        float rw = ggx_fresnel(g, g.view, hr);
+        float ln = absf(dot(L, g.fr.N));
+        float vn = absf(g.vn);
+        float refl = rw * ggx_G(g, L, hr) * d * 0.25f / (ln * vn);
+        float lns = dot(L, g.fr.N);
+        fr = g.ksR * refl * lns;
+        fg = g.ksG * refl * lns;
+        fb = g.ksB * refl * lns;
+    }
 }
 
-// evalBrdf + evalReflectance, src/rlGgx.h:110-119,158-165
 RLS_DEV void ggx_eval(const Ggx &g, V3 L, float &fr, float &fg, float &fb)
 {
-    bool small = absf(g.ksR) < kEps && absf(g.ksG) < kEps && absf(g.ksB) < kEps;
-    if (is_zero(L) || small) {
-        fr = 0.0f; fg = 0.0f; fb = 0.0f;
-        return;
-    }
-    float refl = ggx_reflection(g, g.view, L, g.fr.N);
-    float ln = dot(L, g.fr.N);
-    fr = g.ksR * refl * ln;
-    fg = g.ksG * refl * ln;
-    fb = g.ksB * refl * ln;
+    float unused;
+    ggx_eval_pdf<true, false>(g, L, fr, fg, fb, unused);
 }
 
-// VNDFKernel::evalPdf, src/rlGgx.h:72-80
-RLS_DEV float vndf_pdf(const Ggx &g, V3 i, V3 m)
+RLS_DEV float ggx_pdf(const Ggx &g, V3 L)
 {
-    float in = absf(dot(i, g.fr.N));
-    float pdf = ggx_D(g, m) * ggx_G1(g, i, m, g.fr.N) / in * 0.25f;
-    return maxf(pdf, kEps);
+    float a, b, c, pdf;
+    ggx_eval_pdf<false, true>(g, L, a, b, c, pdf);
+    return pdf;
 }
-
-// evalPdf, src/rlGgx.h:121-127
-RLS_DEV float ggx_pdf(const Ggx &g, V3 L) { return vndf_pdf(g, g.view, normalize(g.view + L)); }
 
 // NDFKernel, src/rlGgx.h:33-50 (alternate, not selected by the reference)
 RLS_DEV V3 ndf_microfacet(const Ggx &g, float rx, float ry)
@@ -343,7 +364,7 @@ RLS_DEV float ggx_sample_weight(const Ggx &g, V3 i, V3 o, V3 m)
     float ih = dot(i, m);
     float mn = absf(dot(m, g.fr.N));
     float in = absf(dot(i, g.fr.N));
-    return ggx_G(g, i, o, m, g.fr.N) * absf(ih / (in * mn));
+    return ggx_G(g, o, m) * absf(ih / (in * mn));
 }
 
 // Refraction of sg->Rd = -view about the microfacet m, eta = iorIn/iorOut (Walter et al. EGSR'07

@@ -314,4 +314,200 @@ RLM_FN float tan32(float x)
     return (float)tan((double)x);                                         // never reached by the closures
 }
 
+// =================================================================================================
+// Wave-friendly forms.  Same arithmetic, same results, but the range cases are expressed as
+// selects around ONE shared division / polynomial instead of separate branches, because the 64
+// lanes of a wavefront land in different ranges and would otherwise execute every branch in turn.
+// tests/native/libm_faithful.cpp checks  *_v == plain form == host libm  on every argument.
+// =================================================================================================
+
+RLM_FN float sel(bool c, float a, float b) { return c ? a : b; }
+
+// atanf for finite x (NaN propagates through the arithmetic; |x| >= 2^25 handled by a select)
+RLM_FN float atan32_v(float x)
+{
+    const float aT0 = u2f(0x3eaaaaabu), aT1 = u2f(0xbe4ccccdu), aT2 = u2f(0x3e124925u), aT3 = u2f(0xbde38e38u),
+                aT4 = u2f(0x3dba2e6eu), aT5 = u2f(0xbd9d8795u), aT6 = u2f(0x3d886b35u), aT7 = u2f(0xbd6ef16bu),
+                aT8 = u2f(0x3d4bda59u), aT9 = u2f(0xbd15a221u), aT10 = u2f(0x3c8569d7u);
+    const int32_t hx = (int32_t)f2u(x);
+    const int32_t ix = hx & 0x7fffffff;
+    const float ax = fabs32(x);
+    const bool r0 = ix < 0x3ee00000;      // |x| < 7/16: no reduction, signed x
+    const bool r1 = ix < 0x3f300000;      // < 11/16
+    const bool r2 = ix < 0x3f980000;      // < 19/16
+    const bool r3 = ix < 0x401c0000;      // < 39/16
+    // t = num / den ; r0 uses x / 1 (exact)
+    const float num = r0 ? x : r1 ? (2.0f * ax - 1.0f) : r2 ? (ax - 1.0f) : r3 ? (ax - 1.5f) : -1.0f;
+    const float den = r0 ? 1.0f : r1 ? (2.0f + ax) : r2 ? (ax + 1.0f) : r3 ? (1.0f + 1.5f * ax) : ax;
+    const float hi = r1 ? u2f(0x3eed6338u) : r2 ? u2f(0x3f490fdau) : r3 ? u2f(0x3f7b985eu) : u2f(0x3fc90fdau);
+    const float lo = r1 ? u2f(0x31ac3769u) : r2 ? u2f(0x33222168u) : r3 ? u2f(0x33140fb4u) : u2f(0x33a22168u);
+    const float t = num / den;
+    const float z = t * t;
+    const float w = z * z;
+    const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    const float ts = t * (s1 + s2);
+    const float small = t - ts;                                   // id < 0
+    float big = hi - ((ts - lo) - t);
+    big = hx < 0 ? -big : big;
+    float res = r0 ? small : big;
+    res = (ix < 0x31000000) ? x : res;                            // |x| < 2^-29
+    const float huge = u2f(0x3fc90fdau) + u2f(0x33a22168u);       // atanhi[3] + atanlo[3]
+    res = (ix >= 0x4c000000 && ix <= 0x7f800000) ? (hx > 0 ? huge : -huge) : res;
+    return res;
+}
+
+// atan2f for finite arguments (the inf cases of e_atan2f.c are not reproduced: the closures never
+// pass infinities; NaN propagates).  x == 1 and y == +-0 need no special case: the general path gives
+// the same bits (atanf is odd; pi - (0 - pi_lo) rounds to pi).
+RLM_FN float atan2_32_v(float y, float x)
+{
+    const float pi_o_2 = u2f(0x3fc90fdbu), pi = u2f(0x40490fdbu), pi_lo = u2f(0xb3bbbd2eu);
+    const int32_t hx = (int32_t)f2u(x), hy = (int32_t)f2u(y);
+    const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    const int32_t k = (iy - ix) >> 23;
+    float z = atan32_v(fabs32(y / x));
+    z = (k > 60) ? (pi_o_2 + 0.5f * pi_lo) : z;
+    z = (hx < 0 && k < -60) ? 0.0f : z;
+    const float zl = z - pi_lo;
+    float res = hx < 0 ? (hy < 0 ? zl - pi : pi - zl) : (hy < 0 ? -z : z);
+    // y == +-0: +-0 for x >= 0 (sign of y), +-pi for x < 0
+    res = (iy == 0) ? (hx < 0 ? (hy < 0 ? -pi : pi) : y) : res;
+    // x == +-0, y != 0
+    res = (ix == 0 && iy != 0) ? (hy < 0 ? -pi_o_2 : pi_o_2) : res;
+    return res;
+}
+
+// acosf for |x| <= 1 (|x| > 1 gives NaN through the sqrt of a negative number)
+RLM_FN float acos32_v(float x)
+{
+    const float pi = u2f(0x40490fdau), pio2_hi = u2f(0x3fc90fdau), pio2_lo = u2f(0x33a22168u);
+    const float pS0 = u2f(0x3e2aaaabu), pS1 = u2f(0xbea6b090u), pS2 = u2f(0x3e4e0aa8u), pS3 = u2f(0xbd241146u),
+                pS4 = u2f(0x3a4f7f04u), pS5 = u2f(0x3811ef08u);
+    const float qS1 = u2f(0xc019d139u), qS2 = u2f(0x4001572du), qS3 = u2f(0xbf303361u), qS4 = u2f(0x3d9dc62eu);
+    const int32_t hx = (int32_t)f2u(x);
+    const int32_t ix = hx & 0x7fffffff;
+    const bool mid = ix < 0x3f000000;                             // |x| < 0.5
+    const bool neg = hx < 0;
+    const float z = mid ? x * x : (neg ? (1.0f + x) * 0.5f : (1.0f - x) * 0.5f);
+    const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const float r = p / q;
+    const float r_mid = pio2_hi - (x - (pio2_lo - x * r));
+    float res = r_mid;
+    if (!mid) {
+        const float s = sqrtf(z);
+        const float df = u2f(f2u(s) & 0xfffff000u);
+        const float c = (z - df * df) / (s + df);
+        const float r_pos = 2.0f * (df + (r * s + c));
+        const float r_neg = pi - 2.0f * (s + (r * s - pio2_lo));
+        res = neg ? r_neg : r_pos;
+    }
+    res = (ix <= 0x23000000) ? pio2_hi + pio2_lo : res;           // |x| < 2^-57
+    res = (ix == 0x3f800000) ? (hx > 0 ? 0.0f : pi + 2.0f * pio2_lo) : res;
+    res = (ix > 0x3f800000) ? (x - x) / (x - x) : res;
+    return res;
+}
+
+// fp64 reduction by pi/2 shared by sinf / cosf / tanf (reduce_fast of s_sincosf.h); |x| < 120
+RLM_FN double reduce_pio2(float y, int *np)
+{
+    const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+    const double x = (double)y;
+    const double r = x * hpi_inv;
+    const int n = ((int32_t)r + 0x800000) >> 24;
+    *np = n;
+    return x - (double)n * hpi;
+}
+
+// sinf and cosf of the same argument, |y| < 120 (one reduction, both polynomials)
+RLM_FN void sincos32_v(float y, float *sinp, float *cosp)
+{
+    const double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5, C3 = -0x1.6c087e89a359dp-10,
+                 C4 = 0x1.99343027bf8c3p-16;
+    const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
+    int n;
+    const double x = reduce_pio2(y, &n);          // n == 0 and x == y whenever |y| < pi/4
+    const double xs = ((n & 3) == 1 || (n & 3) == 2) ? -x : x;
+    const double x2 = x * x;
+    const double x3 = xs * x2;
+    const double s1 = S2 + x2 * S3;
+    const double x5 = x3 * x2;
+    const double sv = xs + x3 * S1;
+    double sres = sv + x5 * s1;
+    const double x4 = x2 * x2;
+    const double c2 = C3 + x2 * C4;
+    const double c1 = C0 + x2 * C1;
+    const double x6 = x4 * x2;
+    const double cv = c1 + x4 * C2;
+    double cres = cv + x6 * c2;
+    cres = (n & 2) ? -cres : cres;                // second table: every cosine coefficient negated
+    float sf = (float)((n & 1) ? cres : sres);
+    float cf = (float)((n & 1) ? sres : cres);
+    const uint32_t top = (f2u(y) >> 20) & 0x7ffu;
+    if (top < 0x398u) { sf = y; cf = 1.0f; }      // |y| < 2^-12
+    *sinp = sf;
+    *cosp = cf;
+}
+
+// tanf for 0 <= |x| < 120: one fp64 reduction, then k_tanf.c with its single division shared
+RLM_FN float tan32_v(float xin)
+{
+    const float pio4 = u2f(0x3f490fdau), pio4lo = u2f(0x33222168u);
+    const float T0 = u2f(0x3eaaaaabu), T1 = u2f(0x3e088889u), T2 = u2f(0x3d5d0dd1u), T3 = u2f(0x3cb327a4u),
+                T4 = u2f(0x3c11371fu), T5 = u2f(0x3b6b6916u), T6 = u2f(0x3abede48u), T7 = u2f(0x3a1a26c8u),
+                T8 = u2f(0x398137b9u), T9 = u2f(0x38a3f445u), T10 = u2f(0x3895c07au), T11 = u2f(0xb79bae5fu),
+                T12 = u2f(0x37d95384u);
+    // s_tanf.c: |x| <= pi/4 goes to the kernel unreduced; the reduction returns n = 0, y0 = x,
+    // y1 = 0 there, so it is applied unconditionally
+    int n;
+    const double dx = reduce_pio2(xin, &n);
+    float x = (float)dx;
+    float y = (float)(dx - (double)x);
+    const bool direct = ((int32_t)f2u(xin) & 0x7fffffff) <= 0x3f490fda;
+    x = direct ? xin : x;
+    y = direct ? 0.0f : y;
+    const int iy = direct ? 1 : 1 - ((n & 1) << 1);
+    const float fiy = (float)iy;
+
+    const int32_t hx = (int32_t)f2u(x);
+    const int32_t ix = hx & 0x7fffffff;
+    const float x_in = x;                                         // for the tiny-argument returns
+    const bool big = ix >= 0x3f2ca140;                            // |x| >= 0.6744
+    const float sgn = (float)(1 - ((hx >> 30) & 2));
+    if (big) {
+        const float xa = hx < 0 ? -x : x;
+        const float ya = hx < 0 ? -y : y;
+        const float zz = pio4 - xa;
+        const float ww = pio4lo - ya;
+        x = zz + ww;
+        y = 0.0f;
+    }
+    const float z = x * x;
+    float w = z * z;
+    float r = T1 + w * (T3 + w * (T5 + w * (T7 + w * (T9 + w * T11))));
+    const float v = z * (T2 + w * (T4 + w * (T6 + w * (T8 + w * (T10 + w * T12)))));
+    const float s = z * x;
+    r = y + z * (s * (r + v) + y);
+    r += T0 * s;
+    w = x + r;
+    // one division: w*w/(w+iy) in the big case, -1/w when the cotangent is wanted
+    const float q = (big ? w * w : -1.0f) / (big ? w + fiy : w);
+    const float r_big = sgn * (fiy - 2.0f * (x - (q - r)));
+    const float zt = u2f(f2u(w) & 0xfffff000u);
+    const float vt = r - (zt - x);
+    const float t = u2f(f2u(q) & 0xfffff000u);
+    const float st = 1.0f + t * zt;
+    const float r_cot = t + q * (st + t * vt);
+    float res = big ? r_big : (iy == 1 ? w : r_cot);
+    // |x| >= 0.6744 and the reflected argument below 2^-13
+    res = (big && fabs32(x) < 0x1p-13f) ? sgn * fiy * (1.0f - 2.0f * fiy * x) : res;
+    // |x| < 2^-13 on entry to the kernel
+    if (((int32_t)f2u(x_in) & 0x7fffffff) < 0x39000000 && (int)x_in == 0) {
+        const int32_t ixx = (int32_t)f2u(x_in) & 0x7fffffff;
+        res = ((ixx | (iy + 1)) == 0) ? 1.0f / fabs32(x_in) : (iy == 1 ? x_in : -1.0f / x_in);
+    }
+    return res;
+}
+
 } // namespace rlm

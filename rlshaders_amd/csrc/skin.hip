@@ -33,8 +33,7 @@ __device__ __forceinline__ LobeOut ggx_lobe(V3 wo, V3 N, V3 T, float cr, float c
     V3 M = vndf_microfacet(w, g.fr, rx, ry);
     o.wi = reflect_direction(g.view, M);
     o.F = ggx_fresnel(g, o.wi, M);
-    ggx_eval(g, o.wi, o.fr, o.fg, o.fb);
-    o.pdf = ggx_pdf(g, o.wi);
+    ggx_eval_pdf<true, true>(g, o.wi, o.fr, o.fg, o.fb, o.pdf);
     return o;
 }
 

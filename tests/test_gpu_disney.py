@@ -105,6 +105,7 @@ def test_integrate_reduced_and_streamed(gpu, oracle):
     od = disney_oracle(oracle, c)
     ref = od.integrate(spp_n, 4321, streamed=True)
     s = disney_sampler(gpu, c)
+    os.environ["RLS_INTEGRATE_GROUP"] = "1"      # one lane per point: sums in the reference's order
     got = {k: host(v) for k, v in s.integrate(spp_n, 4321, streamed=True).items()}
     st = cases.summarize(cases.rel_err(got["wi"], ref["wi"]))
     print("disney integrate streamed wi", st)
@@ -116,6 +117,7 @@ def test_integrate_reduced_and_streamed(gpu, oracle):
         print("disney integrate", k, st)
         assert st["median"] <= 1e-5 and st["frac_gt_1e5"] <= 0.1, (k, st)
     base = {k: host(v) for k, v in s.integrate(spp_n, 4321).items()}
+    del os.environ["RLS_INTEGRATE_GROUP"]
     for k in ("diffuse_sum", "specular_sum", "diffuse_count", "specular_count"):
         assert np.array_equal(base[k].view(np.uint32), got[k].view(np.uint32)), k   # reduced == streamed sums
     for g in ("4", "16"):

@@ -52,7 +52,7 @@ RLS_DEV V3 cross(V3 a, V3 b)
 {
     return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-RLS_DEV float length(V3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+RLS_DEV float length(V3 a) { return rlm::sqrt32(a.x * a.x + a.y * a.y + a.z * a.z); }
 // AiV3Normalize: scale by the reciprocal length, zero vector stays zero
 RLS_DEV V3 normalize(V3 a)
 {
@@ -94,7 +94,7 @@ RLS_DEV float t_tan(float x) { return tanf(x); }
 // src/rlUtil.h:21-29
 RLS_DEV V3 spherical_direction(float cosTheta, float phi)
 {
-    float r = sqrtf(1.0f - sqr(cosTheta));
+    float r = rlm::sqrt32(1.0f - sqr(cosTheta));
     float s, c;
     t_sincos(phi, &s, &c);
     return mk(r * c, r * s, cosTheta);
@@ -131,7 +131,7 @@ RLS_DEV V2 concentric_disk(float rx, float ry)
 RLS_DEV V3 cosine_hemisphere(const Frame &fr, float rx, float ry)
 {
     V2 d = concentric_disk(rx, ry);
-    float z = sqrtf(maxf(0.0f, 1.0f - sqr(d.x) - sqr(d.y)));
+    float z = rlm::sqrt32(maxf(0.0f, 1.0f - sqr(d.x) - sqr(d.y)));
     return to_frame(mk(d.x, d.y, z), fr.U, fr.V, fr.N);
 }
 
@@ -166,7 +166,7 @@ RLS_DEV VndfView vndf_view(V3 view, const Frame &fr, float ax, float ay)
     float B = t_tan(theta);
     w.B = B;
     w.B2 = sqr(B);
-    w.G1 = 2.0f / (1.0f + sqrtf(1.0f + w.B2));
+    w.G1 = 2.0f / (1.0f + rlm::sqrt32(1.0f + w.B2));
     w.invB = 1.0f / B;
     return w;
 }
@@ -174,7 +174,7 @@ RLS_DEV VndfView vndf_view(V3 view, const Frame &fr, float ax, float ay)
 // uniformSample lambda, src/rlGgx.cpp:18-25
 RLS_DEV V2 uniform_slope(float rx, float ry)
 {
-    float r = sqrtf(rx / (1.0f - rx));
+    float r = rlm::sqrt32(rx / (1.0f - rx));
     float phi = kTwoPi * ry;
     float s, c;
     t_sincos(phi, &s, &c);
@@ -194,7 +194,7 @@ RLS_DEV V3 vndf_microfacet(const VndfView &w, const Frame &fr, float rx, float r
         slope = uniform_slope(rx, ry);
     } else {
         float tmp = 1.0f / (A2 - 1.0f);
-        float D = sqrtf(maxf(0.0f, w.B2 * sqr(tmp) - (A2 - w.B2) * tmp));
+        float D = rlm::sqrt32(maxf(0.0f, w.B2 * sqr(tmp) - (A2 - w.B2) * tmp));
         float slopeX1 = w.B * tmp - D;
         float slopeX2 = w.B * tmp + D;
         slope.x = (A < 0.0f || slopeX2 > w.invB) ? slopeX1 : slopeX2;
@@ -209,7 +209,7 @@ RLS_DEV V3 vndf_microfacet(const VndfView &w, const Frame &fr, float rx, float r
         }
         float z = (u * (u * (u * 0.27385f - 0.73369f) + 0.46341f))
                 / (u * (u * (u * 0.093073f + 0.309420f) - 1.0f) + 0.597999f);
-        slope.y = sign * z * sqrtf(1.0f + sqr(slope.x));
+        slope.y = sign * z * rlm::sqrt32(1.0f + sqr(slope.x));
     }
     V3 omega;
     omega.x = -(w.cosPhi * slope.x - w.sinPhi * slope.y) * w.ax;
@@ -244,7 +244,7 @@ RLS_DEV Ggx ggx_make(V3 wo, V3 N, V3 T, bool exiting, float ksR, float ksG, floa
     g.fr.N = N;
     g.fr.U = T;
     g.fr.V = cross(N, T);
-    float aspect = sqrtf(1.0f - anisotropic * 0.9f);
+    float aspect = rlm::sqrt32(1.0f - anisotropic * 0.9f);
     g.ax = maxf(1e-4f, sqr(roughness) / aspect);
     g.ay = maxf(1e-4f, sqr(roughness) * aspect);
     g.rough = maxf(1e-5f, sqr(roughness));
@@ -253,7 +253,7 @@ RLS_DEV Ggx ggx_make(V3 wo, V3 N, V3 T, bool exiting, float ksR, float ksG, floa
     {
         float cosSqr = sqr(g.vn);
         float tanSqr = 1.0f / cosSqr - 1.0f;
-        g.g1v = 2.0f / (1.0f + sqrtf(1.0f + sqr(g.rough) * tanSqr));
+        g.g1v = 2.0f / (1.0f + rlm::sqrt32(1.0f + sqr(g.rough) * tanSqr));
     }
     return g;
 }
@@ -264,7 +264,7 @@ RLS_DEV float ggx_fresnel(const Ggx &g, V3 i, V3 m)
     float c = absf(dot(i, m));
     float gSqr = g.eta2 - 1.0f + c * c;
     if (gSqr < 0.0f) return 1.0f;
-    float gg = sqrtf(gSqr);
+    float gg = rlm::sqrt32(gSqr);
     float gmc = gg - c;
     float gpc = gg + c;
     return 0.5f * sqr(gmc / gpc) * (1.0f + sqr((c * gpc - 1.0f) / (c * gmc + 1.0f)));
@@ -288,7 +288,7 @@ RLS_DEV float ggx_G1(const Ggx &g, V3 v, V3 m, V3 n)
     if (vm * vn < 0.0f) return 0.0f;
     float cosSqr = sqr(vn);
     float tanSqr = 1.0f / cosSqr - 1.0f;
-    float den = 1.0f + sqrtf(1.0f + sqr(g.rough) * tanSqr);
+    float den = 1.0f + rlm::sqrt32(1.0f + sqr(g.rough) * tanSqr);
     return 2.0f / den;
 }
 
@@ -344,7 +344,7 @@ RLS_DEV float ggx_pdf(const Ggx &g, V3 L)
 // NDFKernel, src/rlGgx.h:33-50 (alternate, not selected by the reference)
 RLS_DEV V3 ndf_microfacet(const Ggx &g, float rx, float ry)
 {
-    float gg = sqrtf(rx / (1.0f - rx));
+    float gg = rlm::sqrt32(rx / (1.0f - rx));
     float phi = kTwoPi * ry;
     float s, c;
     t_sincos(phi, &s, &c);
@@ -379,7 +379,7 @@ RLS_DEV bool ggx_refract(const Ggx &g, V3 m, V3 &dir)
     bool refracted = !(k < 0.0f);
     if (refracted) {
         float s = sgnf(dot(i, g.fr.N));
-        float t = eta * c - s * sqrtf(k);
+        float t = eta * c - s * rlm::sqrt32(k);
         dir = m * t - i * eta;
     } else {
         dir = m * (2.0f * c) - i;
@@ -420,7 +420,7 @@ RLS_DEV Disney disney_make(V3 wo, V3 N, V3 T, float bR, float bG, float bB, cons
     d.fr.U = T;
     d.fr.V = cross(N, T);
 
-    float aspect = sqrtf(1.0f - anisotropic * 0.9f);
+    float aspect = rlm::sqrt32(1.0f - anisotropic * 0.9f);
     d.ax = maxf(1e-2f, sqr(d.roughness) / aspect);
     d.ay = maxf(1e-2f, sqr(d.roughness) * aspect);
     d.specRough = sqr(d.roughness);
@@ -445,7 +445,7 @@ RLS_DEV float smithG_GGX(float ndv, float alphaG)
 {
     float a = alphaG * alphaG;
     float b = ndv * ndv;
-    return 1.0f / (ndv + sqrtf(a + b - a * b));
+    return 1.0f / (ndv + rlm::sqrt32(a + b - a * b));
 }
 // src/rlDisney.cpp:545-551
 RLS_DEV float D_GTR1(const Disney &d, float mn2)
@@ -524,8 +524,8 @@ RLS_DEV V3 disney_gtr1_microfacet(const Disney &d, float rx, float ry)
     float phiH = kTwoPi * rx;
     float a2 = sqr(d.roughness);
     float cosThetaH = a2 == 1.0f
-        ? sqrtf(1.0f - ry)
-        : sqrtf((1.0f - powf(a2, 1.0f - ry)) / (1.0f - a2));
+        ? rlm::sqrt32(1.0f - ry)
+        : rlm::sqrt32((1.0f - powf(a2, 1.0f - ry)) / (1.0f - a2));
     V3 omega = spherical_direction(cosThetaH, phiH);
     return normalize(to_frame(omega, d.fr.U, d.fr.V, d.fr.N));
 }
@@ -697,7 +697,7 @@ RLS_DEV float sss_probe_ray(const NdProfile &p, const Frame &fr, float rx, float
     V3 o;
     o.x = c * r;
     o.z = s * r;
-    o.y = sqrtf(rmax * rmax - r * r);
+    o.y = rlm::sqrt32(rmax * rmax - r * r);
     maxdist = o.y * 2.0f;
     if (idx < 2) {
         dir = -fr.N;
@@ -718,9 +718,9 @@ RLS_DEV float sss_mis_pdf(const NdProfile &p, const Frame &fr, V3 disp, V3 sN, b
     V3 o = literal ? to_frame(disp, fr.U, fr.V, fr.N)
                    : mk(dot(disp, fr.U), dot(disp, fr.V), dot(disp, fr.N));
     o = mk(o.x * o.x, o.y * o.y, o.z * o.z);
-    float rr0 = sqrtf(o.y + o.z);
-    float rr1 = sqrtf(o.x + o.z);
-    float rr2 = sqrtf(o.x + o.y);
+    float rr0 = rlm::sqrt32(o.y + o.z);
+    float rr1 = rlm::sqrt32(o.x + o.z);
+    float rr2 = rlm::sqrt32(o.x + o.y);
     return nd_pdf(p, rr0) * absf(dot(fr.U, sN)) * 0.25f
          + nd_pdf(p, rr1) * absf(dot(fr.V, sN)) * 0.25f
          + nd_pdf(p, rr2) * absf(dot(fr.N, sN)) * 0.5f;
@@ -731,7 +731,7 @@ RLS_DEV float sss_cavity_fade(V3 disp, float r, V3 sN, V3 No)
 {
     V3 dd = mk(disp.x / r, disp.y / r, disp.z / r);
     float c = dot(No, dd) < 0.0f ? absf(dot(sN, No)) : clampf(dot(sN, No), -1.0f, 1.0f);
-    return sqrtf((1.0f + c) * 0.5f);
+    return rlm::sqrt32((1.0f + c) * 0.5f);
 }
 
 // ---- counter-based generator: integer hash + exactly rounded ops only (reproducible on a CPU) ----

@@ -55,6 +55,28 @@ RLM_FN float u2f(uint32_t u)
 }
 RLM_FN float fabs32(float x) { return u2f(f2u(x) & 0x7fffffffu); }
 
+// Correctly rounded fp32 square root.  Host: libm's sqrtf.  Device: the compiler's expansion of
+// sqrtf spends 7 of its 16 instructions rescaling arguments below 2^-96 so that the residuals of
+// its final +-1 ulp correction stay normal; the closures' radicands are never that small, so the
+// common path here is the same v_sqrt_f32 + correction without the rescaling, and arguments
+// below 2^-96 (never seen in practice) take the compiler's full sequence.  Identical results.
+RLM_FN float sqrt32(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__builtin_expect(x < 0x1p-96f && x > 0.0f, 0)) return sqrtf(x);
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __uint_as_float(__float_as_uint(s) - 1u);
+    const float sp = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rm = __builtin_fmaf(-sm, s, x);
+    const float rp = __builtin_fmaf(-sp, s, x);
+    s = (0.0f >= rm) ? sm : s;
+    s = (0.0f < rp) ? sp : s;
+    return s;
+#else
+    return sqrtf(x);
+#endif
+}
+
 // ---- atanf: fdlibm s_atanf.c ---------------------------------------------------------------------
 RLM_FN float atan32(float x)
 {
@@ -177,13 +199,13 @@ RLM_FN float acos32(float x)
         const float z = (1.0f + x) * 0.5f;
         const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
         const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
-        const float s = sqrtf(z);
+        const float s = sqrt32(z);
         const float r = p / q;
         const float w = r * s - pio2_lo;
         return pi - 2.0f * (s + w);
     }
     const float z = (1.0f - x) * 0.5f;                                    // x > 0.5
-    const float s = sqrtf(z);
+    const float s = sqrt32(z);
     const float df = u2f(f2u(s) & 0xfffff000u);
     const float c = (z - df * df) / (s + df);
     const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
@@ -396,7 +418,7 @@ RLM_FN float acos32_v(float x)
     const float r_mid = pio2_hi - (x - (pio2_lo - x * r));
     float res = r_mid;
     if (!mid) {
-        const float s = sqrtf(z);
+        const float s = sqrt32(z);
         const float df = u2f(f2u(s) & 0xfffff000u);
         const float c = (z - df * df) / (s + df);
         const float r_pos = 2.0f * (df + (r * s + c));

@@ -175,30 +175,27 @@ def main():
 
     import torch
     import rlshaders_amd as R
+    from rlshaders_amd.sharding import Ranks, shard_range
 
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the closures only run on the HIP path")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    ranks = Ranks(backend="nccl" if world > 1 else None, device=torch.device("cuda", local_rank))
+    rank = ranks.rank
 
     ctx = R.Context(local_rank)
     n = 1 << args.log2_points
-    wl = make_workload(R, ctx, args.workload, n, first=rank * n)
+    # weak scaling: the job is world * n points, rank g owns the index range [g*n, (g+1)*n)
+    first, count = shard_range(world * n, rank, world)
+    assert count == n
+    wl = make_workload(R, ctx, args.workload, n, first=first)
     torch.cuda.synchronize()
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
 
     for _ in range(args.warmup):
         wl.launch()
     torch.cuda.synchronize()
-    barrier()
+    ranks.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ctx.timer_start()
@@ -206,14 +203,10 @@ def main():
         wl.launch()
     ctx.timer_stop()
     torch.cuda.synchronize()
-    barrier()
+    ranks.barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = ctx.timer_elapsed_ms() / max(args.steps, 1)
-
-    if dist is not None:
-        tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms = float(tt[0]), float(tt[1])
+    elapsed, kernel_ms = ranks.max_over_ranks([elapsed, kernel_ms])
 
     if rank == 0:
         samples = world * n * wl.samples_per_point * args.steps
@@ -251,9 +244,7 @@ def main():
                 line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)
 
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":

@@ -40,7 +40,7 @@ __device__ __forceinline__ Ggx load_closure(const rls_ggx_closure &c, int64_t i)
 }
 
 template <int OP>
-__global__ __launch_bounds__(rlsh::kBlock) void ggx_kernel(GgxIO a)
+__global__ RLS_KERNEL_ATTR void ggx_kernel(GgxIO a)
 {
     const int64_t stride = (int64_t)gridDim.x * rlsh::kBlock;
     for (int64_t i = (int64_t)blockIdx.x * rlsh::kBlock + threadIdx.x; i < a.n; i += stride) {

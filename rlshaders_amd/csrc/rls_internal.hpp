@@ -37,7 +37,17 @@ rls_status hip_fail(hipError_t e, const char *what);
         }                                                                   \
     } while (0)
 
-constexpr int kBlock = 256;   // 4 wavefronts of 64
+#ifndef RLS_BLOCK
+#define RLS_BLOCK 256
+#endif
+constexpr int kBlock = RLS_BLOCK;   // 4 wavefronts of 64
+
+// occupancy hint for the closure kernels (waves per SIMD the register allocator must allow)
+#ifdef RLS_WAVES_PER_EU
+#define RLS_KERNEL_ATTR __launch_bounds__(rlsh::kBlock) __attribute__((amdgpu_waves_per_eu(RLS_WAVES_PER_EU, RLS_WAVES_PER_EU)))
+#else
+#define RLS_KERNEL_ATTR __launch_bounds__(rlsh::kBlock)
+#endif
 
 // Pointwise streaming launches: enough workgroups to fill 256 CUs several times over, capped so
 // that very large batches grid-stride instead of queueing millions of workgroups.

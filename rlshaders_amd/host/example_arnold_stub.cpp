@@ -1,0 +1,83 @@
+// example_arnold_stub.cpp -- what an Arnold-side batching stub does with the library, without
+// Arnold: gather the fields rlGgx's shader_evaluate reads from AtShaderGlobals (src/rlGgx.cpp:256-261
+// of the reference) for a set of shading points, run the (sample, eval, pdf) triple for all of them
+// on the GPU, read the results back.
+//
+// The first shading point is the probe configuration recorded in SURVEY.md section 8(c) (outputs of
+// the reference's own closure code); the program prints the triple for it as JSON so that
+// tests/test_gpu_host_cpp.py can compare it with tests/golden/survey_kat.json.  Exit code 0 = ok,
+// 2 = no GPU (message on stderr), 1 = failure.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+#include "rls_batch.hpp"
+
+// the fields of Arnold's AtShaderGlobals the closures use
+struct ShaderGlobalsLite { float Rd[3], N[3], Nf[3]; };
+
+static void polar_frame(const float N[3], float U[3])
+{
+    // stand-in for the closed AiBuildLocalFramePolar: any unit tangent orthogonal to N will do,
+    // the library takes it as an input
+    float a[3] = {std::fabs(N[0]) < 0.57735f ? 1.0f : 0.0f, std::fabs(N[0]) < 0.57735f ? 0.0f : 1.0f, 0.0f};
+    float c[3] = {a[1] * N[2] - a[2] * N[1], a[2] * N[0] - a[0] * N[2], a[0] * N[1] - a[1] * N[0]};
+    float l = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    for (int k = 0; k < 3; k++) U[k] = c[k] / l;
+}
+
+int main(int argc, char **argv)
+{
+    const int n = argc > 1 ? std::atoi(argv[1]) : 1024;
+    try {
+        rlsb::Device dev(0);
+
+        // --- the stub's per-shading-point work: append to the batch -------------------------
+        rlsb::ShadingPoints pts;
+        std::vector<float> rx, ry;
+        {
+            // point 0: N = (0,0,1), U = (1,0,0), wo = (.6, 0, .8), xi = (.25, .75)
+            ShaderGlobalsLite sg = {{-0.6f, 0.0f, -0.8f}, {0, 0, 1}, {0, 0, 1}};
+            float U[3] = {1, 0, 0};
+            pts.add(sg.Rd, sg.N, sg.Nf, U);
+            rx.push_back(0.25f); ry.push_back(0.75f);
+        }
+        unsigned s = 12345u;
+        auto rnd = [&s]() { s = s * 1664525u + 1013904223u; return (float)(s >> 8) * (1.0f / 16777216.0f); };
+        for (int i = 1; i < n; i++) {
+            float z = 0.05f + 0.95f * rnd(), ph = 6.2831853f * rnd(), r = std::sqrt(1 - z * z);
+            ShaderGlobalsLite sg = {{-r * std::cos(ph), -r * std::sin(ph), -z}, {0, 0, 1}, {0, 0, 1}};
+            float U[3];
+            polar_frame(sg.Nf, U);
+            pts.add(sg.Rd, sg.N, sg.Nf, U);
+            rx.push_back(rnd()); ry.push_back(rnd());
+        }
+
+        // --- one batched closure for all of them: specColor 1, ior 1.5, roughness sqrt(.3) ---
+        rlsb::GgxSampler sampler(dev, pts, rlsb::ParamRGB(1, 1, 1), rlsb::Param(1.5f),
+                                 rlsb::Param(std::sqrt(0.3f)));
+        rlsb::Planes drx(dev, rx, 1), dry(dev, ry, 1);
+        rlsb::Planes L(dev, n, 3), f(dev, n, 3), pdf(dev, n, 1), F(dev, n, 1);
+        sampler.evalSample(drx, dry, L, F);       // GgxSampler::evalSample
+        sampler.evalBrdf(L, f);                   // GgxSampler::evalBrdf
+        sampler.evalPdf(L, pdf);                  // GgxSampler::evalPdf
+        dev.synchronize();
+
+        // the fused entry point must give the same bits
+        rlsb::Planes L2(dev, n, 3), f2(dev, n, 3), pdf2(dev, n, 1), F2(dev, n, 1);
+        sampler.sampleEvalPdf(drx, dry, L2, f2, pdf2, F2);
+        std::vector<float> hL = L.download(), hf = f.download(), hp = pdf.download();
+        std::vector<float> hL2 = L2.download(), hf2 = f2.download(), hp2 = pdf2.download();
+        for (size_t i = 0; i < hL.size(); i++)
+            if (hL[i] != hL2[i] || hf[i] != hf2[i]) { std::fprintf(stderr, "fused != separate at %zu\n", i); return 1; }
+        for (size_t i = 0; i < hp.size(); i++)
+            if (hp[i] != hp2[i]) { std::fprintf(stderr, "fused pdf != separate at %zu\n", i); return 1; }
+
+        std::printf("{\"n\": %d, \"L\": [%.9g, %.9g, %.9g], \"f\": %.9g, \"pdf\": %.9g}\n", n, hL[0], hL[(size_t)n],
+                    hL[2 * (size_t)n], hf[0], hp[0]);
+        return 0;
+    } catch (const rlsb::Error &e) {
+        std::fprintf(stderr, "rlshaders_amd: %s\n", e.what());
+        return e.status == RLS_ERR_NO_DEVICE ? 2 : 1;
+    }
+}

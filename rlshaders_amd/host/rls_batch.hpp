@@ -1,0 +1,301 @@
+// rls_batch.hpp -- C++14 host-side mirror of the reference's closure classes over the C ABI
+// (include/rlshaders_amd.h).  Header-only; needs nothing but that header and the shared library.
+//
+// The reference builds one closure object per shading point on the stack and hands Arnold three
+// static callbacks (src/rlGgx.h:97-127, src/rlGgx.cpp:261 of the reference):
+//     rls::GgxSampler sampler(sg, specColor, ior, roughness, anisotropic);
+//     AtVector L = GgxSampler::evalSample(&sampler, rx, ry);
+//     AtColor  f = GgxSampler::evalBrdf(&sampler, &L);
+//     float  pdf = GgxSampler::evalPdf(&sampler, &L);
+// Here the same verbs act on a *batch* of shading points gathered by an Arnold-side stub:
+//     rlsb::ShadingPoints pts;  pts.add(sg.Rd, sg.N, sg.Nf, U);  ...   // once per shading point
+//     rlsb::GgxSampler sampler(dev, pts, specColor, ior, roughness, anisotropic);
+//     sampler.evalSample(rx, ry, L);  sampler.evalBrdf(L, f);  sampler.evalPdf(L, pdf);
+// Error behaviour follows the reference at the value level (zero vector = invalid sample, black,
+// pdf 0, floors); failures of the device layer throw rlsb::Error carrying the rls_status.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "rlshaders_amd.h"
+
+namespace rlsb {
+
+struct Error : std::runtime_error {
+    rls_status status;
+    Error(rls_status s, const std::string &what) : std::runtime_error(what), status(s) {}
+};
+
+inline void check(rls_status s)
+{
+    if (s != RLS_OK) {
+        std::string msg = rls_last_error();
+        if (msg.empty()) msg = rls_status_string(s);
+        throw Error(s, msg);
+    }
+}
+
+// One GPU + the stream the closures launch on.
+class Device {
+public:
+    explicit Device(int ordinal = 0) { check(rls_context_create(ordinal, &ctx_)); }
+    ~Device() { rls_context_destroy(ctx_); }
+    Device(const Device &) = delete;
+    Device &operator=(const Device &) = delete;
+    rls_context *ctx() const { return ctx_; }
+    void synchronize() const { check(rls_context_synchronize(ctx_)); }
+
+private:
+    rls_context *ctx_ = nullptr;
+};
+
+// n x planes floats in device memory, planar (plane p occupies [p*n, (p+1)*n)).
+class Planes {
+public:
+    Planes() = default;
+    Planes(const Device &d, int64_t n, int planes) : dev_(&d), n_(n), planes_(planes)
+    {
+        void *p = nullptr;
+        check(rls_device_alloc(d.ctx(), sizeof(float) * (size_t)n * (size_t)planes, &p));
+        ptr_ = static_cast<float *>(p);
+    }
+    Planes(const Device &d, const std::vector<float> &host, int planes)
+        : Planes(d, (int64_t)(host.size() / (size_t)planes), planes)
+    {
+        upload(host);
+    }
+    ~Planes() { if (ptr_) rls_device_free(dev_->ctx(), ptr_); }
+    Planes(Planes &&o) noexcept { *this = std::move(o); }
+    Planes &operator=(Planes &&o) noexcept
+    {
+        if (this != &o) {
+            if (ptr_) rls_device_free(dev_->ctx(), ptr_);
+            dev_ = o.dev_; ptr_ = o.ptr_; n_ = o.n_; planes_ = o.planes_;
+            o.ptr_ = nullptr;
+        }
+        return *this;
+    }
+    Planes(const Planes &) = delete;
+    Planes &operator=(const Planes &) = delete;
+
+    void upload(const std::vector<float> &host)
+    {
+        if ((int64_t)host.size() != n_ * planes_) throw Error(RLS_ERR_INVALID_ARGUMENT, "Planes::upload: size mismatch");
+        check(rls_copy_to_device(dev_->ctx(), ptr_, host.data(), sizeof(float) * host.size()));
+    }
+    std::vector<float> download() const
+    {
+        std::vector<float> host((size_t)(n_ * planes_));
+        check(rls_copy_to_host(dev_->ctx(), host.data(), ptr_, sizeof(float) * host.size()));
+        return host;
+    }
+    float *plane(int p) const { return ptr_ + (size_t)p * (size_t)n_; }
+    rls_cvec3 cvec3(int first = 0) const { return rls_cvec3{plane(first), plane(first + 1), plane(first + 2)}; }
+    rls_vec3 vec3(int first = 0) const { return rls_vec3{plane(first), plane(first + 1), plane(first + 2)}; }
+    rls_rgb rgb(int first = 0) const { return rls_rgb{plane(first), plane(first + 1), plane(first + 2)}; }
+    int64_t size() const { return n_; }
+    bool empty() const { return ptr_ == nullptr; }
+
+private:
+    const Device *dev_ = nullptr;
+    float *ptr_ = nullptr;
+    int64_t n_ = 0;
+    int planes_ = 0;
+};
+
+// What the closures read from AtShaderGlobals, gathered per shading point by the Arnold-side stub:
+// Rd (-> wo = -Rd), N (unflipped, only for the entering test), Nf (frame normal) and the tangent U
+// that AiBuildLocalFramePolar(&U, &V, &Nf) returned (src/rlGgx.h:137-146).
+struct ShadingPoints {
+    std::vector<float> wo[3], N[3], T[3];
+    std::vector<uint8_t> exiting;
+
+    void add(const float Rd[3], const float Nraw[3], const float Nf[3], const float U[3])
+    {
+        // bool isEntering = AiV3Dot(sg->N, sg->Rd) < AI_EPSILON;   (src/rlGgx.h:137)
+        const float d = Nraw[0] * Rd[0] + Nraw[1] * Rd[1] + Nraw[2] * Rd[2];
+        exiting.push_back(d < 1e-4f ? 0 : 1);
+        for (int k = 0; k < 3; k++) {
+            wo[k].push_back(-Rd[k]);      // mViewDir = -sg->Rd  (src/rlGgx.h:144)
+            N[k].push_back(Nf[k]);        // mBasis.N = mAxisN = sg->Nf  (src/rlGgx.h:145)
+            T[k].push_back(U[k]);
+        }
+    }
+    int64_t size() const { return (int64_t)wo[0].size(); }
+    std::vector<float> planar(const std::vector<float> (&v)[3]) const
+    {
+        std::vector<float> out;
+        out.reserve(v[0].size() * 3);
+        for (int k = 0; k < 3; k++) out.insert(out.end(), v[k].begin(), v[k].end());
+        return out;
+    }
+};
+
+// A node parameter: uniform over the batch (the usual case: not texture-linked) or per point.
+struct Param {
+    float uniform = 0.0f;
+    const float *stream = nullptr;       // device pointer, n floats
+    Param(float u = 0.0f) : uniform(u) {}
+    explicit Param(const float *device_plane) : stream(device_plane) {}
+    rls_param c() const { return rls_param{stream, uniform}; }
+};
+struct ParamRGB {
+    float u[3] = {1.0f, 1.0f, 1.0f};
+    const float *r = nullptr, *g = nullptr, *b = nullptr;
+    ParamRGB() = default;
+    ParamRGB(float ur, float ug, float ub) { u[0] = ur; u[1] = ug; u[2] = ub; }
+    rls_param_rgb c() const { return rls_param_rgb{r, g, b, u[0], u[1], u[2]}; }
+};
+
+// rls::GgxSampler (src/rlGgx.h:92-375), batched.
+class GgxSampler {
+public:
+    GgxSampler(const Device &d, const ShadingPoints &sg, ParamRGB specColor, Param ior, Param roughness,
+               Param anisotropic = Param(0.0f))
+        : dev_(d), n_(sg.size()), wo_(d, sg.planar(sg.wo), 3), N_(d, sg.planar(sg.N), 3), T_(d, sg.planar(sg.T), 3)
+    {
+        c_.wo = wo_.cvec3(); c_.N = N_.cvec3(); c_.T = T_.cvec3();
+        void *p = nullptr;
+        check(rls_device_alloc(d.ctx(), (size_t)n_, &p));
+        exiting_ = static_cast<uint8_t *>(p);
+        check(rls_copy_to_device(d.ctx(), exiting_, sg.exiting.data(), (size_t)n_));
+        c_.exiting = exiting_;
+        c_.KsColor = specColor.c();
+        c_.ior = ior.c();
+        c_.specularRoughness = roughness.c();
+        c_.anisotropic = anisotropic.c();
+    }
+    ~GgxSampler() { if (exiting_) rls_device_free(dev_.ctx(), exiting_); }
+    GgxSampler(const GgxSampler &) = delete;
+    GgxSampler &operator=(const GgxSampler &) = delete;
+
+    int64_t size() const { return n_; }
+    const rls_ggx_closure &closure() const { return c_; }
+
+    // static AtVector evalSample(const void*, float rx, float ry)  (src/rlGgx.h:97-107);
+    // fresnel receives what the reference adds to mReflectWeight
+    void evalSample(const Planes &rx, const Planes &ry, Planes &L, Planes &fresnel) const
+    {
+        check(rls_ggx_sample(dev_.ctx(), n_, &c_, rx.plane(0), ry.plane(0), L.vec3(), fresnel.plane(0)));
+    }
+    // static AtColor evalBrdf(const void*, const AtVector *indir)  (src/rlGgx.h:110-119)
+    void evalBrdf(const Planes &indir, Planes &f) const
+    {
+        check(rls_ggx_eval(dev_.ctx(), n_, &c_, indir.cvec3(), f.rgb()));
+    }
+    // static float evalPdf(const void*, const AtVector *indir)  (src/rlGgx.h:121-127)
+    void evalPdf(const Planes &indir, Planes &pdf) const
+    {
+        check(rls_ggx_pdf(dev_.ctx(), n_, &c_, indir.cvec3(), pdf.plane(0)));
+    }
+    // the triple in one pass
+    void sampleEvalPdf(const Planes &rx, const Planes &ry, Planes &L, Planes &f, Planes &pdf, Planes &fresnel) const
+    {
+        check(rls_ggx_sample_eval_pdf(dev_.ctx(), n_, &c_, rx.plane(0), ry.plane(0), L.vec3(), f.rgb(), pdf.plane(0),
+                                      fresnel.plane(0)));
+    }
+    // per-sample body of integrateRefract  (src/rlGgx.h:228-242)
+    void refractSample(const Planes &rx, const Planes &ry, Planes &dir, Planes &weight) const
+    {
+        check(rls_ggx_refract_sample(dev_.ctx(), n_, &c_, rx.plane(0), ry.plane(0), dir.vec3(), weight.plane(0), nullptr));
+    }
+    // integrateGlossy's sample loop with spp_n^2 samples + getAvgReflectWeight  (src/rlGgx.h:172-184)
+    void integrateGlossy(int spp_n, uint32_t seed, Planes &sum_f_over_pdf, Planes &avgReflectWeight) const
+    {
+        check(rls_ggx_integrate(dev_.ctx(), n_, &c_, spp_n, seed, sum_f_over_pdf.rgb(), avgReflectWeight.plane(0)));
+    }
+
+private:
+    const Device &dev_;
+    int64_t n_;
+    Planes wo_, N_, T_;
+    uint8_t *exiting_ = nullptr;
+    rls_ggx_closure c_{};
+};
+
+// DisneySampler (src/rlDisney.cpp:105-602), batched; parameter names from src/rlDisney.cpp:606-610.
+struct DisneyParams {
+    ParamRGB base_color;
+    Param subsurface, metallic, specular, specular_tint, roughness, anisotropic, sheen, sheen_tint, clearcoat,
+        clearcoat_gloss;
+};
+
+class DisneySampler {
+public:
+    DisneySampler(const Device &d, const ShadingPoints &sg, const DisneyParams &p)
+        : dev_(d), n_(sg.size()), wo_(d, sg.planar(sg.wo), 3), N_(d, sg.planar(sg.N), 3), T_(d, sg.planar(sg.T), 3)
+    {
+        c_.wo = wo_.cvec3(); c_.N = N_.cvec3(); c_.T = T_.cvec3();
+        c_.base_color = p.base_color.c();
+        c_.subsurface = p.subsurface.c(); c_.metallic = p.metallic.c(); c_.specular = p.specular.c();
+        c_.specular_tint = p.specular_tint.c(); c_.roughness = p.roughness.c(); c_.anisotropic = p.anisotropic.c();
+        c_.sheen = p.sheen.c(); c_.sheen_tint = p.sheen_tint.c(); c_.clearcoat = p.clearcoat.c();
+        c_.clearcoat_gloss = p.clearcoat_gloss.c();
+    }
+    // inline void setSampleType(AtUInt16 type)  (src/rlDisney.cpp:194-197)
+    void setSampleType(int ray_type)
+    {
+        if (ray_type != RLS_RAY_DIFFUSE && ray_type != RLS_RAY_GLOSSY)
+            throw Error(RLS_ERR_INVALID_ARGUMENT, "setSampleType: RLS_RAY_DIFFUSE or RLS_RAY_GLOSSY");
+        mSampleType = ray_type;
+    }
+    void evalSample(const Planes &rx, const Planes &ry, Planes &L) const
+    {
+        check(rls_disney_sample(dev_.ctx(), n_, &c_, mSampleType, rx.plane(0), ry.plane(0), L.vec3()));
+    }
+    void evalBrdf(const Planes &indir, Planes &f) const
+    {
+        check(rls_disney_eval(dev_.ctx(), n_, &c_, mSampleType, indir.cvec3(), f.rgb()));
+    }
+    void evalPdf(const Planes &indir, Planes &pdf) const
+    {
+        check(rls_disney_pdf(dev_.ctx(), n_, &c_, mSampleType, indir.cvec3(), pdf.plane(0)));
+    }
+    int64_t size() const { return n_; }
+
+private:
+    const Device &dev_;
+    int64_t n_;
+    Planes wo_, N_, T_;
+    rls_disney_closure c_{};
+    int mSampleType = RLS_RAY_GLOSSY;
+};
+
+// rls::NDProfile (src/rlSss.h:27-61), batched with uniform or streamed distances.
+class NDProfile {
+public:
+    NDProfile(const Device &d, int64_t n) : dev_(d), n_(n)
+    {
+        c_.sss_color = ParamRGB().c();
+        c_.sss_dist_multiplier = Param(1.0f).c();
+        for (auto &x : c_.sss_scatter_dist) x = Param(1.0f).c();
+    }
+    // void setDistance(const AtVector &dist, const AtColor &albedo)  (src/rlSss.cpp:20-34)
+    void setDistance(const float dist[3], const float albedo[3])
+    {
+        for (int k = 0; k < 3; k++) c_.sss_scatter_dist[k] = Param(dist[k]).c();
+        c_.sss_color = ParamRGB(albedo[0], albedo[1], albedo[2]).c();
+    }
+    // getRadius / getPdf / evalProfile  (src/rlSss.cpp:36-106)
+    void sample(const Planes &rx, Planes &r, Planes &pdf, Planes &profile) const
+    {
+        check(rls_nd_sample(dev_.ctx(), n_, &c_, rx.plane(0), r.plane(0), pdf.plane(0), profile.rgb()));
+    }
+    void getPdf(const Planes &r, Planes &pdf) const { check(rls_nd_pdf(dev_.ctx(), n_, &c_, r.plane(0), pdf.plane(0))); }
+    void evalProfile(const Planes &r, Planes &profile) const
+    {
+        check(rls_nd_eval(dev_.ctx(), n_, &c_, r.plane(0), profile.rgb()));
+    }
+
+private:
+    const Device &dev_;
+    int64_t n_;
+    rls_sss_closure c_{};
+};
+
+} // namespace rlsb

@@ -1,0 +1,71 @@
+"""Multi-GPU sharding of a shading-point batch: one process per GPU, contiguous index ranges, no
+collective on the data path.
+
+Every shading point is independent (the reference relies on the same fact: Arnold's render threads
+share nothing), so a batch of ``total`` points splits into ``world`` ranges
+``[g*total/world, (g+1)*total/world)``; each rank generates / receives and processes its own range
+on its own GPU.  The only communication is control-plane: a barrier around the timed region, the
+max-over-ranks of the elapsed time, and (validation only) a gather of per-shard 64-bit checksums.
+torch.distributed supplies it -- backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Tuple
+
+import torch
+
+
+def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """(first index, count) of rank's contiguous shard; the shards tile [0, total) exactly."""
+    if world < 1 or not (0 <= rank < world) or total < 0:
+        raise ValueError(f"bad shard request total={total} rank={rank} world={world}")
+    lo = (total * rank) // world
+    hi = (total * (rank + 1)) // world
+    return lo, hi - lo
+
+
+class Ranks:
+    """Thin wrapper over torch.distributed that degrades to a no-op for a single process."""
+
+    def __init__(self, backend: Optional[str] = None, device: Optional[torch.device] = None):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = device if device is not None else torch.device("cpu")
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend is None:
+                backend = "nccl" if self.device.type == "cuda" else "gloo"
+            kw = {"device_id": self.device} if backend == "nccl" else {}
+            dist.init_process_group(backend, **kw)
+            self.dist = dist
+
+    def barrier(self) -> None:
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max_over_ranks(self, values: List[float]) -> List[float]:
+        if self.dist is None:
+            return list(values)
+        t = torch.tensor(values, dtype=torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(v) for v in t]
+
+    def gather_u64(self, value: int) -> List[int]:
+        """every rank's 64-bit value, in rank order (validation: checksum of checksums)"""
+        if self.dist is None:
+            return [int(value)]
+        # two 32-bit halves in int64 slots: no signed-overflow games
+        mine = torch.tensor([value & 0xFFFFFFFF, (value >> 32) & 0xFFFFFFFF], dtype=torch.int64, device=self.device)
+        out = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(out, mine)
+        return [int(o[0]) | (int(o[1]) << 32) for o in out]
+
+    def close(self) -> None:
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+            self.dist = None

@@ -94,6 +94,27 @@ def test_fused_chain_conditioning(gpu, oracle, mixed):
         assert bad.mean() <= 2e-4, (name, float(bad.mean()), st)
 
 
+def test_chain_within_tolerance_everywhere(gpu, oracle, mixed):
+    """The whole sampled chain -- microfacet, wi, f, pdf, Fresnel, refracted direction and weight --
+    within 1e-5 relative on EVERY point (no statistical allowance): the kernels use the host libm's
+    own algorithms for the angle functions (rls_libm.hpp) and exactly rounded + - * / sqrt, so on
+    a glibc host they reproduce the oracle bit for bit."""
+    c, x = mixed
+    og = ggx_oracle(oracle, c)
+    s = ggx_sampler(gpu, c)
+    ref = og.reflect_refract(x[0], x[1], x[2], x[3])
+    got = [host(t) for t in s.reflectRefract(dev(x[0]), dev(x[1]), dev(x[2]), dev(x[3]))]
+    nbits = 0
+    for nm, a, b in zip(("wi", "f", "pdf", "fresnel", "wt", "weight"), got, ref):
+        st = cases.summarize(cases.rel_err(a, b))
+        nbits += int((a.view(np.uint32) != b.view(np.uint32)).sum())
+        print("ggx chain", nm, st)
+        assert st["nonfinite"] == 0 and st["max"] <= TOL, (nm, st)
+    print("ggx chain: words differing from the oracle:", nbits, "of", sum(a.size for a in got))
+    m = host(s.microfacet(dev(x[0]), dev(x[1])))
+    assert cases.summarize(cases.rel_err(m, og.microfacet(x[0], x[1])))["max"] <= TOL
+
+
 def test_fused_equals_separate_bitwise(gpu, mixed):
     c, x = mixed
     s = ggx_sampler(gpu, c)

@@ -1,0 +1,24 @@
+"""GPU: the C++ host mirror (rlshaders_amd/host/rls_batch.hpp) end to end -- C++ stub -> C ABI -> HIP
+kernels -- against the reference-derived probe values of SURVEY.md 8(c)."""
+import json
+import subprocess
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.mark.gpu
+def test_arnold_stub_example_matches_survey_kat():
+    from rlshaders_amd import build
+    build.build_library()
+    exe = build.build_host_examples()
+    p = subprocess.run([str(exe), "4096"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    got = json.loads(p.stdout.strip().splitlines()[-1])
+    kat = json.loads((ROOT / "tests" / "golden" / "survey_kat.json").read_text())["ggx"]
+    for a, b in zip(got["L"], kat["L"]):
+        assert abs(a - b) <= 2e-9 + 1e-7 * abs(b)
+    assert abs(got["f"] - kat["f"]) <= 1e-5 * kat["f"]
+    assert abs(got["pdf"] - kat["pdf"]) <= 1e-5 * kat["pdf"]

@@ -118,7 +118,13 @@ def cpu_baseline(workload: str, target_seconds: float) -> dict | None:
     import numpy as np
     import oracle_lib as O
     import cases
-    threads = O.hardware_threads()
+    threads = O.hardware_threads()            # CPUs this process may run on (sched_getaffinity)
+    try:                                      # ... capped by a cgroup CPU quota, if the box sets one
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            threads = max(1, min(threads, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
 
     def run(n, seconds):
         c = cases.ggx_mixed(SEED, n)

@@ -48,6 +48,9 @@ def parse_args():
     ap.add_argument("--log2-points", type=int, default=26, help="points per GPU = 2^this (config: 26)")
     ap.add_argument("--workload", default="ggx_reflect_refract",
                     choices=["ggx_reflect_refract", "ggx_reflect", "disney_integrate", "sss_probe", "skin"])
+    ap.add_argument("--math", default="exact", choices=["exact", "fast"],
+                    help="arithmetic of the measured kernels: exact (default, bit-faithful to the CPU closures) "
+                         "or fast (RLS_MATH_FAST)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target seconds of CPU-baseline work")
     return ap.parse_args()
@@ -191,6 +194,7 @@ def main():
     rank = ranks.rank
 
     ctx = R.Context(local_rank)
+    ctx.set_math_mode(args.math == "fast")
     n = 1 << args.log2_points
     # weak scaling: the job is world * n points, rank g owns the index range [g*n, (g+1)*n)
     first, count = shard_range(world * n, rank, world)
@@ -214,6 +218,17 @@ def main():
     kernel_ms = ctx.timer_elapsed_ms() / max(args.steps, 1)
     elapsed, kernel_ms = ranks.max_over_ranks([elapsed, kernel_ms])
 
+    # the other arithmetic mode, a few launches, for the record (not the headline number)
+    ctx.set_math_mode(args.math != "fast")
+    wl.launch()
+    torch.cuda.synchronize()
+    ctx.timer_start()
+    for _ in range(5):
+        wl.launch()
+    ctx.timer_stop()
+    other_ms = ranks.max_over_ranks([ctx.timer_elapsed_ms() / 5])[0]
+    ctx.set_math_mode(args.math == "fast")
+
     if rank == 0:
         samples = world * n * wl.samples_per_point * args.steps
         value = samples / elapsed / 1e9
@@ -233,7 +248,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": wl.desc, "name": wl.name, "points_per_gpu": n,
+            "config": {"workload": wl.desc, "name": wl.name, "math": args.math, "points_per_gpu": n,
                        "samples_per_point": wl.samples_per_point, "sharding": f"index-range x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -244,6 +259,10 @@ def main():
         }
         if tr:
             line["roofline"]["traffic_source"] = tr.get("source")
+        other = "exact" if args.math == "fast" else "fast"
+        line["other_math_mode"] = {"math": other, "kernel_ms": round(other_ms, 5),
+                                   "value": round(world * n * wl.samples_per_point / (other_ms * 1e-3) / 1e9, 4),
+                                   "roofline_frac": round(bytes_per_launch / (other_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(args.workload, args.cpu_seconds)
             if cb:

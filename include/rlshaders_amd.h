@@ -85,6 +85,19 @@ void        rls_context_destroy(rls_context *ctx);
 rls_status  rls_context_set_stream(rls_context *ctx, void *hip_stream);
 rls_status  rls_context_use_own_stream(rls_context *ctx);
 void       *rls_context_get_stream(rls_context *ctx);
+/* Arithmetic of the closure kernels launched through this context.
+ *   RLS_MATH_EXACT (default): IEEE division, correctly rounded sqrt, angle functions that reproduce
+ *     the host libm -- closure outputs agree with the CPU closures bit for bit wherever no
+ *     exp/log/pow is involved, and to ~3e-7 where one is.
+ *   RLS_MATH_FAST: hardware reciprocal / sqrt / sin / cos / exp grade arithmetic (~1 ulp per
+ *     operation) and the visible-normal view analysis by vector algebra instead of the reference's
+ *     atan2f/acosf/tanf round trip.  Same formulas, same conventions; outputs within 1e-5 of the CPU
+ *     closures wherever those are well conditioned.  Roughly 3x fewer
+ *     instructions: the kernels become HBM-bandwidth-bound. */
+#define RLS_MATH_EXACT 0
+#define RLS_MATH_FAST  1
+rls_status  rls_context_set_math_mode(rls_context *ctx, int mode);
+int         rls_context_get_math_mode(const rls_context *ctx);
 rls_status  rls_context_synchronize(rls_context *ctx);
 int         rls_context_device(const rls_context *ctx);
 /* Thread-local text of the most recent failure in the calling thread ("" if none). */

@@ -108,6 +108,8 @@ PROTOTYPES = {
     "rls_context_destroy": (None, [_ctx]),
     "rls_context_set_stream": (C.c_int, [_ctx, _vp]),
     "rls_context_use_own_stream": (C.c_int, [_ctx]),
+    "rls_context_set_math_mode": (C.c_int, [_ctx, C.c_int]),
+    "rls_context_get_math_mode": (C.c_int, [_ctx]),
     "rls_context_get_stream": (_vp, [_ctx]),
     "rls_context_synchronize": (C.c_int, [_ctx]),
     "rls_context_device": (C.c_int, [_ctx]),

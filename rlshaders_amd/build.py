@@ -23,6 +23,7 @@ LIB = LIBDIR / "librlshaders_amd.so"
 ARCH = "gfx950"
 
 SOURCES = ["context.hip", "ggx.hip", "disney.hip", "sss.hip", "skin.hip", "integrate.hip"]
+FAST_UNITS = {"ggx.hip", "disney.hip", "sss.hip", "skin.hip", "integrate.hip"}
 HEADERS = [CSRC / "rls_device.hpp", CSRC / "rls_libm.hpp", CSRC / "rls_internal.hpp",
            PKG.parent / "include" / "rlshaders_amd.h"]
 
@@ -66,10 +67,14 @@ def build_library(force: bool = False, verbose: bool = False, variant: str = "",
     jobs = []
     objs = []
     for src in srcs:
-        obj = objdir / (src.stem + ".o")
-        objs.append(obj)
-        if force or _stale(obj, [src, *HEADERS, Path(__file__)]):
-            jobs.append([hipcc, *HIPCC_FLAGS, *[f"-D{d}" for d in defines], "-c", str(src), "-o", str(obj)])
+        # every closure unit twice: EXACT (carries the C ABI) and FAST (kernels behind a hidden symbol)
+        flavours = [("", "RLS_FAST=0")] + ([("_fast", "RLS_FAST=1")] if src.name in FAST_UNITS else [])
+        for suffix, flag in flavours:
+            obj = objdir / (src.stem + suffix + ".o")
+            objs.append(obj)
+            if force or _stale(obj, [src, *HEADERS, Path(__file__)]):
+                jobs.append([hipcc, *HIPCC_FLAGS, f"-D{flag}", *[f"-D{d}" for d in defines], "-c", str(src),
+                             "-o", str(obj)])
 
     def run(cmd):
         if verbose:

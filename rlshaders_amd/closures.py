@@ -46,6 +46,10 @@ class Context:
         else:
             check(self.lib.rls_context_set_stream(self.handle, C.c_void_p(stream.cuda_stream)))
 
+    def set_math_mode(self, fast: bool) -> None:
+        """False: RLS_MATH_EXACT (default, bit-faithful to the CPU closures); True: RLS_MATH_FAST."""
+        check(self.lib.rls_context_set_math_mode(self.handle, 1 if fast else 0))
+
     def synchronize(self) -> None:
         check(self.lib.rls_context_synchronize(self.handle))
 

@@ -118,6 +118,16 @@ rls_status rls_context_use_own_stream(rls_context *ctx)
 
 void *rls_context_get_stream(rls_context *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
+rls_status rls_context_set_math_mode(rls_context *ctx, int mode)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_REQUIRE(mode == RLS_MATH_EXACT || mode == RLS_MATH_FAST, "mode must be RLS_MATH_EXACT or RLS_MATH_FAST");
+    ctx->fast = mode == RLS_MATH_FAST;
+    return RLS_OK;
+}
+
+int rls_context_get_math_mode(const rls_context *ctx) { return ctx && ctx->fast ? RLS_MATH_FAST : RLS_MATH_EXACT; }
+
 int rls_context_device(const rls_context *ctx) { return ctx ? ctx->device : -1; }
 
 rls_status rls_context_synchronize(rls_context *ctx)

@@ -9,17 +9,8 @@ using namespace rlsd;
 
 namespace {
 
-enum DisneyOp { OP_SAMPLE, OP_EVAL, OP_PDF, OP_FUSED };
-
-struct DisneyIO {
-    rls_disney_closure c;
-    const float *rx, *ry;
-    rls_cvec3 cwi;
-    rls_vec3 wi;
-    rls_rgb f;
-    float *pdf;
-    int64_t n;
-};
+using rlsh::DisneyIO;
+enum { OP_SAMPLE = rlsh::DOP_SAMPLE, OP_EVAL = rlsh::DOP_EVAL, OP_PDF = rlsh::DOP_PDF, OP_FUSED = rlsh::DOP_FUSED };
 
 __device__ __forceinline__ Disney load_closure(const rls_disney_closure &c, int64_t i)
 {
@@ -80,7 +71,7 @@ rls_status check_closure(const rls_disney_closure *c, int lobe)
 }
 
 template <int OP>
-rls_status launch(rls_context *ctx, int lobe, const DisneyIO &io, const char *name)
+rls_status launch_kernel(rls_context *ctx, int lobe, const DisneyIO &io, const char *name)
 {
     dim3 grid = rlsh::grid_for(ctx, io.n);
     if (lobe == RLS_RAY_DIFFUSE)
@@ -90,6 +81,27 @@ rls_status launch(rls_context *ctx, int lobe, const DisneyIO &io, const char *na
     return rlsh::check_launch(name);
 }
 
+} // namespace
+
+#if RLS_FAST
+RLS_HIDDEN rls_status rls_fast_disney(rls_context *ctx, int op, int lobe, const rlsh::DisneyIO *io)
+{
+    switch (op) {
+    case OP_SAMPLE: return launch_kernel<OP_SAMPLE>(ctx, lobe, *io, "rls_disney_sample[fast]");
+    case OP_EVAL: return launch_kernel<OP_EVAL>(ctx, lobe, *io, "rls_disney_eval[fast]");
+    case OP_PDF: return launch_kernel<OP_PDF>(ctx, lobe, *io, "rls_disney_pdf[fast]");
+    default: return launch_kernel<OP_FUSED>(ctx, lobe, *io, "rls_disney_sample_eval_pdf[fast]");
+    }
+}
+#else
+RLS_HIDDEN rls_status rls_fast_disney(rls_context *ctx, int op, int lobe, const rlsh::DisneyIO *io);
+
+namespace {
+template <int OP>
+rls_status launch(rls_context *ctx, int lobe, const DisneyIO &io, const char *name)
+{
+    return ctx->fast ? rls_fast_disney(ctx, OP, lobe, &io) : launch_kernel<OP>(ctx, lobe, io, name);
+}
 } // namespace
 
 #define RLS_PROLOGUE()                                   \
@@ -144,3 +156,5 @@ rls_status rls_disney_sample_eval_pdf(rls_context *ctx, int64_t n, const rls_dis
 }
 
 } // extern "C"
+
+#endif // !RLS_FAST

@@ -11,21 +11,7 @@ using namespace rlsd;
 
 namespace {
 
-enum GgxOp { OP_SAMPLE, OP_EVAL, OP_PDF, OP_FUSED, OP_REFRACT, OP_REFLECT_REFRACT, OP_MICROFACET, OP_NDF_PDF };
-
-struct GgxIO {
-    rls_ggx_closure c;
-    const float *rx, *ry, *rx2, *ry2;
-    rls_cvec3 cwi;
-    rls_vec3 wi;
-    rls_rgb f;
-    float *pdf, *fresnel;
-    rls_vec3 wt;
-    float *weight;
-    uint8_t *refracted;
-    int64_t n;
-    int kernel;
-};
+using namespace rlsh;   // GgxOp, GgxIO
 
 __device__ __forceinline__ Ggx load_closure(const rls_ggx_closure &c, int64_t i)
 {
@@ -111,12 +97,37 @@ rls_status check_closure(const rls_ggx_closure *c)
 }
 
 template <int OP>
-rls_status launch(rls_context *ctx, const GgxIO &io, const char *name)
+rls_status launch_kernel(rls_context *ctx, const GgxIO &io, const char *name)
 {
     hipLaunchKernelGGL(ggx_kernel<OP>, rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
     return rlsh::check_launch(name);
 }
 
+} // namespace
+
+#if RLS_FAST
+RLS_HIDDEN rls_status rls_fast_ggx(rls_context *ctx, int op, const rlsh::GgxIO *io)
+{
+    switch (op) {
+    case OP_SAMPLE: return launch_kernel<OP_SAMPLE>(ctx, *io, "rls_ggx_sample[fast]");
+    case OP_EVAL: return launch_kernel<OP_EVAL>(ctx, *io, "rls_ggx_eval[fast]");
+    case OP_PDF: return launch_kernel<OP_PDF>(ctx, *io, "rls_ggx_pdf[fast]");
+    case OP_FUSED: return launch_kernel<OP_FUSED>(ctx, *io, "rls_ggx_sample_eval_pdf[fast]");
+    case OP_REFRACT: return launch_kernel<OP_REFRACT>(ctx, *io, "rls_ggx_refract_sample[fast]");
+    case OP_REFLECT_REFRACT: return launch_kernel<OP_REFLECT_REFRACT>(ctx, *io, "rls_ggx_reflect_refract[fast]");
+    case OP_MICROFACET: return launch_kernel<OP_MICROFACET>(ctx, *io, "rls_ggx_microfacet[fast]");
+    default: return launch_kernel<OP_NDF_PDF>(ctx, *io, "rls_ggx_ndf_pdf[fast]");
+    }
+}
+#else
+RLS_HIDDEN rls_status rls_fast_ggx(rls_context *ctx, int op, const rlsh::GgxIO *io);
+
+namespace {
+template <int OP>
+rls_status launch(rls_context *ctx, const GgxIO &io, const char *name)
+{
+    return ctx->fast ? rls_fast_ggx(ctx, OP, &io) : launch_kernel<OP>(ctx, io, name);
+}
 } // namespace
 
 #define RLS_PROLOGUE()                                   \
@@ -217,3 +228,5 @@ rls_status rls_ggx_ndf_pdf(rls_context *ctx, int64_t n, const rls_ggx_closure *c
 }
 
 } // extern "C"
+
+#endif // !RLS_FAST

@@ -60,14 +60,8 @@ __device__ __forceinline__ float group_sum(float v)
 }
 
 // ---------------------------------------------------------------------------------------------
-struct GgxIntIO {
-    rls_ggx_closure c;
-    rls_rgb sum;
-    float *avgF;
-    int64_t n;
-    int spp;
-    uint32_t seed;
-};
+using rlsh::GgxIntIO;
+using rlsh::DisneyIntIO;
 
 template <int G>
 __global__ __launch_bounds__(rlsh::kBlock) void ggx_integrate_kernel(GgxIntIO a)
@@ -118,16 +112,6 @@ __global__ __launch_bounds__(rlsh::kBlock) void ggx_integrate_kernel(GgxIntIO a)
 }
 
 // ---------------------------------------------------------------------------------------------
-struct DisneyIntIO {
-    rls_disney_closure c;
-    rls_rgb dsum, ssum;
-    float *dcount, *scount;
-    rls_disney_stream_out st;
-    int streamed;
-    int64_t n;
-    int spp;
-    uint32_t seed;
-};
 
 template <int G>
 __global__ __launch_bounds__(rlsh::kBlock) void disney_integrate_kernel(DisneyIntIO a)
@@ -223,6 +207,21 @@ rls_status launch_g(rls_context *ctx, K k1, K k4, K k16, K k64, int g, const IO 
 
 } // namespace
 
+#if RLS_FAST
+RLS_HIDDEN rls_status rls_fast_ggx_integrate(rls_context *ctx, int g, const rlsh::GgxIntIO *io)
+{
+    return launch_g(ctx, ggx_integrate_kernel<1>, ggx_integrate_kernel<4>, ggx_integrate_kernel<16>,
+                    ggx_integrate_kernel<64>, g, *io, "rls_ggx_integrate[fast]");
+}
+RLS_HIDDEN rls_status rls_fast_disney_integrate(rls_context *ctx, int g, const rlsh::DisneyIntIO *io)
+{
+    return launch_g(ctx, disney_integrate_kernel<1>, disney_integrate_kernel<4>, disney_integrate_kernel<16>,
+                    disney_integrate_kernel<64>, g, *io, "rls_disney_integrate[fast]");
+}
+#else
+RLS_HIDDEN rls_status rls_fast_ggx_integrate(rls_context *ctx, int g, const rlsh::GgxIntIO *io);
+RLS_HIDDEN rls_status rls_fast_disney_integrate(rls_context *ctx, int g, const rlsh::DisneyIntIO *io);
+
 extern "C" {
 
 rls_status rls_ggx_integrate(rls_context *ctx, int64_t n, const rls_ggx_closure *c,
@@ -239,6 +238,7 @@ rls_status rls_ggx_integrate(rls_context *ctx, int64_t n, const rls_ggx_closure 
     GgxIntIO io = {};
     io.c = *c; io.sum = sum_f_over_pdf; io.avgF = avg_reflect_weight; io.n = n; io.spp = spp_n * spp_n; io.seed = seed;
     int g = pick_group(ctx, n, io.spp);
+    if (ctx->fast) return rls_fast_ggx_integrate(ctx, g, &io);
     return launch_g(ctx, ggx_integrate_kernel<1>, ggx_integrate_kernel<4>, ggx_integrate_kernel<16>,
                     ggx_integrate_kernel<64>, g, io, "rls_ggx_integrate");
 }
@@ -268,8 +268,11 @@ rls_status rls_disney_integrate(rls_context *ctx, int64_t n, const rls_disney_cl
     }
     // streamed planes are sample-major: one lane per point keeps every store coalesced
     int g = io.streamed ? 1 : pick_group(ctx, n, io.spp);
+    if (ctx->fast) return rls_fast_disney_integrate(ctx, g, &io);
     return launch_g(ctx, disney_integrate_kernel<1>, disney_integrate_kernel<4>, disney_integrate_kernel<16>,
                     disney_integrate_kernel<64>, g, io, "rls_disney_integrate");
 }
 
 } // extern "C"
+
+#endif // !RLS_FAST

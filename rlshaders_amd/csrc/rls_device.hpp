@@ -39,7 +39,6 @@ RLS_DEV float minf(float a, float b) { return a < b ? a : b; }
 RLS_DEV float clampf(float v, float lo, float hi) { return maxf(lo, minf(v, hi)); }
 // LERP(t, a, b) = (1 - t) * a + b * t
 RLS_DEV float lerpf(float t, float a, float b) { return ((1.0f - t) * a) + (b * t); }
-RLS_DEV float linearstep(float lo, float hi, float t) { return clampf((t - lo) / (hi - lo), 0.0f, 1.0f); }
 RLS_DEV float sgnf(float a) { return a < 0.0f ? -1.0f : 1.0f; }
 
 RLS_DEV V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -51,14 +50,6 @@ RLS_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 RLS_DEV V3 cross(V3 a, V3 b)
 {
     return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
-}
-RLS_DEV float length(V3 a) { return rlm::sqrt32(a.x * a.x + a.y * a.y + a.z * a.z); }
-// AiV3Normalize: scale by the reciprocal length, zero vector stays zero
-RLS_DEV V3 normalize(V3 a)
-{
-    float t = length(a);
-    if (t != 0.0f) t = 1.0f / t;
-    return mk(a.x * t, a.y * t, a.z * t);
 }
 // AiV3RotateToFrame(a, u, v, w) = a.x*u + a.y*v + a.z*w
 RLS_DEV V3 to_frame(V3 a, V3 u, V3 v, V3 w)
@@ -72,29 +63,54 @@ RLS_DEV bool is_finite3(V3 a) { return isfinite(a.x) && isfinite(a.y) && isfinit
 
 struct Frame { V3 U, V, N; };
 
-// ---- angle functions ----------------------------------------------------------------------------
-// RLS_HOST_LIBM = 1 (default): the host-libm-faithful routines of rls_libm.hpp, so sampled
-// directions agree with the CPU closures bit for bit; 0: ROCm's ocml (differs in the last ulp).
-#ifndef RLS_HOST_LIBM
-#define RLS_HOST_LIBM 1
+// ---- arithmetic policy ---------------------------------------------------------------------------
+// RLS_FAST = 0 (the product default, "EXACT"): IEEE division, correctly rounded square root and
+// the host-libm-faithful angle functions of rls_libm.hpp -- every closure output that involves no
+// exp/log/pow is bit-identical to the CPU closures.
+// RLS_FAST = 1 ("FAST", opt-in through rls_context_set_math_mode): v_rcp_f32 / v_sqrt_f32 /
+// v_sin_f32 / v_exp_f32 grade arithmetic (about 1 ulp per operation) and the visible-normal view
+// analysis by vector algebra instead of the reference's angle round trip.  Within 1e-5 of the CPU
+// closures wherever those are well conditioned; see DESIGN.md section 2 for the measured tails.
+#ifndef RLS_FAST
+#define RLS_FAST 0
 #endif
-#if RLS_HOST_LIBM
+#if RLS_FAST
+#define R_DIV(a, b) ((a) * __builtin_amdgcn_rcpf(b))
+#define R_RCP(b) __builtin_amdgcn_rcpf(b)
+#define R_SQRT(x) __builtin_amdgcn_sqrtf(x)
+#define R_EXP(x) __expf(x)
+#define R_LOG(x) __logf(x)
+#define R_POW(x, y) __powf(x, y)
+RLS_DEV void t_sincos(float x, float *s, float *c) { *s = __sinf(x); *c = __cosf(x); }
+#else
+#define R_DIV(a, b) ((a) / (b))
+#define R_RCP(b) (1.0f / (b))
+#define R_SQRT(x) rlm::sqrt32(x)
+#define R_EXP(x) expf(x)
+#define R_LOG(x) logf(x)
+#define R_POW(x, y) powf(x, y)
 RLS_DEV void t_sincos(float x, float *s, float *c) { rlm::sincos32_v(x, s, c); }
 RLS_DEV float t_atan2(float y, float x) { return rlm::atan2_32_v(y, x); }
 RLS_DEV float t_acos(float x) { return rlm::acos32_v(x); }
 RLS_DEV float t_tan(float x) { return rlm::tan32_v(x); }
-#else
-RLS_DEV void t_sincos(float x, float *s, float *c) { sincosf(x, s, c); }
-RLS_DEV float t_atan2(float y, float x) { return atan2f(y, x); }
-RLS_DEV float t_acos(float x) { return acosf(x); }
-RLS_DEV float t_tan(float x) { return tanf(x); }
 #endif
+
+
+RLS_DEV float length(V3 a) { return R_SQRT(a.x * a.x + a.y * a.y + a.z * a.z); }
+// AiV3Normalize: scale by the reciprocal length, zero vector stays zero
+RLS_DEV V3 normalize(V3 a)
+{
+    float t = length(a);
+    if (t != 0.0f) t = R_RCP(t);
+    return mk(a.x * t, a.y * t, a.z * t);
+}
+RLS_DEV float linearstep(float lo, float hi, float t) { return clampf(R_DIV(t - lo, hi - lo), 0.0f, 1.0f); }
 
 // ---- rlUtil ----------------------------------------------------------------------------------
 // src/rlUtil.h:21-29
 RLS_DEV V3 spherical_direction(float cosTheta, float phi)
 {
-    float r = rlm::sqrt32(1.0f - sqr(cosTheta));
+    float r = R_SQRT(1.0f - sqr(cosTheta));
     float s, c;
     t_sincos(phi, &s, &c);
     return mk(r * c, r * s, cosTheta);
@@ -116,10 +132,10 @@ RLS_DEV V2 concentric_disk(float rx, float ry)
     float r, phi;
     if (absf(rx) > absf(ry)) {
         r = rx;
-        phi = kHalfPi * 0.5f * ry / rx;
+        phi = R_DIV(kHalfPi * 0.5f * ry, rx);
     } else {
         r = ry;
-        phi = kHalfPi * (1.0f - 0.5f * rx / ry);
+        phi = kHalfPi * (1.0f - R_DIV(0.5f * rx, ry));
     }
     float s, c;
     t_sincos(phi, &s, &c);
@@ -131,7 +147,7 @@ RLS_DEV V2 concentric_disk(float rx, float ry)
 RLS_DEV V3 cosine_hemisphere(const Frame &fr, float rx, float ry)
 {
     V2 d = concentric_disk(rx, ry);
-    float z = rlm::sqrt32(maxf(0.0f, 1.0f - sqr(d.x) - sqr(d.y)));
+    float z = R_SQRT(maxf(0.0f, 1.0f - sqr(d.x) - sqr(d.y)));
     return to_frame(mk(d.x, d.y, z), fr.U, fr.V, fr.N);
 }
 
@@ -145,6 +161,36 @@ struct VndfView {
     bool nearNormal;        // theta < AI_EPSILON -> uniform slope sample
 };
 
+#if RLS_FAST
+RLS_DEV VndfView vndf_view(V3 view, const Frame &fr, float ax, float ay)
+{
+    // FAST mode: the reference goes view -> (theta, phi) -> direction -> stretch -> (theta', phi') with
+    // atan2f/cosf/sinf/acosf/atan2f/tanf/cosf/sinf; in exact arithmetic that round trip is the identity
+    // on the local view vector, so the stretched direction and the sines/cosines/tangent it needs follow
+    // from dot products, one rsqrt and one rcp.
+    VndfView w;
+    w.ax = ax; w.ay = ay;
+    float cz = clampf(dot(fr.N, view), -1.0f, 1.0f);
+    float sx = dot(fr.U, view) * ax;
+    float sy = dot(fr.V, view) * ay;
+    float h2 = sx * sx + sy * sy;
+    float inv = __builtin_amdgcn_rsqf(h2 + cz * cz);
+    float z = cz * inv;
+    float h = __builtin_amdgcn_sqrtf(h2) * inv;
+    bool flat = !(z < (1.0f - kEps));
+    float invh = __builtin_amdgcn_rsqf(h2);
+    w.cosPhi = (flat || h2 == 0.0f) ? 1.0f : sx * invh;
+    w.sinPhi = (flat || h2 == 0.0f) ? 0.0f : sy * invh;
+    w.nearNormal = flat;
+    float B = flat ? 0.0f : h * __builtin_amdgcn_rcpf(z);
+    w.B = B;
+    w.B2 = sqr(B);
+    w.G1 = R_DIV(2.0f, 1.0f + R_SQRT(1.0f + w.B2));
+    w.invB = R_RCP(B);
+    return w;
+}
+
+#else
 RLS_DEV VndfView vndf_view(V3 view, const Frame &fr, float ax, float ay)
 {
     VndfView w;
@@ -166,15 +212,17 @@ RLS_DEV VndfView vndf_view(V3 view, const Frame &fr, float ax, float ay)
     float B = t_tan(theta);
     w.B = B;
     w.B2 = sqr(B);
-    w.G1 = 2.0f / (1.0f + rlm::sqrt32(1.0f + w.B2));
-    w.invB = 1.0f / B;
+    w.G1 = R_DIV(2.0f, 1.0f + R_SQRT(1.0f + w.B2));
+    w.invB = R_RCP(B);
     return w;
 }
+
+#endif
 
 // uniformSample lambda, src/rlGgx.cpp:18-25
 RLS_DEV V2 uniform_slope(float rx, float ry)
 {
-    float r = rlm::sqrt32(rx / (1.0f - rx));
+    float r = R_SQRT(R_DIV(rx, 1.0f - rx));
     float phi = kTwoPi * ry;
     float s, c;
     t_sincos(phi, &s, &c);
@@ -188,13 +236,13 @@ RLS_DEV V2 uniform_slope(float rx, float ry)
 RLS_DEV V3 vndf_microfacet(const VndfView &w, const Frame &fr, float rx, float ry)
 {
     V2 slope;
-    float A = 2.0f * rx / w.G1 - 1.0f;
+    float A = R_DIV(2.0f * rx, w.G1) - 1.0f;
     float A2 = sqr(A);
     if (w.nearNormal || absf(A2 - 1.0f) < kEps) {
         slope = uniform_slope(rx, ry);
     } else {
-        float tmp = 1.0f / (A2 - 1.0f);
-        float D = rlm::sqrt32(maxf(0.0f, w.B2 * sqr(tmp) - (A2 - w.B2) * tmp));
+        float tmp = R_RCP(A2 - 1.0f);
+        float D = R_SQRT(maxf(0.0f, w.B2 * sqr(tmp) - (A2 - w.B2) * tmp));
         float slopeX1 = w.B * tmp - D;
         float slopeX2 = w.B * tmp + D;
         slope.x = (A < 0.0f || slopeX2 > w.invB) ? slopeX1 : slopeX2;
@@ -207,9 +255,9 @@ RLS_DEV V3 vndf_microfacet(const VndfView &w, const Frame &fr, float rx, float r
             sign = -1.0f;
             u = 2.0f * (0.5f - ry);
         }
-        float z = (u * (u * (u * 0.27385f - 0.73369f) + 0.46341f))
-                / (u * (u * (u * 0.093073f + 0.309420f) - 1.0f) + 0.597999f);
-        slope.y = sign * z * rlm::sqrt32(1.0f + sqr(slope.x));
+        float z = R_DIV(u * (u * (u * 0.27385f - 0.73369f) + 0.46341f),
+                        u * (u * (u * 0.093073f + 0.309420f) - 1.0f) + 0.597999f);
+        slope.y = sign * z * R_SQRT(1.0f + sqr(slope.x));
     }
     V3 omega;
     omega.x = -(w.cosPhi * slope.x - w.sinPhi * slope.y) * w.ax;
@@ -244,16 +292,16 @@ RLS_DEV Ggx ggx_make(V3 wo, V3 N, V3 T, bool exiting, float ksR, float ksG, floa
     g.fr.N = N;
     g.fr.U = T;
     g.fr.V = cross(N, T);
-    float aspect = rlm::sqrt32(1.0f - anisotropic * 0.9f);
-    g.ax = maxf(1e-4f, sqr(roughness) / aspect);
+    float aspect = R_SQRT(1.0f - anisotropic * 0.9f);
+    g.ax = maxf(1e-4f, R_DIV(sqr(roughness), aspect));
     g.ay = maxf(1e-4f, sqr(roughness) * aspect);
     g.rough = maxf(1e-5f, sqr(roughness));
-    g.eta2 = sqr(g.iorOut / g.iorIn);
+    g.eta2 = sqr(R_DIV(g.iorOut, g.iorIn));
     g.vn = dot(wo, N);
     {
         float cosSqr = sqr(g.vn);
-        float tanSqr = 1.0f / cosSqr - 1.0f;
-        g.g1v = 2.0f / (1.0f + rlm::sqrt32(1.0f + sqr(g.rough) * tanSqr));
+        float tanSqr = R_RCP(cosSqr) - 1.0f;
+        g.g1v = R_DIV(2.0f, 1.0f + R_SQRT(1.0f + sqr(g.rough) * tanSqr));
     }
     return g;
 }
@@ -264,10 +312,10 @@ RLS_DEV float ggx_fresnel(const Ggx &g, V3 i, V3 m)
     float c = absf(dot(i, m));
     float gSqr = g.eta2 - 1.0f + c * c;
     if (gSqr < 0.0f) return 1.0f;
-    float gg = rlm::sqrt32(gSqr);
+    float gg = R_SQRT(gSqr);
     float gmc = gg - c;
     float gpc = gg + c;
-    return 0.5f * sqr(gmc / gpc) * (1.0f + sqr((c * gpc - 1.0f) / (c * gmc + 1.0f)));
+    return 0.5f * sqr(R_DIV(gmc, gpc)) * (1.0f + sqr(R_DIV(c * gpc - 1.0f, c * gmc + 1.0f)));
 }
 
 // src/rlGgx.h:332-340
@@ -276,8 +324,8 @@ RLS_DEV float ggx_D(const Ggx &g, V3 m)
     float mu = dot(m, g.fr.U);
     float mv = dot(m, g.fr.V);
     float mn2 = sqr(dot(g.fr.N, m));
-    float den = g.ax * g.ay * sqr(sqr(mu / g.ax) + sqr(mv / g.ay) + mn2);
-    return kInvPi / den;
+    float den = g.ax * g.ay * sqr(sqr(R_DIV(mu, g.ax)) + sqr(R_DIV(mv, g.ay)) + mn2);
+    return R_DIV(kInvPi, den);
 }
 
 // src/rlGgx.h:343-357
@@ -287,9 +335,9 @@ RLS_DEV float ggx_G1(const Ggx &g, V3 v, V3 m, V3 n)
     float vn = dot(v, n);
     if (vm * vn < 0.0f) return 0.0f;
     float cosSqr = sqr(vn);
-    float tanSqr = 1.0f / cosSqr - 1.0f;
-    float den = 1.0f + rlm::sqrt32(1.0f + sqr(g.rough) * tanSqr);
-    return 2.0f / den;
+    float tanSqr = R_RCP(cosSqr) - 1.0f;
+    float den = 1.0f + R_SQRT(1.0f + sqr(g.rough) * tanSqr);
+    return R_DIV(2.0f, den);
 }
 
 // G1(mViewDir, m, mAxisN): the value depends on the view only, the zero test on m
@@ -307,7 +355,7 @@ RLS_DEV void ggx_eval_pdf(const Ggx &g, V3 L, float &fr, float &fg, float &fb, f
     V3 H = normalize(L + g.view);
     float d = ggx_D(g, H);
     if (WANT_PDF) {
-        float p = d * ggx_G1_view(g, H) / absf(g.vn) * 0.25f;
+        float p = R_DIV(d * ggx_G1_view(g, H), absf(g.vn)) * 0.25f;
         pdf = maxf(p, kEps);
     }
     if (WANT_F) {
@@ -320,7 +368,7 @@ RLS_DEV void ggx_eval_pdf(const Ggx &g, V3 L, float &fr, float &fg, float &fb, f
         float rw = ggx_fresnel(g, g.view, hr);
         float ln = absf(dot(L, g.fr.N));
         float vn = absf(g.vn);
-        float refl = rw * ggx_G(g, L, hr) * d * 0.25f / (ln * vn);
+        float refl = R_DIV(rw * ggx_G(g, L, hr) * d * 0.25f, ln * vn);
         float lns = dot(L, g.fr.N);
         fr = g.ksR * refl * lns;
         fg = g.ksG * refl * lns;
@@ -344,7 +392,7 @@ RLS_DEV float ggx_pdf(const Ggx &g, V3 L)
 // NDFKernel, src/rlGgx.h:33-50 (alternate, not selected by the reference)
 RLS_DEV V3 ndf_microfacet(const Ggx &g, float rx, float ry)
 {
-    float gg = rlm::sqrt32(rx / (1.0f - rx));
+    float gg = R_SQRT(R_DIV(rx, 1.0f - rx));
     float phi = kTwoPi * ry;
     float s, c;
     t_sincos(phi, &s, &c);
@@ -355,7 +403,7 @@ RLS_DEV float ndf_pdf(const Ggx &g, V3 i, V3 m)
 {
     float im = absf(dot(i, m));
     float mn = absf(dot(m, g.fr.N));
-    return ggx_D(g, m) * mn * 0.25f / im;
+    return R_DIV(ggx_D(g, m) * mn * 0.25f, im);
 }
 
 // getSampleWeight, src/rlGgx.h:294-301
@@ -364,7 +412,7 @@ RLS_DEV float ggx_sample_weight(const Ggx &g, V3 i, V3 o, V3 m)
     float ih = dot(i, m);
     float mn = absf(dot(m, g.fr.N));
     float in = absf(dot(i, g.fr.N));
-    return ggx_G(g, o, m) * absf(ih / (in * mn));
+    return ggx_G(g, o, m) * absf(R_DIV(ih, in * mn));
 }
 
 // Refraction of sg->Rd = -view about the microfacet m, eta = iorIn/iorOut (Walter et al. EGSR'07
@@ -373,13 +421,13 @@ RLS_DEV float ggx_sample_weight(const Ggx &g, V3 i, V3 o, V3 m)
 RLS_DEV bool ggx_refract(const Ggx &g, V3 m, V3 &dir)
 {
     V3 i = g.view;
-    float eta = g.iorIn / g.iorOut;
+    float eta = R_DIV(g.iorIn, g.iorOut);
     float c = dot(i, m);
     float k = 1.0f - eta * eta * (1.0f - c * c);
     bool refracted = !(k < 0.0f);
     if (refracted) {
         float s = sgnf(dot(i, g.fr.N));
-        float t = eta * c - s * rlm::sqrt32(k);
+        float t = eta * c - s * R_SQRT(k);
         dir = m * t - i * eta;
     } else {
         dir = m * (2.0f * c) - i;
@@ -420,14 +468,14 @@ RLS_DEV Disney disney_make(V3 wo, V3 N, V3 T, float bR, float bG, float bB, cons
     d.fr.U = T;
     d.fr.V = cross(N, T);
 
-    float aspect = rlm::sqrt32(1.0f - anisotropic * 0.9f);
-    d.ax = maxf(1e-2f, sqr(d.roughness) / aspect);
+    float aspect = R_SQRT(1.0f - anisotropic * 0.9f);
+    d.ax = maxf(1e-2f, R_DIV(sqr(d.roughness), aspect));
     d.ay = maxf(1e-2f, sqr(d.roughness) * aspect);
     d.specRough = sqr(d.roughness);
 
     float lum = luminance(bR, bG, bB);
     float tR = 1.0f, tG = 1.0f, tB = 1.0f;
-    if (lum > 0.0f) { tR = bR / lum; tG = bG / lum; tB = bB / lum; }
+    if (lum > 0.0f) { tR = R_DIV(bR, lum); tG = R_DIV(bG, lum); tB = R_DIV(bB, lum); }
     float mR = lerpf(specularTint, 1.0f, tR) * specular;
     float mG = lerpf(specularTint, 1.0f, tG) * specular;
     float mB = lerpf(specularTint, 1.0f, tB) * specular;
@@ -445,23 +493,23 @@ RLS_DEV float smithG_GGX(float ndv, float alphaG)
 {
     float a = alphaG * alphaG;
     float b = ndv * ndv;
-    return 1.0f / (ndv + rlm::sqrt32(a + b - a * b));
+    return R_RCP(ndv + R_SQRT(a + b - a * b));
 }
 // src/rlDisney.cpp:545-551
 RLS_DEV float D_GTR1(const Disney &d, float mn2)
 {
     float alpha = lerpf(d.clearcoatGloss, 0.1f, 0.001f);
     float a2 = sqr(alpha);
-    float den = logf(a2) * (1.0f + (a2 - 1.0f) * mn2);
-    return (a2 - 1.0f) * kInvPi / den;
+    float den = R_LOG(a2) * (1.0f + (a2 - 1.0f) * mn2);
+    return R_DIV((a2 - 1.0f) * kInvPi, den);
 }
 // src/rlDisney.cpp:561-568
 RLS_DEV float D_GTR2Aniso(const Disney &d, V3 m, float mn2)
 {
     float hu = dot(m, d.fr.U);
     float hv = dot(m, d.fr.V);
-    float den = d.ax * d.ay * sqr(sqr(hu / d.ax) + sqr(hv / d.ay) + mn2);
-    return kInvPi / den;
+    float den = d.ax * d.ay * sqr(sqr(R_DIV(hu, d.ax)) + sqr(R_DIV(hv, d.ay)) + mn2);
+    return R_DIV(kInvPi, den);
 }
 
 // evalDiffuse, src/rlDisney.cpp:199-236 (BRDF without the cosine)
@@ -476,13 +524,13 @@ RLS_DEV void disney_eval_diffuse(const Disney &d, V3 L, float &r, float &g, floa
     float vh = dot(d.view, H);     // the reference's "NdotH" (line 210)
     if (vh < kEps || lh < kEps) return;
     float lh2 = sqr(lh);
-    float FL = powf(clampf(1.0f - ln, 0.0f, 1.0f), 5.0f);
-    float FV = powf(clampf(1.0f - vn, 0.0f, 1.0f), 5.0f);
+    float FL = R_POW(clampf(1.0f - ln, 0.0f, 1.0f), 5.0f);
+    float FV = R_POW(clampf(1.0f - vn, 0.0f, 1.0f), 5.0f);
     float F90 = 0.5f + 2.0f * d.roughness * lh2;
     float diffuseFactor = lerpf(FL, 1.0f, F90) * lerpf(FV, 1.0f, F90);
     float Fss90 = d.roughness * lh2;
     float Fss = lerpf(FL, 1.0f, Fss90) * lerpf(FV, 1.0f, Fss90);
-    float ssFactor = 1.25f * (Fss * (1.0f / (ln + vn) - 0.5f) + 0.5f);
+    float ssFactor = 1.25f * (Fss * (R_RCP(ln + vn) - 0.5f) + 0.5f);
     float mix = lerpf(d.subsurface, diffuseFactor, ssFactor);
     float om = 1.0f - d.metallic;
     r = d.baseR * kInvPi * mix * om;
@@ -503,7 +551,7 @@ RLS_DEV void disney_eval_specular(const Disney &d, V3 L, float &r, float &g, flo
     if (nm < kEps || lm < kEps) return;
     float nm2 = sqr(nm);
     float Ds = D_GTR2Aniso(d, M, nm2);
-    float FH = powf(clampf(1.0f - lm, 0.0f, 1.0f), 5.0f);
+    float FH = R_POW(clampf(1.0f - lm, 0.0f, 1.0f), 5.0f);
     float FsR = lerpf(FH, d.f0R, 1.0f);
     float FsG = lerpf(FH, d.f0G, 1.0f);
     float FsB = lerpf(FH, d.f0B, 1.0f);
@@ -524,8 +572,8 @@ RLS_DEV V3 disney_gtr1_microfacet(const Disney &d, float rx, float ry)
     float phiH = kTwoPi * rx;
     float a2 = sqr(d.roughness);
     float cosThetaH = a2 == 1.0f
-        ? rlm::sqrt32(1.0f - ry)
-        : rlm::sqrt32((1.0f - powf(a2, 1.0f - ry)) / (1.0f - a2));
+        ? R_SQRT(1.0f - ry)
+        : R_SQRT(R_DIV(1.0f - R_POW(a2, 1.0f - ry), 1.0f - a2));
     V3 omega = spherical_direction(cosThetaH, phiH);
     return normalize(to_frame(omega, d.fr.U, d.fr.V, d.fr.N));
 }
@@ -534,12 +582,12 @@ RLS_DEV V3 disney_gtr1_microfacet(const Disney &d, float rx, float ry)
 RLS_DEV V3 disney_sample_specular(const Disney &d, const VndfView &w, float rx, float ry)
 {
     V3 M;
-    float gtr2Weight = 1.0f / (d.clearcoat + 1.0f);
+    float gtr2Weight = R_RCP(d.clearcoat + 1.0f);
     if (rx < gtr2Weight) {
-        rx /= gtr2Weight;
+        rx = R_DIV(rx, gtr2Weight);
         M = vndf_microfacet(w, d.fr, rx, ry);
     } else {
-        rx = (rx - gtr2Weight) / (1.0f - gtr2Weight);
+        rx = R_DIV(rx - gtr2Weight, 1.0f - gtr2Weight);
         M = disney_gtr1_microfacet(d, rx, ry);
     }
     if (dot(d.fr.N, M) < 0.0f) return mk(0.0f, 0.0f, 0.0f);
@@ -557,10 +605,10 @@ RLS_DEV float disney_specular_pdf(const Disney &d, V3 i)
     float mn = dot(m, d.fr.N);
     if (mn < 0.0f) return 0.0f;
     float mn2 = sqr(mn);
-    float ccw = d.clearcoat / (d.clearcoat + 1.0f);
+    float ccw = R_DIV(d.clearcoat, d.clearcoat + 1.0f);
     float vn = maxf(1e-4f, dot(d.view, d.fr.N));
-    float Dw = smithG_GGX(im, d.specRough) * D_GTR2Aniso(d, m, mn2) * 2.0f * im / vn;
-    float D = lerpf(ccw, Dw, D_GTR1(d, mn2) * absf(mn) / im);
+    float Dw = R_DIV(smithG_GGX(im, d.specRough) * D_GTR2Aniso(d, m, mn2) * 2.0f * im, vn);
+    float D = lerpf(ccw, Dw, R_DIV(D_GTR1(d, mn2) * absf(mn), im));
     return D * 0.25f;
 }
 
@@ -594,8 +642,8 @@ RLS_DEV NdProfile nd_make(float dx, float dy, float dz)
     p.maxR = maxf(dx, maxf(dy, dz)) * 3.0f;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        p.c1[i] = 1.0f - expf(-p.maxR / p.d[i]);
-        p.c2[i] = 1.0f - expf(-p.maxR / p.d[i] / 3.0f);
+        p.c1[i] = 1.0f - R_EXP(R_DIV(-p.maxR, p.d[i]));
+        p.c2[i] = 1.0f - R_EXP(R_DIV(R_DIV(-p.maxR, p.d[i]), 3.0f));
     }
     return p;
 }
@@ -616,14 +664,14 @@ RLS_DEV float nd_radius(const NdProfile &p, float rx)
         d = p.d[1]; w1 = p.c1[1]; w2 = p.c2[1];
     }
     if (d < kEps) return 0.0f;
-    float w = w1 / (w1 + w2 * 3.0f);
+    float w = R_DIV(w1, w1 + w2 * 3.0f);
     float r;
     if (rx > w) {
         rx = linearstep(w, 1.0f, rx);
-        r = logf(1.0f - rx * w2) * (-d * 3.0f);
+        r = R_LOG(1.0f - rx * w2) * (-d * 3.0f);
     } else {
         rx = linearstep(0.0f, w, rx);
-        r = logf(1.0f - rx * w1) * (-d);
+        r = R_LOG(1.0f - rx * w1) * (-d);
     }
     return r;
 }
@@ -636,11 +684,11 @@ RLS_DEV float nd_pdf(const NdProfile &p, float r)
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         float d = maxf(p.d[i], kEps);
-        float p1 = expf(-r / d);
-        float p2 = expf(-r / d / 3.0f);
-        pdf += (p1 + p2) / d / (p.c1[i] + p.c2[i] * 3.0f);
+        float p1 = R_EXP(R_DIV(-r, d));
+        float p2 = R_EXP(R_DIV(R_DIV(-r, d), 3.0f));
+        pdf += R_DIV(R_DIV(p1 + p2, d), p.c1[i] + p.c2[i] * 3.0f);
     }
-    return pdf / (kTwoPi * r * 3.0f);
+    return R_DIV(pdf, kTwoPi * r * 3.0f);
 }
 
 // evalProfile, src/rlSss.cpp:86-106
@@ -653,7 +701,7 @@ RLS_DEV void nd_profile(const NdProfile &p, float r, float &R, float &G, float &
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         float d = p.d[i];
-        out[i] = d < kEps ? 1.0f : (expf(-r / d) + expf(-r / (3.0f * d))) / (denom * d);
+        out[i] = d < kEps ? 1.0f : R_DIV(R_EXP(R_DIV(-r, d)) + R_EXP(R_DIV(-r, 3.0f * d)), denom * d);
     }
     R = out[0]; G = out[1]; B = out[2];
 }
@@ -697,7 +745,7 @@ RLS_DEV float sss_probe_ray(const NdProfile &p, const Frame &fr, float rx, float
     V3 o;
     o.x = c * r;
     o.z = s * r;
-    o.y = rlm::sqrt32(rmax * rmax - r * r);
+    o.y = R_SQRT(rmax * rmax - r * r);
     maxdist = o.y * 2.0f;
     if (idx < 2) {
         dir = -fr.N;
@@ -718,9 +766,9 @@ RLS_DEV float sss_mis_pdf(const NdProfile &p, const Frame &fr, V3 disp, V3 sN, b
     V3 o = literal ? to_frame(disp, fr.U, fr.V, fr.N)
                    : mk(dot(disp, fr.U), dot(disp, fr.V), dot(disp, fr.N));
     o = mk(o.x * o.x, o.y * o.y, o.z * o.z);
-    float rr0 = rlm::sqrt32(o.y + o.z);
-    float rr1 = rlm::sqrt32(o.x + o.z);
-    float rr2 = rlm::sqrt32(o.x + o.y);
+    float rr0 = R_SQRT(o.y + o.z);
+    float rr1 = R_SQRT(o.x + o.z);
+    float rr2 = R_SQRT(o.x + o.y);
     return nd_pdf(p, rr0) * absf(dot(fr.U, sN)) * 0.25f
          + nd_pdf(p, rr1) * absf(dot(fr.V, sN)) * 0.25f
          + nd_pdf(p, rr2) * absf(dot(fr.N, sN)) * 0.5f;
@@ -729,9 +777,9 @@ RLS_DEV float sss_mis_pdf(const NdProfile &p, const Frame &fr, V3 disp, V3 sN, b
 // cavity fade, src/rlSss.h:401-413
 RLS_DEV float sss_cavity_fade(V3 disp, float r, V3 sN, V3 No)
 {
-    V3 dd = mk(disp.x / r, disp.y / r, disp.z / r);
+    V3 dd = mk(R_DIV(disp.x, r), R_DIV(disp.y, r), R_DIV(disp.z, r));
     float c = dot(No, dd) < 0.0f ? absf(dot(sN, No)) : clampf(dot(sN, No), -1.0f, 1.0f);
-    return rlm::sqrt32((1.0f + c) * 0.5f);
+    return R_SQRT((1.0f + c) * 0.5f);
 }
 
 // ---- counter-based generator: integer hash + exactly rounded ops only (reproducible on a CPU) ----

@@ -16,9 +16,88 @@ struct rls_context {
     hipStream_t own_stream;   // created by the context (may differ from `stream`)
     hipEvent_t ev_start, ev_stop;
     unsigned long long *scratch_u64;   // device, 8 bytes (checksum accumulator)
+    int fast;                 // RLS_MATH_FAST selected (rls_context_set_math_mode)
 };
 
+// Every kernel translation unit is compiled twice: with RLS_FAST=0 it carries the C ABI and the
+// EXACT kernels, with RLS_FAST=1 only the FAST kernels behind one hidden dispatch symbol.
+#define RLS_HIDDEN extern "C" __attribute__((visibility("hidden")))
+
 namespace rlsh {
+
+// ---- launch descriptors shared by the two builds of each unit ------------------------------------
+enum GgxOp { OP_SAMPLE, OP_EVAL, OP_PDF, OP_FUSED, OP_REFRACT, OP_REFLECT_REFRACT, OP_MICROFACET, OP_NDF_PDF };
+struct GgxIO {
+    rls_ggx_closure c;
+    const float *rx, *ry, *rx2, *ry2;
+    rls_cvec3 cwi;
+    rls_vec3 wi;
+    rls_rgb f;
+    float *pdf, *fresnel;
+    rls_vec3 wt;
+    float *weight;
+    uint8_t *refracted;
+    int64_t n;
+    int kernel;
+};
+
+enum DisneyOp { DOP_SAMPLE, DOP_EVAL, DOP_PDF, DOP_FUSED };
+struct DisneyIO {
+    rls_disney_closure c;
+    const float *rx, *ry;
+    rls_cvec3 cwi;
+    rls_vec3 wi;
+    rls_rgb f;
+    float *pdf;
+    int64_t n;
+};
+
+enum SssOp { SOP_ND, SOP_ND_PDF, SOP_ND_EVAL, SOP_PROBE, SOP_MIS };
+struct SssIO {
+    rls_sss_closure c;
+    const float *rx, *ry, *rin;
+    rls_cvec3 P, disp, sampleN;
+    int literal;
+    float *r;
+    rls_vec3 origin, dir;
+    float *maxdist, *pdf;
+    rls_rgb profile;
+    int64_t n;
+};
+enum MiscOp { MOP_CAVITY, MOP_DIFFUSE_DIR, MOP_UTIL };
+struct MiscIO {
+    rls_cvec3 a, b, c;
+    const float *rx, *ry;
+    float *out;
+    rls_vec3 v0, v1;
+    int64_t n;
+};
+
+struct SkinIO {
+    rls_skin_closure c;
+    const float *xi[6];
+    rls_skin_out o;
+    int64_t n;
+};
+
+struct GgxIntIO {
+    rls_ggx_closure c;
+    rls_rgb sum;
+    float *avgF;
+    int64_t n;
+    int spp;
+    uint32_t seed;
+};
+struct DisneyIntIO {
+    rls_disney_closure c;
+    rls_rgb dsum, ssum;
+    float *dcount, *scount;
+    rls_disney_stream_out st;
+    int streamed;
+    int64_t n;
+    int spp;
+    uint32_t seed;
+};
 
 void set_error(const char *fmt, ...);
 rls_status hip_fail(hipError_t e, const char *what);

@@ -14,12 +14,7 @@ using namespace rlsd;
 
 namespace {
 
-struct SkinIO {
-    rls_skin_closure c;
-    const float *xi[6];
-    rls_skin_out o;
-    int64_t n;
-};
+using rlsh::SkinIO;
 
 struct LobeOut { V3 wi; float fr, fg, fb, pdf, F; };
 
@@ -98,7 +93,21 @@ __global__ __launch_bounds__(rlsh::kBlock) void skin_kernel(SkinIO a)
     }
 }
 
+rls_status launch_kernel(rls_context *ctx, const SkinIO &io, const char *name)
+{
+    hipLaunchKernelGGL(skin_kernel, rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
+    return rlsh::check_launch(name);
+}
+
 } // namespace
+
+#if RLS_FAST
+RLS_HIDDEN rls_status rls_fast_skin(rls_context *ctx, const rlsh::SkinIO *io)
+{
+    return launch_kernel(ctx, *io, "rls_skin_sample_eval_pdf[fast]");
+}
+#else
+RLS_HIDDEN rls_status rls_fast_skin(rls_context *ctx, const rlsh::SkinIO *io);
 
 extern "C" {
 
@@ -122,8 +131,9 @@ rls_status rls_skin_sample_eval_pdf(rls_context *ctx, int64_t n, const rls_skin_
     for (int k = 0; k < 6; k++) io.xi[k] = xi[k];
     io.o = *out;
     io.n = n;
-    hipLaunchKernelGGL(skin_kernel, rlsh::grid_for(ctx, n), dim3(rlsh::kBlock), 0, ctx->stream, io);
-    return rlsh::check_launch("rls_skin_sample_eval_pdf");
+    return ctx->fast ? rls_fast_skin(ctx, &io) : launch_kernel(ctx, io, "rls_skin_sample_eval_pdf");
 }
 
 } // extern "C"
+
+#endif // !RLS_FAST

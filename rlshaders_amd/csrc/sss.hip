@@ -11,19 +11,11 @@ using namespace rlsd;
 
 namespace {
 
-enum SssOp { OP_ND, OP_ND_PDF, OP_ND_EVAL, OP_PROBE, OP_MIS };
-
-struct SssIO {
-    rls_sss_closure c;
-    const float *rx, *ry, *rin;
-    rls_cvec3 P, disp, sampleN;
-    int literal;
-    float *r;
-    rls_vec3 origin, dir;
-    float *maxdist, *pdf;
-    rls_rgb profile;
-    int64_t n;
-};
+using rlsh::SssIO;
+using rlsh::MiscIO;
+enum { OP_ND = rlsh::SOP_ND, OP_ND_PDF = rlsh::SOP_ND_PDF, OP_ND_EVAL = rlsh::SOP_ND_EVAL, OP_PROBE = rlsh::SOP_PROBE,
+       OP_MIS = rlsh::SOP_MIS };
+enum { OP_CAVITY = rlsh::MOP_CAVITY, OP_DIFFUSE_DIR = rlsh::MOP_DIFFUSE_DIR, OP_UTIL = rlsh::MOP_UTIL };
 
 __device__ __forceinline__ NdProfile load_profile(const rls_sss_closure &c, int64_t i)
 {
@@ -75,15 +67,6 @@ __global__ __launch_bounds__(rlsh::kBlock) void sss_kernel(SssIO a)
     }
 }
 
-struct MiscIO {
-    rls_cvec3 a, b, c;
-    const float *rx, *ry;
-    float *out;
-    rls_vec3 v0, v1;
-    int64_t n;
-};
-
-enum MiscOp { OP_CAVITY, OP_DIFFUSE_DIR, OP_UTIL };
 
 template <int OP>
 __global__ __launch_bounds__(rlsh::kBlock) void misc_kernel(MiscIO a)
@@ -117,19 +100,55 @@ rls_status check_closure(const rls_sss_closure *c, bool need_frame)
 }
 
 template <int OP>
-rls_status launch(rls_context *ctx, const SssIO &io, const char *name)
+rls_status launch_kernel(rls_context *ctx, const SssIO &io, const char *name)
 {
     hipLaunchKernelGGL(sss_kernel<OP>, rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
     return rlsh::check_launch(name);
 }
 
 template <int OP>
-rls_status launch_misc(rls_context *ctx, const MiscIO &io, const char *name)
+rls_status launch_misc_kernel(rls_context *ctx, const MiscIO &io, const char *name)
 {
     hipLaunchKernelGGL(misc_kernel<OP>, rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
     return rlsh::check_launch(name);
 }
 
+} // namespace
+
+#if RLS_FAST
+RLS_HIDDEN rls_status rls_fast_sss(rls_context *ctx, int op, const rlsh::SssIO *io)
+{
+    switch (op) {
+    case OP_ND: return launch_kernel<OP_ND>(ctx, *io, "rls_nd_sample[fast]");
+    case OP_ND_PDF: return launch_kernel<OP_ND_PDF>(ctx, *io, "rls_nd_pdf[fast]");
+    case OP_ND_EVAL: return launch_kernel<OP_ND_EVAL>(ctx, *io, "rls_nd_eval[fast]");
+    case OP_PROBE: return launch_kernel<OP_PROBE>(ctx, *io, "rls_sss_probe_ray[fast]");
+    default: return launch_kernel<OP_MIS>(ctx, *io, "rls_sss_mis_pdf[fast]");
+    }
+}
+RLS_HIDDEN rls_status rls_fast_misc(rls_context *ctx, int op, const rlsh::MiscIO *io)
+{
+    switch (op) {
+    case OP_CAVITY: return launch_misc_kernel<OP_CAVITY>(ctx, *io, "rls_sss_cavity_fade[fast]");
+    case OP_DIFFUSE_DIR: return launch_misc_kernel<OP_DIFFUSE_DIR>(ctx, *io, "rls_sss_sample_diffuse_direction[fast]");
+    default: return launch_misc_kernel<OP_UTIL>(ctx, *io, "rls_util_directions[fast]");
+    }
+}
+#else
+RLS_HIDDEN rls_status rls_fast_sss(rls_context *ctx, int op, const rlsh::SssIO *io);
+RLS_HIDDEN rls_status rls_fast_misc(rls_context *ctx, int op, const rlsh::MiscIO *io);
+
+namespace {
+template <int OP>
+rls_status launch(rls_context *ctx, const SssIO &io, const char *name)
+{
+    return ctx->fast ? rls_fast_sss(ctx, OP, &io) : launch_kernel<OP>(ctx, io, name);
+}
+template <int OP>
+rls_status launch_misc(rls_context *ctx, const MiscIO &io, const char *name)
+{
+    return ctx->fast ? rls_fast_misc(ctx, OP, &io) : launch_misc_kernel<OP>(ctx, io, name);
+}
 } // namespace
 
 #define RLS_PROLOGUE(frame)                              \
@@ -230,3 +249,5 @@ rls_status rls_util_directions(rls_context *ctx, int64_t n, const float *a, cons
 }
 
 } // extern "C"
+
+#endif // !RLS_FAST

@@ -132,6 +132,9 @@ constexpr int kBlock = RLS_BLOCK;   // 4 wavefronts of 64
 // that very large batches grid-stride instead of queueing millions of workgroups.
 inline dim3 grid_for(const rls_context *ctx, int64_t n, int points_per_block = kBlock)
 {
+    // called right before every launch: make the context's device current for this host thread
+    // (a host may drive several contexts, one per GPU, from one thread)
+    (void)hipSetDevice(ctx->device);
     int64_t want = (n + points_per_block - 1) / points_per_block;
     int64_t cap = (int64_t)ctx->compute_units * ctx->blocks_per_cu;
     if (want < 1) want = 1;

@@ -24,7 +24,7 @@ ARCH = "gfx950"
 
 SOURCES = ["context.hip", "ggx.hip", "disney.hip", "sss.hip", "skin.hip", "integrate.hip"]
 FAST_UNITS = {"ggx.hip", "disney.hip", "sss.hip", "skin.hip", "integrate.hip"}
-HEADERS = [CSRC / "rls_device.hpp", CSRC / "rls_libm.hpp", CSRC / "rls_internal.hpp",
+HEADERS = [CSRC / "rls_device.hpp", CSRC / "rls_libm.hpp", CSRC / "rls_libm_tables.inc", CSRC / "rls_internal.hpp",
            PKG.parent / "include" / "rlshaders_amd.h"]
 
 HIPCC_FLAGS = [

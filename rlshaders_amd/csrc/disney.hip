@@ -34,6 +34,7 @@ __device__ __forceinline__ Disney load_closure(const rls_disney_closure &c, int6
 template <int OP, bool DIFFUSE>
 __global__ __launch_bounds__(rlsh::kBlock) void disney_kernel(DisneyIO a)
 {
+    stage_libm_tables();   // powf / logf tables -> LDS (EXACT mode)
     const int64_t stride = (int64_t)gridDim.x * rlsh::kBlock;
     for (int64_t i = (int64_t)blockIdx.x * rlsh::kBlock + threadIdx.x; i < a.n; i += stride) {
         Disney d = load_closure(a.c, i);

@@ -117,6 +117,7 @@ template <int G>
 __global__ __launch_bounds__(rlsh::kBlock) void disney_integrate_kernel(DisneyIntIO a)
 {
     __shared__ uint32_t tab[2][kMaxSpp];
+    stage_libm_tables();   // powf / logf tables -> LDS (EXACT mode)
     stage_table(tab, a.spp);
     const int sub = threadIdx.x % G;
     const int64_t groups_per_block = rlsh::kBlock / G;

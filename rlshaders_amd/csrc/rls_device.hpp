@@ -82,13 +82,27 @@ struct Frame { V3 U, V, N; };
 #define R_LOG(x) __logf(x)
 #define R_POW(x, y) __powf(x, y)
 RLS_DEV void t_sincos(float x, float *s, float *c) { *s = __sinf(x); *c = __cosf(x); }
+RLS_DEV void stage_libm_tables() {}
 #else
 #define R_DIV(a, b) ((a) / (b))
 #define R_RCP(b) (1.0f / (b))
 #define R_SQRT(x) rlm::sqrt32(x)
-#define R_EXP(x) expf(x)
-#define R_LOG(x) logf(x)
-#define R_POW(x, y) powf(x, y)
+// exp / log / pow: the host libm's table-driven fp64 algorithms (rls_libm.hpp).  The tables live
+// in LDS (640 B per workgroup; each table is at most one 256-byte bank row, so the per-lane
+// lookups are conflict-free); a kernel that evaluates any of the three calls
+// stage_libm_tables() once before its loop.
+static __device__ __constant__ rlm::Tables c_libm_tables = RLM_TABLES_INIT;
+static __shared__ rlm::Tables s_libm_tables;
+RLS_DEV void stage_libm_tables()
+{
+    const uint64_t *src = reinterpret_cast<const uint64_t *>(&c_libm_tables);
+    uint64_t *dst = reinterpret_cast<uint64_t *>(&s_libm_tables);
+    for (unsigned t = threadIdx.x; t < sizeof(rlm::Tables) / 8; t += blockDim.x) dst[t] = src[t];
+    __syncthreads();
+}
+#define R_EXP(x) rlm::exp32(x, s_libm_tables)
+#define R_LOG(x) rlm::log32(x, s_libm_tables)
+#define R_POW(x, y) rlm::pow32(x, y, s_libm_tables)
 RLS_DEV void t_sincos(float x, float *s, float *c) { rlm::sincos32_v(x, s, c); }
 RLS_DEV float t_atan2(float y, float x) { return rlm::atan2_32_v(y, x); }
 RLS_DEV float t_acos(float x) { return rlm::acos32_v(x); }

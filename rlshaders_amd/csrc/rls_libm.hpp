@@ -337,6 +337,156 @@ RLM_FN float tan32(float x)
 }
 
 // =================================================================================================
+// expf / logf / powf: the fp64 table-driven algorithms of glibc >= 2.28 (ARM optimized-routines:
+// e_expf.c, e_logf.c, e_powf.c).  The tables (rls_libm_tables.inc, generated and cross-checked by
+// tools/gen_libm_tables.py) are passed in: a static object on the host, an LDS copy on the device
+// (each is exactly one 256-byte LDS bank row or less, so per-lane lookups are conflict-free).
+// =================================================================================================
+#include "rls_libm_tables.inc"
+
+struct Tables {
+    uint64_t exp2t[32];
+    double invc[16], logc[16], log2c[16];
+};
+#define RLM_TABLES_INIT { RLM_EXP2_TABLE, RLM_LOG_INVC, RLM_LOG_LOGC, RLM_LOG_LOG2C }
+
+RLM_FN uint64_t d2u(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint64_t)__double_as_longlong(x);
+#else
+    uint64_t u; memcpy(&u, &x, 8); return u;
+#endif
+}
+RLM_FN double u2d(uint64_t u)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __longlong_as_double((long long)u);
+#else
+    double x; memcpy(&x, &u, 8); return x;
+#endif
+}
+
+// 2^(x/32-scaled) core shared by expf and powf: s * (C0 r^3 + C1 r^2 + C2 r + 1)
+RLM_FN float exp2_core(double z, double shift, double c0, double c1, double c2, const Tables &t, uint64_t sign_bias)
+{
+    double kd = z + shift;
+    const uint64_t ki = d2u(kd);
+    kd -= shift;
+    const double r = z - kd;
+    uint64_t tt = t.exp2t[ki % 32];
+    tt += (ki + sign_bias) << (52 - 5);
+    const double s = u2d(tt);
+    const double zz = c0 * r + c1;
+    const double r2 = r * r;
+    double y = c2 * r + 1.0;
+    y = zz * r2 + y;
+    y = y * s;
+    return (float)y;
+}
+
+RLM_FN float exp32(float x, const Tables &t)
+{
+    const uint32_t abstop = (f2u(x) >> 20) & 0x7ffu;
+    if (abstop >= 0x42bu) {                                              // |x| >= 88 or NaN
+        if (f2u(x) == 0xff800000u) return 0.0f;
+        if (abstop >= 0x7f8u) return x + x;
+        if (x > 0x1.62e42ep6f) return u2f(0x7f800000u);                 // overflow
+        if (x < -0x1.9fe368p6f) return 0.0f;                            // underflow
+    }
+    const double N = 32.0;
+    const double z = (0x1.71547652b82fep+0 * N) * (double)x;
+    return exp2_core(z, 0x1.8p+52, 0x1.c6af84b912394p-5 / N / N / N, 0x1.ebfce50fac4f3p-3 / N / N,
+                     0x1.62e42ff0c52d6p-1 / N, t, 0);
+}
+
+RLM_FN float log32(float x, const Tables &t)
+{
+    uint32_t ix = f2u(x);
+    if (ix == 0x3f800000u) return 0.0f;
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
+        if (ix * 2 == 0) return -u2f(0x7f800000u);                      // log(0) = -inf
+        if (ix == 0x7f800000u) return x;                                // log(inf) = inf
+        if ((ix & 0x80000000u) || ix * 2 >= 0xff000000u) return (x - x) / (x - x);   // negative or NaN
+        ix = f2u(x * 0x1p23f);                                          // subnormal: normalise
+        ix -= 23u << 23;
+    }
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> (23 - 4)) % 16);
+    const int k = (int32_t)tmp >> 23;
+    const uint32_t iz = ix - (tmp & (0x1ffu << 23));
+    const double invc = t.invc[i], logc = t.logc[i];
+    const double z = (double)u2f(iz);
+    const double r = z * invc - 1.0;
+    const double y0 = logc + (double)k * 0x1.62e42fefa39efp-1;
+    const double r2 = r * r;
+    double y = 0x1.5575b0be00b6ap-2 * r + -0x1.ffffef20a4123p-2;
+    y = -0x1.00ea348b88334p-2 * r2 + y;
+    y = y * r2 + (y0 + r);
+    return (float)y;
+}
+
+// powf for x >= 0 (the closures raise clamped, non-negative bases; x < 0 yields NaN here)
+RLM_FN float pow32(float x, float y, const Tables &t)
+{
+    uint32_t ix = f2u(x);
+    const uint32_t iy = f2u(y);
+    const bool yspecial = (2u * iy - 1u) >= (2u * 0x7f800000u - 1u);    // y is 0, inf or nan
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u || yspecial) {
+        if (yspecial) {
+            if (2u * iy == 0) return 1.0f;
+            if (ix == 0x3f800000u) return 1.0f;
+            if (2u * ix > 2u * 0x7f800000u || 2u * iy > 2u * 0x7f800000u) return x + y;
+            if (2u * ix == 2u * 0x3f800000u) return 1.0f;
+            if ((2u * ix < 2u * 0x3f800000u) == !(iy & 0x80000000u)) return 0.0f;
+            return y * y;
+        }
+        if ((2u * ix - 1u) >= (2u * 0x7f800000u - 1u)) {                // x is 0, inf or nan
+            float x2 = x * x;
+            if (ix & 0x80000000u) {                                     // -0 / -inf: odd integer y keeps the sign
+                const int e = (int)(iy >> 23) & 0xff;
+                bool odd = false;
+                if (e >= 0x7f && e <= 0x7f + 23) {
+                    const uint32_t bit = 1u << (0x7f + 23 - e);
+                    odd = !(iy & (bit - 1u)) && (iy & bit);
+                }
+                if (odd) x2 = -x2;
+            }
+            return (iy & 0x80000000u) ? 1.0f / x2 : x2;
+        }
+        if (ix & 0x80000000u) return (x - x) / (x - x);
+        if (ix < 0x00800000u) {                                         // subnormal x
+            ix = f2u(x * 0x1p23f);
+            ix &= 0x7fffffffu;
+            ix -= 23u << 23;
+        }
+    }
+    // log2_inline
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> (23 - 4)) % 16);
+    const uint32_t top = tmp & 0xff800000u;
+    const uint32_t iz = ix - top;
+    const int k = (int32_t)top >> 23;
+    const double invc = t.invc[i], logc = t.log2c[i];
+    const double z = (double)u2f(iz);
+    const double r = z * invc - 1.0;
+    const double y0 = logc + (double)k;
+    const double r2 = r * r;
+    double yy = 0x1.27616c9496e0bp-2 * r + -0x1.71969a075c67ap-2;
+    const double p = 0x1.ec70a6ca7baddp-2 * r + -0x1.7154748bef6c8p-1;
+    const double r4 = r2 * r2;
+    double q = 0x1.71547652ab82bp0 * r + y0;
+    q = p * r2 + q;
+    yy = yy * r4 + q;
+    const double ylogx = (double)y * yy;
+    if (((d2u(ylogx) >> 47) & 0xffffu) >= (d2u(126.0) >> 47)) {         // |y log2 x| >= 126
+        if (ylogx > 0x1.fffffffd1d571p+6) return u2f(0x7f800000u);
+        if (ylogx <= -150.0) return 0.0f;
+    }
+    return exp2_core(ylogx, 0x1.8p+52 / 32.0, 0x1.c6af84b912394p-5, 0x1.ebfce50fac4f3p-3, 0x1.62e42ff0c52d6p-1, t, 0);
+}
+
+// =================================================================================================
 // Wave-friendly forms.  Same arithmetic, same results, but the range cases are expressed as
 // selects around ONE shared division / polynomial instead of separate branches, because the 64
 // lanes of a wavefront land in different ranges and would otherwise execute every branch in turn.

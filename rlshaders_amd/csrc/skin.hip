@@ -34,6 +34,7 @@ __device__ __forceinline__ LobeOut ggx_lobe(V3 wo, V3 N, V3 T, float cr, float c
 
 __global__ __launch_bounds__(rlsh::kBlock) void skin_kernel(SkinIO a)
 {
+    stage_libm_tables();   // expf / logf tables -> LDS (EXACT mode)
     const int64_t stride = (int64_t)gridDim.x * rlsh::kBlock;
     for (int64_t i = (int64_t)blockIdx.x * rlsh::kBlock + threadIdx.x; i < a.n; i += stride) {
         const rls_skin_closure &c = a.c;

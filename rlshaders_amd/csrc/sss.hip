@@ -30,6 +30,7 @@ __device__ __forceinline__ NdProfile load_profile(const rls_sss_closure &c, int6
 template <int OP>
 __global__ __launch_bounds__(rlsh::kBlock) void sss_kernel(SssIO a)
 {
+    stage_libm_tables();   // expf / logf tables -> LDS (EXACT mode)
     const int64_t stride = (int64_t)gridDim.x * rlsh::kBlock;
     for (int64_t i = (int64_t)blockIdx.x * rlsh::kBlock + threadIdx.x; i < a.n; i += stride) {
         NdProfile p = load_profile(a.c, i);

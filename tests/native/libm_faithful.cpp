@@ -26,8 +26,28 @@ struct Acc { long bad = 0, total = 0; int64_t maxulp = 0; void add(float got, fl
 int main(int argc, char **argv)
 {
     long n = argc > 1 ? atol(argv[1]) : 4000000;
+    static const rlm::Tables tab = RLM_TABLES_INIT;
+    Acc a_exp, a_log, a_pow;
     Acc a_atan, a_atan2, a_acos, a_tan, a_sin, a_cos, v_atan, v_atan2, v_acos, v_tan, v_sin, v_cos;
     for (long i = 0; i < n; i++) {
+        // expf / logf / powf
+        float ex = 193.0f * u01() - 104.0f;
+        a_exp.add(rlm::exp32(ex, tab), expf(ex));
+        float ex2 = -30.0f * u01();
+        a_exp.add(rlm::exp32(ex2, tab), expf(ex2));
+        float ex3 = exp2f(-20.0f * u01()) * (rnd() & 1 ? 1.0f : -1.0f);
+        a_exp.add(rlm::exp32(ex3, tab), expf(ex3));
+        float lg = exp2f(60.0f * u01() - 30.0f);
+        a_log.add(rlm::log32(lg, tab), logf(lg));
+        float lg2 = 1.0f + (u01() - 0.5f) * exp2f(-12.0f * u01());
+        a_log.add(rlm::log32(lg2, tab), logf(lg2));
+        float lg3 = u01();
+        a_log.add(rlm::log32(lg3, tab), logf(lg3));
+        float pb = u01(), pe = u01();
+        a_pow.add(rlm::pow32(pb, 5.0f, tab), powf(pb, 5.0f));
+        a_pow.add(rlm::pow32(pb, pe, tab), powf(pb, pe));
+        float pb2 = 100.0f * u01(), pe2 = 20.0f * u01() - 10.0f;
+        a_pow.add(rlm::pow32(pb2, pe2, tab), powf(pb2, pe2));
         // atanf over many magnitudes
         float m = exp2f(40.0f * u01() - 30.0f) * (rnd() & 1 ? 1.0f : -1.0f);
         a_atan.add(rlm::atan32(m), atanf(m)); v_atan.add(rlm::atan32_v(m), atanf(m));
@@ -80,6 +100,15 @@ int main(int argc, char **argv)
         rlm::sincos32_v(v, &s, &co); v_sin.add(s, sinf(v)); v_cos.add(co, cosf(v));
         for (float w : sp) { a_atan2.add(rlm::atan2_32(v, w), atan2f(v, w)); v_atan2.add(rlm::atan2_32_v(v, w), atan2f(v, w)); }
     }
+    const float spv[] = { 0.0f, -0.0f, 1.0f, 0.5f, 2.0f, 1e-40f, 1e-38f, 88.0f, -103.0f, -104.5f, 89.0f, 3.4e38f };
+    for (float v : spv) {
+        a_exp.add(rlm::exp32(v, tab), expf(v));
+        if (v >= 0.0f) a_log.add(rlm::log32(v, tab), logf(v));
+        for (float w : spv) if (v >= 0.0f) a_pow.add(rlm::pow32(v, w, tab), powf(v, w));
+    }
+    printf("expf %ld %ld %lld\n", a_exp.bad, a_exp.total, (long long)a_exp.maxulp);
+    printf("logf %ld %ld %lld\n", a_log.bad, a_log.total, (long long)a_log.maxulp);
+    printf("powf %ld %ld %lld\n", a_pow.bad, a_pow.total, (long long)a_pow.maxulp);
     printf("atanf %ld %ld %lld\n", a_atan.bad, a_atan.total, (long long)a_atan.maxulp);
     printf("atan2f %ld %ld %lld\n", a_atan2.bad, a_atan2.total, (long long)a_atan2.maxulp);
     printf("acosf %ld %ld %lld\n", a_acos.bad, a_acos.total, (long long)a_acos.maxulp);

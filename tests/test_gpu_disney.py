@@ -1,6 +1,6 @@
 """GPU parity of the rlDisney closure kernels against the CPU oracle, through the C ABI.
-Decoupled eval/pdf use powf/logf on top of exact arithmetic, so they are held to the plain 1e-5
-bound; sampled directions and the fused chain are held statistically (see test_gpu_ggx.py)."""
+EXACT mode restates the host libm's powf / logf (and the angle functions), so decoupled eval/pdf,
+sampled directions, the fused chain and the n^2-spp sums all reproduce the oracle (cases.assert_tight)."""
 import numpy as np
 import pytest
 
@@ -53,8 +53,7 @@ def test_sample_and_fused(gpu, oracle, mixed, lobe, name):
     for k, nm in enumerate(("wi", "f", "pdf")):
         st = cases.summarize(cases.rel_err(got[k][..., both], ref[k][..., both]))
         print("disney", name, "fused", nm, st)
-        assert st["nonfinite"] == 0
-        assert st["median"] <= 2e-6 and st["frac_gt_1e5"] <= 6e-3, (nm, st)
+        cases.assert_tight(st, (name, nm))
     # zero sample -> black, pdf 0
     assert np.all(got[1][:, z_got] == 0) and np.all(got[2][z_got] == 0)
 
@@ -74,7 +73,7 @@ def test_testsuite_presets(gpu, oracle, preset):
         for k, nm in enumerate(("wi", "f", "pdf")):
             st = cases.summarize(cases.rel_err(got[k], ref[k]))
             print(preset, name, nm, st)
-            assert st["nonfinite"] == 0 and st["frac_gt_1e5"] <= 6e-3, (preset, name, nm, st)
+            cases.assert_tight(st, (preset, name, nm))
         f = host(s.evalBrdf(dev(ref[0])))
         assert cases.summarize(cases.rel_err(f, ref[1]))["max"] <= TOL
 
@@ -109,13 +108,13 @@ def test_integrate_reduced_and_streamed(gpu, oracle):
     got = {k: host(v) for k, v in s.integrate(spp_n, 4321, streamed=True).items()}
     st = cases.summarize(cases.rel_err(got["wi"], ref["wi"]))
     print("disney integrate streamed wi", st)
-    assert st["frac_gt_1e5"] <= 6e-3
+    cases.assert_tight(st, "streamed wi")
     for k in ("diffuse_count", "specular_count"):
-        assert (got[k] != ref[k]).mean() <= 2e-3, k
+        assert (got[k] != ref[k]).sum() <= 1, k
     for k in ("diffuse_sum", "specular_sum"):
         st = cases.summarize(cases.rel_err(got[k], ref[k]))
         print("disney integrate", k, st)
-        assert st["median"] <= 1e-5 and st["frac_gt_1e5"] <= 0.1, (k, st)
+        cases.assert_tight(st, k)
     base = {k: host(v) for k, v in s.integrate(spp_n, 4321).items()}
     del os.environ["RLS_INTEGRATE_GROUP"]
     for k in ("diffuse_sum", "specular_sum", "diffuse_count", "specular_count"):

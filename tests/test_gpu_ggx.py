@@ -1,10 +1,10 @@
 """GPU parity of the rlGgx closure kernels against the CPU oracle, through the C ABI.
 
-Protocol: (1) decoupled eval / pdf on the oracle's own wi -- only + - * / sqrt, so
-bit-exact agreement is expected and anything above 1e-5 relative fails; (2) sampled directions within
-1e-5 for >= 99.9 % of points (device and host libm round atan2f/acosf/tanf/sincosf differently);
-(3) the chained fused kernel reported statistically, with every outlier required to sit on a point
-where the oracle itself moves by more than the error under a 1-ulp nudge of xi.
+EXACT mode (the default) uses exactly rounded + - * / sqrt and the host libm's own algorithms for the
+angle functions (rls_libm.hpp), so decoupled eval / pdf, sampled directions and the whole chained
+kernel reproduce the oracle: every test holds the 1e-5 tolerance on every point (cases.assert_tight
+allows one point per batch for glibc's FMA-contracted fp64 polynomials).  The conditioning protocol of
+SURVEY.md 8(c) is kept as a secondary check and is what RLS_MATH_FAST is held to (test_gpu_fast_mode.py).
 """
 import numpy as np
 import pytest
@@ -49,11 +49,10 @@ def test_sample_direction(gpu, oracle, mixed):
     e = cases.rel_err(host(wi), wi_ref)
     st = cases.summarize(e)
     print("ggx sample direction", st)
-    assert st["nonfinite"] == 0
-    assert st["frac_gt_1e5"] <= 1e-3, st
+    cases.assert_tight(st, "wi")
     eF = cases.summarize(cases.rel_err(host(F), F_ref))
     print("ggx sample fresnel", eF)
-    assert eF["frac_gt_1e5"] <= 2e-3, eF
+    cases.assert_tight(eF, "fresnel")
     # unit length, upper hemisphere not required (reflect can dip below for grazing facets)
     ln = np.linalg.norm(host(wi).astype(np.float64), axis=0)
     assert np.abs(ln - 1).max() < 1e-5
@@ -136,8 +135,9 @@ def test_refract_and_reflect_refract(gpu, oracle, mixed):
     sw = cases.summarize(cases.rel_err(host(w), w_ref))
     print("ggx refract dir", st)
     print("ggx refract weight", sw)
-    assert st["frac_gt_1e5"] <= 2e-3 and sw["frac_gt_1e5"] <= 5e-3
-    assert (host(flag) != flag_ref).mean() <= 1e-4
+    cases.assert_tight(st, "refract dir")
+    cases.assert_tight(sw, "refract weight")
+    assert (host(flag) != flag_ref).sum() <= 1
     # the one-pass kernel = reflect triple + refract sample, bit for bit
     out = s.reflectRefract(dev(x[0]), dev(x[1]), dev(x[2]), dev(x[3]))
     tri = s.sampleEvalPdf(dev(x[0]), dev(x[1]))
@@ -158,11 +158,11 @@ def test_exiting_and_tir(gpu, oracle):
     assert 0 < flag_ref.mean() < 1, "case must contain both refraction and TIR"
     s = ggx_sampler(gpu, c, exiting=exiting)
     wt, w, flag = s.refractSample(dev(x[0]), dev(x[1]))
-    assert (host(flag) != flag_ref).mean() <= 1e-3
+    assert (host(flag) != flag_ref).sum() <= 1
     same = host(flag) == flag_ref
     st = cases.summarize(cases.rel_err(host(wt)[:, same], wt_ref[:, same]))
     print("ggx exiting refract dir", st)
-    assert st["frac_gt_1e5"] <= 3e-3
+    cases.assert_tight(st, "exiting refract dir")
     wi_ref = og.sample(x[0], x[1])[0]
     f = host(s.evalBrdf(dev(wi_ref)))
     assert cases.summarize(cases.rel_err(f, og.eval(wi_ref)))["max"] <= TOL
@@ -183,7 +183,7 @@ def test_testsuite_presets(gpu, oracle, name):
     for k, nm in enumerate(("wi", "f", "pdf", "fresnel")):
         st = cases.summarize(cases.rel_err(got[k], ref[k]))
         print(name, nm, st)
-        assert st["nonfinite"] == 0 and st["frac_gt_1e5"] <= 5e-3, (name, nm, st)
+        cases.assert_tight(st, (name, nm))
     # decoupled: exact
     f = host(s.evalBrdf(dev(ref[0])))
     assert cases.summarize(cases.rel_err(f, ref[1]))["max"] <= TOL
@@ -200,14 +200,14 @@ def test_edge_cases(gpu, oracle):
     fin = np.isfinite(ref[0]).all(axis=0) & np.isfinite(ref[1]).all(axis=0) & np.isfinite(ref[2])
     # where the reference itself produces inf/nan (xi -> 1 in the uniform-slope branch) the kernel must too
     gfin = np.isfinite(got[0]).all(axis=0) & np.isfinite(got[1]).all(axis=0) & np.isfinite(got[2])
-    assert (fin != gfin).mean() <= 1e-3
+    assert (fin != gfin).sum() <= 1
     both = fin & gfin
     for k, nm in enumerate(("wi", "f", "pdf", "fresnel")):
         a = got[k][..., both]
         b = ref[k][..., both]
         st = cases.summarize(cases.rel_err(a, b))
         print("ggx edge", nm, st)
-        assert st["frac_gt_1e5"] <= 2e-2, (nm, st)
+        cases.assert_tight(st, ("edge", nm))
     # black Ks regime (index % 8 == 7): exactly zero
     k7 = (np.arange(n) % 8) == 7
     assert np.all(got[1][:, k7] == 0)
@@ -227,7 +227,7 @@ def test_microfacet_kernels(gpu, oracle, mixed):
         m = host(s.microfacet(dev(x[0]), dev(x[1]), kern))
         st = cases.summarize(cases.rel_err(m, og.microfacet(x[0], x[1], ndf)))
         print("microfacet", "ndf" if ndf else "vndf", st)
-        assert st["frac_gt_1e5"] <= 1e-3
+        cases.assert_tight(st, "microfacet")
     wi = og.sample(x[0], x[1])[0]
     st = cases.summarize(cases.rel_err(host(s.ndfPdf(dev(wi))), og.ndf_pdf(wi)))
     assert st["max"] <= TOL

@@ -55,8 +55,8 @@ def test_ggx_integrate(gpu, oracle):
     ss = cases.summarize(cases.rel_err(sm, s_ref))
     print("ggx integrate avg fresnel", sa)
     print("ggx integrate sum f/pdf", ss)
-    assert sa["max"] <= 1e-4 and sa["median"] <= 1e-6          # mean of 64 well-conditioned terms
-    assert ss["median"] <= 1e-5 and ss["frac_gt_1e5"] <= 0.25 and ss["p99"] <= 1e-3
+    cases.assert_tight(sa, "avg reflect weight")               # G = 1 sums in the reference's order
+    cases.assert_tight(ss, "sum f/pdf")
     for g in ("4", "16", "64"):
         os.environ["RLS_INTEGRATE_GROUP"] = g
         try:
@@ -112,4 +112,4 @@ def test_full_size_properties(gpu, oracle):
     for nm, a, b in zip(("wi", "f", "pdf", "fresnel", "wt", "weight"), (wi, f, pdf, F, wt, w), ref):
         st = cases.summarize(cases.rel_err(sub(a), b))
         print("full-size spot", nm, st)
-        assert st["median"] <= 2e-6 and st["frac_gt_1e5"] <= 6e-3, (nm, st)
+        cases.assert_tight(st, ("full-size spot", nm))

@@ -197,9 +197,12 @@ def test_edge_cases(gpu, oracle):
     ref = og.sample_eval_pdf(x[0], x[1])
     s = ggx_sampler(gpu, c)
     got = [host(t) for t in s.sampleEvalPdf(dev(x[0]), dev(x[1]))]
-    fin = np.isfinite(ref[0]).all(axis=0) & np.isfinite(ref[1]).all(axis=0) & np.isfinite(ref[2])
+    fin = (np.isfinite(ref[0]).all(axis=0) & np.isfinite(ref[1]).all(axis=0) & np.isfinite(ref[2])
+           & np.isfinite(ref[3]))
     # where the reference itself produces inf/nan (xi -> 1 in the uniform-slope branch) the kernel must too
-    gfin = np.isfinite(got[0]).all(axis=0) & np.isfinite(got[1]).all(axis=0) & np.isfinite(got[2])
+    gfin = (np.isfinite(got[0]).all(axis=0) & np.isfinite(got[1]).all(axis=0) & np.isfinite(got[2])
+            & np.isfinite(got[3]))
+    assert (~fin).sum() > 0, "the edge set must contain points where the reference itself is not finite"
     assert (fin != gfin).sum() <= 1
     both = fin & gfin
     for k, nm in enumerate(("wi", "f", "pdf", "fresnel")):

@@ -1,0 +1,75 @@
+"""CPU: the closure parameter surface is the reference's -- same names, types and defaults
+(tests/golden/param_surface.json, extracted from the reference's node_parameters blocks and
+rlShaders.mtd by tools/extract_param_surface.py).  Parameters the closure path does not consume
+(diffuse Oren-Nayar lobe, Ks/Kt post-scales, opacity, AOV names, indirect scales) are listed
+explicitly as out of path so that nothing is silently missing."""
+import json
+from pathlib import Path
+
+from rlshaders_amd import _capi as capi
+from rlshaders_amd.closures import SkinShader
+
+G = json.loads((Path(__file__).parent / "golden" / "param_surface.json").read_text())["nodes"]
+
+# declared by the reference's nodes, consumed outside the closure layer
+OUT_OF_PATH = {
+    "rlGgx": {"KdColor", "Kd", "diffuseRoughness", "Ks", "KtColor", "Kt", "opacity", "opacity_color"},
+    "rlDisney": {"opacity", "indirectDiffuseScale", "indirectSpecularScale"},
+    "rlSkin": {"sss_cavity_fadeout", "opacity", "opacity_color"},
+}
+
+
+def fields(struct):
+    return {n: t for n, t in struct._fields_}
+
+
+def check(node, struct, rename=None):
+    rename = rename or {}
+    f = fields(struct)
+    for p in G[node]["parameters"]:
+        name = p["name"]
+        if name in OUT_OF_PATH[node]:
+            continue
+        fld = rename.get(name, name)
+        assert fld in f, f"{node}.{name} missing from the C-ABI closure struct"
+        if p["type"] == "RGB":
+            assert f[fld] is capi.ParamRgb, (node, name)
+        elif p["type"] == "VEC":
+            assert f[fld]._length_ == 3 and f[fld]._type_ is capi.Param, (node, name)
+        else:
+            assert f[fld] is capi.Param, (node, name)
+
+
+def test_rlggx_parameters():
+    check("rlGgx", capi.GgxClosure)
+    assert [p["name"] for p in G["rlGgx"]["parameters"]][:4] == ["KdColor", "Kd", "diffuseRoughness", "KsColor"]
+    assert G["rlGgx"]["mtd"]["maya.id"] == "0x04700001"
+
+
+def test_rldisney_parameters():
+    check("rlDisney", capi.DisneyClosure)
+    scal = [p["name"] for p in G["rlDisney"]["parameters"] if p["type"] == "FLT" and p["name"] not in OUT_OF_PATH["rlDisney"]]
+    assert tuple(scal) == capi.DISNEY_SCALARS          # same order as src/rlDisney.cpp:608-610
+    assert all(p["default"] == [0.0] for p in G["rlDisney"]["parameters"] if p["name"] in scal)
+
+
+def test_rlskin_parameters_and_defaults():
+    check("rlSkin", capi.SkinClosure)
+    for p in G["rlSkin"]["parameters"]:
+        if p["name"] in OUT_OF_PATH["rlSkin"]:
+            continue
+        d = SkinShader.DEFAULTS[p["name"]]
+        got = list(d) if isinstance(d, (tuple, list)) else [d]
+        assert got == p["default"], (p["name"], got, p["default"])
+    # UI ranges in the .mtd are consistent with the defaults
+    for name, r in G["rlSkin"]["mtd"]["attrs"].items():
+        if name in SkinShader.DEFAULTS and "min" in r:
+            assert SkinShader.DEFAULTS[name] >= r["min"]
+
+
+def test_header_names_every_consumed_parameter():
+    text = (Path(__file__).resolve().parent.parent / "include" / "rlshaders_amd.h").read_text()
+    for node in G:
+        for p in G[node]["parameters"]:
+            if p["name"] not in OUT_OF_PATH[node]:
+                assert p["name"] in text, (node, p["name"])

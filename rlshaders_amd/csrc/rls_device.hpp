@@ -81,12 +81,25 @@ struct Frame { V3 U, V, N; };
 #define R_EXP(x) __expf(x)
 #define R_LOG(x) __logf(x)
 #define R_POW(x, y) __powf(x, y)
+// the visible-normal slope equations amplify every rounding error: there,
+// and only there, FAST spends a Newton step on the reciprocal (~0.5 ulp) and the exact sqrt
+RLS_DEV float refined_div(float a, float b)
+{
+    float r = __builtin_amdgcn_rcpf(b);
+    float q = a * r;
+    float e = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(e, r, q);
+}
+#define R_DIVH(a, b) refined_div(a, b)
+#define R_SQRTH(x) rlm::sqrt32(x)
 RLS_DEV void t_sincos(float x, float *s, float *c) { *s = __sinf(x); *c = __cosf(x); }
 RLS_DEV void stage_libm_tables() {}
 #else
 #define R_DIV(a, b) ((a) / (b))
 #define R_RCP(b) (1.0f / (b))
 #define R_SQRT(x) rlm::sqrt32(x)
+#define R_DIVH(a, b) ((a) / (b))
+#define R_SQRTH(x) rlm::sqrt32(x)
 // exp / log / pow: the host libm's table-driven fp64 algorithms (rls_libm.hpp).  The tables live
 // in LDS (640 B per workgroup; each table is at most one 256-byte bank row, so the per-lane
 // lookups are conflict-free); a kernel that evaluates any of the three calls
@@ -116,6 +129,14 @@ RLS_DEV V3 normalize(V3 a)
 {
     float t = length(a);
     if (t != 0.0f) t = R_RCP(t);
+    return mk(a.x * t, a.y * t, a.z * t);
+}
+// normalize() for vectors whose direction feeds a sharply peaked function (the microfacet normal
+// and the half vector under D(h) at low roughness): FAST keeps these at ~0.5 ulp; EXACT is unchanged
+RLS_DEV V3 normalize_h(V3 a)
+{
+    float t = R_SQRTH(a.x * a.x + a.y * a.y + a.z * a.z);
+    if (t != 0.0f) t = R_DIVH(1.0f, t);
     return mk(a.x * t, a.y * t, a.z * t);
 }
 RLS_DEV float linearstep(float lo, float hi, float t) { return clampf(R_DIV(t - lo, hi - lo), 0.0f, 1.0f); }
@@ -188,18 +209,16 @@ RLS_DEV VndfView vndf_view(V3 view, const Frame &fr, float ax, float ay)
     float sx = dot(fr.U, view) * ax;
     float sy = dot(fr.V, view) * ay;
     float h2 = sx * sx + sy * sy;
-    float inv = __builtin_amdgcn_rsqf(h2 + cz * cz);
-    float z = cz * inv;
-    float h = __builtin_amdgcn_sqrtf(h2) * inv;
+    float z = R_DIVH(cz, R_SQRTH(h2 + cz * cz));          // cos(theta') of the stretched view
+    float h = R_SQRTH(h2);
     bool flat = !(z < (1.0f - kEps));
-    float invh = __builtin_amdgcn_rsqf(h2);
-    w.cosPhi = (flat || h2 == 0.0f) ? 1.0f : sx * invh;
-    w.sinPhi = (flat || h2 == 0.0f) ? 0.0f : sy * invh;
+    w.cosPhi = (flat || h2 == 0.0f) ? 1.0f : R_DIVH(sx, h);
+    w.sinPhi = (flat || h2 == 0.0f) ? 0.0f : R_DIVH(sy, h);
     w.nearNormal = flat;
-    float B = flat ? 0.0f : h * __builtin_amdgcn_rcpf(z);
+    float B = flat ? 0.0f : R_DIVH(h, cz);                 // tan(theta') = |(sx,sy)| / cz
     w.B = B;
     w.B2 = sqr(B);
-    w.G1 = R_DIV(2.0f, 1.0f + R_SQRT(1.0f + w.B2));
+    w.G1 = R_DIVH(2.0f, 1.0f + R_SQRTH(1.0f + w.B2));
     w.invB = R_RCP(B);
     return w;
 }
@@ -250,13 +269,13 @@ RLS_DEV V2 uniform_slope(float rx, float ry)
 RLS_DEV V3 vndf_microfacet(const VndfView &w, const Frame &fr, float rx, float ry)
 {
     V2 slope;
-    float A = R_DIV(2.0f * rx, w.G1) - 1.0f;
+    float A = R_DIVH(2.0f * rx, w.G1) - 1.0f;
     float A2 = sqr(A);
     if (w.nearNormal || absf(A2 - 1.0f) < kEps) {
         slope = uniform_slope(rx, ry);
     } else {
-        float tmp = R_RCP(A2 - 1.0f);
-        float D = R_SQRT(maxf(0.0f, w.B2 * sqr(tmp) - (A2 - w.B2) * tmp));
+        float tmp = R_DIVH(1.0f, A2 - 1.0f);
+        float D = R_SQRTH(maxf(0.0f, w.B2 * sqr(tmp) - (A2 - w.B2) * tmp));
         float slopeX1 = w.B * tmp - D;
         float slopeX2 = w.B * tmp + D;
         slope.x = (A < 0.0f || slopeX2 > w.invB) ? slopeX1 : slopeX2;
@@ -269,15 +288,15 @@ RLS_DEV V3 vndf_microfacet(const VndfView &w, const Frame &fr, float rx, float r
             sign = -1.0f;
             u = 2.0f * (0.5f - ry);
         }
-        float z = R_DIV(u * (u * (u * 0.27385f - 0.73369f) + 0.46341f),
+        float z = R_DIVH(u * (u * (u * 0.27385f - 0.73369f) + 0.46341f),
                         u * (u * (u * 0.093073f + 0.309420f) - 1.0f) + 0.597999f);
-        slope.y = sign * z * R_SQRT(1.0f + sqr(slope.x));
+        slope.y = sign * z * R_SQRTH(1.0f + sqr(slope.x));
     }
     V3 omega;
     omega.x = -(w.cosPhi * slope.x - w.sinPhi * slope.y) * w.ax;
     omega.y = -(w.sinPhi * slope.x + w.cosPhi * slope.y) * w.ay;
     omega.z = 1.0f;
-    return normalize(to_frame(omega, fr.U, fr.V, fr.N));
+    return normalize_h(to_frame(omega, fr.U, fr.V, fr.N));
 }
 
 // ---- rlGgx closure state, src/rlGgx.h:130-156 ---------------------------------------------------
@@ -338,7 +357,7 @@ RLS_DEV float ggx_D(const Ggx &g, V3 m)
     float mu = dot(m, g.fr.U);
     float mv = dot(m, g.fr.V);
     float mn2 = sqr(dot(g.fr.N, m));
-    float den = g.ax * g.ay * sqr(sqr(R_DIV(mu, g.ax)) + sqr(R_DIV(mv, g.ay)) + mn2);
+    float den = g.ax * g.ay * sqr(sqr(R_DIVH(mu, g.ax)) + sqr(R_DIVH(mv, g.ay)) + mn2);
     return R_DIV(kInvPi, den);
 }
 
@@ -366,7 +385,7 @@ RLS_DEV float ggx_G(const Ggx &g, V3 o, V3 m) { return ggx_G1_view(g, m) * ggx_G
 template <bool WANT_F, bool WANT_PDF>
 RLS_DEV void ggx_eval_pdf(const Ggx &g, V3 L, float &fr, float &fg, float &fb, float &pdf)
 {
-    V3 H = normalize(L + g.view);
+    V3 H = normalize_h(L + g.view);
     float d = ggx_D(g, H);
     if (WANT_PDF) {
         float p = R_DIV(d * ggx_G1_view(g, H), absf(g.vn)) * 0.25f;

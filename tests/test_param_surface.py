@@ -73,3 +73,45 @@ def test_header_names_every_consumed_parameter():
         for p in G[node]["parameters"]:
             if p["name"] not in OUT_OF_PATH[node]:
                 assert p["name"] in text, (node, p["name"])
+
+
+def test_product_parameter_table_matches_reference():
+    """rlshaders_amd.params.NODES (what a stub declares) == the reference's node_parameters + .mtd"""
+    from rlshaders_amd import params
+    for node, spec in G.items():
+        mine = [p for p in params.NODES[node]["params"] if p.type != "STR"]
+        ref = spec["parameters"]
+        assert [p.name for p in mine] == [p["name"] for p in ref], node           # declaration order
+        for a, b in zip(mine, ref):
+            assert a.type == b["type"] and list(a.default) == b["default"], (node, a.name)
+            assert a.closure == (a.name not in OUT_OF_PATH[node]), (node, a.name)
+        assert params.NODES[node]["maya.id"] == spec["mtd"]["maya.id"]
+        # UI ranges of rlShaders.mtd (rlDisney sets its ranges in code, so its .mtd block has none)
+        for attr, r in spec["mtd"]["attrs"].items():
+            p = next(p for p in mine if p.name == attr)
+            assert {k: v for k, v in (("min", p.min), ("max", p.max), ("softmax", p.softmax)) if v is not None} == r
+
+
+def test_emitted_mtd_round_trips():
+    """the emitted metadata file parses back to the reference's ids and attribute ranges"""
+    import re
+    from rlshaders_amd import params
+    node = attr = None
+    got = {}
+    for line in params.emit_mtd().splitlines():
+        t = line.strip()
+        m = re.match(r"\[node (\w+)\]", t)
+        if m:
+            node = m.group(1); got[node] = {"maya.id": None, "attrs": {}}; continue
+        m = re.match(r"\[attr (\w+)\]", t)
+        if m:
+            attr = m.group(1); got[node]["attrs"][attr] = {}; continue
+        m = re.match(r"maya\.id\s+INT\s+(\S+)", t)
+        if m:
+            got[node]["maya.id"] = m.group(1); continue
+        m = re.match(r"(min|max|softmax)\s+FLOAT\s+(\S+)", t)
+        if m:
+            got[node]["attrs"][attr][m.group(1)] = float(m.group(2))
+    for n, spec in G.items():
+        assert got[n]["maya.id"] == spec["mtd"]["maya.id"]
+        assert got[n]["attrs"] == spec["mtd"]["attrs"], n

@@ -23,6 +23,9 @@ void set_error(const char *fmt, ...)
 rls_status hip_fail(hipError_t e, const char *what)
 {
     set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    // the failure is reported through our status; do not leave it as the runtime's "last error" for
+    // whoever shares the process (a framework would otherwise see e.g. a stale out-of-memory)
+    (void)hipGetLastError();
     return e == hipErrorOutOfMemory ? RLS_ERR_OUT_OF_MEMORY : RLS_ERR_HIP;
 }
 

@@ -201,6 +201,17 @@ rls_status rls_disney_integrate(rls_context *ctx, int64_t n, const rls_disney_cl
                                 rls_rgb specular_sum, float *specular_count,
                                 const rls_disney_stream_out *stream /* optional */);
 
+/* Alternates the reference compiles but never selects (mSampleFromVisibleNormal is hard-wired to
+ * true, src/rlDisney.cpp:191): the plain-NDF microfacet samplers, the matching pdf branch and D_GTR2. */
+#define RLS_DISNEY_ALT_GTR2_ANISO 0   /* sampleGTR2AnisoDirection, src/rlDisney.cpp:406-414 -> microfacet normal */
+#define RLS_DISNEY_ALT_GTR2       1   /* sampleGTR2Direction, src/rlDisney.cpp:504-512 -> direction, not normalised */
+rls_status rls_disney_alt_sample(rls_context *ctx, int64_t n, const rls_disney_closure *c, int kind,
+                                 const float *rx, const float *ry, rls_vec3 m);
+/* evalSpecularPdf with mSampleFromVisibleNormal == false (src/rlDisney.cpp:541-542) */
+rls_status rls_disney_alt_pdf(rls_context *ctx, int64_t n, const rls_disney_closure *c, rls_cvec3 wi, float *pdf);
+/* D_GTR2 (src/rlDisney.cpp:553-559) */
+rls_status rls_disney_d_gtr2(rls_context *ctx, int64_t n, const rls_disney_closure *c, rls_cvec3 m, float *d);
+
 /* ------------------------------------------------------------------------------------------
  * rlSss: NDProfile + SssSampler<NDProfile> hot parts (src/rlSss.h:27-61,143-167,246-266,
  * 401-413,487-545; src/rlSss.cpp:20-106).  Parameter names: src/rlSkin.cpp:109-115.
@@ -219,6 +230,11 @@ rls_status rls_nd_sample(rls_context *ctx, int64_t n, const rls_sss_closure *c, 
                          float *r, float *pdf, rls_rgb profile);
 rls_status rls_nd_pdf(rls_context *ctx, int64_t n, const rls_sss_closure *c, const float *r, float *pdf);
 rls_status rls_nd_eval(rls_context *ctx, int64_t n, const rls_sss_closure *c, const float *r, rls_rgb profile);
+/* GaussianProfile (src/rlSss.h:63-97), the alternate profile the reference leaves commented out
+ * (src/rlSkin.cpp:242): setDistance(dist.x) then getRadius(rx), getPdf(r), evalProfile(r).  Arnold's
+ * closed fast_exp is replaced by exp (parity unpinned). */
+rls_status rls_gaussian_sample(rls_context *ctx, int64_t n, rls_param dist_x, const float *rx,
+                               float *r, float *pdf, float *profile);
 /* getProbeRay (src/rlSss.h:487-533): offset = ray.origin - sg->P, dir, maxdist, r; plus pdf(r)
  * and profile(r).  P (optional, all three planes or none) is added to the offset. */
 rls_status rls_sss_probe_ray(rls_context *ctx, int64_t n, const rls_sss_closure *c,

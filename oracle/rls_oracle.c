@@ -549,13 +549,31 @@ static orc_v3 disney_sample_gtr1(const orc_disney *d, float rx, float ry)
 }
 
 /* src/rlDisney.cpp:406-414 (dead: mSampleFromVisibleNormal = true) */
-static orc_v3 disney_sample_gtr2_aniso(const orc_disney *d, float rx, float ry)
+orc_v3 orc_disney_sample_gtr2_aniso(const orc_disney *d, float rx, float ry)
 {
     float gg = sqrtf(ry / (1.0f - ry));
     float phi = AI_PITIMES2 * rx;
     orc_v3 omega = v3(gg * d->alphaX * cosf(phi), gg * d->alphaY * sinf(phi), 1.0f);
     omega = v3rotate_to_frame(omega, d->axisU, d->axisV, d->axisN);
     return v3normalize(omega);
+}
+
+/* src/rlDisney.cpp:504-512 (dead) */
+orc_v3 orc_disney_sample_gtr2(const orc_disney *d, float rx, float ry)
+{
+    float thetaM = atanf(d->roughness * sqrtf(rx / (1.0f - rx)));
+    float phiM = AI_PITIMES2 * ry;
+    orc_v3 omega = orc_spherical_direction(cosf(thetaM), phiM);
+    return v3rotate_to_frame(omega, d->axisU, d->axisV, d->axisN);
+}
+
+/* src/rlDisney.cpp:553-559 (dead) */
+float orc_disney_D_GTR2(const orc_disney *d, orc_v3 m)
+{
+    float MdotN = v3dot(m, d->axisN);
+    float a2 = SQRf(d->roughness);
+    float denominator = AI_PI * SQRf(1.0f + (a2 - 1.0f) * SQRf(MdotN));
+    return a2 / denominator;
 }
 
 /* src/rlDisney.cpp:367-390 */
@@ -567,7 +585,7 @@ orc_v3 orc_disney_sample_specular(const orc_disney *d, float rx, float ry)
         rx /= gtr2Weight;
         M = d->sampleFromVisibleNormal
             ? vndf_microfacet(d->viewDir, d->axisU, d->axisV, d->axisN, d->alphaX, d->alphaY, rx, ry)
-            : disney_sample_gtr2_aniso(d, rx, ry);
+            : orc_disney_sample_gtr2_aniso(d, rx, ry);
     } else {
         rx = (rx - gtr2Weight) / (1.0f - gtr2Weight);
         M = disney_sample_gtr1(d, rx, ry);
@@ -1124,6 +1142,68 @@ void orc_batch_disney_sample_eval_pdf(int64_t n, const orc_disney_soa *in, int l
 {
     disney_job j = { .in = in, .lobe = lobe, .rx = rx, .ry = ry, .wi = wi, .f = f, .pdf = pdf, .mode = DIS_FUSED };
     parallel_for(n, nthreads, disney_range, &j);
+}
+
+typedef struct { const orc_disney_soa *in; int kind; const float *rx, *ry; orc_cv3p v; orc_v3p out3; float *out1; } dalt_job;
+
+/* kind 0: sampleGTR2AnisoDirection, 1: sampleGTR2Direction, 2: non-VNDF evalSpecularPdf(v), 3: D_GTR2(v) */
+static void dalt_range(int64_t lo, int64_t hi, void *ctx)
+{
+    dalt_job *j = (dalt_job *)ctx;
+    for (int64_t i = lo; i < hi; i++) {
+        orc_disney d;
+        float s[10];
+        for (int k = 0; k < 10; k++) s[k] = j->in->scalars[k][i];
+        orc_disney_init(&d, ld3(j->in->wo, i), ld3(j->in->N, i), ld3(j->in->T, i), ldc(j->in->base_color, i), s);
+        switch (j->kind) {
+        case 0: st3(j->out3, i, orc_disney_sample_gtr2_aniso(&d, j->rx[i], j->ry[i])); break;
+        case 1: st3(j->out3, i, orc_disney_sample_gtr2(&d, j->rx[i], j->ry[i])); break;
+        case 2: d.sampleFromVisibleNormal = 0; j->out1[i] = orc_disney_specular_pdf(&d, ld3(j->v, i)); break;
+        default: j->out1[i] = orc_disney_D_GTR2(&d, ld3(j->v, i)); break;
+        }
+    }
+}
+
+void orc_batch_disney_alt(int64_t n, const orc_disney_soa *in, int kind, const float *rx, const float *ry,
+                          orc_cv3p v, orc_v3p out3, float *out1, int nthreads)
+{
+    dalt_job j = { in, kind, rx, ry, v, out3, out1 };
+    parallel_for(n, nthreads, dalt_range, &j);
+}
+
+/* ------------------------------- GaussianProfile (dead) -------------------------------- */
+/* src/rlSss.h:71-76 */
+void orc_gauss_set_distance(orc_gauss *g, float dist_x)
+{
+    g->maxRadius = dist_x;
+    g->variance = SQRf(g->maxRadius) / 12.46f;
+    g->norm = 1.0f - expf(-SQRf(g->maxRadius) * 0.5f / g->variance);
+}
+/* src/rlSss.h:78-81 */
+float orc_gauss_get_radius(const orc_gauss *g, float rx) { return sqrtf(-2.0f * g->variance * logf(1.0f - rx * g->norm)); }
+/* src/rlSss.h:88-91 */
+float orc_gauss_eval_profile(const orc_gauss *g, float r)
+{
+    return 0.15915494f / g->variance * expf(-r * r * 0.5f / g->variance);
+}
+/* src/rlSss.h:83-86 */
+float orc_gauss_get_pdf(const orc_gauss *g, float r) { return orc_gauss_eval_profile(g, r) / g->norm; }
+
+typedef struct { const float *d, *rx; float *r, *pdf, *prof; } gauss_job;
+static void gauss_range(int64_t lo, int64_t hi, void *ctx)
+{
+    gauss_job *j = (gauss_job *)ctx;
+    for (int64_t i = lo; i < hi; i++) {
+        orc_gauss g;
+        orc_gauss_set_distance(&g, j->d[i]);
+        float r = orc_gauss_get_radius(&g, j->rx[i]);
+        j->r[i] = r; j->pdf[i] = orc_gauss_get_pdf(&g, r); j->prof[i] = orc_gauss_eval_profile(&g, r);
+    }
+}
+void orc_batch_gauss(int64_t n, const float *dist_x, const float *rx, float *r, float *pdf, float *profile, int nthreads)
+{
+    gauss_job j = { dist_x, rx, r, pdf, profile };
+    parallel_for(n, nthreads, gauss_range, &j);
 }
 
 /* ------------------------------------- SSS batches ------------------------------------- */

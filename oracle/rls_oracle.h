@@ -116,6 +116,24 @@ orc_v3  orc_disney_eval_sample(const orc_disney *d, float rx, float ry);
 orc_rgb orc_disney_eval_brdf(const orc_disney *d, orc_v3 indir);
 float   orc_disney_eval_pdf(const orc_disney *d, orc_v3 indir);
 
+/* alternates the reference compiles but never selects (mSampleFromVisibleNormal = true,
+ * src/rlDisney.cpp:191): sampleGTR2AnisoDirection (406-414), sampleGTR2Direction (504-512, returns an
+ * un-normalised direction), D_GTR2 (553-559); the non-VNDF branch of evalSpecularPdf (541-542) is
+ * reached by clearing d->sampleFromVisibleNormal */
+orc_v3  orc_disney_sample_gtr2_aniso(const orc_disney *d, float rx, float ry);
+orc_v3  orc_disney_sample_gtr2(const orc_disney *d, float rx, float ry);
+float   orc_disney_D_GTR2(const orc_disney *d, orc_v3 m);
+
+/* GaussianProfile (src/rlSss.h:63-97; not instantiated: src/rlSkin.cpp:242 is commented out).  Arnold's
+ * closed fast_exp is replaced by expf: PARITY UNPINNED. */
+typedef struct { float variance, maxRadius, norm; } orc_gauss;
+void    orc_gauss_set_distance(orc_gauss *g, float dist_x);
+float   orc_gauss_get_radius(const orc_gauss *g, float rx);
+float   orc_gauss_get_pdf(const orc_gauss *g, float r);
+float   orc_gauss_eval_profile(const orc_gauss *g, float r);
+void    orc_batch_gauss(int64_t n, const float *dist_x, const float *rx, float *r, float *pdf, float *profile,
+                        int nthreads);
+
 /* ---- rlSss: NDProfile (src/rlSss.h:27-61, src/rlSss.cpp:20-106) --------------------- */
 typedef struct {
     float distance[3];
@@ -218,6 +236,11 @@ void orc_batch_disney_pdf(int64_t n, const orc_disney_soa *in, int lobe, orc_cv3
 void orc_batch_disney_sample_eval_pdf(int64_t n, const orc_disney_soa *in, int lobe,
                                       const float *rx, const float *ry,
                                       orc_v3p wi, orc_v3p f, float *pdf, int nthreads);
+
+/* kind 0: sampleGTR2AnisoDirection(rx,ry) -> out3, 1: sampleGTR2Direction -> out3,
+   2: non-VNDF evalSpecularPdf(v) -> out1, 3: D_GTR2(v) -> out1 */
+void orc_batch_disney_alt(int64_t n, const orc_disney_soa *in, int kind, const float *rx, const float *ry,
+                          orc_cv3p v, orc_v3p out3, float *out1, int nthreads);
 
 typedef struct {
     orc_cv3p sss_scatter_dist;   /* already multiplied by sss_dist_multiplier unless mult given */

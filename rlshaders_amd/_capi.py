@@ -144,6 +144,10 @@ PROTOTYPES = {
                                              Vec3, Rgb, _vp]),
     "rls_disney_integrate": (C.c_int, [_ctx, _i64, C.POINTER(DisneyClosure), C.c_int, C.c_uint32,
                                        Rgb, _vp, Rgb, _vp, C.POINTER(DisneyStreamOut)]),
+    "rls_disney_alt_sample": (C.c_int, [_ctx, _i64, C.POINTER(DisneyClosure), C.c_int, _vp, _vp, Vec3]),
+    "rls_disney_alt_pdf": (C.c_int, [_ctx, _i64, C.POINTER(DisneyClosure), CVec3, _vp]),
+    "rls_disney_d_gtr2": (C.c_int, [_ctx, _i64, C.POINTER(DisneyClosure), CVec3, _vp]),
+    "rls_gaussian_sample": (C.c_int, [_ctx, _i64, Param, _vp, _vp, _vp, _vp]),
     # rlSss
     "rls_nd_sample": (C.c_int, [_ctx, _i64, C.POINTER(SssClosure), _vp, _vp, _vp, Rgb]),
     "rls_nd_pdf": (C.c_int, [_ctx, _i64, C.POINTER(SssClosure), _vp, _vp]),

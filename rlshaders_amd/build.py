@@ -22,8 +22,8 @@ OBJDIR = PKG / "build"
 LIB = LIBDIR / "librlshaders_amd.so"
 ARCH = "gfx950"
 
-SOURCES = ["context.hip", "ggx.hip", "disney.hip", "sss.hip", "skin.hip", "integrate.hip"]
-FAST_UNITS = {"ggx.hip", "disney.hip", "sss.hip", "skin.hip", "integrate.hip"}
+SOURCES = ["context.hip", "ggx.hip", "disney.hip", "sss.hip", "skin.hip", "integrate.hip", "alternates.hip"]
+FAST_UNITS = {"ggx.hip", "disney.hip", "sss.hip", "skin.hip", "integrate.hip", "alternates.hip"}
 HEADERS = [CSRC / "rls_device.hpp", CSRC / "rls_libm.hpp", CSRC / "rls_libm_tables.inc", CSRC / "rls_internal.hpp",
            PKG.parent / "include" / "rlshaders_amd.h"]
 

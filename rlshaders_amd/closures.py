@@ -298,6 +298,29 @@ class DisneySampler:
                                                  rgb(f, n, "f"), plane(pdf, n, "pdf")))
         return wi, f, pdf
 
+    # -- alternates the reference compiles but never selects (mSampleFromVisibleNormal = true) -------
+    def altSample(self, kind: int, rx, ry):
+        """kind 0: sampleGTR2AnisoDirection (src/rlDisney.cpp:406-414), 1: sampleGTR2Direction (504-512)."""
+        n, ctx = self.n, self.ctx
+        m = ctx.empty(3, n)
+        check(ctx.lib.rls_disney_alt_sample(ctx.handle, n, C.byref(self.c), int(kind), plane(rx, n, "rx"),
+                                            plane(ry, n, "ry"), vec3(m, n, "m")))
+        return m
+
+    def altPdf(self, indir):
+        """evalSpecularPdf with mSampleFromVisibleNormal == false (src/rlDisney.cpp:541-542)."""
+        n, ctx = self.n, self.ctx
+        pdf = ctx.empty(n)
+        check(ctx.lib.rls_disney_alt_pdf(ctx.handle, n, C.byref(self.c), cvec3(indir, n, "indir"), plane(pdf, n, "pdf")))
+        return pdf
+
+    def dGtr2(self, m):
+        """D_GTR2 (src/rlDisney.cpp:553-559)."""
+        n, ctx = self.n, self.ctx
+        d = ctx.empty(n)
+        check(ctx.lib.rls_disney_d_gtr2(ctx.handle, n, C.byref(self.c), cvec3(m, n, "m"), plane(d, n, "d")))
+        return d
+
     def integrate(self, spp_n: int, seed: int, streamed: bool = False, out=None):
         """Both lobes, spp_n^2 samples each -> dict(diffuse_sum, diffuse_count, specular_sum,
         specular_count[, wi, f, pdf as [3, 2*spp*n] / [2*spp*n] sample-major planes])."""
@@ -370,6 +393,24 @@ class NDProfile:
         prof = ctx.empty(3, n)
         check(ctx.lib.rls_nd_eval(ctx.handle, n, C.byref(self.c), plane(r, n, "r"), rgb(prof, n, "profile")))
         return prof
+
+
+class GaussianProfile:
+    """Batched ``rls::GaussianProfile`` (src/rlSss.h:63-97), the profile rlSkin leaves commented out
+    (src/rlSkin.cpp:242).  ``dist_x`` = dist.x of setDistance: a float or an [n] plane."""
+
+    def __init__(self, ctx: Context, n: int, dist_x: Scalar):
+        self.ctx, self.n = ctx, int(n)
+        self._keep = dist_x
+        self.p = param(dist_x, self.n, "dist_x")
+
+    def sample(self, rx):
+        """getRadius(rx), getPdf(r), evalProfile(r) -> (r, pdf, profile)"""
+        n, ctx = self.n, self.ctx
+        r, pdf, prof = ctx.empty(n), ctx.empty(n), ctx.empty(n)
+        check(ctx.lib.rls_gaussian_sample(ctx.handle, n, self.p, plane(rx, n, "rx"), plane(r, n, "r"),
+                                          plane(pdf, n, "pdf"), plane(prof, n, "profile")))
+        return r, pdf, prof
 
 
 class SssSampler:

@@ -1,0 +1,140 @@
+// alternates.hip -- closures the reference compiles but never selects, kept so that every function
+// of its closure files has a batched counterpart: the plain-NDF microfacet samplers of rlDisney
+// (sampleGTR2AnisoDirection, sampleGTR2Direction, src/rlDisney.cpp:406-414,504-512), the non-VNDF
+// branch of evalSpecularPdf (541-542), D_GTR2 (553-559) and GaussianProfile (src/rlSss.h:63-97).
+// Pointwise, HBM-bound, same layout rules as the selected closures.
+#include "rls_internal.hpp"
+
+using namespace rlsd;
+
+namespace {
+
+using rlsh::AltIO;
+using namespace rlsh;   // AOP_*
+
+__device__ __forceinline__ Disney load_closure(const rls_disney_closure &c, int64_t i)
+{
+    V3 wo = ld3(c.wo, i), N = ld3(c.N, i), T = ld3(c.T, i);
+    float br, bg, bb;
+    ldrgb(c.base_color, i, br, bg, bb);
+    float s[10];
+    s[0] = ldp(c.subsurface, i); s[1] = ldp(c.metallic, i); s[2] = ldp(c.specular, i);
+    s[3] = ldp(c.specular_tint, i); s[4] = ldp(c.roughness, i); s[5] = ldp(c.anisotropic, i);
+    s[6] = ldp(c.sheen, i); s[7] = ldp(c.sheen_tint, i); s[8] = ldp(c.clearcoat, i);
+    s[9] = ldp(c.clearcoat_gloss, i);
+    return disney_make(wo, N, T, br, bg, bb, s);
+}
+
+template <int OP>
+__global__ __launch_bounds__(rlsh::kBlock) void alt_kernel(AltIO a)
+{
+    stage_libm_tables();
+    const int64_t stride = (int64_t)gridDim.x * rlsh::kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * rlsh::kBlock + threadIdx.x; i < a.n; i += stride) {
+        if (OP == AOP_GAUSS) {
+            GaussProfile g = gauss_make(ldp(a.dist_x, i));
+            float r = gauss_radius(g, ldg(a.rx, i));
+            stg(a.r, i, r);
+            stg(a.pdf, i, gauss_pdf(g, r));
+            stg(a.profile, i, gauss_profile(g, r));
+        } else {
+            Disney d = load_closure(a.c, i);
+            if (OP == AOP_GTR2_ANISO) st3(a.out3, i, disney_gtr2_aniso_microfacet(d, ldg(a.rx, i), ldg(a.ry, i)));
+            else if (OP == AOP_GTR2) st3(a.out3, i, disney_gtr2_direction(d, ldg(a.rx, i), ldg(a.ry, i)));
+            else if (OP == AOP_NDF_PDF) stg(a.out1, i, disney_specular_pdf_ndf(d, ld3(a.v, i)));
+            else stg(a.out1, i, D_GTR2(d, ld3(a.v, i)));
+        }
+    }
+}
+
+template <int OP>
+rls_status launch_kernel(rls_context *ctx, const AltIO &io, const char *name)
+{
+    hipLaunchKernelGGL(alt_kernel<OP>, rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
+    return rlsh::check_launch(name);
+}
+
+rls_status dispatch(rls_context *ctx, int op, const AltIO &io, const char *name)
+{
+    switch (op) {
+    case AOP_GTR2_ANISO: return launch_kernel<AOP_GTR2_ANISO>(ctx, io, name);
+    case AOP_GTR2: return launch_kernel<AOP_GTR2>(ctx, io, name);
+    case AOP_NDF_PDF: return launch_kernel<AOP_NDF_PDF>(ctx, io, name);
+    case AOP_D_GTR2: return launch_kernel<AOP_D_GTR2>(ctx, io, name);
+    default: return launch_kernel<AOP_GAUSS>(ctx, io, name);
+    }
+}
+
+} // namespace
+
+#if RLS_FAST
+RLS_HIDDEN rls_status rls_fast_alt(rls_context *ctx, int op, const rlsh::AltIO *io) { return dispatch(ctx, op, *io, "alternates[fast]"); }
+#else
+RLS_HIDDEN rls_status rls_fast_alt(rls_context *ctx, int op, const rlsh::AltIO *io);
+
+namespace {
+rls_status run(rls_context *ctx, int op, const AltIO &io, const char *name)
+{
+    return ctx->fast ? rls_fast_alt(ctx, op, &io) : dispatch(ctx, op, io, name);
+}
+rls_status check_closure(const rls_disney_closure *c)
+{
+    RLS_REQUIRE(c != nullptr, "closure is NULL");
+    RLS_REQUIRE(rlsh::has3(c->wo) && rlsh::has3(c->N) && rlsh::has3(c->T), "wo/N/T plane is NULL");
+    RLS_REQUIRE(rlsh::ok_rgb(c->base_color), "base_color planes must be all set or all NULL");
+    return RLS_OK;
+}
+} // namespace
+
+#define RLS_PROLOGUE()                                   \
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");          \
+    RLS_REQUIRE(n >= 0, "n < 0");                        \
+    if (n == 0) return RLS_OK;
+
+extern "C" {
+
+rls_status rls_disney_alt_sample(rls_context *ctx, int64_t n, const rls_disney_closure *c, int kind,
+                                 const float *rx, const float *ry, rls_vec3 m)
+{
+    RLS_PROLOGUE();
+    { rls_status s = check_closure(c); if (s != RLS_OK) return s; }
+    RLS_REQUIRE(kind == RLS_DISNEY_ALT_GTR2_ANISO || kind == RLS_DISNEY_ALT_GTR2, "unknown alternate sampler");
+    RLS_REQUIRE(rx && ry && rlsh::has3(m), "NULL plane");
+    AltIO io = {};
+    io.c = *c; io.rx = rx; io.ry = ry; io.out3 = m; io.n = n;
+    return run(ctx, kind == RLS_DISNEY_ALT_GTR2_ANISO ? AOP_GTR2_ANISO : AOP_GTR2, io, "rls_disney_alt_sample");
+}
+
+rls_status rls_disney_alt_pdf(rls_context *ctx, int64_t n, const rls_disney_closure *c, rls_cvec3 wi, float *pdf)
+{
+    RLS_PROLOGUE();
+    { rls_status s = check_closure(c); if (s != RLS_OK) return s; }
+    RLS_REQUIRE(rlsh::has3(wi) && pdf, "NULL plane");
+    AltIO io = {};
+    io.c = *c; io.v = wi; io.out1 = pdf; io.n = n;
+    return run(ctx, AOP_NDF_PDF, io, "rls_disney_alt_pdf");
+}
+
+rls_status rls_disney_d_gtr2(rls_context *ctx, int64_t n, const rls_disney_closure *c, rls_cvec3 m, float *d)
+{
+    RLS_PROLOGUE();
+    { rls_status s = check_closure(c); if (s != RLS_OK) return s; }
+    RLS_REQUIRE(rlsh::has3(m) && d, "NULL plane");
+    AltIO io = {};
+    io.c = *c; io.v = m; io.out1 = d; io.n = n;
+    return run(ctx, AOP_D_GTR2, io, "rls_disney_d_gtr2");
+}
+
+rls_status rls_gaussian_sample(rls_context *ctx, int64_t n, rls_param dist_x, const float *rx,
+                               float *r, float *pdf, float *profile)
+{
+    RLS_PROLOGUE();
+    RLS_REQUIRE(rx && r && pdf && profile, "NULL plane");
+    AltIO io = {};
+    io.dist_x = dist_x; io.rx = rx; io.r = r; io.pdf = pdf; io.profile = profile; io.n = n;
+    return run(ctx, AOP_GAUSS, io, "rls_gaussian_sample");
+}
+
+} // extern "C"
+
+#endif // !RLS_FAST

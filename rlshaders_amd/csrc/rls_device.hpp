@@ -611,6 +611,68 @@ RLS_DEV V3 disney_gtr1_microfacet(const Disney &d, float rx, float ry)
     return normalize(to_frame(omega, d.fr.U, d.fr.V, d.fr.N));
 }
 
+// Alternates the reference compiles but never selects (mSampleFromVisibleNormal = true, src/rlDisney.cpp:191)
+// sampleGTR2AnisoDirection, src/rlDisney.cpp:406-414
+RLS_DEV V3 disney_gtr2_aniso_microfacet(const Disney &d, float rx, float ry)
+{
+    float gg = R_SQRT(R_DIV(ry, 1.0f - ry));
+    float phi = kTwoPi * rx;
+    float s, c;
+    t_sincos(phi, &s, &c);
+    V3 omega = mk(gg * d.ax * c, gg * d.ay * s, 1.0f);
+    return normalize(to_frame(omega, d.fr.U, d.fr.V, d.fr.N));
+}
+// sampleGTR2Direction, src/rlDisney.cpp:504-512 (returns the rotated direction without normalising)
+RLS_DEV V3 disney_gtr2_direction(const Disney &d, float rx, float ry)
+{
+    float t = d.roughness * R_SQRT(R_DIV(rx, 1.0f - rx));
+#if RLS_FAST
+    float cosTheta = __builtin_amdgcn_rsqf(1.0f + t * t);              // cos(atan(t))
+#else
+    float st, cosTheta;
+    t_sincos(rlm::atan32_v(t), &st, &cosTheta);                         // cosf(atanf(t))
+#endif
+    V3 omega = spherical_direction(cosTheta, kTwoPi * ry);
+    return to_frame(omega, d.fr.U, d.fr.V, d.fr.N);
+}
+// D_GTR2, src/rlDisney.cpp:553-559
+RLS_DEV float D_GTR2(const Disney &d, V3 m)
+{
+    float mn = dot(m, d.fr.N);
+    float a2 = sqr(d.roughness);
+    float den = kPi * sqr(1.0f + (a2 - 1.0f) * sqr(mn));
+    return R_DIV(a2, den);
+}
+// evalSpecularPdf with mSampleFromVisibleNormal == false, src/rlDisney.cpp:520-532,541-542
+RLS_DEV float disney_specular_pdf_ndf(const Disney &d, V3 i)
+{
+    V3 m = normalize(i + d.view);
+    float im = absf(dot(i, m));
+    float mn = dot(m, d.fr.N);
+    if (mn < 0.0f) return 0.0f;
+    float mn2 = sqr(mn);
+    float ccw = R_DIV(d.clearcoat, d.clearcoat + 1.0f);
+    float D = lerpf(ccw, D_GTR2Aniso(d, m, mn2), D_GTR1(d, mn2));
+    return R_DIV(D * absf(mn) * 0.25f, im);
+}
+
+// GaussianProfile, src/rlSss.h:63-97 (not instantiated by the reference; Arnold's closed fast_exp -> exp)
+struct GaussProfile { float variance, maxR, norm; };
+RLS_DEV GaussProfile gauss_make(float dist_x)
+{
+    GaussProfile g;
+    g.maxR = dist_x;
+    g.variance = R_DIV(sqr(g.maxR), 12.46f);
+    g.norm = 1.0f - R_EXP(R_DIV(-sqr(g.maxR) * 0.5f, g.variance));
+    return g;
+}
+RLS_DEV float gauss_radius(const GaussProfile &g, float rx) { return R_SQRT(-2.0f * g.variance * R_LOG(1.0f - rx * g.norm)); }
+RLS_DEV float gauss_profile(const GaussProfile &g, float r)
+{
+    return R_DIV(0.15915494f, g.variance) * R_EXP(R_DIV(-r * r * 0.5f, g.variance));
+}
+RLS_DEV float gauss_pdf(const GaussProfile &g, float r) { return R_DIV(gauss_profile(g, r), g.norm); }
+
 // sampleSpecularDirection, src/rlDisney.cpp:367-390 (visible-normal branch; 191: always true)
 RLS_DEV V3 disney_sample_specular(const Disney &d, const VndfView &w, float rx, float ry)
 {

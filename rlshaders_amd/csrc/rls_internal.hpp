@@ -73,6 +73,18 @@ struct MiscIO {
     int64_t n;
 };
 
+enum AltOp { AOP_GTR2_ANISO, AOP_GTR2, AOP_NDF_PDF, AOP_D_GTR2, AOP_GAUSS };
+struct AltIO {
+    rls_disney_closure c;
+    const float *rx, *ry;
+    rls_cvec3 v;
+    rls_vec3 out3;
+    float *out1;
+    rls_param dist_x;
+    float *r, *pdf, *profile;
+    int64_t n;
+};
+
 struct SkinIO {
     rls_skin_closure c;
     const float *xi[6];

@@ -63,7 +63,9 @@ RLM_FN float fabs32(float x) { return u2f(f2u(x) & 0x7fffffffu); }
 RLM_FN float sqrt32(float x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
+#ifndef RLS_SQRT_NO_FALLBACK
     if (__builtin_expect(x < 0x1p-96f && x > 0.0f, 0)) return sqrtf(x);
+#endif
     float s = __builtin_amdgcn_sqrtf(x);
     const float sm = __uint_as_float(__float_as_uint(s) - 1u);
     const float sp = __uint_as_float(__float_as_uint(s) + 1u);

@@ -259,6 +259,17 @@ class Disney:
                                                _p(pdf), self.nthreads)
         return wi, f, pdf
 
+    def alt(self, kind, rx=None, ry=None, v=None):
+        """kind 0/1: alternate microfacet samplers -> [3,n]; 2: non-VNDF pdf(v); 3: D_GTR2(v) -> [n]"""
+        n = self.n
+        out3, out1 = np.zeros((3, n), np.float32), np.zeros(n, np.float32)
+        rx = f32(rx) if rx is not None else out1
+        ry = f32(ry) if ry is not None else out1
+        v = f32(v) if v is not None else out3
+        lib().orc_batch_disney_alt(C.c_int64(n), C.byref(self.soa), int(kind), _p(rx), _p(ry), _v(v), _v(out3),
+                                   _p(out1), self.nthreads)
+        return out3 if kind < 2 else out1
+
     def integrate(self, spp_n, seed, streamed=False):
         n = self.n
         spp = spp_n * spp_n
@@ -403,3 +414,12 @@ def gen_aniso(seed, first, n):
     out = np.empty(n, np.float32)
     lib().orc_gen_aniso(C.c_uint32(seed), C.c_uint64(first), C.c_int64(n), _p(out))
     return out
+
+
+def gauss(dist_x, rx, nthreads=1):
+    rx = f32(rx)
+    n = rx.shape[0]
+    d = _full(dist_x, n)
+    r, pdf, prof = (np.empty(n, np.float32) for _ in range(3))
+    lib().orc_batch_gauss(C.c_int64(n), _p(d), _p(rx), _p(r), _p(pdf), _p(prof), nthreads)
+    return r, pdf, prof

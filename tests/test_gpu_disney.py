@@ -130,3 +130,21 @@ def test_integrate_reduced_and_streamed(gpu, oracle):
         for k in ("diffuse_sum", "specular_sum"):
             e = cases.rel_err(alt[k], base[k])
             assert np.quantile(e, 0.999) <= 1e-4, (g, k, float(e.max()))     # summation order only
+
+
+def test_unselected_alternates(gpu, oracle, mixed):
+    """the plain-NDF samplers, the non-VNDF pdf branch and D_GTR2 (src/rlDisney.cpp:406-414,504-512,541-542,
+    553-559): compiled by the reference, never selected (191); kept batched for completeness"""
+    c, x = mixed
+    od = disney_oracle(oracle, c)
+    s = disney_sampler(gpu, c)
+    for kind in (0, 1):
+        st = cases.summarize(cases.rel_err(host(s.altSample(kind, dev(x[0]), dev(x[1]))), od.alt(kind, x[0], x[1])))
+        print("disney alt sampler", kind, st)
+        cases.assert_tight(st, ("alt sampler", kind))
+    wi = od.sample(R.RLS_RAY_GLOSSY, x[0], x[1])
+    st = cases.summarize(cases.rel_err(host(s.altPdf(dev(wi))), od.alt(2, v=wi)))
+    print("disney alt pdf", st)
+    cases.assert_tight(st, "alt pdf")
+    st = cases.summarize(cases.rel_err(host(s.dGtr2(dev(wi))), od.alt(3, v=wi)))
+    cases.assert_tight(st, "D_GTR2")

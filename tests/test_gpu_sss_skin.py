@@ -150,3 +150,24 @@ def test_skin_presets(gpu, oracle, preset):
     if p["specular_weight"] <= 1e-4:
         assert np.all(got["spec_f"] == 0) and np.all(got["specularFresnel"] == 0)
         assert np.array_equal(got["sssWeight"], np.full(n, p["sss_weight"], np.float32))
+
+
+def test_gaussian_profile_alternate(gpu, oracle, mixed):
+    """GaussianProfile (src/rlSss.h:63-97), not instantiated by the reference; fast_exp -> exp (unpinned)"""
+    c, x = mixed
+    d = np.ascontiguousarray(c["dist"][0])
+    ref = oracle.gauss(d, x[0])
+    got = [host(t) for t in R.GaussianProfile(gpu, N, dev(d)).sample(dev(x[0]))]
+    for nm, a, b in zip(("r", "pdf", "profile"), got, ref):
+        st = cases.summarize(cases.rel_err(a, b))
+        print("gaussian", nm, st)
+        cases.assert_tight(st, ("gaussian", nm))
+    # uniform distance
+    got_u = [host(t) for t in R.GaussianProfile(gpu, N, 1.5).sample(dev(x[0]))]
+    ref_u = oracle.gauss(1.5, x[0])
+    assert np.array_equal(got_u[0].view(np.uint32), ref_u[0].view(np.uint32))
+    # the pdf integrates the radial density: int pdf(r) 2 pi r dr over [0, maxR] = 1 (numerically, dist 1)
+    rr = np.linspace(1e-6, 1.0, 200001, dtype=np.float64)
+    var = 1.0 / 12.46
+    dens = np.exp(-rr * rr / 2 / var) / (2 * np.pi * var) / (1 - np.exp(-0.5 / var)) * 2 * np.pi * rr
+    assert abs(np.trapezoid(dens, rr) - 1.0) < 1e-6

@@ -86,9 +86,9 @@ rls_status  rls_context_set_stream(rls_context *ctx, void *hip_stream);
 rls_status  rls_context_use_own_stream(rls_context *ctx);
 void       *rls_context_get_stream(rls_context *ctx);
 /* Arithmetic of the closure kernels launched through this context.
- *   RLS_MATH_EXACT (default): IEEE division, correctly rounded sqrt, angle functions that reproduce
- *     the host libm -- closure outputs agree with the CPU closures bit for bit wherever no
- *     exp/log/pow is involved, and to ~3e-7 where one is.
+ *   RLS_MATH_EXACT (default): IEEE division, correctly rounded sqrt, and elementary functions
+ *     (atan2f acosf tanf sinf cosf expf logf powf) that restate the host libm's (glibc) algorithms --
+ *     closure outputs agree with the CPU closures bit for bit.
  *   RLS_MATH_FAST: hardware reciprocal / sqrt / sin / cos / exp grade arithmetic (~1 ulp per
  *     operation) and the visible-normal view analysis by vector algebra instead of the reference's
  *     atan2f/acosf/tanf round trip.  Same formulas, same conventions; outputs within 1e-5 of the CPU

@@ -14,12 +14,12 @@ def test_device_libm_matches_host_libm(tmp_path):
                     str(ROOT / "tests" / "native" / "libm_faithful.cpp"), "-o", str(exe), "-lm"], check=True)
     out = subprocess.run([str(exe), "2000000"], capture_output=True, text=True, check=True).stdout
     rows = {l.split()[0]: tuple(int(x) for x in l.split()[1:]) for l in out.strip().splitlines()}
-    assert len(rows) == 12, out
+    assert len(rows) == 15, out
     for name, (bad, total, maxulp) in rows.items():
         assert total >= 4_000_000, (name, total)
-        if name.startswith("cosf") or name.startswith("sinf"):
-            # glibc's FMA-multiarch sinf/cosf contract the fp64 polynomial; the final fp32 rounding
-            # differs from the uncontracted evaluation on ~2e-7 of arguments, by one ulp
+        if name.split("_")[0] in ("cosf", "sinf", "expf", "powf"):
+            # glibc's FMA-multiarch sinf/cosf/expf/powf contract their fp64 polynomials; the final fp32
+            # rounding differs from the uncontracted evaluation on ~2e-7 of arguments, by one ulp
             assert bad <= total * 2e-6 and maxulp <= 1, (name, bad, total, maxulp)
         else:
             assert bad == 0, (name, bad, total, maxulp)

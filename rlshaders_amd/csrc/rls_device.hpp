@@ -196,8 +196,16 @@ struct VndfView {
     bool nearNormal;        // theta < AI_EPSILON -> uniform slope sample
 };
 
+// The view direction in the local frame as the reference obtains it -- independent of the roughness,
+// so closures that share (wo, N, T) but differ in alpha (rlSkin's sheen and specular lobes) compute
+// it once.  EXACT: sphericalDirection(clamp(N.V), atan2f(V.V, U.V)) (src/rlGgx.cpp:68-72);
+// FAST: the dot products themselves.
 #if RLS_FAST
-RLS_DEV VndfView vndf_view(V3 view, const Frame &fr, float ax, float ay)
+RLS_DEV V3 vndf_local(V3 view, const Frame &fr)
+{
+    return mk(dot(fr.U, view), dot(fr.V, view), clampf(dot(fr.N, view), -1.0f, 1.0f));
+}
+RLS_DEV VndfView vndf_view_from(V3 local, float ax, float ay)
 {
     // FAST mode: the reference goes view -> (theta, phi) -> direction -> stretch -> (theta', phi') with
     // atan2f/cosf/sinf/acosf/atan2f/tanf/cosf/sinf; in exact arithmetic that round trip is the identity
@@ -205,9 +213,9 @@ RLS_DEV VndfView vndf_view(V3 view, const Frame &fr, float ax, float ay)
     // from dot products, one rsqrt and one rcp.
     VndfView w;
     w.ax = ax; w.ay = ay;
-    float cz = clampf(dot(fr.N, view), -1.0f, 1.0f);
-    float sx = dot(fr.U, view) * ax;
-    float sy = dot(fr.V, view) * ay;
+    float cz = local.z;
+    float sx = local.x * ax;
+    float sy = local.y * ay;
     float h2 = sx * sx + sy * sy;
     float z = R_DIVH(cz, R_SQRTH(h2 + cz * cz));          // cos(theta') of the stretched view
     float h = R_SQRTH(h2);
@@ -224,13 +232,17 @@ RLS_DEV VndfView vndf_view(V3 view, const Frame &fr, float ax, float ay)
 }
 
 #else
-RLS_DEV VndfView vndf_view(V3 view, const Frame &fr, float ax, float ay)
+RLS_DEV V3 vndf_local(V3 view, const Frame &fr)
+{
+    float cosThetaV = clampf(dot(fr.N, view), -1.0f, 1.0f);
+    float phiV = t_atan2(dot(fr.V, view), dot(fr.U, view));
+    return spherical_direction(cosThetaV, phiV);
+}
+RLS_DEV VndfView vndf_view_from(V3 local, float ax, float ay)
 {
     VndfView w;
     w.ax = ax; w.ay = ay;
-    float cosThetaV = clampf(dot(fr.N, view), -1.0f, 1.0f);
-    float phiV = t_atan2(dot(fr.V, view), dot(fr.U, view));
-    V3 v = spherical_direction(cosThetaV, phiV);
+    V3 v = local;
     v.x *= ax;
     v.y *= ay;
     v = normalize(v);
@@ -251,6 +263,11 @@ RLS_DEV VndfView vndf_view(V3 view, const Frame &fr, float ax, float ay)
 }
 
 #endif
+
+RLS_DEV VndfView vndf_view(V3 view, const Frame &fr, float ax, float ay)
+{
+    return vndf_view_from(vndf_local(view, fr), ax, ay);
+}
 
 // uniformSample lambda, src/rlGgx.cpp:18-25
 RLS_DEV V2 uniform_slope(float rx, float ry)

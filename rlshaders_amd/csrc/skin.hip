@@ -19,12 +19,13 @@ using rlsh::SkinIO;
 struct LobeOut { V3 wi; float fr, fg, fb, pdf, F; };
 
 // One isotropic GGX lobe of rlSkin (src/rlSkin.cpp:192,215: anisotropic defaulted to 0).
-__device__ __forceinline__ LobeOut ggx_lobe(V3 wo, V3 N, V3 T, float cr, float cg, float cb,
+__device__ __forceinline__ LobeOut ggx_lobe(V3 wo, V3 N, V3 T, V3 local, float cr, float cg, float cb,
                                             float ior, float rough, float rx, float ry)
 {
     LobeOut o;
     Ggx g = ggx_make(wo, N, T, false, cr, cg, cb, ior, rough, 0.0f);
-    VndfView w = vndf_view(g.view, g.fr, g.ax, g.ay);
+    // `local` = the view in the shared (T, N x T, N) frame: the same for both lobes, computed once
+    VndfView w = vndf_view_from(local, g.ax, g.ay);
     V3 M = vndf_microfacet(w, g.fr, rx, ry);
     o.wi = reflect_direction(g.view, M);
     o.F = ggx_fresnel(g, o.wi, M);
@@ -42,6 +43,9 @@ __global__ __launch_bounds__(rlsh::kBlock) void skin_kernel(SkinIO a)
 
         float sheenFresnel = 0.0f, specularFresnel = 0.0f;
         LobeOut sh = {}, sp = {};
+        Frame gfr;
+        gfr.N = N; gfr.U = T; gfr.V = cross(N, T);
+        V3 local = vndf_local(wo, gfr);
 
         float sheenWeight = ldp(c.sheen_weight, i);
         float shr, shg, shb;
@@ -49,7 +53,7 @@ __global__ __launch_bounds__(rlsh::kBlock) void skin_kernel(SkinIO a)
         float sheenIor = ldp(c.sheen_ior, i), sheenRough = ldp(c.sheen_roughness, i);
         float rx0 = ldg(a.xi[0], i), ry0 = ldg(a.xi[1], i);
         if (sheenWeight > kEps) {                                           // src/rlSkin.cpp:191
-            sh = ggx_lobe(wo, N, T, shr, shg, shb, sheenIor, sheenRough, rx0, ry0);
+            sh = ggx_lobe(wo, N, T, local, shr, shg, shb, sheenIor, sheenRough, rx0, ry0);
             sheenFresnel = sh.F * sheenWeight;                              // :204 (one sample)
         }
 
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(rlsh::kBlock) void skin_kernel(SkinIO a)
         float specIor = ldp(c.specular_ior, i), specRough = ldp(c.specular_roughness, i);
         float rx1 = ldg(a.xi[2], i), ry1 = ldg(a.xi[3], i);
         if (specWeight > kEps) {                                            // :214
-            sp = ggx_lobe(wo, N, T, spr, spg, spb, specIor, specRough, rx1, ry1);
+            sp = ggx_lobe(wo, N, T, local, spr, spg, spb, specIor, specRough, rx1, ry1);
             specularFresnel = sp.F * specWeight;                            // :228
         }
 

@@ -189,11 +189,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the closures only run on the HIP path")
-    torch.cuda.set_device(local_rank)
-    ranks = Ranks(backend="nccl" if world > 1 else None, device=torch.device("cuda", local_rank))
+    # one rank per GPU.  RLS_DIST_BACKEND=gloo (tests only) lets several ranks share one GPU so that the
+    # multi-rank control path can be exercised on a single-GPU box, where RCCL refuses duplicate devices.
+    backend = os.environ.get("RLS_DIST_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    torch.cuda.set_device(device_index)
+    ranks = Ranks(backend=backend if world > 1 else None,
+                  device=torch.device("cuda", device_index) if backend == "nccl" else torch.device("cpu"))
     rank = ranks.rank
 
-    ctx = R.Context(local_rank)
+    ctx = R.Context(device_index)
     ctx.set_math_mode(args.math == "fast")
     n = 1 << args.log2_points
     # weak scaling: the job is world * n points, rank g owns the index range [g*n, (g+1)*n)

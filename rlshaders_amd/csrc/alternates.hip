@@ -25,7 +25,7 @@ __device__ __forceinline__ Disney load_closure(const rls_disney_closure &c, int6
     return disney_make(wo, N, T, br, bg, bb, s);
 }
 
-template <int OP>
+template <int OP, int FAST_MATH = RLS_FAST>
 __global__ __launch_bounds__(rlsh::kBlock) void alt_kernel(AltIO a)
 {
     stage_libm_tables();

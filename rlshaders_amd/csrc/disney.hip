@@ -31,7 +31,7 @@ __device__ __forceinline__ Disney load_closure(const rls_disney_closure &c, int6
     return disney_make(wo, N, T, br, bg, bb, s);
 }
 
-template <int OP, bool DIFFUSE>
+template <int OP, bool DIFFUSE, int FAST_MATH = RLS_FAST>
 __global__ __launch_bounds__(rlsh::kBlock) void disney_kernel(DisneyIO a)
 {
     stage_libm_tables();   // powf / logf tables -> LDS (EXACT mode)

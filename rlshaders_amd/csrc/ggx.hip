@@ -25,7 +25,7 @@ __device__ __forceinline__ Ggx load_closure(const rls_ggx_closure &c, int64_t i)
     return ggx_make(wo, N, T, exiting, kr, kg, kb, ior, rough, aniso);
 }
 
-template <int OP>
+template <int OP, int FAST_MATH = RLS_FAST>   // FAST_MATH only tags the kernel name (profiles tell the two builds apart)
 __global__ RLS_KERNEL_ATTR void ggx_kernel(GgxIO a)
 {
     const int64_t stride = (int64_t)gridDim.x * rlsh::kBlock;

@@ -63,7 +63,7 @@ __device__ __forceinline__ float group_sum(float v)
 using rlsh::GgxIntIO;
 using rlsh::DisneyIntIO;
 
-template <int G>
+template <int G, int FAST_MATH = RLS_FAST>
 __global__ __launch_bounds__(rlsh::kBlock) void ggx_integrate_kernel(GgxIntIO a)
 {
     __shared__ uint32_t tab[2][kMaxSpp];
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(rlsh::kBlock) void ggx_integrate_kernel(GgxIntIO a)
 
 // ---------------------------------------------------------------------------------------------
 
-template <int G>
+template <int G, int FAST_MATH = RLS_FAST>
 __global__ __launch_bounds__(rlsh::kBlock) void disney_integrate_kernel(DisneyIntIO a)
 {
     __shared__ uint32_t tab[2][kMaxSpp];

@@ -33,6 +33,7 @@ __device__ __forceinline__ LobeOut ggx_lobe(V3 wo, V3 N, V3 T, V3 local, float c
     return o;
 }
 
+template <int FAST_MATH = RLS_FAST>
 __global__ __launch_bounds__(rlsh::kBlock) void skin_kernel(SkinIO a)
 {
     stage_libm_tables();   // expf / logf tables -> LDS (EXACT mode)
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(rlsh::kBlock) void skin_kernel(SkinIO a)
 
 rls_status launch_kernel(rls_context *ctx, const SkinIO &io, const char *name)
 {
-    hipLaunchKernelGGL(skin_kernel, rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
+    hipLaunchKernelGGL(skin_kernel<>, rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
     return rlsh::check_launch(name);
 }
 

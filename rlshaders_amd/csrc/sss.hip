@@ -27,7 +27,7 @@ __device__ __forceinline__ NdProfile load_profile(const rls_sss_closure &c, int6
     return nd_make(dx, dy, dz);
 }
 
-template <int OP>
+template <int OP, int FAST_MATH = RLS_FAST>
 __global__ __launch_bounds__(rlsh::kBlock) void sss_kernel(SssIO a)
 {
     stage_libm_tables();   // expf / logf tables -> LDS (EXACT mode)
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(rlsh::kBlock) void sss_kernel(SssIO a)
 }
 
 
-template <int OP>
+template <int OP, int FAST_MATH = RLS_FAST>
 __global__ __launch_bounds__(rlsh::kBlock) void misc_kernel(MiscIO a)
 {
     const int64_t stride = (int64_t)gridDim.x * rlsh::kBlock;

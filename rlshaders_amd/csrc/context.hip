@@ -98,6 +98,9 @@ void rls_context_destroy(rls_context *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    // work queued on the context's own stream must not outlive the context's scratch memory; a
+    // caller-provided stream is the caller's to drain
+    if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     if (ctx->scratch_u64) (void)hipFree(ctx->scratch_u64);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);

@@ -47,7 +47,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2-points", type=int, default=26, help="points per GPU = 2^this (config: 26)")
     ap.add_argument("--workload", default="ggx_reflect_refract",
-                    choices=["ggx_reflect_refract", "ggx_reflect", "disney_integrate", "sss_probe", "skin"])
+                    choices=["ggx_reflect_refract", "ggx_reflect", "disney_integrate", "sss_probe", "sss_scatter", "skin"])
     ap.add_argument("--math", default="exact", choices=["exact", "fast"],
                     help="arithmetic of the measured kernels: exact (default, bit-faithful to the CPU closures) "
                          "or fast (RLS_MATH_FAST)")
@@ -98,6 +98,15 @@ def make_workload(R, ctx, name: str, n: int, first: int):
                "pdf": ctx.empty(n), "profile": ctx.empty(3, n)}
         return Workload(name, 1, (14 + 12) * 4, lambda: s.getProbeRay(xi[0], xi[1], out=out),
                         "sss_kernel<OP_PROBE>", "rlSss ND probe ray + pdf + profile (SURVEY 8d config 4)")
+    if name == "sss_scatter":
+        # shading points on the unit sphere (P = geometric normal), 16 probe rays each
+        s = R.SssSampler(ctx, N, T, albedo=u3(S_KS), dist=u3(S_PARAM0, 0.02, 0.3))
+        scene = R.make_scene("sphere", sphere_radius=1.0, light_dir=(0.0, 0.6, 0.8), use_cavity_fade=True)
+        out = ctx.empty(3, n)
+        return Workload(name, 16, (15 + 3) * 4, lambda: s.integrateScatter(N, scene, 4, SEED, out=out),
+                        "sss_scatter_kernel<1>",
+                        "rlSss integrateScatter, 16 probe rays per point on an analytic sphere (SURVEY 8f rank 3; "
+                        "VALU-bound)")
     if name == "skin":
         p = dict(sss_color=u3(S_PARAM0), sss_weight=u(S_PARAM0 + 3), sss_dist_multiplier=u(S_PARAM0 + 4, 0.5, 1.5),
                  sss_scatter_dist=u3(S_PARAM0 + 5, 0.1, 2.1),

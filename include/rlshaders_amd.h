@@ -252,6 +252,35 @@ rls_status rls_sss_cavity_fade(rls_context *ctx, int64_t n, rls_cvec3 disp, rls_
 rls_status rls_sss_sample_diffuse_direction(rls_context *ctx, int64_t n, rls_cvec3 normal, rls_cvec3 T,
                                             const float *rx, const float *ry, rls_vec3 wi);
 
+/* SssSampler::integrateScatter (src/rlSss.h:167-280): spp_n^2 probe rays per shading point
+ * (getProbeRay, 487-533), each traced through the scene (traceProbe, 293-356), every hit shaded
+ * (shadeProbeSample, 361-424: radius cut-off, cavity fade, evalLightSample x evalProfile), the
+ * samples combined with the three-axis MIS pdf (246-268), result = sss_color * sum / spp.
+ * What the reference obtains from the closed renderer is supplied by an analytic scene
+ * (parity unpinned): AiTraceProbe -> ray/plane or ray/sphere intersection (at most two hits;
+ * kMaxProbeDepth = 12 is never reached); AiLights* + AiEvaluateLightSample(AiOrenNayarMIS*, sigma 0)
+ * -> one distant light on a Lambertian surface, E = light_color / pi * max(0, N.L), optionally lit
+ * only where dot(P - gate_point, gate_normal) > 0 (a light/shadow edge, as in the reference's
+ * "diffusion decay" test 0010); integrateDiffuse (456-484) -> 0 (shouldTraceDiffuse false).
+ * Samples: the per-point scrambled (0,2)-sequence of rls_ggx_integrate. */
+#define RLS_SCENE_PLANE  0
+#define RLS_SCENE_SPHERE 1
+typedef struct rls_sss_scene {
+    int   geometry;
+    float plane_point[3], plane_normal[3];      /* unit normal, pointing out of the medium         */
+    float sphere_center[3], sphere_radius;
+    float light_dir[3], light_color[3];         /* unit vector towards the light; radiance         */
+    int   has_gate;
+    float gate_point[3], gate_normal[3];
+    int   use_cavity_fade;                      /* data->useCavityFade(), src/rlSss.h:401          */
+    int   literal_matrix;                       /* see rls_sss_mis_pdf                              */
+} rls_sss_scene;
+/* P: sg->P per shading point; result: integrateScatter's return value; mean_depth (optional):
+ * shaded probe hits per probe ray (msgData->probeDepth averaged over the samples). */
+rls_status rls_sss_integrate_scatter(rls_context *ctx, int64_t n, const rls_sss_closure *c, rls_cvec3 P,
+                                     const rls_sss_scene *scene, int spp_n, uint32_t seed,
+                                     rls_rgb result, float *mean_depth);
+
 /* ------------------------------------------------------------------------------------------
  * rlSkin composite: sheen GGX + specular GGX + NDProfile SSS with the layer-weight arithmetic
  * of shader_evaluate (src/rlSkin.cpp:174-246).  Parameter names: src/rlSkin.cpp:109-128.

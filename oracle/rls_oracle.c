@@ -1490,6 +1490,114 @@ void orc_batch_util(int64_t n, const float *a, const float *b, orc_v3p spherical
     parallel_for(n, nthreads, util_range, &j);
 }
 
+/* ========================= integrateScatter over an analytic scene ====================== */
+/* src/rlSss.h:167-280 (sample loop + MIS combine), 293-356 (traceProbe), 361-424
+ * (shadeProbeSample), 439-454 (evalLightSample).  See orc_scene in rls_oracle.h for what stands
+ * in for the closed Arnold calls. */
+
+static inline orc_v3 arr3(const float a[3]) { return v3(a[0], a[1], a[2]); }
+
+int orc_scene_trace(const orc_scene *sc, orc_v3 O, orc_v3 D, float maxdist, float t[2], orc_v3 hitP[2], orc_v3 hitN[2])
+{
+    float cand[2];
+    int nc = 0;
+    if (sc->geometry == 0) {
+        orc_v3 n = arr3(sc->plane_normal);
+        float denom = v3dot(n, D);
+        if (denom != 0.0f) cand[nc++] = v3dot(n, v3sub(arr3(sc->plane_point), O)) / denom;
+    } else {
+        orc_v3 oc = v3sub(O, arr3(sc->sphere_center));
+        float a = v3dot(D, D);
+        float b = v3dot(oc, D);
+        float c = v3dot(oc, oc) - sc->sphere_radius * sc->sphere_radius;
+        float disc = b * b - a * c;
+        if (!(disc < 0.0f) && a != 0.0f) {
+            float sq = sqrtf(disc);
+            cand[nc++] = (-b - sq) / a;
+            cand[nc++] = (-b + sq) / a;
+        }
+    }
+    int nh = 0;
+    for (int k = 0; k < nc; k++) {
+        if (!(cand[k] > 0.0f && cand[k] <= maxdist)) continue;
+        t[nh] = cand[k];
+        hitP[nh] = v3add(O, v3scale(D, cand[k]));
+        hitN[nh] = sc->geometry == 0 ? arr3(sc->plane_normal)
+                                     : v3normalize(v3sub(hitP[nh], arr3(sc->sphere_center)));
+        nh++;
+    }
+    return nh;
+}
+
+typedef struct {
+    const orc_sss_soa *in; int has_dPdu; orc_cv3p P; const orc_scene *sc; int spp; uint32_t seed;
+    orc_v3p result; float *depth;
+} scatter_job;
+
+static void scatter_range(int64_t lo, int64_t hi, void *ctx)
+{
+    scatter_job *j = (scatter_job *)ctx;
+    const orc_scene *sc = j->sc;
+    const orc_v3 Ldir = arr3(sc->light_dir);
+    for (int64_t i = lo; i < hi; i++) {
+        orc_rgb albedo = j->in->sss_color.x ? ldc(j->in->sss_color, i) : RGB_WHITE;
+        orc_sss S;
+        orc_sss_init(&S, ld3(j->in->N, i), ld3(j->in->T, i), j->has_dPdu, albedo, sss_dist(j->in, i));
+        const orc_v3 Po = ld3(j->P, i), No = S.axisN;
+        float accR = 0.0f, accG = 0.0f, accB = 0.0f, accD = 0.0f;
+        for (int s = 0; s < j->spp; s++) {
+            float rx, ry;
+            orc_sample_02(j->seed, (uint64_t)i, 0, (uint32_t)s, &rx, &ry);
+            orc_v3 off, dir; float maxdist;
+            (void)orc_sss_get_probe_ray(&S, rx, ry, &off, &dir, &maxdist);          /* :228 */
+            float t[2]; orc_v3 hp[2], hn[2];
+            int nh = orc_scene_trace(sc, v3add(Po, off), dir, maxdist, t, hp, hn);  /* AiTraceProbe, :293 */
+            /* probeSampleArray, :245 */
+            orc_rgb irr[2]; orc_v3 disp[2], sN[2];
+            int depth = 0;
+            orc_v3 prev = Po;
+            for (int k = 0; k < nh; k++) {
+                if (!(v3length(v3sub(prev, hp[k])) > AI_EPSILON)) continue;         /* :316-317 */
+                prev = hp[k];
+                /* shadeProbeSample, :379-420 */
+                orc_v3 d = v3sub(hp[k], Po);
+                float r = v3length(d);
+                if (r > S.profile.maxRadius) continue;
+                float fade = 1.0f;
+                if (sc->use_cavity_fade) fade = orc_sss_cavity_fade(d, r, hn[k], No);
+                if (fade > AI_EPSILON) {
+                    /* evalLightSample, :439-454: Lambert (Oren-Nayar, sigma 0) under one distant light */
+                    float w = AI_ONEOVERPI * MAXf(0.0f, v3dot(hn[k], Ldir));
+                    if (sc->has_gate &&
+                        !(v3dot(v3sub(hp[k], arr3(sc->gate_point)), arr3(sc->gate_normal)) > 0.0f)) w = 0.0f;
+                    orc_rgb prof = orc_nd_eval_profile(&S.profile, r);
+                    irr[depth] = rgb(sc->light_color[0] * w * prof.r * fade, sc->light_color[1] * w * prof.g * fade,
+                                     sc->light_color[2] * w * prof.b * fade);
+                    disp[depth] = d; sN[depth] = hn[k];
+                    depth++;
+                }
+            }
+            for (int k = 0; k < depth; k++) {                                        /* :246-268 */
+                if (irr[k].r == 0.0f && irr[k].g == 0.0f && irr[k].b == 0.0f) continue;
+                float pdf = orc_sss_mis_pdf(&S, disp[k], sN[k], sc->literal_matrix);
+                accR += irr[k].r / pdf; accG += irr[k].g / pdf; accB += irr[k].b / pdf;
+            }
+            accD += (float)depth;
+        }
+        float inv = 1.0f / (float)j->spp;                                            /* AiSamplerGetSampleInvCount */
+        stc(j->result, i, rgb(albedo.r * accR * inv, albedo.g * accG * inv, albedo.b * accB * inv));
+        if (j->depth) j->depth[i] = accD * inv;
+    }
+}
+
+void orc_batch_sss_integrate_scatter(int64_t n, const orc_sss_soa *in, int has_dPdu, orc_cv3p P,
+                                     const orc_scene *sc, int spp_n, uint32_t seed,
+                                     orc_v3p result, float *mean_depth, int nthreads)
+{
+    scatter_job j = { in, has_dPdu, P, sc, spp_n * spp_n, seed, result, mean_depth };
+    parallel_for(n, nthreads, scatter_range, &j);
+}
+
 /* ================================ synthetic generator ================================== */
 /* Counter-based: value = f(seed, point index, stream id).  Integer hashing plus + - * / sqrt
  * only, so the device generator (rlshaders_amd/csrc/gen.hip) reproduces it bit for bit. */

@@ -290,6 +290,29 @@ void orc_batch_disney_integrate(int64_t n, const orc_disney_soa *in, int spp_n, 
                                 orc_v3p dsum, float *dcount, orc_v3p ssum, float *scount,
                                 orc_v3p s_wi, orc_v3p s_f, float *s_pdf, int nthreads);
 
+/* SssSampler::integrateScatter (src/rlSss.h:167-280) with traceProbe / shadeProbeSample / evalLightSample
+ * (293-356, 361-424, 439-454) over an analytic scene: the closed AiTraceProbe becomes a ray/plane or
+ * ray/sphere intersection, the closed AiLights* / AiEvaluateLightSample(AiOrenNayarMIS*, sigma = 0)
+ * becomes one distant light on a Lambertian surface (E = light_color / pi * max(0, N.L)), optionally
+ * gated by a half-space (lit where dot(P - gate_point, gate_normal) > 0: the light/shadow edge of the
+ * reference's "diffusion decay" test scene).  integrateDiffuse (456-484) contributes nothing
+ * (shouldTraceDiffuse false).  Same layout as rls_sss_scene in include/rlshaders_amd.h. */
+typedef struct {
+    int   geometry;                       /* 0: plane, 1: sphere */
+    float plane_point[3], plane_normal[3];
+    float sphere_center[3], sphere_radius;
+    float light_dir[3], light_color[3];
+    int   has_gate;
+    float gate_point[3], gate_normal[3];
+    int   use_cavity_fade;
+    int   literal_matrix;
+} orc_scene;
+/* up to two probe hits of (O, D, maxdist) in ascending t; returns the count */
+int  orc_scene_trace(const orc_scene *sc, orc_v3 O, orc_v3 D, float maxdist, float t[2], orc_v3 hitP[2], orc_v3 hitN[2]);
+void orc_batch_sss_integrate_scatter(int64_t n, const orc_sss_soa *in, int has_dPdu, orc_cv3p P,
+                                     const orc_scene *sc, int spp_n, uint32_t seed,
+                                     orc_v3p result, float *mean_depth, int nthreads);
+
 /* utility closures, batch form (a2-a5) */
 void orc_batch_util(int64_t n, const float *a, const float *b, orc_v3p spherical, orc_v3p disk, int nthreads);
 

@@ -79,6 +79,20 @@ class SssClosure(C.Structure):
                 ("has_dPdu", C.c_int)]
 
 
+class SssScene(C.Structure):
+    """rls_sss_scene."""
+    _fields_ = [("geometry", C.c_int),
+                ("plane_point", C.c_float * 3), ("plane_normal", C.c_float * 3),
+                ("sphere_center", C.c_float * 3), ("sphere_radius", C.c_float),
+                ("light_dir", C.c_float * 3), ("light_color", C.c_float * 3),
+                ("has_gate", C.c_int),
+                ("gate_point", C.c_float * 3), ("gate_normal", C.c_float * 3),
+                ("use_cavity_fade", C.c_int), ("literal_matrix", C.c_int)]
+
+
+RLS_SCENE_PLANE, RLS_SCENE_SPHERE = 0, 1
+
+
 class SkinClosure(C.Structure):
     _fields_ = [("wo", CVec3), ("N", CVec3), ("T", CVec3),
                 ("sss_color", ParamRgb),
@@ -157,6 +171,8 @@ PROTOTYPES = {
     "rls_sss_mis_pdf": (C.c_int, [_ctx, _i64, C.POINTER(SssClosure), CVec3, CVec3, C.c_int, _vp]),
     "rls_sss_cavity_fade": (C.c_int, [_ctx, _i64, CVec3, CVec3, CVec3, _vp]),
     "rls_sss_sample_diffuse_direction": (C.c_int, [_ctx, _i64, CVec3, CVec3, _vp, _vp, Vec3]),
+    "rls_sss_integrate_scatter": (C.c_int, [_ctx, _i64, C.POINTER(SssClosure), CVec3, C.POINTER(SssScene),
+                                            C.c_int, C.c_uint32, Rgb, _vp]),
     # rlSkin
     "rls_skin_sample_eval_pdf": (C.c_int, [_ctx, _i64, C.POINTER(SkinClosure), C.POINTER(_vp), C.POINTER(SkinOut)]),
     # rlUtil, generator, checksum

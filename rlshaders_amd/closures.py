@@ -444,6 +444,17 @@ class SssSampler:
                                       cvec3(sampleN, n, "sampleN"), 1 if literal_matrix else 0, plane(pdf, n, "pdf")))
         return pdf
 
+    def integrateScatter(self, P, scene: "capi.SssScene", spp_n: int, seed: int, want_depth: bool = False, out=None):
+        """src/rlSss.h:167-280 over an analytic scene (see rls_sss_integrate_scatter) -> result [3,n]
+        (and the mean number of shaded probe hits per probe ray)."""
+        n, ctx = self.n, self.ctx
+        result = out if out is not None else ctx.empty(3, n)
+        depth = ctx.empty(n) if want_depth else None
+        check(ctx.lib.rls_sss_integrate_scatter(
+            ctx.handle, n, C.byref(self.c), cvec3(P, n, "P"), C.byref(scene), int(spp_n), int(seed) & 0xFFFFFFFF,
+            rgb(result, n, "result"), plane(depth, n, "mean_depth") if want_depth else None))
+        return (result, depth) if want_depth else result
+
     @staticmethod
     def cavityFade(ctx: Context, disp, sampleN, No):
         """src/rlSss.h:401-413."""
@@ -461,6 +472,28 @@ class SssSampler:
         check(ctx.lib.rls_sss_sample_diffuse_direction(ctx.handle, n, cvec3(normal, n, "normal"), cvec3(T, n, "T"),
                                                        plane(rx, n, "rx"), plane(ry, n, "ry"), vec3(wi, n, "wi")))
         return wi
+
+
+def make_scene(geometry="plane", plane_point=(0.0, 0.0, 0.0), plane_normal=(0.0, 0.0, 1.0),
+               sphere_center=(0.0, 0.0, 0.0), sphere_radius=1.0,
+               light_dir=(0.0, 0.0, 1.0), light_color=(1.0, 1.0, 1.0),
+               gate_point=None, gate_normal=(1.0, 0.0, 0.0),
+               use_cavity_fade=False, literal_matrix=False) -> "capi.SssScene":
+    """The analytic scene of ``SssSampler.integrateScatter`` (rls_sss_scene)."""
+    sc = capi.SssScene()
+    sc.geometry = {"plane": capi.RLS_SCENE_PLANE, "sphere": capi.RLS_SCENE_SPHERE}[geometry]
+    sc.plane_point[:] = plane_point
+    sc.plane_normal[:] = plane_normal
+    sc.sphere_center[:] = sphere_center
+    sc.sphere_radius = sphere_radius
+    sc.light_dir[:] = light_dir
+    sc.light_color[:] = light_color
+    sc.has_gate = 0 if gate_point is None else 1
+    sc.gate_point[:] = gate_point if gate_point is not None else (0.0, 0.0, 0.0)
+    sc.gate_normal[:] = gate_normal
+    sc.use_cavity_fade = 1 if use_cavity_fade else 0
+    sc.literal_matrix = 1 if literal_matrix else 0
+    return sc
 
 
 # ================================================================================================

@@ -184,6 +184,121 @@ __global__ __launch_bounds__(rlsh::kBlock) void disney_integrate_kernel(DisneyIn
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// SssSampler::integrateScatter over an analytic scene (src/rlSss.h:167-280, 293-356, 361-424,
+// 439-454; include/rlshaders_amd.h, rls_sss_integrate_scatter, says what stands in for the closed
+// renderer).  The reference shades every hit of a probe ray first and combines them afterwards;
+// hit k's combination only adds to the running sums, so shading and combining hit by hit gives
+// the same sums in the same order.
+using rlsh::ScatterIO;
+
+RLS_DEV V3 arr3(const float (&a)[3]) { return mk(a[0], a[1], a[2]); }
+
+__device__ __forceinline__ NdProfile scatter_profile(const rls_sss_closure &c, int64_t i)
+{
+    float m = ldp(c.sss_dist_multiplier, i);   // src/rlSkin.cpp:235-236
+    return nd_make(ldp(c.sss_scatter_dist[0], i) * m, ldp(c.sss_scatter_dist[1], i) * m,
+                   ldp(c.sss_scatter_dist[2], i) * m);
+}
+
+template <int G, int FAST_MATH = RLS_FAST>
+__global__ __launch_bounds__(rlsh::kBlock) void sss_scatter_kernel(ScatterIO a)
+{
+    __shared__ uint32_t tab[2][kMaxSpp];
+    stage_libm_tables();
+    stage_table(tab, a.spp);
+    const rls_sss_scene &sc = a.scene;
+    const bool sphere = sc.geometry == RLS_SCENE_SPHERE;
+    const V3 planeN = arr3(sc.plane_normal), planeP = arr3(sc.plane_point), center = arr3(sc.sphere_center);
+    const V3 Ldir = arr3(sc.light_dir), gateP = arr3(sc.gate_point), gateN = arr3(sc.gate_normal);
+    const int sub = threadIdx.x % G;
+    const int64_t groups_per_block = rlsh::kBlock / G;
+    const int64_t stride = (int64_t)gridDim.x * groups_per_block;
+    const int64_t rounds = (a.n + stride - 1) / stride;
+    int64_t i = (int64_t)blockIdx.x * groups_per_block + threadIdx.x / G;
+    for (int64_t it = 0; it < rounds; it++, i += stride) {
+        const bool live = i < a.n;
+        const int64_t ii = live ? i : a.n - 1;
+        const rls_sss_closure &c = a.c;
+        NdProfile p = scatter_profile(c, ii);
+        Frame fr = sss_frame(ld3(c.N, ii), ld3(c.T, ii), c.has_dPdu != 0);
+        const V3 Po = ld3(a.P, ii);
+        float br, bg, bb;
+        ldrgb(c.sss_color, ii, br, bg, bb);
+        const uint32_t sx = hash_u32(a.seed, (uint64_t)ii, kScrambleStream);
+        const uint32_t sy = hash_u32(a.seed, (uint64_t)ii, kScrambleStream + 1);
+
+        float accR = 0.0f, accG = 0.0f, accB = 0.0f, accD = 0.0f;
+        for (int s = sub; s < a.spp; s += G) {
+            float rx = bits_u01(tab[0][s] ^ sx);
+            float ry = bits_u01(tab[1][s] ^ sy);
+            V3 off, dir;
+            float maxdist;
+            sss_probe_ray(p, fr, rx, ry, off, dir, maxdist);                     // :228
+            const V3 O = Po + off;
+            // AiTraceProbe (:293): the roots of the ray against the plane / sphere, ascending
+            float cand[2];
+            bool has[2] = { false, false };
+            if (sphere) {
+                V3 oc = O - center;
+                float qa = dot(dir, dir);
+                float qb = dot(oc, dir);
+                float qc = dot(oc, oc) - sc.sphere_radius * sc.sphere_radius;
+                float disc = qb * qb - qa * qc;
+                if (!(disc < 0.0f) && qa != 0.0f) {
+                    float sq = R_SQRT(disc);
+                    cand[0] = R_DIV(-qb - sq, qa);
+                    cand[1] = R_DIV(-qb + sq, qa);
+                    has[0] = has[1] = true;
+                }
+            } else {
+                float denom = dot(planeN, dir);
+                if (denom != 0.0f) {
+                    cand[0] = R_DIV(dot(planeN, planeP - O), denom);
+                    has[0] = true;
+                }
+            }
+            V3 prev = Po;
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                if (!has[k] || !(cand[k] > 0.0f && cand[k] <= maxdist)) continue;
+                const V3 hp = O + dir * cand[k];
+                const V3 hn = sphere ? normalize(hp - center) : planeN;
+                if (!(length(prev - hp) > kEps)) continue;                       // :316-317
+                prev = hp;
+                // shadeProbeSample, :379-420
+                const V3 d = hp - Po;
+                const float r = length(d);
+                if (r > p.maxR) continue;
+                float fade = 1.0f;
+                if (sc.use_cavity_fade) fade = sss_cavity_fade(d, r, hn, fr.N);
+                if (!(fade > kEps)) continue;
+                accD += 1.0f;
+                // evalLightSample, :439-454
+                float w = kInvPi * maxf(0.0f, dot(hn, Ldir));
+                if (sc.has_gate && !(dot(hp - gateP, gateN) > 0.0f)) w = 0.0f;
+                float pr, pg, pb;
+                nd_profile(p, r, pr, pg, pb);
+                const float iR = sc.light_color[0] * w * pr * fade;
+                const float iG = sc.light_color[1] * w * pg * fade;
+                const float iB = sc.light_color[2] * w * pb * fade;
+                if (iR == 0.0f && iG == 0.0f && iB == 0.0f) continue;            // :249
+                const float pdf = sss_mis_pdf(p, fr, d, hn, sc.literal_matrix != 0);
+                accR += R_DIV(iR, pdf); accG += R_DIV(iG, pdf); accB += R_DIV(iB, pdf);
+            }
+        }
+        if (G > 1) {
+            accR = group_sum<G>(accR); accG = group_sum<G>(accG);
+            accB = group_sum<G>(accB); accD = group_sum<G>(accD);
+        }
+        if (live && sub == 0) {
+            const float inv = 1.0f / (float)a.spp;                               // AiSamplerGetSampleInvCount
+            strgb(a.result, i, br * accR * inv, bg * accG * inv, bb * accB * inv);
+            if (a.depth) stg(a.depth, i, accD * inv);
+        }
+    }
+}
+
 // lanes per point: fill >= ~4 waves per SIMD on every CU when the batch is small
 int pick_group(const rls_context *ctx, int64_t n, int spp)
 {
@@ -219,9 +334,15 @@ RLS_HIDDEN rls_status rls_fast_disney_integrate(rls_context *ctx, int g, const r
     return launch_g(ctx, disney_integrate_kernel<1>, disney_integrate_kernel<4>, disney_integrate_kernel<16>,
                     disney_integrate_kernel<64>, g, *io, "rls_disney_integrate[fast]");
 }
+RLS_HIDDEN rls_status rls_fast_sss_scatter(rls_context *ctx, int g, const rlsh::ScatterIO *io)
+{
+    return launch_g(ctx, sss_scatter_kernel<1>, sss_scatter_kernel<4>, sss_scatter_kernel<16>,
+                    sss_scatter_kernel<64>, g, *io, "rls_sss_integrate_scatter[fast]");
+}
 #else
 RLS_HIDDEN rls_status rls_fast_ggx_integrate(rls_context *ctx, int g, const rlsh::GgxIntIO *io);
 RLS_HIDDEN rls_status rls_fast_disney_integrate(rls_context *ctx, int g, const rlsh::DisneyIntIO *io);
+RLS_HIDDEN rls_status rls_fast_sss_scatter(rls_context *ctx, int g, const rlsh::ScatterIO *io);
 
 extern "C" {
 
@@ -272,6 +393,28 @@ rls_status rls_disney_integrate(rls_context *ctx, int64_t n, const rls_disney_cl
     if (ctx->fast) return rls_fast_disney_integrate(ctx, g, &io);
     return launch_g(ctx, disney_integrate_kernel<1>, disney_integrate_kernel<4>, disney_integrate_kernel<16>,
                     disney_integrate_kernel<64>, g, io, "rls_disney_integrate");
+}
+
+rls_status rls_sss_integrate_scatter(rls_context *ctx, int64_t n, const rls_sss_closure *c, rls_cvec3 P,
+                                     const rls_sss_scene *scene, int spp_n, uint32_t seed,
+                                     rls_rgb result, float *mean_depth)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_REQUIRE(n >= 0, "n < 0");
+    RLS_REQUIRE(spp_n >= 1 && spp_n * spp_n <= kMaxSpp, "spp_n must be in [1, 16]");
+    if (n == 0) return RLS_OK;
+    RLS_REQUIRE(c != nullptr && scene != nullptr, "closure or scene is NULL");
+    RLS_REQUIRE(rlsh::has3(c->N) && rlsh::has3(c->T) && rlsh::has3(P), "N/T/P plane is NULL");
+    RLS_REQUIRE(rlsh::ok_rgb(c->sss_color), "sss_color planes must be all set or all NULL");
+    RLS_REQUIRE(scene->geometry == RLS_SCENE_PLANE || scene->geometry == RLS_SCENE_SPHERE, "unknown scene geometry");
+    RLS_REQUIRE(rlsh::has3(result), "NULL output plane");
+    ScatterIO io = {};
+    io.c = *c; io.P = P; io.scene = *scene; io.result = result; io.depth = mean_depth;
+    io.n = n; io.spp = spp_n * spp_n; io.seed = seed;
+    int g = pick_group(ctx, n, io.spp);
+    if (ctx->fast) return rls_fast_sss_scatter(ctx, g, &io);
+    return launch_g(ctx, sss_scatter_kernel<1>, sss_scatter_kernel<4>, sss_scatter_kernel<16>,
+                    sss_scatter_kernel<64>, g, io, "rls_sss_integrate_scatter");
 }
 
 } // extern "C"

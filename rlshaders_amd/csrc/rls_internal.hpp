@@ -111,6 +111,17 @@ struct DisneyIntIO {
     uint32_t seed;
 };
 
+struct ScatterIO {
+    rls_sss_closure c;
+    rls_cvec3 P;
+    rls_sss_scene scene;
+    rls_rgb result;
+    float *depth;
+    int64_t n;
+    int spp;
+    uint32_t seed;
+};
+
 void set_error(const char *fmt, ...);
 rls_status hip_fail(hipError_t e, const char *what);
 

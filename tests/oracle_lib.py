@@ -342,6 +342,58 @@ class Sss:
         return pdf
 
 
+class Scene(C.Structure):
+    """orc_scene (same layout as rls_sss_scene)."""
+    _fields_ = [("geometry", C.c_int),
+                ("plane_point", C.c_float * 3), ("plane_normal", C.c_float * 3),
+                ("sphere_center", C.c_float * 3), ("sphere_radius", C.c_float),
+                ("light_dir", C.c_float * 3), ("light_color", C.c_float * 3),
+                ("has_gate", C.c_int),
+                ("gate_point", C.c_float * 3), ("gate_normal", C.c_float * 3),
+                ("use_cavity_fade", C.c_int), ("literal_matrix", C.c_int)]
+
+
+def make_scene(geometry="plane", plane_point=(0, 0, 0), plane_normal=(0, 0, 1), sphere_center=(0, 0, 0),
+               sphere_radius=1.0, light_dir=(0, 0, 1), light_color=(1, 1, 1), gate_point=None, gate_normal=(1, 0, 0),
+               use_cavity_fade=False, literal_matrix=False) -> Scene:
+    sc = Scene()
+    sc.geometry = {"plane": 0, "sphere": 1}[geometry]
+    sc.plane_point[:] = plane_point
+    sc.plane_normal[:] = plane_normal
+    sc.sphere_center[:] = sphere_center
+    sc.sphere_radius = sphere_radius
+    sc.light_dir[:] = light_dir
+    sc.light_color[:] = light_color
+    sc.has_gate = int(gate_point is not None)
+    sc.gate_point[:] = gate_point if gate_point is not None else (0, 0, 0)
+    sc.gate_normal[:] = gate_normal
+    sc.use_cavity_fade = int(use_cavity_fade)
+    sc.literal_matrix = int(literal_matrix)
+    return sc
+
+
+def scene_trace(scene: Scene, O, D, maxdist):
+    """orc_scene_trace -> (count, t[2], hitP[2][3], hitN[2][3])"""
+    t = (C.c_float * 2)()
+    hp, hn = (V3 * 2)(), (V3 * 2)()
+    fn = lib().orc_scene_trace
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(Scene), V3, V3, C.c_float, fp, C.POINTER(V3), C.POINTER(V3)]
+    k = fn(C.byref(scene), V3(*map(float, O)), V3(*map(float, D)), float(maxdist), t, hp, hn)
+    return k, [t[i] for i in range(k)], [(hp[i].x, hp[i].y, hp[i].z) for i in range(k)], \
+        [(hn[i].x, hn[i].y, hn[i].z) for i in range(k)]
+
+
+def integrate_scatter(sss: "Sss", P, scene: Scene, spp_n, seed):
+    """orc_batch_sss_integrate_scatter -> (result [3,n], mean_depth [n])"""
+    n = sss.n
+    P = f32(P)
+    result, depth = np.empty((3, n), np.float32), np.empty(n, np.float32)
+    lib().orc_batch_sss_integrate_scatter(C.c_int64(n), C.byref(sss.soa), sss.has_dPdu, _v(P), C.byref(scene),
+                                          int(spp_n), C.c_uint32(seed), _v(result), _p(depth), sss.nthreads)
+    return result, depth
+
+
 def cavity_fade(disp, sampleN, No, nthreads=1):
     disp, sampleN, No = f32(disp), f32(sampleN), f32(No)
     n = disp.shape[1]

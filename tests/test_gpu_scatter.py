@@ -68,8 +68,8 @@ def _run_both(ctx, oracle, c, so, sg, spp_n, seed, has_dPdu=True, group=1):
 
 @pytest.mark.parametrize("variant", ["plain", "cavity", "gate", "literal", "polar_frame", "bent_normal"])
 def test_sphere_parity(gpu, oracle, variant):
-    c = _sphere_case(oracle, N, 1.0, (0.3, -0.2, 0.1), bend=0.3 if variant == "bent_normal" else 0.0)
-    kw = dict(geometry="sphere", sphere_center=(0.3, -0.2, 0.1), sphere_radius=1.0,
+    c = _sphere_case(oracle, N, 0.35, (0.3, -0.2, 0.1), bend=0.3 if variant == "bent_normal" else 0.0)
+    kw = dict(geometry="sphere", sphere_center=(0.3, -0.2, 0.1), sphere_radius=0.35,
               light_dir=(0.0, 0.6, 0.8), light_color=(1.5, 1.0, 0.25))
     if variant == "cavity":
         kw["use_cavity_fade"] = True
@@ -130,8 +130,8 @@ def test_fast_mode_within_roundoff(oracle):
     ctx = R.Context(0)
     ctx.set_math_mode(True)
     try:
-        c = _sphere_case(oracle, N, 1.0, (0.0, 0.0, 0.0))
-        so, sg = _scene_pair(oracle, geometry="sphere", sphere_radius=1.0, light_dir=(0.0, 0.6, 0.8),
+        c = _sphere_case(oracle, N, 0.35, (0.0, 0.0, 0.0))
+        so, sg = _scene_pair(oracle, geometry="sphere", sphere_radius=0.35, light_dir=(0.0, 0.6, 0.8),
                              use_cavity_fade=True)
         _, ref, dref, got, dgot = _run_both(ctx, oracle, c, so, sg, 4, 99)
         st = cases.summarize(cases.rel_err(got, ref))

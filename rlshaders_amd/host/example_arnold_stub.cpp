@@ -73,8 +73,46 @@ int main(int argc, char **argv)
         for (size_t i = 0; i < hp.size(); i++)
             if (hp[i] != hp2[i]) { std::fprintf(stderr, "fused pdf != separate at %zu\n", i); return 1; }
 
-        std::printf("{\"n\": %d, \"L\": [%.9g, %.9g, %.9g], \"f\": %.9g, \"pdf\": %.9g}\n", n, hL[0], hL[(size_t)n],
-                    hL[2 * (size_t)n], hf[0], hp[0]);
+        // --- rlSkin on the same shading points (defaults of src/rlSkin.cpp:109-128, sheen switched on) ---
+        rlsb::SkinParams sp;
+        sp.sheen_weight = rlsb::Param(0.25f);
+        rlsb::SkinShader skin(dev, pts, sp);
+        std::vector<float> xi6((size_t)n * 6);
+        for (auto &v : xi6) v = rnd();
+        rlsb::Planes dxi(dev, xi6, 6), skin_out(dev, n, rlsb::SkinShader::kOutPlanes);
+        skin.sampleEvalPdf(dxi, skin_out);
+        std::vector<float> hs = skin_out.download();
+        const float sss_w = hs[23 * (size_t)n], spec_F = hs[22 * (size_t)n], sheen_F = hs[21 * (size_t)n];
+
+        // --- SssSampler::integrateScatter: points on the lit plane z = 0, 16 probe rays each ------------
+        std::vector<float> ns((size_t)n * 3, 0.0f), du((size_t)n * 3, 0.0f), pp((size_t)n * 3, 0.0f);
+        for (int i = 0; i < n; i++) {
+            ns[2 * (size_t)n + i] = 1.0f;                                  // Ns = (0,0,1)
+            float ph = 6.2831853f * rnd();
+            du[i] = std::cos(ph); du[(size_t)n + i] = std::sin(ph);        // dPdu in the plane
+            pp[i] = rnd(); pp[(size_t)n + i] = rnd();                      // P
+        }
+        rlsb::Planes dNs(dev, ns, 3), dDu(dev, du, 3), dP(dev, pp, 3), scat(dev, n, 3);
+        const float dist[3] = {0.05f, 0.1f, 0.2f};
+        rlsb::SssSampler sss(dev, dNs, dDu, rlsb::ParamRGB(0.8f, 0.5f, 0.3f), dist);
+        rls_sss_scene scene = {};
+        scene.geometry = RLS_SCENE_PLANE;
+        scene.plane_normal[2] = 1.0f;
+        scene.light_dir[2] = 1.0f;
+        scene.light_color[0] = 2.0f; scene.light_color[1] = 1.0f; scene.light_color[2] = 0.5f;
+        sss.integrateScatter(dP, scene, 4, 77u, scat);
+        std::vector<float> hsc = scat.download();
+        double mean[3] = {0, 0, 0};
+        for (int k = 0; k < 3; k++) {
+            for (int i = 0; i < n; i++) mean[k] += hsc[(size_t)k * n + i];
+            mean[k] /= n;
+        }
+
+        std::printf("{\"n\": %d, \"L\": [%.9g, %.9g, %.9g], \"f\": %.9g, \"pdf\": %.9g, "
+                    "\"skin\": {\"sssWeight\": %.9g, \"specularFresnel\": %.9g, \"sheenFresnel\": %.9g}, "
+                    "\"scatter_mean\": [%.9g, %.9g, %.9g]}\n",
+                    n, hL[0], hL[(size_t)n], hL[2 * (size_t)n], hf[0], hp[0], sss_w, spec_F, sheen_F,
+                    mean[0], mean[1], mean[2]);
         return 0;
     } catch (const rlsb::Error &e) {
         std::fprintf(stderr, "rlshaders_amd: %s\n", e.what());

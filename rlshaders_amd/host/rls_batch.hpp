@@ -298,4 +298,92 @@ private:
     rls_sss_closure c_{};
 };
 
+// rls::SssSampler<NDProfile> (src/rlSss.h:100-560), batched.  Ns = sg->Ns and dPdu = sg->dPdu per
+// shading point (the constructor's frame, 143-158), P = sg->P.
+class SssSampler {
+public:
+    SssSampler(const Device &d, const Planes &Ns, const Planes &dPdu, ParamRGB albedo, const float dist[3],
+               Param multiplier = Param(1.0f), bool has_dPdu = true)
+        : dev_(d), n_(Ns.size())
+    {
+        c_.sss_color = albedo.c();
+        c_.sss_dist_multiplier = multiplier.c();
+        for (int k = 0; k < 3; k++) c_.sss_scatter_dist[k] = Param(dist[k]).c();
+        c_.N = Ns.cvec3();
+        c_.T = dPdu.cvec3();
+        c_.has_dPdu = has_dPdu ? 1 : 0;
+    }
+    // float getProbeRay(rx, ry, origin, ray)  (src/rlSss.h:487-533), plus pdf(r) and profile(r)
+    void getProbeRay(const Planes &rx, const Planes &ry, const Planes &P, Planes &r, Planes &origin, Planes &dir,
+                     Planes &maxdist, Planes &pdf, Planes &profile) const
+    {
+        check(rls_sss_probe_ray(dev_.ctx(), n_, &c_, rx.plane(0), ry.plane(0), P.cvec3(), r.plane(0), origin.vec3(),
+                                dir.vec3(), maxdist.plane(0), pdf.plane(0), profile.rgb()));
+    }
+    // the MIS pdf of one probe hit (src/rlSss.h:246-266)
+    void misPdf(const Planes &disp, const Planes &sampleN, Planes &pdf, bool literal_matrix = false) const
+    {
+        check(rls_sss_mis_pdf(dev_.ctx(), n_, &c_, disp.cvec3(), sampleN.cvec3(), literal_matrix ? 1 : 0, pdf.plane(0)));
+    }
+    // AtColor integrateScatter(sg, data)  (src/rlSss.h:167-280) over an analytic scene
+    void integrateScatter(const Planes &P, const rls_sss_scene &scene, int spp_n, uint32_t seed, Planes &result) const
+    {
+        check(rls_sss_integrate_scatter(dev_.ctx(), n_, &c_, P.cvec3(), &scene, spp_n, seed, result.rgb(), nullptr));
+    }
+
+private:
+    const Device &dev_;
+    int64_t n_;
+    rls_sss_closure c_{};
+};
+
+// rlSkin's lobe composition (shader_evaluate, src/rlSkin.cpp:174-246), batched; parameter names and
+// defaults of node_parameters (src/rlSkin.cpp:109-128).
+struct SkinParams {
+    ParamRGB sss_color{1.0f, 1.0f, 1.0f};
+    Param sss_weight{1.0f}, sss_dist_multiplier{1.0f};
+    Param sss_scatter_dist[3] = {Param(1.0f), Param(1.0f), Param(1.0f)};
+    ParamRGB specular_color{1.0f, 1.0f, 1.0f};
+    Param specular_weight{0.6f}, specular_roughness{0.5f}, specular_ior{1.44f};
+    ParamRGB sheen_color{1.0f, 1.0f, 1.0f};
+    Param sheen_weight{0.0f}, sheen_roughness{0.35f}, sheen_ior{1.44f};
+};
+
+class SkinShader {
+public:
+    SkinShader(const Device &d, const ShadingPoints &sg, const SkinParams &p)
+        : dev_(d), n_(sg.size()), wo_(d, sg.planar(sg.wo), 3), N_(d, sg.planar(sg.N), 3), T_(d, sg.planar(sg.T), 3)
+    {
+        c_.wo = wo_.cvec3(); c_.N = N_.cvec3(); c_.T = T_.cvec3();
+        c_.sss_color = p.sss_color.c(); c_.sss_weight = p.sss_weight.c();
+        c_.sss_dist_multiplier = p.sss_dist_multiplier.c();
+        for (int k = 0; k < 3; k++) c_.sss_scatter_dist[k] = p.sss_scatter_dist[k].c();
+        c_.specular_color = p.specular_color.c(); c_.specular_weight = p.specular_weight.c();
+        c_.specular_roughness = p.specular_roughness.c(); c_.specular_ior = p.specular_ior.c();
+        c_.sheen_color = p.sheen_color.c(); c_.sheen_weight = p.sheen_weight.c();
+        c_.sheen_roughness = p.sheen_roughness.c(); c_.sheen_ior = p.sheen_ior.c();
+    }
+    // xi: 6 planes {sheen rx, ry, specular rx, ry, sss rx, ry};  out: 27 planes in rls_skin_out order
+    // (sheen wi3 f3 pdf fresnel, specular wi3 f3 pdf fresnel, r, r_pdf, profile3, sheenFresnel,
+    // specularFresnel, sssWeight)
+    void sampleEvalPdf(const Planes &xi, Planes &out) const
+    {
+        const float *x[6];
+        for (int k = 0; k < 6; k++) x[k] = xi.plane(k);
+        rls_skin_out o{};
+        o.sheen_wi = out.vec3(0); o.sheen_f = out.rgb(3); o.sheen_pdf = out.plane(6); o.sheen_fresnel = out.plane(7);
+        o.spec_wi = out.vec3(8);  o.spec_f = out.rgb(11); o.spec_pdf = out.plane(14); o.spec_fresnel = out.plane(15);
+        o.r = out.plane(16); o.r_pdf = out.plane(17); o.profile = out.rgb(18);
+        o.sheenFresnel = out.plane(21); o.specularFresnel = out.plane(22); o.sssWeight = out.plane(23);
+        check(rls_skin_sample_eval_pdf(dev_.ctx(), n_, &c_, x, &o));
+    }
+    static constexpr int kOutPlanes = 24;
+
+private:
+    const Device &dev_;
+    int64_t n_;
+    Planes wo_, N_, T_;
+    rls_skin_closure c_{};
+};
+
 } // namespace rlsb

@@ -22,3 +22,14 @@ def test_arnold_stub_example_matches_survey_kat():
         assert abs(a - b) <= 2e-9 + 1e-7 * abs(b)
     assert abs(got["f"] - kat["f"]) <= 1e-5 * kat["f"]
     assert abs(got["pdf"] - kat["pdf"]) <= 1e-5 * kat["pdf"]
+    # rlSkin through the C++ mirror: layer weights are Fresnel complements in (0, 1)
+    sk = got["skin"]
+    assert 0.0 < sk["specularFresnel"] < 1.0 and 0.0 < sk["sheenFresnel"] < 1.0 and 0.0 < sk["sssWeight"] <= 1.0
+    # SssSampler::integrateScatter through the C++ mirror: the uniformly lit plane converges to the
+    # closed-form mass of the profile inside maxRadius (tests/test_oracle_scatter.py)
+    import math
+    dist, albedo, light = (0.05, 0.1, 0.2), (0.8, 0.5, 0.3), (2.0, 1.0, 0.5)
+    rmax = 3 * max(dist)
+    for d, a, e, m in zip(dist, albedo, light, got["scatter_mean"]):
+        want = a * e / math.pi * (1 - (math.exp(-rmax / d) + 3 * math.exp(-rmax / (3 * d))) / 4)
+        assert abs(m / want - 1) < 0.03

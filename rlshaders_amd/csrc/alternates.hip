@@ -12,7 +12,7 @@ namespace {
 using rlsh::AltIO;
 using namespace rlsh;   // AOP_*
 
-__device__ __forceinline__ Disney load_closure(const rls_disney_closure &c, int64_t i)
+__device__ __forceinline__ Disney load_closure(const rls_disney_closure &c, Idx i)
 {
     V3 wo = ld3(c.wo, i), N = ld3(c.N, i), T = ld3(c.T, i);
     float br, bg, bb;
@@ -30,7 +30,9 @@ __global__ __launch_bounds__(rlsh::kBlock) void alt_kernel(AltIO a)
 {
     stage_libm_tables();
     const int64_t stride = (int64_t)gridDim.x * rlsh::kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * rlsh::kBlock + threadIdx.x; i < a.n; i += stride) {
+    for (int64_t base = (int64_t)blockIdx.x * rlsh::kBlock; base < a.n; base += stride) {
+        const Idx i = make_idx(base);
+        if (i.full() >= a.n) continue;
         if (OP == AOP_GAUSS) {
             GaussProfile g = gauss_make(ldp(a.dist_x, i));
             float r = gauss_radius(g, ldg(a.rx, i));

@@ -12,32 +12,35 @@ namespace {
 using rlsh::DisneyIO;
 enum { OP_SAMPLE = rlsh::DOP_SAMPLE, OP_EVAL = rlsh::DOP_EVAL, OP_PDF = rlsh::DOP_PDF, OP_FUSED = rlsh::DOP_FUSED };
 
-__device__ __forceinline__ Disney load_closure(const rls_disney_closure &c, int64_t i)
+template <bool STREAMED>
+__device__ __forceinline__ Disney load_closure(const rls_disney_closure &c, Idx i)
 {
     V3 wo = ld3(c.wo, i), N = ld3(c.N, i), T = ld3(c.T, i);
     float br, bg, bb;
-    ldrgb(c.base_color, i, br, bg, bb);
+    ldrgb<STREAMED>(c.base_color, i, br, bg, bb);
     float s[10];
-    s[0] = ldp(c.subsurface, i);
-    s[1] = ldp(c.metallic, i);
-    s[2] = ldp(c.specular, i);
-    s[3] = ldp(c.specular_tint, i);
-    s[4] = ldp(c.roughness, i);
-    s[5] = ldp(c.anisotropic, i);
-    s[6] = ldp(c.sheen, i);
-    s[7] = ldp(c.sheen_tint, i);
-    s[8] = ldp(c.clearcoat, i);
-    s[9] = ldp(c.clearcoat_gloss, i);
+    s[0] = ldp<STREAMED>(c.subsurface, i);
+    s[1] = ldp<STREAMED>(c.metallic, i);
+    s[2] = ldp<STREAMED>(c.specular, i);
+    s[3] = ldp<STREAMED>(c.specular_tint, i);
+    s[4] = ldp<STREAMED>(c.roughness, i);
+    s[5] = ldp<STREAMED>(c.anisotropic, i);
+    s[6] = ldp<STREAMED>(c.sheen, i);
+    s[7] = ldp<STREAMED>(c.sheen_tint, i);
+    s[8] = ldp<STREAMED>(c.clearcoat, i);
+    s[9] = ldp<STREAMED>(c.clearcoat_gloss, i);
     return disney_make(wo, N, T, br, bg, bb, s);
 }
 
-template <int OP, bool DIFFUSE, int FAST_MATH = RLS_FAST>
+template <int OP, bool DIFFUSE, int FAST_MATH, bool STREAMED>
 __global__ __launch_bounds__(rlsh::kBlock) void disney_kernel(DisneyIO a)
 {
     stage_libm_tables();   // powf / logf tables -> LDS (EXACT mode)
     const int64_t stride = (int64_t)gridDim.x * rlsh::kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * rlsh::kBlock + threadIdx.x; i < a.n; i += stride) {
-        Disney d = load_closure(a.c, i);
+    for (int64_t base = (int64_t)blockIdx.x * rlsh::kBlock; base < a.n; base += stride) {
+        const Idx i = make_idx(base);
+        if (i.full() >= a.n) continue;
+        Disney d = load_closure<STREAMED>(a.c, i);
         V3 L;
         if (OP == OP_SAMPLE || OP == OP_FUSED) {
             float rx = ldg(a.rx, i), ry = ldg(a.ry, i);
@@ -75,10 +78,18 @@ template <int OP>
 rls_status launch_kernel(rls_context *ctx, int lobe, const DisneyIO &io, const char *name)
 {
     dim3 grid = rlsh::grid_for(ctx, io.n);
-    if (lobe == RLS_RAY_DIFFUSE)
-        hipLaunchKernelGGL((disney_kernel<OP, true>), grid, dim3(rlsh::kBlock), 0, ctx->stream, io);
-    else
-        hipLaunchKernelGGL((disney_kernel<OP, false>), grid, dim3(rlsh::kBlock), 0, ctx->stream, io);
+    const rls_disney_closure &c = io.c;
+    const bool streamed = c.base_color.r && c.subsurface.v && c.metallic.v && c.specular.v && c.specular_tint.v &&
+                          c.roughness.v && c.anisotropic.v && c.sheen.v && c.sheen_tint.v && c.clearcoat.v &&
+                          c.clearcoat_gloss.v;
+    const dim3 block(rlsh::kBlock);
+    if (lobe == RLS_RAY_DIFFUSE) {
+        if (streamed) hipLaunchKernelGGL((disney_kernel<OP, true, RLS_FAST, true>), grid, block, 0, ctx->stream, io);
+        else hipLaunchKernelGGL((disney_kernel<OP, true, RLS_FAST, false>), grid, block, 0, ctx->stream, io);
+    } else {
+        if (streamed) hipLaunchKernelGGL((disney_kernel<OP, false, RLS_FAST, true>), grid, block, 0, ctx->stream, io);
+        else hipLaunchKernelGGL((disney_kernel<OP, false, RLS_FAST, false>), grid, block, 0, ctx->stream, io);
+    }
     return rlsh::check_launch(name);
 }
 

@@ -13,24 +13,29 @@ namespace {
 
 using namespace rlsh;   // GgxOp, GgxIO
 
-__device__ __forceinline__ Ggx load_closure(const rls_ggx_closure &c, int64_t i)
+template <bool STREAMED>
+__device__ __forceinline__ Ggx load_closure(const rls_ggx_closure &c, Idx i)
 {
     V3 wo = ld3(c.wo, i), N = ld3(c.N, i), T = ld3(c.T, i);
     float kr, kg, kb;
-    ldrgb(c.KsColor, i, kr, kg, kb);
-    float rough = ldp(c.specularRoughness, i);
-    float ior = ldp(c.ior, i);
-    float aniso = ldp(c.anisotropic, i);
-    bool exiting = c.exiting ? (c.exiting[i] != 0) : false;
+    ldrgb<STREAMED>(c.KsColor, i, kr, kg, kb);
+    float rough = ldp<STREAMED>(c.specularRoughness, i);
+    float ior = ldp<STREAMED>(c.ior, i);
+    float aniso = ldp<STREAMED>(c.anisotropic, i);
+    bool exiting = c.exiting ? (c.exiting[i.full()] != 0) : false;
     return ggx_make(wo, N, T, exiting, kr, kg, kb, ior, rough, aniso);
 }
 
-template <int OP, int FAST_MATH = RLS_FAST>   // FAST_MATH only tags the kernel name (profiles tell the two builds apart)
+// FAST_MATH only tags the kernel name (profiles tell the two builds apart); STREAMED: every closure
+// parameter is a per-point plane (no stream-or-uniform tests in the loop)
+template <int OP, int FAST_MATH, bool STREAMED>
 __global__ RLS_KERNEL_ATTR void ggx_kernel(GgxIO a)
 {
     const int64_t stride = (int64_t)gridDim.x * rlsh::kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * rlsh::kBlock + threadIdx.x; i < a.n; i += stride) {
-        Ggx g = load_closure(a.c, i);
+    for (int64_t base = (int64_t)blockIdx.x * rlsh::kBlock; base < a.n; base += stride) {
+        const Idx i = make_idx(base);
+        if (i.full() >= a.n) continue;
+        Ggx g = load_closure<STREAMED>(a.c, i);
 
         if (OP == OP_SAMPLE || OP == OP_FUSED || OP == OP_REFLECT_REFRACT) {
             float rx = ldg(a.rx, i), ry = ldg(a.ry, i);
@@ -70,7 +75,7 @@ __global__ RLS_KERNEL_ATTR void ggx_kernel(GgxIO a)
             bool ok = ggx_refract(g, M, dir);
             st3(a.wt, i, dir);
             stg(a.weight, i, ggx_sample_weight(g, g.view, dir, M));
-            if (a.refracted) a.refracted[i] = ok ? 1 : 0;
+            if (a.refracted) a.refracted[i.full()] = ok ? 1 : 0;
         } else if (OP == OP_MICROFACET) {
             float rx = ldg(a.rx, i), ry = ldg(a.ry, i);
             V3 M;
@@ -99,7 +104,16 @@ rls_status check_closure(const rls_ggx_closure *c)
 template <int OP>
 rls_status launch_kernel(rls_context *ctx, const GgxIO &io, const char *name)
 {
-    hipLaunchKernelGGL(ggx_kernel<OP>, rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
+    const rls_ggx_closure &c = io.c;
+#ifdef RLS_NO_STREAMED   // experiment switch
+    const bool streamed = false;
+#else
+    const bool streamed = c.KsColor.r && c.specularRoughness.v && c.ior.v && c.anisotropic.v;
+#endif
+    if (streamed)
+        hipLaunchKernelGGL((ggx_kernel<OP, RLS_FAST, true>), rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
+    else
+        hipLaunchKernelGGL((ggx_kernel<OP, RLS_FAST, false>), rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
     return rlsh::check_launch(name);
 }
 

@@ -918,4 +918,44 @@ RLS_DEV float hash_u01(uint32_t seed, uint64_t index, uint32_t stream)
 RLS_DEV float ldg(const float *p, int64_t i) { return __builtin_nontemporal_load(p + i); }
 RLS_DEV void stg(float *p, int64_t i, float v) { __builtin_nontemporal_store(v, p + i); }
 
+// A point index split into a wave-uniform 64-bit part and a 32-bit lane part: `p + base` is scalar
+// arithmetic and the access becomes global_load_dword v, v_lane_offset, s[base] -- no 64-bit vector
+// add per plane (31 planes per point in the reflect+refract kernel).
+struct Idx {
+    int64_t base;     // first point of this workgroup's tile in this iteration
+    uint32_t lane;    // threadIdx.x
+    uint32_t byte;    // 4 * threadIdx.x, the 32-bit vector offset of the access
+    RLS_DEV int64_t full() const { return base + (int64_t)lane; }
+};
+// The empty asm keeps the zero-extension of the lane's byte offset inside the loop body: hoisted out
+// of it (as a 64-bit register pair) instruction selection no longer sees "uniform base + zext(32-bit
+// offset)" and falls back to a 64-bit vector add per access.
+RLS_DEV Idx make_idx(int64_t base)
+{
+    uint32_t byte = threadIdx.x * 4u;
+    asm volatile("" : "+v"(byte));
+    Idx i = { base, threadIdx.x, byte };
+    return i;
+}
+#ifdef RLS_NO_SADDR   // experiment switch: 64-bit vector addressing
+RLS_DEV const float *at(const float *p, Idx i) { return p + i.full(); }
+RLS_DEV float *at(float *p, Idx i) { return p + i.full(); }
+#else
+RLS_DEV const float *at(const float *p, Idx i)
+{
+    return reinterpret_cast<const float *>(reinterpret_cast<const char *>(p + i.base) + i.byte);
+}
+RLS_DEV float *at(float *p, Idx i)
+{
+    return reinterpret_cast<float *>(reinterpret_cast<char *>(p + i.base) + i.byte);
+}
+#endif
+RLS_DEV float ldg(const float *p, Idx i) { return __builtin_nontemporal_load(at(p, i)); }
+RLS_DEV void stg(float *p, Idx i, float v)
+{
+    // stores sit in later basic blocks than make_idx(): renew the barrier so the zext is local again
+    asm volatile("" : "+v"(i.byte));
+    __builtin_nontemporal_store(v, at(p, i));
+}
+
 } // namespace rlsd

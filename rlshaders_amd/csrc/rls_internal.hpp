@@ -182,16 +182,23 @@ inline bool ok_rgb(const rls_param_rgb &p) { return (p.r && p.g && p.b) || (!p.r
 // device-side views of the ABI structs ---------------------------------------------------------
 namespace rlsd {
 
-RLS_DEV float ldp(const rls_param &p, int64_t i) { return p.v ? ldg(p.v, i) : p.u; }
-RLS_DEV V3 ld3(const rls_cvec3 &p, int64_t i) { return mk(ldg(p.x, i), ldg(p.y, i), ldg(p.z, i)); }
-RLS_DEV void st3(const rls_vec3 &p, int64_t i, V3 v) { stg(p.x, i, v.x); stg(p.y, i, v.y); stg(p.z, i, v.z); }
-RLS_DEV void strgb(const rls_rgb &p, int64_t i, float r, float g, float b)
+// I: int64_t or Idx.  STREAMED: every optional parameter plane is present (checked on the host), so the
+// per-parameter "stream or uniform" test -- a scalar branch per parameter per iteration -- disappears.
+template <bool STREAMED = false, class I>
+RLS_DEV float ldp(const rls_param &p, I i) { return (STREAMED || p.v) ? ldg(p.v, i) : p.u; }
+template <class I>
+RLS_DEV V3 ld3(const rls_cvec3 &p, I i) { return mk(ldg(p.x, i), ldg(p.y, i), ldg(p.z, i)); }
+template <class I>
+RLS_DEV void st3(const rls_vec3 &p, I i, V3 v) { stg(p.x, i, v.x); stg(p.y, i, v.y); stg(p.z, i, v.z); }
+template <class I>
+RLS_DEV void strgb(const rls_rgb &p, I i, float r, float g, float b)
 {
     stg(p.r, i, r); stg(p.g, i, g); stg(p.b, i, b);
 }
-RLS_DEV void ldrgb(const rls_param_rgb &p, int64_t i, float &r, float &g, float &b)
+template <bool STREAMED = false, class I>
+RLS_DEV void ldrgb(const rls_param_rgb &p, I i, float &r, float &g, float &b)
 {
-    if (p.r) { r = ldg(p.r, i); g = ldg(p.g, i); b = ldg(p.b, i); }
+    if (STREAMED || p.r) { r = ldg(p.r, i); g = ldg(p.g, i); b = ldg(p.b, i); }
     else { r = p.ur; g = p.ug; b = p.ub; }
 }
 

@@ -33,12 +33,15 @@ __device__ __forceinline__ LobeOut ggx_lobe(V3 wo, V3 N, V3 T, V3 local, float c
     return o;
 }
 
-template <int FAST_MATH = RLS_FAST>
+// STREAMED: every parameter is a per-point plane (checked on the host)
+template <int FAST_MATH, bool STREAMED>
 __global__ __launch_bounds__(rlsh::kBlock) void skin_kernel(SkinIO a)
 {
     stage_libm_tables();   // expf / logf tables -> LDS (EXACT mode)
     const int64_t stride = (int64_t)gridDim.x * rlsh::kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * rlsh::kBlock + threadIdx.x; i < a.n; i += stride) {
+    for (int64_t base = (int64_t)blockIdx.x * rlsh::kBlock; base < a.n; base += stride) {
+        const Idx i = make_idx(base);
+        if (i.full() >= a.n) continue;
         const rls_skin_closure &c = a.c;
         V3 wo = ld3(c.wo, i), N = ld3(c.N, i), T = ld3(c.T, i);
 
@@ -48,31 +51,31 @@ __global__ __launch_bounds__(rlsh::kBlock) void skin_kernel(SkinIO a)
         gfr.N = N; gfr.U = T; gfr.V = cross(N, T);
         V3 local = vndf_local(wo, gfr);
 
-        float sheenWeight = ldp(c.sheen_weight, i);
+        float sheenWeight = ldp<STREAMED>(c.sheen_weight, i);
         float shr, shg, shb;
-        ldrgb(c.sheen_color, i, shr, shg, shb);
-        float sheenIor = ldp(c.sheen_ior, i), sheenRough = ldp(c.sheen_roughness, i);
+        ldrgb<STREAMED>(c.sheen_color, i, shr, shg, shb);
+        float sheenIor = ldp<STREAMED>(c.sheen_ior, i), sheenRough = ldp<STREAMED>(c.sheen_roughness, i);
         float rx0 = ldg(a.xi[0], i), ry0 = ldg(a.xi[1], i);
         if (sheenWeight > kEps) {                                           // src/rlSkin.cpp:191
             sh = ggx_lobe(wo, N, T, local, shr, shg, shb, sheenIor, sheenRough, rx0, ry0);
             sheenFresnel = sh.F * sheenWeight;                              // :204 (one sample)
         }
 
-        float specWeight = ldp(c.specular_weight, i);
+        float specWeight = ldp<STREAMED>(c.specular_weight, i);
         float spr, spg, spb;
-        ldrgb(c.specular_color, i, spr, spg, spb);
-        float specIor = ldp(c.specular_ior, i), specRough = ldp(c.specular_roughness, i);
+        ldrgb<STREAMED>(c.specular_color, i, spr, spg, spb);
+        float specIor = ldp<STREAMED>(c.specular_ior, i), specRough = ldp<STREAMED>(c.specular_roughness, i);
         float rx1 = ldg(a.xi[2], i), ry1 = ldg(a.xi[3], i);
         if (specWeight > kEps) {                                            // :214
             sp = ggx_lobe(wo, N, T, local, spr, spg, spb, specIor, specRough, rx1, ry1);
             specularFresnel = sp.F * specWeight;                            // :228
         }
 
-        float mult = ldp(c.sss_dist_multiplier, i);                         // :235-236
-        float dx = ldp(c.sss_scatter_dist[0], i) * mult;
-        float dy = ldp(c.sss_scatter_dist[1], i) * mult;
-        float dz = ldp(c.sss_scatter_dist[2], i) * mult;
-        float sssWeight = ldp(c.sss_weight, i);
+        float mult = ldp<STREAMED>(c.sss_dist_multiplier, i);                         // :235-236
+        float dx = ldp<STREAMED>(c.sss_scatter_dist[0], i) * mult;
+        float dy = ldp<STREAMED>(c.sss_scatter_dist[1], i) * mult;
+        float dz = ldp<STREAMED>(c.sss_scatter_dist[2], i) * mult;
+        float sssWeight = ldp<STREAMED>(c.sss_weight, i);
         sssWeight *= 1.0f - specularFresnel * (1.0f - sheenFresnel);        // :238
         float rx2 = ldg(a.xi[4], i), ry2 = ldg(a.xi[5], i);
 
@@ -101,7 +104,15 @@ __global__ __launch_bounds__(rlsh::kBlock) void skin_kernel(SkinIO a)
 
 rls_status launch_kernel(rls_context *ctx, const SkinIO &io, const char *name)
 {
-    hipLaunchKernelGGL(skin_kernel<>, rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
+    const rls_skin_closure &c = io.c;
+    const bool streamed = c.sss_color.r && c.sss_weight.v && c.sss_dist_multiplier.v && c.sss_scatter_dist[0].v &&
+                          c.sss_scatter_dist[1].v && c.sss_scatter_dist[2].v && c.specular_color.r &&
+                          c.specular_weight.v && c.specular_roughness.v && c.specular_ior.v && c.sheen_color.r &&
+                          c.sheen_weight.v && c.sheen_roughness.v && c.sheen_ior.v;
+    if (streamed)
+        hipLaunchKernelGGL((skin_kernel<RLS_FAST, true>), rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
+    else
+        hipLaunchKernelGGL((skin_kernel<RLS_FAST, false>), rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
     return rlsh::check_launch(name);
 }
 

@@ -17,7 +17,8 @@ enum { OP_ND = rlsh::SOP_ND, OP_ND_PDF = rlsh::SOP_ND_PDF, OP_ND_EVAL = rlsh::SO
        OP_MIS = rlsh::SOP_MIS };
 enum { OP_CAVITY = rlsh::MOP_CAVITY, OP_DIFFUSE_DIR = rlsh::MOP_DIFFUSE_DIR, OP_UTIL = rlsh::MOP_UTIL };
 
-__device__ __forceinline__ NdProfile load_profile(const rls_sss_closure &c, int64_t i)
+template <class I>
+__device__ __forceinline__ NdProfile load_profile(const rls_sss_closure &c, I i)
 {
     // scatterDist = sss_scatter_dist * sss_dist_multiplier (src/rlSkin.cpp:235-236)
     float m = ldp(c.sss_dist_multiplier, i);
@@ -32,7 +33,9 @@ __global__ __launch_bounds__(rlsh::kBlock) void sss_kernel(SssIO a)
 {
     stage_libm_tables();   // expf / logf tables -> LDS (EXACT mode)
     const int64_t stride = (int64_t)gridDim.x * rlsh::kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * rlsh::kBlock + threadIdx.x; i < a.n; i += stride) {
+    for (int64_t base = (int64_t)blockIdx.x * rlsh::kBlock; base < a.n; base += stride) {
+        const Idx i = make_idx(base);
+        if (i.full() >= a.n) continue;
         NdProfile p = load_profile(a.c, i);
         if (OP == OP_ND) {
             float r = nd_radius(p, ldg(a.rx, i));
@@ -73,7 +76,9 @@ template <int OP, int FAST_MATH = RLS_FAST>
 __global__ __launch_bounds__(rlsh::kBlock) void misc_kernel(MiscIO a)
 {
     const int64_t stride = (int64_t)gridDim.x * rlsh::kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * rlsh::kBlock + threadIdx.x; i < a.n; i += stride) {
+    for (int64_t base = (int64_t)blockIdx.x * rlsh::kBlock; base < a.n; base += stride) {
+        const Idx i = make_idx(base);
+        if (i.full() >= a.n) continue;
         if (OP == OP_CAVITY) {
             V3 disp = ld3(a.a, i);
             stg(a.out, i, sss_cavity_fade(disp, length(disp), ld3(a.b, i), ld3(a.c, i)));

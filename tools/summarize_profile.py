@@ -15,8 +15,9 @@ def pmc(dirname, sub):
 def main():
     tag = sys.argv[1]
     workload = sys.argv[2] if len(sys.argv) > 2 else "ggx_reflect_refract"
-    # kernels carry their arithmetic mode as a trailing template argument: <OP, 0> = EXACT, <OP, 1> = FAST
-    ksub = sys.argv[3] if len(sys.argv) > 3 else "ggx_kernel<5, 0>"
+    # kernels carry their arithmetic mode as a template argument: <OP, 0, ...> = EXACT, <OP, 1, ...> = FAST
+    # (the last argument says whether every closure parameter is a per-point plane)
+    ksub = sys.argv[3] if len(sys.argv) > 3 else "ggx_kernel<5, 0,"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = os.path.join(root, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(root, "profiles")

@@ -118,6 +118,21 @@ rls_status  rls_timer_start(rls_context *ctx);
 rls_status  rls_timer_stop(rls_context *ctx);
 rls_status  rls_timer_elapsed_ms(rls_context *ctx, float *ms);   /* synchronises on the stop event */
 
+/* Launch graphs.  A renderer that flushes small batches (a bucket's worth of shading points) through
+ * the same device buffers again and again is launch-bound, not kernel-bound: record the rls_* calls of
+ * one flush once and replay them as a single HIP graph launch.  Between begin and end every closure /
+ * integrator / generator entry point called on this context from this thread is recorded instead
+ * of executed (same arguments, same math mode); calls that synchronise with the host --
+ * rls_context_synchronize, rls_copy_*, rls_checksum, rls_timer_elapsed_ms, rls_device_alloc/free --
+ * are not allowed while recording.  The context must be on a real stream (its own, or one given to
+ * rls_context_set_stream), not on the NULL stream.  No reference counterpart (Arnold calls the
+ * closures inline, src/rlGgx.cpp:286-295). */
+typedef struct rls_graph rls_graph;
+rls_status  rls_graph_begin_capture(rls_context *ctx);
+rls_status  rls_graph_end_capture(rls_context *ctx, rls_graph **out);
+rls_status  rls_graph_launch(rls_context *ctx, rls_graph *graph);      /* asynchronous, on the context's stream */
+void        rls_graph_destroy(rls_graph *graph);
+
 /* ------------------------------------------------------------------------------------------
  * rlGgx closure: rls::GgxSamplerT<VNDFKernel>  (src/rlGgx.h:92-373, src/rlGgx.cpp:14-99)
  * Parameter names: src/rlGgx.cpp:172-186 (KsColor, specularRoughness, ior, anisotropic).

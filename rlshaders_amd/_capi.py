@@ -139,6 +139,10 @@ PROTOTYPES = {
     "rls_timer_start": (C.c_int, [_ctx]),
     "rls_timer_stop": (C.c_int, [_ctx]),
     "rls_timer_elapsed_ms": (C.c_int, [_ctx, C.POINTER(C.c_float)]),
+    "rls_graph_begin_capture": (C.c_int, [_ctx]),
+    "rls_graph_end_capture": (C.c_int, [_ctx, C.POINTER(_vp)]),
+    "rls_graph_launch": (C.c_int, [_ctx, _vp]),
+    "rls_graph_destroy": (None, [_vp]),
     # rlGgx
     "rls_ggx_sample": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), _vp, _vp, Vec3, _vp]),
     "rls_ggx_eval": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), CVec3, Rgb]),

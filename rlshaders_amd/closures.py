@@ -53,6 +53,12 @@ class Context:
     def synchronize(self) -> None:
         check(self.lib.rls_context_synchronize(self.handle))
 
+    def capture(self) -> "GraphCapture":
+        """``with ctx.capture() as g: <closure calls>`` records the calls into a launch graph instead of
+        running them; afterwards ``g.launch()`` replays them in one go (rls_graph_*).  The outputs must be
+        passed in (``out=...``): tensors allocated while recording would be freed before the replay."""
+        return GraphCapture(self)
+
     def timer_start(self) -> None:
         check(self.lib.rls_timer_start(self.handle))
 
@@ -87,6 +93,43 @@ class Context:
     # -- helpers --------------------------------------------------------------------------------
     def empty(self, *shape) -> torch.Tensor:
         return torch.empty(*shape, dtype=torch.float32, device=self.torch_device)
+
+
+class GraphCapture:
+    """A recorded sequence of closure launches (rls_graph)."""
+
+    def __init__(self, ctx: Context):
+        self.ctx, self.handle = ctx, None
+
+    def __enter__(self):
+        check(self.ctx.lib.rls_graph_begin_capture(self.ctx.handle))
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        h = C.c_void_p()
+        st = self.ctx.lib.rls_graph_end_capture(self.ctx.handle, C.byref(h))
+        if exc_type is None:
+            check(st)
+            self.handle = h
+        elif st == 0:
+            self.ctx.lib.rls_graph_destroy(h)
+        return False
+
+    def launch(self) -> None:
+        if self.handle is None:
+            raise RuntimeError("GraphCapture.launch: nothing was recorded")
+        check(self.ctx.lib.rls_graph_launch(self.ctx.handle, self.handle))
+
+    def close(self) -> None:
+        if self.handle is not None:
+            self.ctx.lib.rls_graph_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _chk(t: torch.Tensor, n: Optional[int], rows: Optional[int], what: str) -> None:
@@ -199,11 +242,12 @@ class GgxSampler:
                                               plane(F, n, "fresnel")))
         return wi, f, pdf, F
 
-    def refractSample(self, rx, ry):
-        """Per-sample body of integrateRefract (src/rlGgx.h:228-242) -> (wt, weight, refracted)."""
+    def refractSample(self, rx, ry, out=None):
+        """Per-sample body of integrateRefract (src/rlGgx.h:228-242) -> (wt, weight, refracted);
+        ``out`` = (wt, weight) or (wt, weight, refracted)."""
         n, ctx = self.n, self.ctx
-        wt, w = ctx.empty(3, n), ctx.empty(n)
-        flag = torch.empty(n, dtype=torch.uint8, device=ctx.torch_device)
+        wt, w = (out[0], out[1]) if out is not None else (ctx.empty(3, n), ctx.empty(n))
+        flag = out[2] if out is not None and len(out) > 2 else torch.empty(n, dtype=torch.uint8, device=ctx.torch_device)
         check(ctx.lib.rls_ggx_refract_sample(ctx.handle, n, C.byref(self.c), plane(rx, n, "rx"), plane(ry, n, "ry"),
                                              vec3(wt, n, "wt"), plane(w, n, "weight"), flag.data_ptr()))
         return wt, w, flag

@@ -100,6 +100,11 @@ void rls_context_destroy(rls_context *ctx)
     (void)hipSetDevice(ctx->device);
     // work queued on the context's own stream must not outlive the context's scratch memory; a
     // caller-provided stream is the caller's to drain
+    if (ctx->capturing) {   // abandon an unfinished recording
+        hipGraph_t g = nullptr;
+        if (hipStreamEndCapture(ctx->stream, &g) == hipSuccess && g) (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+    }
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     if (ctx->scratch_u64) (void)hipFree(ctx->scratch_u64);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
@@ -111,6 +116,7 @@ void rls_context_destroy(rls_context *ctx)
 rls_status rls_context_set_stream(rls_context *ctx, void *hip_stream)
 {
     RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_REQUIRE(!ctx->capturing, "not allowed while a launch graph is being recorded");
     ctx->stream = (hipStream_t)hip_stream;
     return RLS_OK;
 }
@@ -118,6 +124,7 @@ rls_status rls_context_set_stream(rls_context *ctx, void *hip_stream)
 rls_status rls_context_use_own_stream(rls_context *ctx)
 {
     RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_REQUIRE(!ctx->capturing, "not allowed while a launch graph is being recorded");
     ctx->stream = ctx->own_stream;
     return RLS_OK;
 }
@@ -139,6 +146,7 @@ int rls_context_device(const rls_context *ctx) { return ctx ? ctx->device : -1; 
 rls_status rls_context_synchronize(rls_context *ctx)
 {
     RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_REQUIRE(!ctx->capturing, "not allowed while a launch graph is being recorded");
     RLS_HIP_TRY(hipStreamSynchronize(ctx->stream));
     return RLS_OK;
 }
@@ -167,6 +175,7 @@ rls_status rls_device_info(rls_context *ctx, int *compute_units, size_t *hbm_tot
 rls_status rls_device_alloc(rls_context *ctx, size_t bytes, void **out)
 {
     RLS_REQUIRE(ctx != nullptr && out != nullptr, "NULL argument");
+    RLS_REQUIRE(!ctx->capturing, "not allowed while a launch graph is being recorded");
     *out = nullptr;
     if (bytes == 0) return RLS_OK;
     RLS_HIP_TRY(hipSetDevice(ctx->device));
@@ -177,6 +186,7 @@ rls_status rls_device_alloc(rls_context *ctx, size_t bytes, void **out)
 rls_status rls_device_free(rls_context *ctx, void *p)
 {
     RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_REQUIRE(!ctx->capturing, "not allowed while a launch graph is being recorded");
     if (!p) return RLS_OK;
     RLS_HIP_TRY(hipSetDevice(ctx->device));
     RLS_HIP_TRY(hipFree(p));
@@ -186,6 +196,7 @@ rls_status rls_device_free(rls_context *ctx, void *p)
 rls_status rls_copy_to_device(rls_context *ctx, void *dst, const void *src_host, size_t bytes)
 {
     RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_REQUIRE(!ctx->capturing, "not allowed while a launch graph is being recorded");
     if (bytes == 0) return RLS_OK;
     RLS_REQUIRE(dst != nullptr && src_host != nullptr, "NULL buffer");
     RLS_HIP_TRY(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -196,6 +207,7 @@ rls_status rls_copy_to_device(rls_context *ctx, void *dst, const void *src_host,
 rls_status rls_copy_to_host(rls_context *ctx, void *dst_host, const void *src, size_t bytes)
 {
     RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_REQUIRE(!ctx->capturing, "not allowed while a launch graph is being recorded");
     if (bytes == 0) return RLS_OK;
     RLS_REQUIRE(dst_host != nullptr && src != nullptr, "NULL buffer");
     RLS_HIP_TRY(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -220,9 +232,73 @@ rls_status rls_timer_stop(rls_context *ctx)
 rls_status rls_timer_elapsed_ms(rls_context *ctx, float *ms)
 {
     RLS_REQUIRE(ctx != nullptr && ms != nullptr, "NULL argument");
+    RLS_REQUIRE(!ctx->capturing, "not allowed while a launch graph is being recorded");
     RLS_HIP_TRY(hipEventSynchronize(ctx->ev_stop));
     RLS_HIP_TRY(hipEventElapsedTime(ms, ctx->ev_start, ctx->ev_stop));
     return RLS_OK;
+}
+
+// ---- launch graphs ---------------------------------------------------------------------------
+struct rls_graph {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    int device;
+};
+
+rls_status rls_graph_begin_capture(rls_context *ctx)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_REQUIRE(ctx->stream != nullptr, "the NULL stream cannot be captured: use the context's own stream");
+    RLS_REQUIRE(!ctx->capturing, "a capture is already in progress on this context");
+    RLS_HIP_TRY(hipSetDevice(ctx->device));
+    // thread-local: other host threads driving other contexts keep running normally
+    RLS_HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    ctx->capturing = 1;
+    return RLS_OK;
+}
+
+rls_status rls_graph_end_capture(rls_context *ctx, rls_graph **out)
+{
+    RLS_REQUIRE(ctx != nullptr && out != nullptr, "NULL argument");
+    RLS_REQUIRE(ctx->capturing, "no capture in progress");
+    *out = nullptr;
+    ctx->capturing = 0;
+    hipGraph_t graph = nullptr;
+    RLS_HIP_TRY(hipStreamEndCapture(ctx->stream, &graph));
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(graph);
+        return rlsh::hip_fail(e, "hipGraphInstantiate");
+    }
+    rls_graph *g = (rls_graph *)calloc(1, sizeof(rls_graph));
+    if (!g) {
+        (void)hipGraphExecDestroy(exec);
+        (void)hipGraphDestroy(graph);
+        rlsh::set_error("rls_graph_end_capture: out of host memory");
+        return RLS_ERR_HIP;
+    }
+    g->graph = graph; g->exec = exec; g->device = ctx->device;
+    *out = g;
+    return RLS_OK;
+}
+
+rls_status rls_graph_launch(rls_context *ctx, rls_graph *graph)
+{
+    RLS_REQUIRE(ctx != nullptr && graph != nullptr, "NULL argument");
+    RLS_REQUIRE(graph->device == ctx->device, "graph was recorded on another device");
+    RLS_REQUIRE(!ctx->capturing, "a capture is in progress on this context");
+    RLS_HIP_TRY(hipSetDevice(ctx->device));
+    RLS_HIP_TRY(hipGraphLaunch(graph->exec, ctx->stream));
+    return RLS_OK;
+}
+
+void rls_graph_destroy(rls_graph *graph)
+{
+    if (!graph) return;
+    (void)hipGraphExecDestroy(graph->exec);
+    (void)hipGraphDestroy(graph->graph);
+    free(graph);
 }
 
 } // extern "C"
@@ -363,6 +439,7 @@ rls_status rls_gen_aniso(rls_context *ctx, uint32_t seed, uint64_t first_index, 
 rls_status rls_checksum(rls_context *ctx, int64_t n, const float *data, uint64_t *out_host)
 {
     RLS_REQUIRE(ctx != nullptr && out_host != nullptr, "NULL argument");
+    RLS_REQUIRE(!ctx->capturing, "not allowed while a launch graph is being recorded");
     RLS_REQUIRE(n >= 0, "n < 0");
     *out_host = 0;
     if (n == 0) return RLS_OK;

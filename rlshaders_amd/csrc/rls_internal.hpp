@@ -17,6 +17,7 @@ struct rls_context {
     hipEvent_t ev_start, ev_stop;
     unsigned long long *scratch_u64;   // device, 8 bytes (checksum accumulator)
     int fast;                 // RLS_MATH_FAST selected (rls_context_set_math_mode)
+    int capturing;            // between rls_graph_begin_capture and rls_graph_end_capture
 };
 
 // Every kernel translation unit is compiled twice: with RLS_FAST=0 it carries the C ABI and the

@@ -73,6 +73,21 @@ int main(int argc, char **argv)
         for (size_t i = 0; i < hp.size(); i++)
             if (hp[i] != hp2[i]) { std::fprintf(stderr, "fused pdf != separate at %zu\n", i); return 1; }
 
+        // --- the same flush recorded once and replayed as one graph launch ---------------------------------
+        rlsb::Planes L3(dev, n, 3), f3(dev, n, 3), pdf3(dev, n, 1), F3(dev, n, 1);
+        rlsb::Graph flush(dev, [&] {
+            sampler.evalSample(drx, dry, L3, F3);
+            sampler.evalBrdf(L3, f3);
+            sampler.evalPdf(L3, pdf3);
+        });
+        flush.launch();
+        dev.synchronize();
+        std::vector<float> hf3 = f3.download(), hp3 = pdf3.download();
+        for (size_t i = 0; i < hf.size(); i++)
+            if (hf[i] != hf3[i]) { std::fprintf(stderr, "graph replay != direct at %zu\n", i); return 1; }
+        for (size_t i = 0; i < hp.size(); i++)
+            if (hp[i] != hp3[i]) { std::fprintf(stderr, "graph replay pdf != direct at %zu\n", i); return 1; }
+
         // --- rlSkin on the same shading points (defaults of src/rlSkin.cpp:109-128, sheen switched on) ---
         rlsb::SkinParams sp;
         sp.sheen_weight = rlsb::Param(0.25f);

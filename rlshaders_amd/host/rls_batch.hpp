@@ -54,6 +54,34 @@ private:
     rls_context *ctx_ = nullptr;
 };
 
+// A recorded flush (rls_graph): `Graph g(dev, [&] { sampler.evalSample(...); sampler.evalBrdf(...); });`
+// records the calls the callable makes on `dev` instead of running them; g.launch() replays them as one
+// HIP graph launch on the same buffers -- for a stub that flushes small batches every bucket.
+class Graph {
+public:
+    template <typename Calls>
+    Graph(const Device &d, Calls &&calls) : dev_(d)
+    {
+        check(rls_graph_begin_capture(d.ctx()));
+        try {
+            calls();
+        } catch (...) {
+            rls_graph *g = nullptr;
+            if (rls_graph_end_capture(d.ctx(), &g) == RLS_OK) rls_graph_destroy(g);
+            throw;
+        }
+        check(rls_graph_end_capture(d.ctx(), &g_));
+    }
+    ~Graph() { rls_graph_destroy(g_); }
+    Graph(const Graph &) = delete;
+    Graph &operator=(const Graph &) = delete;
+    void launch() const { check(rls_graph_launch(dev_.ctx(), g_)); }
+
+private:
+    const Device &dev_;
+    rls_graph *g_ = nullptr;
+};
+
 // n x planes floats in device memory, planar (plane p occupies [p*n, (p+1)*n)).
 class Planes {
 public:

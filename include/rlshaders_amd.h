@@ -184,6 +184,36 @@ rls_status rls_ggx_integrate(rls_context *ctx, int64_t n, const rls_ggx_closure 
                              int spp_n, uint32_t seed,
                              rls_rgb sum_f_over_pdf, float *avg_reflect_weight);
 
+/* Direct lighting of the rlGgx node: the light loop of shader_evaluate (src/rlGgx.cpp:274-299) --
+ *     diffuse  += AiEvaluateLightSample(sg, diffData, AiOrenNayarMISSample, ..BRDF, ..PDF)
+ *     specular += sampler.evalLightSample(sg)        (AiEvaluateLightSample over the GGX triple,
+ *                                                      src/rlGgx.h:167-170)
+ * followed by diffuse *= KdColor * Kd and specular *= Ks: the two direct AOVs (src/rlGgx.cpp:307-308).
+ * Arnold's light loop, AiEvaluateLightSample and the Oren-Nayar MIS closure are closed; documented
+ * stand-ins (parity unpinned): one spherical area light sampled uniformly over the cone it subtends
+ * from sg->P, no occluders; the qualitative Oren-Nayar model (SIGGRAPH'94) with cosine-weighted
+ * sampling about N; the two-sample estimator with the power heuristic w_a = p_a^2 / (p_a^2 + p_b^2)
+ * over spp_n^2 light samples (shared by both lobes) and spp_n^2 BSDF samples per lobe; directions below
+ * the shading normal contribute nothing.  The per-point partial sums of the G lanes that share a
+ * shading point are reduced with wave shuffles.  mis_mode selects the estimator: both strategies, light
+ * samples only, BSDF samples only -- equal in expectation when sample / eval / pdf are consistent. */
+#define RLS_MIS_BOTH       0
+#define RLS_MIS_LIGHT_ONLY 1
+#define RLS_MIS_BSDF_ONLY  2
+typedef struct rls_sphere_light {
+    float center[3], radius;
+    float radiance[3];
+    int   mis_mode;
+} rls_sphere_light;
+/* the node parameters of the light loop that are not part of the specular closure (src/rlGgx.cpp:170-175) */
+typedef struct rls_ggx_shader {
+    rls_param_rgb KdColor;
+    rls_param     Kd, diffuseRoughness, Ks;
+} rls_ggx_shader;
+rls_status rls_ggx_direct_lighting(rls_context *ctx, int64_t n, const rls_ggx_closure *c, const rls_ggx_shader *sh,
+                                   rls_cvec3 P, const rls_sphere_light *light, int spp_n, uint32_t seed,
+                                   rls_rgb direct_diffuse, rls_rgb direct_specular);
+
 /* ------------------------------------------------------------------------------------------
  * rlDisney closure: DisneySampler (src/rlDisney.cpp:105-602)
  * Parameter names: src/rlDisney.cpp:606-610.

@@ -1598,6 +1598,147 @@ void orc_batch_sss_integrate_scatter(int64_t n, const orc_sss_soa *in, int has_d
     parallel_for(n, nthreads, scatter_range, &j);
 }
 
+/* ============================== rlGgx direct lighting ================================== */
+/* src/rlGgx.cpp:274-299 with stand-ins for the closed light loop (see rls_oracle.h) */
+
+void orc_oren_nayar_init(orc_oren_nayar *o, orc_v3 N, orc_v3 T, float sigma)
+{
+    float s2 = sigma * sigma;
+    o->N = N; o->T = T;
+    o->A = 1.0f - 0.5f * (s2 / (s2 + 0.33f));
+    o->B = 0.45f * (s2 / (s2 + 0.09f));
+}
+
+float orc_oren_nayar_brdf(const orc_oren_nayar *o, orc_v3 wo, orc_v3 wi)
+{
+    float ci = v3dot(o->N, wi), co = v3dot(o->N, wo);
+    if (!(ci > 0.0f) || !(co > 0.0f)) return 0.0f;
+    float si = sqrtf(MAXf(0.0f, 1.0f - ci * ci)), so = sqrtf(MAXf(0.0f, 1.0f - co * co));
+    float cphi = 0.0f;
+    if (si > AI_EPSILON && so > AI_EPSILON) cphi = MAXf(0.0f, (v3dot(wi, wo) - ci * co) / (si * so));
+    float sinAlpha, tanBeta;                     /* alpha = max(theta_i, theta_o), beta = min */
+    if (ci > co) { sinAlpha = so; tanBeta = si / ci; }
+    else         { sinAlpha = si; tanBeta = so / co; }
+    return AI_ONEOVERPI * (o->A + o->B * cphi * sinAlpha * tanBeta) * ci;
+}
+
+float orc_oren_nayar_pdf(const orc_oren_nayar *o, orc_v3 wi)
+{
+    float ci = v3dot(o->N, wi);
+    return ci > 0.0f ? ci * AI_ONEOVERPI : 0.0f;
+}
+
+typedef struct { int valid; orc_v3 d, u, v, w; float c2, cosMax, pdf; } light_cone;
+
+/* the cone the sphere subtends from P: axis w, basis (u, v) (Duff et al. 2017), uniform pdf */
+static light_cone cone_make(const orc_light *lt, orc_v3 P)
+{
+    light_cone c;
+    memset(&c, 0, sizeof(c));
+    c.d = v3sub(arr3(lt->center), P);
+    float dist2 = v3dot(c.d, c.d), r2 = lt->radius * lt->radius;
+    c.c2 = dist2 - r2;
+    if (!(c.c2 > 0.0f)) return c;                 /* inside the light */
+    c.valid = 1;
+    float sin2 = r2 / dist2;
+    c.cosMax = sqrtf(MAXf(0.0f, 1.0f - sin2));
+    c.pdf = 1.0f / (AI_PITIMES2 * (sin2 / (1.0f + c.cosMax)));   /* 1 - cosMax = sin^2 / (1 + cosMax) */
+    float inv = 1.0f / sqrtf(dist2);
+    c.w = v3scale(c.d, inv);
+    float sg = copysignf(1.0f, c.w.z);
+    float a = -1.0f / (sg + c.w.z);
+    float b = c.w.x * c.w.y * a;
+    c.u = v3(1.0f + sg * c.w.x * c.w.x * a, sg * b, -sg * c.w.x);
+    c.v = v3(b, sg + c.w.y * c.w.y * a, -c.w.y);
+    return c;
+}
+
+static orc_v3 cone_sample(const light_cone *c, float rx, float ry)
+{
+    float ct = 1.0f - rx * (1.0f - c->cosMax);
+    float st = sqrtf(MAXf(0.0f, 1.0f - ct * ct));
+    float phi = AI_PITIMES2 * ry;
+    float x = st * cosf(phi), y = st * sinf(phi);
+    return v3add(v3add(v3scale(c->u, x), v3scale(c->v, y)), v3scale(c->w, ct));
+}
+
+static int cone_hit(const light_cone *c, orc_v3 dir)
+{
+    float b = v3dot(c->d, dir);
+    return b > 0.0f && !(b * b - c->c2 * v3dot(dir, dir) < 0.0f);
+}
+
+static inline float power_heuristic(float pa, float pb) { return (pa * pa) / (pa * pa + pb * pb); }
+
+typedef struct {
+    const orc_ggx_soa *in; const orc_ggx_shader_soa *sh; orc_cv3p P; const orc_light *lt; int spp; uint32_t seed;
+    orc_v3p dd, ds;
+} light_job;
+
+static void light_range(int64_t lo, int64_t hi, void *ctx)
+{
+    light_job *j = (light_job *)ctx;
+    const int mode = j->lt->mis_mode;
+    for (int64_t i = lo; i < hi; i++) {
+        orc_ggx g;
+        ggx_load(j->in, i, &g);
+        const orc_v3 N = ld3(j->in->N, i), T = ld3(j->in->T, i), wo = ld3(j->in->wo, i);
+        orc_oren_nayar on;
+        orc_oren_nayar_init(&on, N, T, j->sh->Kd_roughness[i]);
+        light_cone c = cone_make(j->lt, ld3(j->P, i));
+        float sR = 0.0f, sG = 0.0f, sB = 0.0f, dA = 0.0f;
+        for (int s = 0; s < j->spp && c.valid; s++) {
+            float rx, ry;
+            if (mode != 2) {                                   /* one light sample, both lobes */
+                orc_sample_02(j->seed, (uint64_t)i, 0, (uint32_t)s, &rx, &ry);
+                orc_v3 L = cone_sample(&c, rx, ry);
+                if (v3dot(L, N) > 0.0f) {
+                    orc_rgb f = orc_ggx_eval_brdf(&g, L);
+                    float pb = orc_ggx_eval_pdf(&g, L);
+                    float w = mode == 1 ? 1.0f : power_heuristic(c.pdf, pb);
+                    sR += f.r * w / c.pdf; sG += f.g * w / c.pdf; sB += f.b * w / c.pdf;
+                    float fd = orc_oren_nayar_brdf(&on, wo, L);
+                    float wd = mode == 1 ? 1.0f : power_heuristic(c.pdf, orc_oren_nayar_pdf(&on, L));
+                    dA += fd * wd / c.pdf;
+                }
+            }
+            if (mode != 1) {                                   /* one BSDF sample per lobe */
+                orc_sample_02(j->seed, (uint64_t)i, 1, (uint32_t)s, &rx, &ry);
+                orc_v3 L = orc_ggx_eval_sample(&g, rx, ry);
+                if (!v3iszero(L) && v3dot(L, N) > 0.0f && cone_hit(&c, L)) {
+                    orc_rgb f = orc_ggx_eval_brdf(&g, L);
+                    float pb = orc_ggx_eval_pdf(&g, L);
+                    float w = mode == 2 ? 1.0f : power_heuristic(pb, c.pdf);
+                    sR += f.r * w / pb; sG += f.g * w / pb; sB += f.b * w / pb;
+                }
+                orc_sample_02(j->seed, (uint64_t)i, 2, (uint32_t)s, &rx, &ry);
+                orc_v3 Ld = orc_sss_sample_diffuse_direction(rx, ry, N, T);
+                float pd = orc_oren_nayar_pdf(&on, Ld);
+                if (pd > 0.0f && cone_hit(&c, Ld)) {
+                    float fd = orc_oren_nayar_brdf(&on, wo, Ld);
+                    float wd = mode == 2 ? 1.0f : power_heuristic(pd, c.pdf);
+                    dA += fd * wd / pd;
+                }
+            }
+        }
+        const float inv = 1.0f / (float)j->spp;
+        const float ks = j->sh->Ks[i], kd = j->sh->Kd[i];
+        const orc_rgb kdc = ldc(j->sh->Kd_color, i);
+        const float *rad = j->lt->radiance;
+        stc(j->ds, i, rgb(rad[0] * ks * sR * inv, rad[1] * ks * sG * inv, rad[2] * ks * sB * inv));
+        stc(j->dd, i, rgb(rad[0] * (kdc.r * kd) * dA * inv, rad[1] * (kdc.g * kd) * dA * inv,
+                          rad[2] * (kdc.b * kd) * dA * inv));
+    }
+}
+
+void orc_batch_ggx_direct_lighting(int64_t n, const orc_ggx_soa *in, const orc_ggx_shader_soa *sh, orc_cv3p P,
+                                   const orc_light *light, int spp_n, uint32_t seed,
+                                   orc_v3p direct_diffuse, orc_v3p direct_specular, int nthreads)
+{
+    light_job j = { in, sh, P, light, spp_n * spp_n, seed, direct_diffuse, direct_specular };
+    parallel_for(n, nthreads, light_range, &j);
+}
+
 /* ================================ synthetic generator ================================== */
 /* Counter-based: value = f(seed, point index, stream id).  Integer hashing plus + - * / sqrt
  * only, so the device generator (rlshaders_amd/csrc/gen.hip) reproduces it bit for bit. */

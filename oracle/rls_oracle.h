@@ -313,6 +313,33 @@ void orc_batch_sss_integrate_scatter(int64_t n, const orc_sss_soa *in, int has_d
                                      const orc_scene *sc, int spp_n, uint32_t seed,
                                      orc_v3p result, float *mean_depth, int nthreads);
 
+/* Direct lighting of the rlGgx node (shader_evaluate's light loop, src/rlGgx.cpp:274-299): per light
+ * sample `diffuse += AiEvaluateLightSample(sg, diffData, AiOrenNayarMIS*)` and `specular +=
+ * sampler.evalLightSample(sg)` (= AiEvaluateLightSample over the GGX triple, src/rlGgx.h:167-170),
+ * then diffuse *= Kd_color * Kd, specular *= Ks.  Arnold's light loop, AiEvaluateLightSample and the
+ * Oren-Nayar MIS closure are closed; documented stand-ins (parity unpinned): one spherical area light
+ * sampled uniformly over the cone it subtends, the qualitative Oren-Nayar model (SIGGRAPH'94) with
+ * cosine-weighted sampling, and the two-sample estimator with the power heuristic
+ * w_a = p_a^2 / (p_a^2 + p_b^2) over spp_n^2 light samples and spp_n^2 BSDF samples per lobe.
+ * mis_mode 1 / 2 keep only the light / only the BSDF samples (weight 1): the three modes have the same
+ * expectation, which is what the tests check.  Same layout as rls_sphere_light. */
+typedef struct {
+    float center[3], radius;
+    float radiance[3];
+    int   mis_mode;
+} orc_light;
+typedef struct {
+    orc_cv3p Kd_color;
+    const float *Kd, *Kd_roughness, *Ks;
+} orc_ggx_shader_soa;
+typedef struct { orc_v3 N, T; float A, B; } orc_oren_nayar;
+void  orc_oren_nayar_init(orc_oren_nayar *o, orc_v3 N, orc_v3 T, float sigma);
+float orc_oren_nayar_brdf(const orc_oren_nayar *o, orc_v3 wo, orc_v3 wi);   /* BRDF x cos(theta_i) */
+float orc_oren_nayar_pdf(const orc_oren_nayar *o, orc_v3 wi);
+void  orc_batch_ggx_direct_lighting(int64_t n, const orc_ggx_soa *in, const orc_ggx_shader_soa *sh, orc_cv3p P,
+                                    const orc_light *light, int spp_n, uint32_t seed,
+                                    orc_v3p direct_diffuse, orc_v3p direct_specular, int nthreads);
+
 /* utility closures, batch form (a2-a5) */
 void orc_batch_util(int64_t n, const float *a, const float *b, orc_v3p spherical, orc_v3p disk, int nthreads);
 

@@ -79,6 +79,19 @@ class SssClosure(C.Structure):
                 ("has_dPdu", C.c_int)]
 
 
+class SphereLight(C.Structure):
+    """rls_sphere_light"""
+    _fields_ = [("center", C.c_float * 3), ("radius", C.c_float), ("radiance", C.c_float * 3), ("mis_mode", C.c_int)]
+
+
+class GgxShader(C.Structure):
+    """rls_ggx_shader: KdColor, Kd, diffuseRoughness, Ks (src/rlGgx.cpp:170-175)"""
+    _fields_ = [("KdColor", ParamRgb), ("Kd", Param), ("diffuseRoughness", Param), ("Ks", Param)]
+
+
+RLS_MIS_BOTH, RLS_MIS_LIGHT_ONLY, RLS_MIS_BSDF_ONLY = 0, 1, 2
+
+
 class SssScene(C.Structure):
     """rls_sss_scene."""
     _fields_ = [("geometry", C.c_int),
@@ -153,6 +166,8 @@ PROTOTYPES = {
                                           Vec3, Rgb, _vp, _vp, Vec3, _vp]),
     "rls_ggx_microfacet": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), C.c_int, _vp, _vp, Vec3]),
     "rls_ggx_ndf_pdf": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), CVec3, _vp]),
+    "rls_ggx_direct_lighting": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), C.POINTER(GgxShader), CVec3,
+                                          C.POINTER(SphereLight), C.c_int, C.c_uint32, Rgb, Rgb]),
     "rls_ggx_integrate": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), C.c_int, C.c_uint32, Rgb, _vp]),
     # rlDisney
     "rls_disney_sample": (C.c_int, [_ctx, _i64, C.POINTER(DisneyClosure), C.c_int, _vp, _vp, Vec3]),

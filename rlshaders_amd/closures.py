@@ -264,6 +264,19 @@ class GgxSampler:
             vec3(wt, n, "wt"), plane(w, n, "weight")))
         return out
 
+    def directLighting(self, P, light: "capi.SphereLight", spp_n: int, seed: int, KdColor: Color = (1.0, 1.0, 1.0),
+                       Kd: Scalar = 0.5, diffuseRoughness: Scalar = 0.0, Ks: Scalar = 0.5, out=None):
+        """The light loop of rlGgx's shader_evaluate (src/rlGgx.cpp:274-299) under one spherical light ->
+        (direct_diffuse [3,n], direct_specular [3,n]); parameter names and defaults of src/rlGgx.cpp:170-175."""
+        n, ctx = self.n, self.ctx
+        dd, ds = out if out is not None else (ctx.empty(3, n), ctx.empty(3, n))
+        sh = capi.GgxShader(param_rgb(KdColor, n, "KdColor"), param(Kd, n, "Kd"),
+                            param(diffuseRoughness, n, "diffuseRoughness"), param(Ks, n, "Ks"))
+        check(ctx.lib.rls_ggx_direct_lighting(ctx.handle, n, C.byref(self.c), C.byref(sh), cvec3(P, n, "P"),
+                                              C.byref(light), int(spp_n), int(seed) & 0xFFFFFFFF,
+                                              rgb(dd, n, "direct_diffuse"), rgb(ds, n, "direct_specular")))
+        return dd, ds
+
     def microfacet(self, rx, ry, kernel: int = RLS_KERNEL_VNDF):
         """VNDFKernel::evalSample (src/rlGgx.cpp:63-99) or NDFKernel::evalSample (src/rlGgx.h:33-41)."""
         n, ctx = self.n, self.ctx
@@ -516,6 +529,16 @@ class SssSampler:
         check(ctx.lib.rls_sss_sample_diffuse_direction(ctx.handle, n, cvec3(normal, n, "normal"), cvec3(T, n, "T"),
                                                        plane(rx, n, "rx"), plane(ry, n, "ry"), vec3(wi, n, "wi")))
         return wi
+
+
+def make_light(center=(0.0, 0.0, 5.0), radius=1.0, radiance=(1.0, 1.0, 1.0), mis_mode=capi.RLS_MIS_BOTH) -> "capi.SphereLight":
+    """The spherical area light of ``GgxSampler.directLighting`` (rls_sphere_light)."""
+    lt = capi.SphereLight()
+    lt.center[:] = center
+    lt.radius = radius
+    lt.radiance[:] = radiance
+    lt.mis_mode = mis_mode
+    return lt
 
 
 def make_scene(geometry="plane", plane_point=(0.0, 0.0, 0.0), plane_normal=(0.0, 0.0, 1.0),

@@ -51,6 +51,8 @@ __device__ __forceinline__ void stage_table(uint32_t (*tab)[kMaxSpp], int spp)
     __syncthreads();
 }
 
+RLS_DEV V3 arr3(const float (&a)[3]) { return mk(a[0], a[1], a[2]); }
+
 template <int G>
 __device__ __forceinline__ float group_sum(float v)
 {
@@ -192,7 +194,6 @@ __global__ __launch_bounds__(rlsh::kBlock) void disney_integrate_kernel(DisneyIn
 // the same sums in the same order.
 using rlsh::ScatterIO;
 
-RLS_DEV V3 arr3(const float (&a)[3]) { return mk(a[0], a[1], a[2]); }
 
 __device__ __forceinline__ NdProfile scatter_profile(const rls_sss_closure &c, int64_t i)
 {
@@ -299,6 +300,90 @@ __global__ __launch_bounds__(rlsh::kBlock) void sss_scatter_kernel(ScatterIO a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Direct lighting of the rlGgx node (src/rlGgx.cpp:274-299); include/rlshaders_amd.h,
+// rls_ggx_direct_lighting, says what stands in for the closed light loop.
+using rlsh::LightIO;
+
+template <int G, int FAST_MATH = RLS_FAST>
+__global__ __launch_bounds__(rlsh::kBlock) void ggx_direct_kernel(LightIO a)
+{
+    __shared__ uint32_t tab[2][kMaxSpp];
+    stage_table(tab, a.spp);
+    const int mode = a.light.mis_mode;
+    const V3 center = arr3(a.light.center);
+    const int sub = threadIdx.x % G;
+    const int64_t groups_per_block = rlsh::kBlock / G;
+    const int64_t stride = (int64_t)gridDim.x * groups_per_block;
+    const int64_t rounds = (a.n + stride - 1) / stride;
+    int64_t i = (int64_t)blockIdx.x * groups_per_block + threadIdx.x / G;
+    for (int64_t it = 0; it < rounds; it++, i += stride) {
+        const bool live = i < a.n;
+        const int64_t ii = live ? i : a.n - 1;
+        const rls_ggx_closure &c = a.c;
+        V3 wo = ld3(c.wo, ii), N = ld3(c.N, ii), T = ld3(c.T, ii);
+        float kr, kg, kb;
+        ldrgb(c.KsColor, ii, kr, kg, kb);
+        bool exiting = c.exiting ? (c.exiting[ii] != 0) : false;
+        Ggx g = ggx_make(wo, N, T, exiting, kr, kg, kb, ldp(c.ior, ii), ldp(c.specularRoughness, ii),
+                         ldp(c.anisotropic, ii));
+        VndfView w = vndf_view(g.view, g.fr, g.ax, g.ay);
+        OrenNayar on = oren_nayar_make(N, ldp(a.sh.diffuseRoughness, ii));
+        LightCone cone = cone_make(center, a.light.radius, ld3(a.P, ii));
+        uint32_t scr[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) scr[k] = hash_u32(a.seed, (uint64_t)ii, kScrambleStream + k);
+
+        float sR = 0.0f, sG = 0.0f, sB = 0.0f, dA = 0.0f;
+        for (int s = sub; s < a.spp && cone.valid; s += G) {
+            if (mode != RLS_MIS_BSDF_ONLY) {                     // one light sample, both lobes
+                float rx = bits_u01(tab[0][s] ^ scr[0]), ry = bits_u01(tab[1][s] ^ scr[1]);
+                V3 L = cone_sample(cone, rx, ry);
+                if (dot(L, N) > 0.0f) {
+                    float fr, fg, fb, pb;
+                    ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pb);
+                    float wgt = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, pb);
+                    sR += R_DIV(fr * wgt, cone.pdf); sG += R_DIV(fg * wgt, cone.pdf); sB += R_DIV(fb * wgt, cone.pdf);
+                    float fd = oren_nayar_brdf(on, wo, L);
+                    float wd = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, oren_nayar_pdf(on, L));
+                    dA += R_DIV(fd * wd, cone.pdf);
+                }
+            }
+            if (mode != RLS_MIS_LIGHT_ONLY) {                    // one BSDF sample per lobe
+                float rx = bits_u01(tab[0][s] ^ scr[2]), ry = bits_u01(tab[1][s] ^ scr[3]);
+                V3 M = vndf_microfacet(w, g.fr, rx, ry);
+                V3 L = reflect_direction(g.view, M);
+                if (!is_zero(L) && dot(L, N) > 0.0f && cone_hit(cone, L)) {
+                    float fr, fg, fb, pb;
+                    ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pb);
+                    float wgt = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(pb, cone.pdf);
+                    sR += R_DIV(fr * wgt, pb); sG += R_DIV(fg * wgt, pb); sB += R_DIV(fb * wgt, pb);
+                }
+                rx = bits_u01(tab[0][s] ^ scr[4]); ry = bits_u01(tab[1][s] ^ scr[5]);
+                V3 Ld = cosine_hemisphere(g.fr, rx, ry);
+                float pd = oren_nayar_pdf(on, Ld);
+                if (pd > 0.0f && cone_hit(cone, Ld)) {
+                    float fd = oren_nayar_brdf(on, wo, Ld);
+                    float wd = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(pd, cone.pdf);
+                    dA += R_DIV(fd * wd, pd);
+                }
+            }
+        }
+        if (G > 1) {
+            sR = group_sum<G>(sR); sG = group_sum<G>(sG); sB = group_sum<G>(sB); dA = group_sum<G>(dA);
+        }
+        if (live && sub == 0) {
+            const float inv = 1.0f / (float)a.spp;
+            const float ks = ldp(a.sh.Ks, ii), kd = ldp(a.sh.Kd, ii);
+            float dr, dg, db;
+            ldrgb(a.sh.KdColor, ii, dr, dg, db);
+            const float *rad = a.light.radiance;
+            strgb(a.ds, i, rad[0] * ks * sR * inv, rad[1] * ks * sG * inv, rad[2] * ks * sB * inv);
+            strgb(a.dd, i, rad[0] * (dr * kd) * dA * inv, rad[1] * (dg * kd) * dA * inv, rad[2] * (db * kd) * dA * inv);
+        }
+    }
+}
+
 // lanes per point: fill >= ~4 waves per SIMD on every CU when the batch is small
 int pick_group(const rls_context *ctx, int64_t n, int spp)
 {
@@ -334,6 +419,11 @@ RLS_HIDDEN rls_status rls_fast_disney_integrate(rls_context *ctx, int g, const r
     return launch_g(ctx, disney_integrate_kernel<1>, disney_integrate_kernel<4>, disney_integrate_kernel<16>,
                     disney_integrate_kernel<64>, g, *io, "rls_disney_integrate[fast]");
 }
+RLS_HIDDEN rls_status rls_fast_ggx_direct(rls_context *ctx, int g, const rlsh::LightIO *io)
+{
+    return launch_g(ctx, ggx_direct_kernel<1>, ggx_direct_kernel<4>, ggx_direct_kernel<16>,
+                    ggx_direct_kernel<64>, g, *io, "rls_ggx_direct_lighting[fast]");
+}
 RLS_HIDDEN rls_status rls_fast_sss_scatter(rls_context *ctx, int g, const rlsh::ScatterIO *io)
 {
     return launch_g(ctx, sss_scatter_kernel<1>, sss_scatter_kernel<4>, sss_scatter_kernel<16>,
@@ -343,6 +433,7 @@ RLS_HIDDEN rls_status rls_fast_sss_scatter(rls_context *ctx, int g, const rlsh::
 RLS_HIDDEN rls_status rls_fast_ggx_integrate(rls_context *ctx, int g, const rlsh::GgxIntIO *io);
 RLS_HIDDEN rls_status rls_fast_disney_integrate(rls_context *ctx, int g, const rlsh::DisneyIntIO *io);
 RLS_HIDDEN rls_status rls_fast_sss_scatter(rls_context *ctx, int g, const rlsh::ScatterIO *io);
+RLS_HIDDEN rls_status rls_fast_ggx_direct(rls_context *ctx, int g, const rlsh::LightIO *io);
 
 extern "C" {
 
@@ -415,6 +506,29 @@ rls_status rls_sss_integrate_scatter(rls_context *ctx, int64_t n, const rls_sss_
     if (ctx->fast) return rls_fast_sss_scatter(ctx, g, &io);
     return launch_g(ctx, sss_scatter_kernel<1>, sss_scatter_kernel<4>, sss_scatter_kernel<16>,
                     sss_scatter_kernel<64>, g, io, "rls_sss_integrate_scatter");
+}
+
+rls_status rls_ggx_direct_lighting(rls_context *ctx, int64_t n, const rls_ggx_closure *c, const rls_ggx_shader *sh,
+                                   rls_cvec3 P, const rls_sphere_light *light, int spp_n, uint32_t seed,
+                                   rls_rgb direct_diffuse, rls_rgb direct_specular)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_REQUIRE(n >= 0, "n < 0");
+    RLS_REQUIRE(spp_n >= 1 && spp_n * spp_n <= kMaxSpp, "spp_n must be in [1, 16]");
+    if (n == 0) return RLS_OK;
+    RLS_REQUIRE(c != nullptr && sh != nullptr && light != nullptr, "closure, shader or light is NULL");
+    RLS_REQUIRE(rlsh::has3(c->wo) && rlsh::has3(c->N) && rlsh::has3(c->T) && rlsh::has3(P), "wo/N/T/P plane is NULL");
+    RLS_REQUIRE(rlsh::ok_rgb(c->KsColor) && rlsh::ok_rgb(sh->KdColor), "colour planes must be all set or all NULL");
+    RLS_REQUIRE(light->mis_mode >= RLS_MIS_BOTH && light->mis_mode <= RLS_MIS_BSDF_ONLY, "unknown mis_mode");
+    RLS_REQUIRE(light->radius > 0.0f, "light radius must be positive");
+    RLS_REQUIRE(rlsh::has3(direct_diffuse) && rlsh::has3(direct_specular), "NULL output plane");
+    LightIO io = {};
+    io.c = *c; io.sh = *sh; io.P = P; io.light = *light; io.dd = direct_diffuse; io.ds = direct_specular;
+    io.n = n; io.spp = spp_n * spp_n; io.seed = seed;
+    int g = pick_group(ctx, n, io.spp);
+    if (ctx->fast) return rls_fast_ggx_direct(ctx, g, &io);
+    return launch_g(ctx, ggx_direct_kernel<1>, ggx_direct_kernel<4>, ggx_direct_kernel<16>,
+                    ggx_direct_kernel<64>, g, io, "rls_ggx_direct_lighting");
 }
 
 } // extern "C"

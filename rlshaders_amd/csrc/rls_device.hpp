@@ -894,6 +894,74 @@ RLS_DEV float sss_cavity_fade(V3 disp, float r, V3 sN, V3 No)
     return R_SQRT((1.0f + c) * 0.5f);
 }
 
+// ---- rlGgx direct lighting: stand-ins for the closed light services (include/rlshaders_amd.h,
+// rls_ggx_direct_lighting) ------------------------------------------------------------------------
+// qualitative Oren-Nayar (SIGGRAPH'94), BRDF x cos(theta_i); cosine-weighted pdf
+struct OrenNayar { V3 N; float A, B; };
+RLS_DEV OrenNayar oren_nayar_make(V3 N, float sigma)
+{
+    OrenNayar o;
+    float s2 = sigma * sigma;
+    o.N = N;
+    o.A = 1.0f - 0.5f * R_DIV(s2, s2 + 0.33f);
+    o.B = 0.45f * R_DIV(s2, s2 + 0.09f);
+    return o;
+}
+RLS_DEV float oren_nayar_brdf(const OrenNayar &o, V3 wo, V3 wi)
+{
+    float ci = dot(o.N, wi), co = dot(o.N, wo);
+    if (!(ci > 0.0f) || !(co > 0.0f)) return 0.0f;
+    float si = R_SQRT(maxf(0.0f, 1.0f - ci * ci)), so = R_SQRT(maxf(0.0f, 1.0f - co * co));
+    float cphi = 0.0f;
+    if (si > kEps && so > kEps) cphi = maxf(0.0f, R_DIV(dot(wi, wo) - ci * co, si * so));
+    float sinAlpha, tanBeta;
+    if (ci > co) { sinAlpha = so; tanBeta = R_DIV(si, ci); }
+    else         { sinAlpha = si; tanBeta = R_DIV(so, co); }
+    return kInvPi * (o.A + o.B * cphi * sinAlpha * tanBeta) * ci;
+}
+RLS_DEV float oren_nayar_pdf(const OrenNayar &o, V3 wi)
+{
+    float ci = dot(o.N, wi);
+    return ci > 0.0f ? ci * kInvPi : 0.0f;
+}
+
+// the cone a spherical light subtends from P: axis w, basis (u, v) (Duff et al. 2017), uniform pdf
+struct LightCone { bool valid; V3 d, u, v, w; float c2, cosMax, pdf; };
+RLS_DEV LightCone cone_make(V3 center, float radius, V3 P)
+{
+    LightCone c;
+    c.d = center - P;
+    float dist2 = dot(c.d, c.d), r2 = radius * radius;
+    c.c2 = dist2 - r2;
+    c.valid = c.c2 > 0.0f;
+    float sin2 = R_DIV(r2, dist2);
+    c.cosMax = R_SQRT(maxf(0.0f, 1.0f - sin2));
+    c.pdf = R_DIV(1.0f, kTwoPi * R_DIV(sin2, 1.0f + c.cosMax));
+    float inv = R_DIV(1.0f, R_SQRT(dist2));
+    c.w = c.d * inv;
+    float sg = __builtin_copysignf(1.0f, c.w.z);
+    float a = R_DIV(-1.0f, sg + c.w.z);
+    float b = c.w.x * c.w.y * a;
+    c.u = mk(1.0f + sg * c.w.x * c.w.x * a, sg * b, -sg * c.w.x);
+    c.v = mk(b, sg + c.w.y * c.w.y * a, -c.w.y);
+    return c;
+}
+RLS_DEV V3 cone_sample(const LightCone &c, float rx, float ry)
+{
+    float ct = 1.0f - rx * (1.0f - c.cosMax);
+    float st = R_SQRT(maxf(0.0f, 1.0f - ct * ct));
+    float sn, cs;
+    t_sincos(kTwoPi * ry, &sn, &cs);
+    float x = st * cs, y = st * sn;
+    return c.u * x + c.v * y + c.w * ct;
+}
+RLS_DEV bool cone_hit(const LightCone &c, V3 dir)
+{
+    float b = dot(c.d, dir);
+    return b > 0.0f && !(b * b - c.c2 * dot(dir, dir) < 0.0f);
+}
+RLS_DEV float power_heuristic(float pa, float pb) { return R_DIV(pa * pa, pa * pa + pb * pb); }
+
 // ---- counter-based generator: integer hash + exactly rounded ops only (reproducible on a CPU) ----
 RLS_DEV uint32_t mix32(uint32_t h)
 {

@@ -112,6 +112,17 @@ struct DisneyIntIO {
     uint32_t seed;
 };
 
+struct LightIO {
+    rls_ggx_closure c;
+    rls_ggx_shader sh;
+    rls_cvec3 P;
+    rls_sphere_light light;
+    rls_rgb dd, ds;
+    int64_t n;
+    int spp;
+    uint32_t seed;
+};
+
 struct ScatterIO {
     rls_sss_closure c;
     rls_cvec3 P;

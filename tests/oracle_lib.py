@@ -46,6 +46,24 @@ class GgxSoa(C.Structure):
                 ("specularRoughness", fp), ("ior", fp), ("anisotropic", fp), ("exiting", C.POINTER(C.c_uint8))]
 
 
+class Light(C.Structure):
+    """orc_light (same layout as rls_sphere_light)."""
+    _fields_ = [("center", C.c_float * 3), ("radius", C.c_float), ("radiance", C.c_float * 3), ("mis_mode", C.c_int)]
+
+
+def make_light(center=(0, 0, 5), radius=1.0, radiance=(1, 1, 1), mis_mode=0) -> Light:
+    lt = Light()
+    lt.center[:] = center
+    lt.radius = radius
+    lt.radiance[:] = radiance
+    lt.mis_mode = mis_mode
+    return lt
+
+
+class GgxShaderSoa(C.Structure):
+    _fields_ = [("Kd_color", CV3P), ("Kd", fp), ("Kd_roughness", fp), ("Ks", fp)]
+
+
 class DisneySoa(C.Structure):
     _fields_ = [("wo", CV3P), ("N", CV3P), ("T", CV3P), ("base_color", CV3P), ("scalars", fp * 10)]
 
@@ -212,6 +230,17 @@ class Ggx:
         pdf = np.empty(n, np.float32)
         lib().orc_batch_ggx_ndf_pdf(C.c_int64(n), C.byref(self.soa), _v(wi), _p(pdf), self.nthreads)
         return pdf
+
+    def direct_lighting(self, P, light: "Light", spp_n, seed, Kd_color=(1, 1, 1), Kd=1.0, Kd_roughness=0.0, Ks=1.0):
+        """orc_batch_ggx_direct_lighting -> (direct_diffuse [3,n], direct_specular [3,n])"""
+        n = self.n
+        P = f32(P)
+        kdc, kd, kdr, ks = _full3(Kd_color, n), _full(Kd, n), _full(Kd_roughness, n), _full(Ks, n)
+        sh = GgxShaderSoa(_v(kdc), _p(kd), _p(kdr), _p(ks))
+        dd, ds = np.empty((3, n), np.float32), np.empty((3, n), np.float32)
+        lib().orc_batch_ggx_direct_lighting(C.c_int64(n), C.byref(self.soa), C.byref(sh), _v(P), C.byref(light),
+                                            int(spp_n), C.c_uint32(seed), _v(dd), _v(ds), self.nthreads)
+        return dd, ds
 
     def integrate(self, spp_n, seed):
         n = self.n

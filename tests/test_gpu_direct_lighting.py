@@ -1,0 +1,119 @@
+"""GPU parity of rls_ggx_direct_lighting (the light loop of rlGgx's shader_evaluate, src/rlGgx.cpp:274-299,
+with documented stand-ins for the closed light services) against the oracle, in the three estimator
+modes, plus the MIS consistency check at a sample count the oracle does not reach."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import rlshaders_amd as R
+from gpu_util import dev, ggx_oracle, ggx_sampler, host
+
+pytestmark = pytest.mark.gpu
+
+N = 1 << 14
+
+
+def _pair(oracle, **kw):
+    lo = oracle.make_light(**kw)
+    return lo, R._capi.SphereLight.from_buffer_copy(bytes(lo))
+
+
+def _with_group(g, fn):
+    os.environ["RLS_INTEGRATE_GROUP"] = str(g)
+    try:
+        return fn()
+    finally:
+        del os.environ["RLS_INTEGRATE_GROUP"]
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_parity_mixed_closures(gpu, oracle, mode):
+    c = cases.ggx_mixed(cases.SEED_PARITY, N)
+    # shading points scattered in a slab, light above it: cones from a few degrees to half the sky
+    P = (cases.xi(cases.SEED_PARITY, N, 3) * np.array([[4.0], [4.0], [1.0]], np.float32)).astype(np.float32)
+    kd = oracle.gen_uniform(cases.SEED_PARITY, 0, N, oracle.S_PARAM0 + 0)
+    kdr = oracle.gen_uniform(cases.SEED_PARITY, 0, N, oracle.S_PARAM0 + 1)
+    ks = oracle.gen_uniform(cases.SEED_PARITY, 0, N, oracle.S_PARAM0 + 2)
+    kdc = np.stack([oracle.gen_uniform(cases.SEED_PARITY, 0, N, oracle.S_PARAM0 + 3 + j) for j in range(3)])
+    lo, lg = _pair(oracle, center=(2.0, 2.0, 3.0), radius=1.25, radiance=(3.0, 2.0, 1.0), mis_mode=mode)
+    og = ggx_oracle(oracle, c, nthreads=oracle.hardware_threads())
+    dd_ref, ds_ref = og.direct_lighting(P, lo, 4, 321, Kd_color=kdc, Kd=kd, Kd_roughness=kdr, Ks=ks)
+    s = ggx_sampler(gpu, c)
+    run = lambda: [host(t) for t in s.directLighting(dev(P), lg, 4, 321, KdColor=dev(kdc), Kd=dev(kd),
+                                                      diffuseRoughness=dev(kdr), Ks=dev(ks))]
+    dd, ds = _with_group(1, run)
+    sd, ss = cases.summarize(cases.rel_err(dd, dd_ref)), cases.summarize(cases.rel_err(ds, ds_ref))
+    print("direct lighting mode", mode, "diffuse", sd)
+    print("direct lighting mode", mode, "specular", ss)
+    cases.assert_tight(sd, "direct diffuse")
+    cases.assert_tight(ss, "direct specular")
+    assert (dd_ref > 0).mean() > 0.5 and (ds_ref > 0).mean() > 0.3
+    for g in (4, 16, 64):
+        dd2, ds2 = _with_group(g, run)
+        assert np.quantile(cases.rel_err(dd2, dd), 0.999) <= 2e-5, g
+        assert np.quantile(cases.rel_err(ds2, ds), 0.999) <= 1e-4, g
+
+
+def test_uniform_parameters_and_edge_lights(gpu, oracle):
+    n = 4096
+    c = cases.ggx_mixed(cases.SEED_EDGE, n)
+    P = np.zeros((3, n), np.float32)
+    og = ggx_oracle(oracle, c)
+    s = ggx_sampler(gpu, c)
+    for kw in (dict(center=(0.0, 0.0, 0.5), radius=1.0),          # shading points inside the light: black
+               dict(center=(0.3, -0.2, 40.0), radius=0.05),       # a few arc minutes wide
+               dict(center=(0.0, 0.0, 1.2), radius=1.0)):         # most of the sky
+        lo, lg = _pair(oracle, **kw)
+        dd_ref, ds_ref = og.direct_lighting(P, lo, 3, 5, Kd_color=(0.8, 0.7, 0.6), Kd=0.5, Kd_roughness=0.3, Ks=0.5)
+        dd, ds = _with_group(1, lambda: [host(t) for t in s.directLighting(
+            dev(P), lg, 3, 5, KdColor=(0.8, 0.7, 0.6), Kd=0.5, diffuseRoughness=0.3, Ks=0.5)])
+        cases.assert_tight(cases.summarize(cases.rel_err(dd, dd_ref)), f"diffuse {kw}")
+        cases.assert_tight(cases.summarize(cases.rel_err(ds, ds_ref)), f"specular {kw}")
+
+
+def test_mis_consistency_at_scale(gpu):
+    """2^18 identical closures x 64 samples per strategy: light-only, BSDF-only and MIS estimates agree."""
+    import torch
+    n = 1 << 18
+    wo = torch.tensor([0.5, 0.0, 0.85], device="cuda"); wo = (wo / wo.norm()).reshape(3, 1).repeat(1, n).contiguous()
+    Ns = torch.zeros(3, n, device="cuda"); Ns[2] = 1
+    ang = torch.rand(n, device="cuda") * 6.2831853
+    T = torch.stack([torch.cos(ang), torch.sin(ang), torch.zeros_like(ang)])
+    P = torch.zeros(3, n, device="cuda")
+    g = R.GgxSampler(gpu, wo, Ns, T, specColor=(0.9, 0.8, 0.7), ior=1.6, roughness=0.25, anisotropic=0.4)
+    means = {}
+    for mode in (0, 1, 2):
+        lt = R.make_light(center=(-2.0, 0.3, 3.5), radius=1.0, mis_mode=mode)
+        dd, ds = g.directLighting(P, lt, 8, 11, KdColor=(1, 1, 1), Kd=1.0, diffuseRoughness=0.5, Ks=1.0)
+        means[mode] = (dd.double().mean(dim=1).cpu().numpy(), ds.double().mean(dim=1).cpu().numpy())
+    for mode in (1, 2):
+        np.testing.assert_allclose(means[mode][0], means[0][0], rtol=5e-3)
+        np.testing.assert_allclose(means[mode][1], means[0][1], rtol=5e-3)
+
+
+def test_fast_mode_and_argument_checks(oracle):
+    ctx = R.Context(0)
+    ctx.set_math_mode(True)
+    try:
+        c = cases.ggx_mixed(cases.SEED_PARITY, N)
+        P = (cases.xi(cases.SEED_PARITY, N, 3) * np.array([[4.0], [4.0], [1.0]], np.float32)).astype(np.float32)
+        lo, lg = _pair(oracle, center=(2.0, 2.0, 3.0), radius=1.25)
+        dd_ref, ds_ref = ggx_oracle(oracle, c, nthreads=4).direct_lighting(P, lo, 4, 321, Kd=0.5, Ks=0.5)
+        s = ggx_sampler(ctx, c)
+        dd, ds = _with_group(1, lambda: [host(t) for t in s.directLighting(dev(P), lg, 4, 321)])
+        sd, ss = cases.summarize(cases.rel_err(dd, dd_ref)), cases.summarize(cases.rel_err(ds, ds_ref))
+        print("direct lighting FAST diffuse", sd)
+        print("direct lighting FAST specular", ss)
+        assert sd["nonfinite"] == 0 and ss["nonfinite"] == 0
+        assert sd["median"] <= 1e-5 and sd["p99"] <= 1e-3
+        assert ss["median"] <= 1e-4 and ss["p99"] <= 5e-2     # a BSDF sample grazing the light's rim flips in or out
+        lg.mis_mode = 7
+        with pytest.raises(R.RlsError):
+            s.directLighting(dev(P), lg, 4, 1)
+        lg.mis_mode, lg.radius = 0, 0.0
+        with pytest.raises(R.RlsError):
+            s.directLighting(dev(P), lg, 4, 1)
+    finally:
+        ctx.close()

@@ -237,6 +237,16 @@ public:
     {
         check(rls_ggx_integrate(dev_.ctx(), n_, &c_, spp_n, seed, sum_f_over_pdf.rgb(), avgReflectWeight.plane(0)));
     }
+    // the light loop of shader_evaluate (src/rlGgx.cpp:274-299) under one spherical area light:
+    // direct_diffuse (Oren-Nayar, KdColor * Kd) and direct_specular (this closure, Ks)
+    void directLighting(const Planes &P, const rls_sphere_light &light, int spp_n, uint32_t seed, ParamRGB KdColor,
+                        Param Kd, Param diffuseRoughness, Param Ks, Planes &direct_diffuse,
+                        Planes &direct_specular) const
+    {
+        rls_ggx_shader sh{KdColor.c(), Kd.c(), diffuseRoughness.c(), Ks.c()};
+        check(rls_ggx_direct_lighting(dev_.ctx(), n_, &c_, &sh, P.cvec3(), &light, spp_n, seed, direct_diffuse.rgb(),
+                                      direct_specular.rgb()));
+    }
 
 private:
     const Device &dev_;

@@ -49,7 +49,7 @@ def test_parity_mixed_closures(gpu, oracle, mode):
     print("direct lighting mode", mode, "specular", ss)
     cases.assert_tight(sd, "direct diffuse")
     cases.assert_tight(ss, "direct specular")
-    assert (dd_ref > 0).mean() > 0.5 and (ds_ref > 0).mean() > 0.3
+    assert (dd_ref > 0).mean() > 0.2 and (ds_ref > 0).mean() > 0.1        # random frames: the light is below half of them
     for g in (4, 16, 64):
         dd2, ds2 = _with_group(g, run)
         assert np.quantile(cases.rel_err(dd2, dd), 0.999) <= 2e-5, g

@@ -51,7 +51,7 @@ class SampleWriter:
         f = make_closure(d.shape[1]).evalBrdf(d)
         return f.reshape(3, self.h * sub, self.w * sub).permute(1, 2, 0).cpu().numpy()
 
-    def pdf_image(self, make_closure, sub: int = 4) -> np.ndarray:
+    def pdf_image(self, make_closure, sub: int = 16) -> np.ndarray:
         """probability of each (h x w) bin: evalPdf on a sub x sub grid per bin times the solid angle"""
         d = self.grid_directions(sub)
         p = make_closure(d.shape[1]).evalPdf(d).reshape(self.h * sub, self.w * sub).double()
@@ -84,14 +84,16 @@ class SampleWriter:
         return hist.cpu().numpy(), int(below.sum()), int(zero.sum())
 
     # ---- sample density against pdf -------------------------------------------------------------
-    def compare(self, make_closure, count: int, seed: int = 1, min_expected: float = 50.0) -> dict:
+    def compare(self, make_closure, count: int, seed: int = 1, min_expected: float = 50.0, sub: int = 16) -> dict:
         hist, below, zero = self.writeSample(make_closure, count, seed)
-        prob = self.pdf_image(make_closure)
+        prob = self.pdf_image(make_closure, sub)
         expected = prob * count
         use = expected >= min_expected
         chi2 = float((((hist - expected) ** 2) / np.maximum(expected, 1e-30))[use].sum())
         dof = int(use.sum())
-        return dict(chi2_per_dof=chi2 / max(dof, 1), dof=dof, pdf_mass=float(prob.sum()),
+        big = expected >= 1.0e4            # bins whose counting noise is below 1 %
+        dev = float(np.abs(hist[big] / expected[big] - 1.0).max()) if big.any() else 0.0
+        return dict(chi2_per_dof=chi2 / max(dof, 1), dof=dof, max_rel_dev=dev, big_bins=int(big.sum()), pdf_mass=float(prob.sum()),
                     sampled_mass=float(hist.sum()) / count, covered_mass=float(prob[use].sum()),
                     below_horizon=below, invalid=zero, count=count)
 

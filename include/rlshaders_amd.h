@@ -372,6 +372,26 @@ rls_status rls_gen_aniso(rls_context *ctx, uint32_t seed, uint64_t first_index, 
 /* order-independent 64-bit checksum of n floats (sum of per-element hashes of the bit patterns) */
 rls_status rls_checksum(rls_context *ctx, int64_t n, const float *data, uint64_t *out_host);
 
+/* Validation only: out[i] = one elementary function of the context's arithmetic mode, evaluated on the device
+ * by the routines the closure kernels use (RLS_MATH_EXACT: the host-libm-faithful ones; RLS_MATH_FAST: the
+ * hardware ones).  tools/libm_exhaustive.py sweeps all 2^32 arguments of the unary functions through it. */
+#define RLS_FN_SQRT  0   /* sqrtf(x)     */
+#define RLS_FN_DIV   1   /* x / y        */
+#define RLS_FN_ATAN2 2   /* atan2f(x, y) */
+#define RLS_FN_ACOS  3
+#define RLS_FN_TAN   4
+#define RLS_FN_SIN   5
+#define RLS_FN_COS   6
+#define RLS_FN_EXP   7
+#define RLS_FN_LOG   8
+#define RLS_FN_POW   9   /* powf(x, y)   */
+/* the forms the closure kernels call for their angles, which are bounded by construction (results of atan2f /
+ * acosf, or 2 pi xi): identical to RLS_FN_TAN / _SIN / _COS for |x| < 120 and for NaN, unspecified beyond */
+#define RLS_FN_TAN_BOUNDED 10
+#define RLS_FN_SIN_BOUNDED 11
+#define RLS_FN_COS_BOUNDED 12
+rls_status rls_libm_eval(rls_context *ctx, int fn, int64_t n, const float *x, const float *y, float *out);
+
 #ifdef __cplusplus
 }
 #endif

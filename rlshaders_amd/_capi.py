@@ -152,6 +152,7 @@ PROTOTYPES = {
     "rls_timer_start": (C.c_int, [_ctx]),
     "rls_timer_stop": (C.c_int, [_ctx]),
     "rls_timer_elapsed_ms": (C.c_int, [_ctx, C.POINTER(C.c_float)]),
+    "rls_libm_eval": (C.c_int, [_ctx, C.c_int, _i64, _vp, _vp, _vp]),
     "rls_graph_begin_capture": (C.c_int, [_ctx]),
     "rls_graph_end_capture": (C.c_int, [_ctx, C.POINTER(_vp)]),
     "rls_graph_launch": (C.c_int, [_ctx, _vp]),

@@ -33,7 +33,37 @@ __global__ __launch_bounds__(rlsh::kBlock) void alt_kernel(AltIO a)
     for (int64_t base = (int64_t)blockIdx.x * rlsh::kBlock; base < a.n; base += stride) {
         const Idx i = make_idx(base);
         if (i.full() >= a.n) continue;
-        if (OP == AOP_GAUSS) {
+        if (OP == AOP_LIBM) {
+            // one elementary function of the current arithmetic mode, exactly as the closures call it
+            const float x = ldg(a.rx, i), y = a.ry ? ldg(a.ry, i) : 0.0f;
+            float r, unused;
+            switch (a.fn) {
+            case RLS_FN_SQRT: r = R_SQRT(x); break;
+            case RLS_FN_DIV: r = R_DIV(x, y); break;
+#if RLS_FAST   // FAST closures never call atan2f / acosf / tanf (the view analysis is algebraic): ROCm's own libm
+            case RLS_FN_ATAN2: r = atan2f(x, y); break;
+            case RLS_FN_ACOS: r = acosf(x); break;
+            case RLS_FN_TAN: r = tanf(x); break;
+            case RLS_FN_SIN: t_sincos(x, &r, &unused); break;
+            case RLS_FN_COS: t_sincos(x, &unused, &r); break;
+            case RLS_FN_TAN_BOUNDED: r = tanf(x); break;
+#else
+            case RLS_FN_ATAN2: r = t_atan2(x, y); break;
+            case RLS_FN_ACOS: r = t_acos(x); break;
+            case RLS_FN_TAN: r = rlm::tan32_v<true>(x); break;
+            case RLS_FN_SIN: rlm::sincos32_v<true>(x, &r, &unused); break;
+            case RLS_FN_COS: rlm::sincos32_v<true>(x, &unused, &r); break;
+            case RLS_FN_TAN_BOUNDED: r = t_tan(x); break;
+#endif
+            case RLS_FN_SIN_BOUNDED: t_sincos(x, &r, &unused); break;
+            case RLS_FN_COS_BOUNDED: t_sincos(x, &unused, &r); break;
+            case RLS_FN_EXP: r = R_EXP(x); break;
+            case RLS_FN_LOG: r = R_LOG(x); break;
+            case RLS_FN_POW: r = R_POW(x, y); break;
+            default: r = 0.0f; break;
+            }
+            stg(a.out1, i, r);
+        } else if (OP == AOP_GAUSS) {
             GaussProfile g = gauss_make(ldp(a.dist_x, i));
             float r = gauss_radius(g, ldg(a.rx, i));
             stg(a.r, i, r);
@@ -63,6 +93,7 @@ rls_status dispatch(rls_context *ctx, int op, const AltIO &io, const char *name)
     case AOP_GTR2: return launch_kernel<AOP_GTR2>(ctx, io, name);
     case AOP_NDF_PDF: return launch_kernel<AOP_NDF_PDF>(ctx, io, name);
     case AOP_D_GTR2: return launch_kernel<AOP_D_GTR2>(ctx, io, name);
+    case AOP_LIBM: return launch_kernel<AOP_LIBM>(ctx, io, name);
     default: return launch_kernel<AOP_GAUSS>(ctx, io, name);
     }
 }
@@ -135,6 +166,17 @@ rls_status rls_gaussian_sample(rls_context *ctx, int64_t n, rls_param dist_x, co
     AltIO io = {};
     io.dist_x = dist_x; io.rx = rx; io.r = r; io.pdf = pdf; io.profile = profile; io.n = n;
     return run(ctx, AOP_GAUSS, io, "rls_gaussian_sample");
+}
+
+rls_status rls_libm_eval(rls_context *ctx, int fn, int64_t n, const float *x, const float *y, float *out)
+{
+    RLS_PROLOGUE();
+    RLS_REQUIRE(fn >= RLS_FN_SQRT && fn <= RLS_FN_COS_BOUNDED, "unknown function id");
+    const bool binary = fn == RLS_FN_DIV || fn == RLS_FN_ATAN2 || fn == RLS_FN_POW;
+    RLS_REQUIRE(x && out && (!binary || y), "NULL plane");
+    AltIO io = {};
+    io.rx = x; io.ry = binary ? y : nullptr; io.out1 = out; io.fn = fn; io.n = n;
+    return run(ctx, AOP_LIBM, io, "rls_libm_eval");
 }
 
 } // extern "C"

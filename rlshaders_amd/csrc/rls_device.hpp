@@ -116,10 +116,11 @@ RLS_DEV void stage_libm_tables()
 #define R_EXP(x) rlm::exp32(x, s_libm_tables)
 #define R_LOG(x) rlm::log32(x, s_libm_tables)
 #define R_POW(x, y) rlm::pow32(x, y, s_libm_tables)
-RLS_DEV void t_sincos(float x, float *s, float *c) { rlm::sincos32_v(x, s, c); }
+// closure angles are bounded by construction: the forms without the |x| >= 120 branch (rls_libm.hpp)
+RLS_DEV void t_sincos(float x, float *s, float *c) { rlm::sincos32_v<false>(x, s, c); }
 RLS_DEV float t_atan2(float y, float x) { return rlm::atan2_32_v(y, x); }
 RLS_DEV float t_acos(float x) { return rlm::acos32_v(x); }
-RLS_DEV float t_tan(float x) { return rlm::tan32_v(x); }
+RLS_DEV float t_tan(float x) { return rlm::tan32_v<false>(x); }
 #endif
 
 

@@ -74,7 +74,7 @@ struct MiscIO {
     int64_t n;
 };
 
-enum AltOp { AOP_GTR2_ANISO, AOP_GTR2, AOP_NDF_PDF, AOP_D_GTR2, AOP_GAUSS };
+enum AltOp { AOP_GTR2_ANISO, AOP_GTR2, AOP_NDF_PDF, AOP_D_GTR2, AOP_GAUSS, AOP_LIBM };
 struct AltIO {
     rls_disney_closure c;
     const float *rx, *ry;
@@ -83,6 +83,7 @@ struct AltIO {
     float *out1;
     rls_param dist_x;
     float *r, *pdf, *profile;
+    int fn;                 // AOP_LIBM: RLS_FN_*
     int64_t n;
 };
 

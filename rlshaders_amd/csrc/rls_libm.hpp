@@ -64,7 +64,8 @@ RLM_FN float sqrt32(float x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
 #ifndef RLS_SQRT_NO_FALLBACK
-    if (__builtin_expect(x < 0x1p-96f && x > 0.0f, 0)) return sqrtf(x);
+    // |x| < 2^-96, x != 0 (negative subnormals included: v_sqrt_f32 would flush them to -0 instead of NaN)
+    if (__builtin_expect((f2u(x) & 0x7fffffffu) - 1u < 0x0f800000u - 1u, 0)) return sqrtf(x);
 #endif
     float s = __builtin_amdgcn_sqrtf(x);
     const float sm = __uint_as_float(__float_as_uint(s) - 1u);
@@ -265,6 +266,31 @@ RLM_FN float kernel_tan32(float x, float y, int iy)
 }
 
 
+// ---- reduce_large of glibc's s_sincosf.h: |x| >= 120, against 192 bits of 4/pi -------------------------
+// Returns |x| reduced to [-pi/4, pi/4] and the quadrant; never reached by the closures (their angles come out
+// of atan2f / acosf / 2 pi xi), so whole wavefronts skip it.
+RLM_FN double reduce_large(uint32_t xi, int *np)
+{
+    static const uint32_t inv_pio4[24] = {
+        0xa2u, 0xa2f9u, 0xa2f983u, 0xa2f9836eu, 0xf9836e4eu, 0x836e4e44u, 0x6e4e4415u, 0x4e441529u,
+        0x441529fcu, 0x1529fc27u, 0x29fc2757u, 0xfc2757d1u, 0x2757d1f5u, 0x57d1f534u, 0xd1f534ddu, 0xf534ddc0u,
+        0x34ddc0dbu, 0xddc0db62u, 0xc0db6295u, 0xdb629599u, 0x6295993cu, 0x95993c43u, 0x993c4390u, 0x3c439041u };
+    const double pi63 = 0x1.921FB54442D18p-62;
+    const uint32_t *arr = &inv_pio4[(xi >> 26) & 15];
+    const int shift = (int)(xi >> 23) & 7;
+    xi = (xi & 0xffffffu) | 0x800000u;
+    xi <<= shift;
+    uint64_t res0 = (uint64_t)(uint32_t)(xi * arr[0]);
+    const uint64_t res1 = (uint64_t)xi * arr[4];
+    const uint64_t res2 = (uint64_t)xi * arr[8];
+    res0 = (res2 >> 32) | (res0 << 32);
+    res0 += res1;
+    const uint64_t n = (res0 + (1ULL << 61)) >> 62;
+    res0 -= n << 62;
+    *np = (int)n;
+    return (double)(int64_t)res0 * pi63;
+}
+
 // ---- sinf / cosf: glibc >= 2.28 s_sincosf.h ----------------------------------------------------------
 // Returns both values; each equals what sinf(x) / cosf(x) return separately.
 RLM_FN void sincos32(float y, float *sinp, float *cosp)
@@ -276,7 +302,7 @@ RLM_FN void sincos32(float y, float *sinp, float *cosp)
     const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
     const uint32_t top = (f2u(y) >> 20) & 0x7ffu;
     double x = (double)y;
-    int n = 0;
+    int n = 0, m = 0;
     bool tiny = false;
     if (top < 0x3f4u) {                                                   // abstop12(y) < abstop12(pi/4)
         tiny = top < 0x398u;                                              // |y| < 2^-12: sin = y, cos = 1
@@ -284,15 +310,18 @@ RLM_FN void sincos32(float y, float *sinp, float *cosp)
         const double r = x * hpi_inv;
         n = ((int32_t)r + 0x800000) >> 24;
         x = x - (double)n * hpi;
+    } else if (top < 0x7f8u) {                                            // |y| >= 120, finite
+        x = reduce_large(f2u(y), &n);
+        m = n + (int)(f2u(y) >> 31);                                      // signs include the argument's
     } else {
-        // huge or non-finite argument: not produced by the closures
-        *sinp = (float)sin(x);
-        *cosp = (float)cos(x);
+        *sinp = y - y;                                                    // inf or NaN
+        *cosp = y - y;
         return;
     }
-    // quadrant handling of sinf/cosf: sign[n&3] applied to x, second table (negated cosine) if n&2
-    const double sgn = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
-    const double cs = (n & 2) ? -1.0 : 1.0;
+    if (top < 0x42fu) m = n;
+    // quadrant handling of sinf/cosf: sign[m&3] applied to x, second table (negated cosine) if m&2
+    const double sgn = ((m & 3) == 1 || (m & 3) == 2) ? -1.0 : 1.0;
+    const double cs = (m & 2) ? -1.0 : 1.0;
     const double xs = x * sgn;
     const double x2 = x * x;
     // sine polynomial in xs
@@ -335,7 +364,13 @@ RLM_FN float tan32(float x)
         const float y1 = (float)(dx - (double)y0);
         return kernel_tan32(y0, y1, 1 - ((n & 1) << 1));
     }
-    return (float)tan((double)x);                                         // never reached by the closures
+    if (ix >= 0x7f800000) return x - x;                                   // inf or NaN
+    int n;
+    double dx = reduce_large(f2u(x), &n);                                 // __ieee754_rem_pio2f, large branch
+    if (hx < 0) { dx = -dx; n = -n; }
+    const float y0 = (float)dx;
+    const float y1 = (float)(dx - (double)y0);
+    return kernel_tan32(y0, y1, 1 - ((n & 1) << 1));
 }
 
 // =================================================================================================
@@ -428,10 +463,22 @@ RLM_FN float log32(float x, const Tables &t)
     return (float)y;
 }
 
-// powf for x >= 0 (the closures raise clamped, non-negative bases; x < 0 yields NaN here)
+// 0: y is not an integer, 1: odd integer, 2: even integer (glibc e_powf.c checkint)
+RLM_FN int pow_checkint(uint32_t iy)
+{
+    const int e = (int)(iy >> 23) & 0xff;
+    if (e < 0x7f) return 0;
+    if (e > 0x7f + 23) return 2;
+    if (iy & ((1u << (0x7f + 23 - e)) - 1u)) return 0;
+    if (iy & (1u << (0x7f + 23 - e))) return 1;
+    return 2;
+}
+
+// powf (glibc e_powf.c)
 RLM_FN float pow32(float x, float y, const Tables &t)
 {
     uint32_t ix = f2u(x);
+    uint64_t sign_bias = 0;
     const uint32_t iy = f2u(y);
     const bool yspecial = (2u * iy - 1u) >= (2u * 0x7f800000u - 1u);    // y is 0, inf or nan
     if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u || yspecial) {
@@ -445,18 +492,15 @@ RLM_FN float pow32(float x, float y, const Tables &t)
         }
         if ((2u * ix - 1u) >= (2u * 0x7f800000u - 1u)) {                // x is 0, inf or nan
             float x2 = x * x;
-            if (ix & 0x80000000u) {                                     // -0 / -inf: odd integer y keeps the sign
-                const int e = (int)(iy >> 23) & 0xff;
-                bool odd = false;
-                if (e >= 0x7f && e <= 0x7f + 23) {
-                    const uint32_t bit = 1u << (0x7f + 23 - e);
-                    odd = !(iy & (bit - 1u)) && (iy & bit);
-                }
-                if (odd) x2 = -x2;
-            }
+            if ((ix & 0x80000000u) && pow_checkint(iy) == 1) x2 = -x2;  // -0 / -inf: odd integer y keeps the sign
             return (iy & 0x80000000u) ? 1.0f / x2 : x2;
         }
-        if (ix & 0x80000000u) return (x - x) / (x - x);
+        if (ix & 0x80000000u) {                                         // finite x < 0
+            const int yint = pow_checkint(iy);
+            if (yint == 0) return (x - x) / (x - x);
+            if (yint == 1) sign_bias = 1u << (5 + 11);
+            ix &= 0x7fffffffu;
+        }
         if (ix < 0x00800000u) {                                         // subnormal x
             ix = f2u(x * 0x1p23f);
             ix &= 0x7fffffffu;
@@ -482,10 +526,11 @@ RLM_FN float pow32(float x, float y, const Tables &t)
     yy = yy * r4 + q;
     const double ylogx = (double)y * yy;
     if (((d2u(ylogx) >> 47) & 0xffffu) >= (d2u(126.0) >> 47)) {         // |y log2 x| >= 126
-        if (ylogx > 0x1.fffffffd1d571p+6) return u2f(0x7f800000u);
-        if (ylogx <= -150.0) return 0.0f;
+        if (ylogx > 0x1.fffffffd1d571p+6) return u2f(sign_bias ? 0xff800000u : 0x7f800000u);
+        if (ylogx <= -150.0) return sign_bias ? -0.0f : 0.0f;
     }
-    return exp2_core(ylogx, 0x1.8p+52 / 32.0, 0x1.c6af84b912394p-5, 0x1.ebfce50fac4f3p-3, 0x1.62e42ff0c52d6p-1, t, 0);
+    return exp2_core(ylogx, 0x1.8p+52 / 32.0, 0x1.c6af84b912394p-5, 0x1.ebfce50fac4f3p-3, 0x1.62e42ff0c52d6p-1, t,
+                     sign_bias);
 }
 
 // =================================================================================================
@@ -531,14 +576,15 @@ RLM_FN float atan32_v(float x)
     return res;
 }
 
-// atan2f for finite arguments (the inf cases of e_atan2f.c are not reproduced: the closures never
-// pass infinities; NaN propagates).  x == 1 and y == +-0 need no special case: the general path gives
-// the same bits (atanf is odd; pi - (0 - pi_lo) rounds to pi).
+// atan2f.  Infinite or NaN arguments take the branchy routine above (never seen by the closures, so the
+// branch is skipped by whole wavefronts).  x == 1 and y == +-0 need no special case: the general path
+// gives the same bits (atanf is odd; pi - (0 - pi_lo) rounds to pi).
 RLM_FN float atan2_32_v(float y, float x)
 {
     const float pi_o_2 = u2f(0x3fc90fdbu), pi = u2f(0x40490fdbu), pi_lo = u2f(0xb3bbbd2eu);
     const int32_t hx = (int32_t)f2u(x), hy = (int32_t)f2u(y);
     const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    if (__builtin_expect(ix >= 0x7f800000 || iy >= 0x7f800000, 0)) return atan2_32(y, x);
     const int32_t k = (iy - ix) >> 23;
     float z = atan32_v(fabs32(y / x));
     z = (k > 60) ? (pi_o_2 + 0.5f * pi_lo) : z;
@@ -583,26 +629,40 @@ RLM_FN float acos32_v(float x)
     return res;
 }
 
-// fp64 reduction by pi/2 shared by sinf / cosf / tanf (reduce_fast of s_sincosf.h); |x| < 120
-RLM_FN double reduce_pio2(float y, int *np)
+// fp64 reduction by pi/2 shared by sinf / cosf / tanf: reduce_fast of s_sincosf.h for |y| < 120, reduce_large
+// beyond (then the result is |y| reduced, *large_negative tells the caller about the sign; inf / NaN -> NaN).
+// FULL = false drops the branch for |y| >= 120: the form the closure kernels use, whose angles are bounded by
+// construction (results of atan2f / acosf, or 2 pi xi with xi in [0, 1)); NaN still propagates.  The branch is
+// never taken there, but its presence costs 1.7 % of the reflect+refract kernel.
+template <bool FULL>
+RLM_FN double reduce_pio2(float y, int *np, bool *large_negative)
 {
     const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
     const double x = (double)y;
+    *large_negative = false;
+    if (FULL && __builtin_expect(((f2u(y) >> 20) & 0x7ffu) >= 0x42fu, 0)) {
+        if (((f2u(y) >> 23) & 0xffu) == 0xffu) { *np = 0; return (double)(y - y); }
+        *large_negative = (f2u(y) >> 31) != 0;
+        return reduce_large(f2u(y), np);
+    }
     const double r = x * hpi_inv;
     const int n = ((int32_t)r + 0x800000) >> 24;
     *np = n;
     return x - (double)n * hpi;
 }
 
-// sinf and cosf of the same argument, |y| < 120 (one reduction, both polynomials)
+// sinf and cosf of the same argument (one reduction, both polynomials)
+template <bool FULL = true>
 RLM_FN void sincos32_v(float y, float *sinp, float *cosp)
 {
     const double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5, C3 = -0x1.6c087e89a359dp-10,
                  C4 = 0x1.99343027bf8c3p-16;
     const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
     int n;
-    const double x = reduce_pio2(y, &n);          // n == 0 and x == y whenever |y| < pi/4
-    const double xs = ((n & 3) == 1 || (n & 3) == 2) ? -x : x;
+    bool lneg;
+    const double x = reduce_pio2<FULL>(y, &n, &lneg);   // n == 0 and x == y whenever |y| < pi/4
+    const int m = n + (lneg ? 1 : 0);             // s_sinf.c / s_cosf.c: signs from n + sign beyond 120
+    const double xs = ((m & 3) == 1 || (m & 3) == 2) ? -x : x;
     const double x2 = x * x;
     const double x3 = xs * x2;
     const double s1 = S2 + x2 * S3;
@@ -615,7 +675,7 @@ RLM_FN void sincos32_v(float y, float *sinp, float *cosp)
     const double x6 = x4 * x2;
     const double cv = c1 + x4 * C2;
     double cres = cv + x6 * c2;
-    cres = (n & 2) ? -cres : cres;                // second table: every cosine coefficient negated
+    cres = (m & 2) ? -cres : cres;                // second table: every cosine coefficient negated
     float sf = (float)((n & 1) ? cres : sres);
     float cf = (float)((n & 1) ? sres : cres);
     const uint32_t top = (f2u(y) >> 20) & 0x7ffu;
@@ -624,7 +684,8 @@ RLM_FN void sincos32_v(float y, float *sinp, float *cosp)
     *cosp = cf;
 }
 
-// tanf for 0 <= |x| < 120: one fp64 reduction, then k_tanf.c with its single division shared
+// tanf: one fp64 reduction, then k_tanf.c with its single division shared
+template <bool FULL = true>
 RLM_FN float tan32_v(float xin)
 {
     const float pio4 = u2f(0x3f490fdau), pio4lo = u2f(0x33222168u);
@@ -635,7 +696,9 @@ RLM_FN float tan32_v(float xin)
     // s_tanf.c: |x| <= pi/4 goes to the kernel unreduced; the reduction returns n = 0, y0 = x,
     // y1 = 0 there, so it is applied unconditionally
     int n;
-    const double dx = reduce_pio2(xin, &n);
+    bool lneg;
+    double dx = reduce_pio2<FULL>(xin, &n, &lneg);
+    if (lneg) { dx = -dx; n = -n; }
     float x = (float)dx;
     float y = (float)(dx - (double)x);
     const bool direct = ((int32_t)f2u(xin) & 0x7fffffff) <= 0x3f490fda;

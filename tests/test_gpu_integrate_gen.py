@@ -116,46 +116,11 @@ def test_full_size_properties(gpu, oracle):
 
 
 def test_large_parity_sweep(gpu, oracle):
-    """2^22 device-generated points per closure against the oracle: how many output WORDS differ at all.
-    (Expected: none, or a handful from glibc's FMA-contracted fp64 polynomials, ~2e-7 per sinf/cosf/expf/powf call.)"""
-    import torch
-    n = 1 << 22
-    ctx = gpu
-    th = oracle.hardware_threads()
-    wo, N, T = R.gen_frame(ctx, 4242, 0, n)
-    u = lambda stream, lo=0.0, hi=1.0: R.gen_uniform(ctx, 4242, 0, n, stream, lo, hi)
-    hostf = lambda t: t.contiguous().cpu().numpy()
-    # --- rlGgx reflect + refract
-    Ks = torch.stack([u(8 + j) for j in range(3)])
-    rough, ior, aniso = u(5, 0.05, 1.0), u(6, 1.05, 2.55), R.gen_aniso(ctx, 4242, 0, n)
-    xi = [u(11 + j) for j in range(6)]
-    g = R.GgxSampler(ctx, wo, N, T, specColor=Ks, ior=ior, roughness=rough, anisotropic=aniso)
-    got = [hostf(t) for t in g.reflectRefract(*xi[:4])]
-    c = dict(wo=hostf(wo), N=hostf(N), T=hostf(T), KsColor=hostf(Ks), roughness=hostf(rough), ior=hostf(ior),
-             anisotropic=hostf(aniso))
-    ref = ggx_oracle(oracle, c, nthreads=th).reflect_refract(*[hostf(t) for t in xi[:4]])
-    report = {}
-    def tally(name, got, ref):
-        words = sum(int((a.view(np.uint32) != b.view(np.uint32)).sum()) for a, b in zip(got, ref))
-        total = sum(a.size for a in got)
-        worst = max(float(cases.rel_err(a, b).max()) for a, b in zip(got, ref))
-        beyond = sum(int((cases.rel_err(a, b) > 1e-5).sum()) for a, b in zip(got, ref))
-        report[name] = (words, total, worst, beyond)
-        print(f"sweep {name}: {words} of {total} words differ, max rel err {worst:.3g}, values beyond 1e-5: {beyond}")
-        assert words <= 64 and beyond <= 4, (name, report[name])
-    tally("ggx reflect+refract", got, ref)
-    # --- rlDisney both lobes
-    sc = {k: u(32 + j) for j, k in enumerate(R._capi.DISNEY_SCALARS)}
-    d = R.DisneySampler(ctx, wo, N, T, base_color=Ks, **sc)
-    od = oracle.Disney(c["wo"], c["N"], c["T"], base_color=c["KsColor"], nthreads=th, **{k: hostf(v) for k, v in sc.items()})
-    for lobe, nm in ((R.RLS_RAY_DIFFUSE, "diffuse"), (R.RLS_RAY_GLOSSY, "glossy")):
-        d.setSampleType(lobe)
-        tally(f"disney {nm}", [hostf(t) for t in d.sampleEvalPdf(xi[0], xi[1])],
-              od.sample_eval_pdf(lobe, hostf(xi[0]), hostf(xi[1])))
-    # --- rlSss probe
-    dist = torch.stack([u(32 + j, 0.1, 2.1) for j in range(3)])
-    s = R.SssSampler(ctx, N, T, Ks, dist)
-    gp = s.getProbeRay(xi[0], xi[1])
-    rp = oracle.Sss(n, hostf(dist), c["KsColor"], N=c["N"], T=c["T"], nthreads=th).probe(hostf(xi[0]), hostf(xi[1]))
-    keys = ("r", "origin", "dir", "maxdist", "pdf", "profile")
-    tally("sss probe", [hostf(gp[k]) for k in keys], [rp[k] for k in keys])
+    """2^22 device-generated points per closure family against the oracle: how many output WORDS differ at all.
+    (Expected: none, or a handful from glibc's FMA-contracted fp64 polynomials, ~1e-8 per sinf/cosf/expf/powf call.)
+    tools/parity_soak.py runs the same sweep at 2^24 points x 4 seeds; profiles/r01_parity_soak.json."""
+    import parity_sweep
+    report = parity_sweep.sweep(gpu, 1 << 22, 4242)
+    assert len(report) == 8
+    for name, r in report.items():
+        assert r["words_differing"] <= 64 and r["beyond_1e5"] <= 4, (name, r)

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Parity soak: every closure family on 2^24 device-generated shading points per seed, GPU (RLS_MATH_EXACT)
+against the oracle, counted in output words that differ.  usage: tools/parity_soak.py [--out FILE]
+[--log2-points 24] [--seeds 4242,99,7,1234]"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+import parity_sweep  # noqa: E402
+import rlshaders_amd as R  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="")
+    ap.add_argument("--log2-points", type=int, default=24)
+    ap.add_argument("--seeds", default="4242,99,7,1234")
+    args = ap.parse_args()
+    ctx = R.Context(0)
+    total = {}
+    t0 = time.time()
+    seeds = [int(s) for s in args.seeds.split(",")]
+    for seed in seeds:
+        for name, r in parity_sweep.sweep(ctx, 1 << args.log2_points, seed).items():
+            t = total.setdefault(name, dict(words_differing=0, words=0, max_rel_err=0.0, beyond_1e5=0))
+            t["words_differing"] += r["words_differing"]
+            t["words"] += r["words"]
+            t["beyond_1e5"] += r["beyond_1e5"]
+            t["max_rel_err"] = max(t["max_rel_err"], r["max_rel_err"])
+    summary = dict(points_per_seed=1 << args.log2_points, seeds=seeds, mode="RLS_MATH_EXACT",
+                   seconds=round(time.time() - t0, 1), closures=total,
+                   words=sum(t["words"] for t in total.values()),
+                   words_differing=sum(t["words_differing"] for t in total.values()))
+    print(json.dumps(summary, indent=1))
+    if args.out:
+        Path(args.out).write_text(json.dumps(summary, indent=1))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

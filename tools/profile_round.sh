@@ -6,6 +6,7 @@ set -u
 TAG=${1:-r01}
 R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
+rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $R
 BENCH="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline"

@@ -67,9 +67,13 @@ def main():
     ap.add_argument("--log2-chunk", type=int, default=26)
     ap.add_argument("--quick", action="store_true", help="every 64th chunk only")
     ap.add_argument("--only", default="")
+    ap.add_argument("--math", default="exact", choices=["exact", "fast"],
+                    help="fast: characterise the RLS_MATH_FAST (hardware) forms -- error in ulp against the host libm on "
+                         "the arguments closures produce")
     args = ap.parse_args()
     hl = host_lib()
     ctx = R.Context(0)
+    ctx.set_math_mode(args.math == "fast")
     nthreads = len(os.sched_getaffinity(0))
     chunk = 1 << args.log2_chunk
     fp = C.POINTER(C.c_float)
@@ -83,6 +87,8 @@ def main():
         max_port = max_libm = 0
         first = None
         done = 0
+        fast_max = fast_gt1 = fast_gt4 = fast_nonfinite = 0
+        fast_sum = fast_abs = 0.0
         t0 = time.time()
         gen = torch.Generator(device="cuda"); gen.manual_seed(1234 + fn)
         for c in range(total_chunks):
@@ -109,6 +115,41 @@ def main():
             port, libm = np.empty(chunk, np.float32), np.empty(chunk, np.float32)
             hl.libm_host_eval(fn, chunk, xd.ctypes.data_as(fp), yd.ctypes.data_as(fp) if binary else None,
                               port.ctypes.data_as(fp), libm.ctypes.data_as(fp), nthreads)
+            if args.math == "fast":
+                # the domain the closures use each function on (normal, finite, moderate magnitudes)
+                ax = np.abs(xd)
+                keep = np.isfinite(xd) & (ax > 1e-30) & (ax < 1e30)
+                if name.startswith(("sinf", "cosf", "tanf")):
+                    keep &= ax <= 6.2831855
+                if name.startswith("tanf"):
+                    with np.errstate(all="ignore"):
+                        keep &= np.abs(np.cos(xd.astype(np.float64))) > 1e-3
+                if name == "acosf":
+                    keep &= ax <= 1.0
+                if name in ("sqrtf", "logf"):
+                    keep &= xd > 0
+                if name == "expf":
+                    keep &= ax < 87.0
+                if binary:
+                    ay = np.abs(yd)
+                    keep &= np.isfinite(yd) & (ay > 1e-30) & (ay < 1e30)
+                if name == "powf":
+                    keep &= (xd > 0) & (ax < 1e3) & (ax > 1e-3) & (ay < 20.0)
+                if name == "div":
+                    with np.errstate(all="ignore"):
+                        q = np.abs(xd.astype(np.float64) / yd.astype(np.float64))
+                    keep &= (q > 1e-30) & (q < 1e30)
+                xd, od, port, libm = xd[keep], od[keep], port[keep], libm[keep]
+                in_domain = int(keep.sum())
+                fin = np.isfinite(od) & np.isfinite(libm)
+                d = np.abs(ulp_key(od[fin]) - ulp_key(libm[fin]))
+                fast_max = max(fast_max, int(d.max()) if d.size else 0)
+                fast_gt1 += int((d > 1).sum()); fast_gt4 += int((d > 4).sum()); fast_sum += float(d.sum())
+                fast_nonfinite += int((~fin).sum())
+                if fin.any():
+                    fast_abs = max(fast_abs, float(np.abs(od[fin].astype(np.float64) - libm[fin].astype(np.float64)).max()))
+                done += in_domain
+                continue
             if name in BOUNDED:
                 keep = (np.abs(xd) < 120.0) | np.isnan(xd)
                 xd, od, port, libm = xd[keep], od[keep], port[keep], libm[keep]
@@ -122,12 +163,28 @@ def main():
             b, m, _ = compare(od, libm)
             bad_libm += b; max_libm = max(max_libm, m)
             done += in_domain
+        if args.math == "fast":
+            res[name] = dict(arguments_in_domain=done, max_ulp=fast_max, mean_ulp=fast_sum / max(done, 1),
+                             fraction_beyond_1ulp=fast_gt1 / max(done, 1), fraction_beyond_4ulp=fast_gt4 / max(done, 1),
+                             max_abs_err=fast_abs, nonfinite_mismatch=fast_nonfinite, seconds=round(time.time() - t0, 1))
+            print(name, json.dumps(res[name]), flush=True)
+            continue
         res[name] = dict(arguments=done, exhaustive=(not binary and not args.quick),
                          domain="|x| < 120 or NaN" if name in BOUNDED else "all bit patterns",
                          mismatch_vs_same_source_on_host=bad_port, max_ulp_vs_same_source=max_port,
                          mismatch_vs_host_libm=bad_libm, max_ulp_vs_host_libm=max_libm,
                          first_mismatch=first, seconds=round(time.time() - t0, 1))
         print(name, json.dumps(res[name]), flush=True)
+    if args.math == "fast":
+        summary = dict(mode="RLS_MATH_FAST", functions=res,
+                       note="error of the hardware forms in ulp of the host libm's result, over every fp32 argument in the "
+                            "domain the closures use (|x| in (1e-30, 1e30); angles within 2 pi, tanf away from its poles; "
+                            "acosf on [-1, 1]; expf below 87; powf for bases in (1e-3, 1e3) and |y| < 20)")
+        if args.out:
+            Path(args.out).parent.mkdir(parents=True, exist_ok=True)
+            Path(args.out).write_text(json.dumps(summary, indent=1))
+        ctx.close()
+        return
     summary = dict(mode="RLS_MATH_EXACT", host_threads=nthreads, functions=res,
                    note="device = rls_libm_eval on gfx950; same source on host = rlshaders_amd/csrc/rls_libm.hpp built with "
                         "g++ -ffp-contract=off; host libm = glibc of this image (its FMA multiarch sinf/cosf/expf/powf "

@@ -29,8 +29,8 @@ template <int OP, int FAST_MATH = RLS_FAST>
 __global__ __launch_bounds__(rlsh::kBlock) void alt_kernel(AltIO a)
 {
     stage_libm_tables();
-    const int64_t stride = (int64_t)gridDim.x * rlsh::kBlock;
-    for (int64_t base = (int64_t)blockIdx.x * rlsh::kBlock; base < a.n; base += stride) {
+    const TileRange tiles = tile_range(a.n);
+    for (int64_t base = tiles.first; base < tiles.end; base += tiles.step) {
         const Idx i = make_idx(base);
         if (i.full() >= a.n) continue;
         if (OP == AOP_LIBM) {

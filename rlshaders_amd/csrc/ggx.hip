@@ -31,8 +31,8 @@ __device__ __forceinline__ Ggx load_closure(const rls_ggx_closure &c, Idx i)
 template <int OP, int FAST_MATH, bool STREAMED>
 __global__ RLS_KERNEL_ATTR void ggx_kernel(GgxIO a)
 {
-    const int64_t stride = (int64_t)gridDim.x * rlsh::kBlock;
-    for (int64_t base = (int64_t)blockIdx.x * rlsh::kBlock; base < a.n; base += stride) {
+    const TileRange tiles = tile_range(a.n);
+    for (int64_t base = tiles.first; base < tiles.end; base += tiles.step) {
         const Idx i = make_idx(base);
         if (i.full() >= a.n) continue;
         Ggx g = load_closure<STREAMED>(a.c, i);

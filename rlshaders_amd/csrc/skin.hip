@@ -38,8 +38,8 @@ template <int FAST_MATH, bool STREAMED>
 __global__ __launch_bounds__(rlsh::kBlock) void skin_kernel(SkinIO a)
 {
     stage_libm_tables();   // expf / logf tables -> LDS (EXACT mode)
-    const int64_t stride = (int64_t)gridDim.x * rlsh::kBlock;
-    for (int64_t base = (int64_t)blockIdx.x * rlsh::kBlock; base < a.n; base += stride) {
+    const TileRange tiles = tile_range(a.n);
+    for (int64_t base = tiles.first; base < tiles.end; base += tiles.step) {
         const Idx i = make_idx(base);
         if (i.full() >= a.n) continue;
         const rls_skin_closure &c = a.c;

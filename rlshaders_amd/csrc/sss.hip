@@ -32,8 +32,8 @@ template <int OP, int FAST_MATH = RLS_FAST>
 __global__ __launch_bounds__(rlsh::kBlock) void sss_kernel(SssIO a)
 {
     stage_libm_tables();   // expf / logf tables -> LDS (EXACT mode)
-    const int64_t stride = (int64_t)gridDim.x * rlsh::kBlock;
-    for (int64_t base = (int64_t)blockIdx.x * rlsh::kBlock; base < a.n; base += stride) {
+    const TileRange tiles = tile_range(a.n);
+    for (int64_t base = tiles.first; base < tiles.end; base += tiles.step) {
         const Idx i = make_idx(base);
         if (i.full() >= a.n) continue;
         NdProfile p = load_profile(a.c, i);
@@ -75,8 +75,8 @@ __global__ __launch_bounds__(rlsh::kBlock) void sss_kernel(SssIO a)
 template <int OP, int FAST_MATH = RLS_FAST>
 __global__ __launch_bounds__(rlsh::kBlock) void misc_kernel(MiscIO a)
 {
-    const int64_t stride = (int64_t)gridDim.x * rlsh::kBlock;
-    for (int64_t base = (int64_t)blockIdx.x * rlsh::kBlock; base < a.n; base += stride) {
+    const TileRange tiles = tile_range(a.n);
+    for (int64_t base = tiles.first; base < tiles.end; base += tiles.step) {
         const Idx i = make_idx(base);
         if (i.full() >= a.n) continue;
         if (OP == OP_CAVITY) {

@@ -13,11 +13,21 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 template <typename V> struct W { static constexpr int n = sizeof(V) / 4; };
 
-template <typename V, int WORK>
+// XCD = 1: workgroups are dealt round-robin to the 8 XCDs; give each XCD one contiguous eighth of every plane
+// instead of every eighth tile
+template <typename V, int WORK, int XCD = 0>
 __global__ __launch_bounds__(256) void k(Planes p, long n_vec)
 {
     const long stride = (long)gridDim.x * 256;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += stride) {
+    long first = (long)blockIdx.x * 256;
+    long step = stride, end = n_vec;
+    if (XCD) {
+        const long per_xcd = n_vec / 8, x = blockIdx.x % 8, b = blockIdx.x / 8;
+        first = x * per_xcd + b * 256;
+        step = (long)(gridDim.x / 8) * 256;
+        end = (x + 1) * per_xcd;
+    }
+    for (long i = first + threadIdx.x; i < end; i += step) {
         V v[19];
 #pragma unroll
         for (int j = 0; j < 19; j++) v[j] = __builtin_nontemporal_load(reinterpret_cast<const V *>(p.in[j]) + i);
@@ -44,7 +54,7 @@ __global__ __launch_bounds__(256) void k(Planes p, long n_vec)
     }
 }
 
-template <typename V, int WORK>
+template <typename V, int WORK, int XCD = 0>
 void run(const Planes &p, long n, const char *name, int blocks_per_cu)
 {
     hipEvent_t a, b;
@@ -52,9 +62,9 @@ void run(const Planes &p, long n, const char *name, int blocks_per_cu)
     const long nv = n / W<V>::n;
     long want = (nv + 255) / 256, cap = 256L * blocks_per_cu;
     dim3 grid((unsigned)(want < cap ? want : cap));
-    for (int w = 0; w < 2; w++) hipLaunchKernelGGL((k<V, WORK>), grid, dim3(256), 0, 0, p, nv);
+    for (int w = 0; w < 2; w++) hipLaunchKernelGGL((k<V, WORK, XCD>), grid, dim3(256), 0, 0, p, nv);
     CHECK(hipEventRecord(a));
-    for (int r = 0; r < 10; r++) hipLaunchKernelGGL((k<V, WORK>), grid, dim3(256), 0, 0, p, nv);
+    for (int r = 0; r < 10; r++) hipLaunchKernelGGL((k<V, WORK, XCD>), grid, dim3(256), 0, 0, p, nv);
     CHECK(hipEventRecord(b));
     CHECK(hipEventSynchronize(b));
     float ms; CHECK(hipEventElapsedTime(&ms, a, b)); ms /= 10;
@@ -76,6 +86,12 @@ int main()
     run<float, 400>(p, n, "dword", 64);
     run<f2, 400>(p, n, "dwordx2", 64);
     run<f4, 400>(p, n, "dwordx4", 64);
+    run<float, 0, 1>(p, n, "dword/xcd", 64);
+    run<f2, 0, 1>(p, n, "x2/xcd", 64);
+    run<f4, 0, 1>(p, n, "x4/xcd", 64);
+    run<float, 0, 1>(p, n, "dword/xcd", 16);
+    run<float, 400, 1>(p, n, "dword/xcd", 64);
+    run<float, 0>(p, n, "dword", 64);
     run<float, 800>(p, n, "dword", 64);
     run<f2, 800>(p, n, "dwordx2", 64);
     return 0;

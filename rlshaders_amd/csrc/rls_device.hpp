@@ -93,6 +93,7 @@ RLS_DEV float refined_div(float a, float b)
 #define R_DIVH(a, b) refined_div(a, b)
 #define R_SQRTH(x) rlm::sqrt32(x)
 RLS_DEV void t_sincos(float x, float *s, float *c) { *s = __sinf(x); *c = __cosf(x); }
+RLS_DEV void t_sincos_any(float x, float *s, float *c) { t_sincos(x, s, c); }
 RLS_DEV void stage_libm_tables() {}
 #else
 #define R_DIV(a, b) ((a) / (b))
@@ -116,8 +117,11 @@ RLS_DEV void stage_libm_tables()
 #define R_EXP(x) rlm::exp32(x, s_libm_tables)
 #define R_LOG(x) rlm::log32(x, s_libm_tables)
 #define R_POW(x, y) rlm::pow32(x, y, s_libm_tables)
-// closure angles are bounded by construction: the forms without the |x| >= 120 branch (rls_libm.hpp)
+// t_sincos / t_tan: angles bounded by construction (results of atan2f / acosf, the concentric-disk mapping, the
+// in-kernel sampler) -- the forms without the |x| >= 120 branch (rls_libm.hpp).  t_sincos_any: angles computed from
+// caller-supplied random numbers (2 pi xi); full domain, so that even numbers outside [0, 1) give what the CPU gives.
 RLS_DEV void t_sincos(float x, float *s, float *c) { rlm::sincos32_v<false>(x, s, c); }
+RLS_DEV void t_sincos_any(float x, float *s, float *c) { rlm::sincos32_v<true>(x, s, c); }
 RLS_DEV float t_atan2(float y, float x) { return rlm::atan2_32_v(y, x); }
 RLS_DEV float t_acos(float x) { return rlm::acos32_v(x); }
 RLS_DEV float t_tan(float x) { return rlm::tan32_v<false>(x); }
@@ -144,11 +148,13 @@ RLS_DEV float linearstep(float lo, float hi, float t) { return clampf(R_DIV(t - 
 
 // ---- rlUtil ----------------------------------------------------------------------------------
 // src/rlUtil.h:21-29
+template <bool BOUNDED_PHI = false>
 RLS_DEV V3 spherical_direction(float cosTheta, float phi)
 {
     float r = R_SQRT(1.0f - sqr(cosTheta));
     float s, c;
-    t_sincos(phi, &s, &c);
+    if (BOUNDED_PHI) t_sincos(phi, &s, &c);
+    else t_sincos_any(phi, &s, &c);
     return mk(r * c, r * s, cosTheta);
 }
 // src/rlUtil.h:31-34
@@ -237,7 +243,7 @@ RLS_DEV V3 vndf_local(V3 view, const Frame &fr)
 {
     float cosThetaV = clampf(dot(fr.N, view), -1.0f, 1.0f);
     float phiV = t_atan2(dot(fr.V, view), dot(fr.U, view));
-    return spherical_direction(cosThetaV, phiV);
+    return spherical_direction<true>(cosThetaV, phiV);          // phiV = atan2f(...)
 }
 RLS_DEV VndfView vndf_view_from(V3 local, float ax, float ay)
 {
@@ -276,7 +282,7 @@ RLS_DEV V2 uniform_slope(float rx, float ry)
     float r = R_SQRT(R_DIV(rx, 1.0f - rx));
     float phi = kTwoPi * ry;
     float s, c;
-    t_sincos(phi, &s, &c);
+    t_sincos_any(phi, &s, &c);
     V2 slope;
     slope.x = r * c;
     slope.y = r * s;
@@ -446,7 +452,7 @@ RLS_DEV V3 ndf_microfacet(const Ggx &g, float rx, float ry)
     float gg = R_SQRT(R_DIV(rx, 1.0f - rx));
     float phi = kTwoPi * ry;
     float s, c;
-    t_sincos(phi, &s, &c);
+    t_sincos_any(phi, &s, &c);
     V3 omega = mk(gg * g.ax * c, gg * g.ay * s, 1.0f);
     return normalize(to_frame(omega, g.fr.U, g.fr.V, g.fr.N));
 }
@@ -636,7 +642,7 @@ RLS_DEV V3 disney_gtr2_aniso_microfacet(const Disney &d, float rx, float ry)
     float gg = R_SQRT(R_DIV(ry, 1.0f - ry));
     float phi = kTwoPi * rx;
     float s, c;
-    t_sincos(phi, &s, &c);
+    t_sincos_any(phi, &s, &c);
     V3 omega = mk(gg * d.ax * c, gg * d.ay * s, 1.0f);
     return normalize(to_frame(omega, d.fr.U, d.fr.V, d.fr.N));
 }
@@ -854,7 +860,7 @@ RLS_DEV float sss_probe_ray(const NdProfile &p, const Frame &fr, float rx, float
     float rmax = p.maxR;
     float phi = kTwoPi * ry;
     float s, c;
-    t_sincos(phi, &s, &c);
+    t_sincos_any(phi, &s, &c);
     V3 o;
     o.x = c * r;
     o.z = s * r;

@@ -51,6 +51,9 @@ def parse_args():
     ap.add_argument("--math", default="exact", choices=["exact", "fast"],
                     help="arithmetic of the measured kernels: exact (default, bit-faithful to the CPU closures) "
                          "or fast (RLS_MATH_FAST)")
+    ap.add_argument("--arena-candidates", type=int, default=6,
+                    help="equally sized blocks probed for the workload's plane arena (the fastest is kept); 1 = one arena, no "
+                         "probing; 0 = no arena, every plane group its own allocation (for comparison)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target seconds of CPU-baseline work")
     return ap.parse_args()
@@ -65,49 +68,64 @@ class Workload:
         self.launch, self.kernel, self.desc = launch, kernel, desc
 
 
-def make_workload(R, ctx, name: str, n: int, first: int):
-    import torch
-    u = lambda stream, lo=0.0, hi=1.0: R.gen_uniform(ctx, SEED, first, n, stream, lo, hi)
-    u3 = lambda stream, lo=0.0, hi=1.0: torch.stack([u(stream + j, lo, hi) for j in range(3)])
-    wo, N, T = R.gen_frame(ctx, SEED, first, n)
+# planes (n floats each) a workload reads and writes: sizes its arena
+PLANES = {"ggx_reflect_refract": 19 + 12, "ggx_reflect": 17 + 8, "disney_integrate": 22 + 8, "sss_probe": 17 + 12,
+          "sss_scatter": 15 + 3, "skin": 35 + 24}     # (the generator's wo planes included where the closure ignores them)
+
+
+def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1):
+    """All planes of the workload live in one arena (R.Arena): one allocation, and with candidates > 1 the
+    fastest of that many equally sized blocks ("Placement")."""
+    A = R.Arena(ctx, n, PLANES[name], candidates)
+    u = lambda stream, lo=0.0, hi=1.0: R.gen_uniform(ctx, SEED, first, n, stream, lo, hi, out=A.plane())
+
+    def u3(stream, lo=0.0, hi=1.0):
+        t = A.planes(3)
+        for j in range(3):
+            R.gen_uniform(ctx, SEED, first, n, stream + j, lo, hi, out=t[j])
+        return t
+
+    wo, N, T = R.gen_frame(ctx, SEED, first, n, out=(A.planes(3), A.planes(3), A.planes(3)))
     if name in ("ggx_reflect_refract", "ggx_reflect"):
         g = R.GgxSampler(ctx, wo, N, T, specColor=u3(S_KS), ior=u(S_IOR, 1.05, 2.55),
-                         roughness=u(S_ROUGH, 0.05, 1.0), anisotropic=R.gen_aniso(ctx, SEED, first, n))
-        xi = [u(S_XI0 + j) for j in range(4)]
+                         roughness=u(S_ROUGH, 0.05, 1.0), anisotropic=R.gen_aniso(ctx, SEED, first, n, out=A.plane()))
+        xi = [u(S_XI0 + j) for j in range(4 if name == "ggx_reflect_refract" else 2)]
         if name == "ggx_reflect_refract":
-            out = (ctx.empty(3, n), ctx.empty(3, n), ctx.empty(n), ctx.empty(n), ctx.empty(3, n), ctx.empty(n))
+            out = (A.planes(3), A.planes(3), A.plane(), A.plane(), A.planes(3), A.plane())
             # in: wo3 N3 T3 Ks3 rough ior aniso xi4 = 19 f; out: wi3 f3 pdf F wt3 weight = 12 f
-            return Workload(name, 2, (19 + 12) * 4, lambda: g.reflectRefract(xi[0], xi[1], xi[2], xi[3], out=out),
-                            "ggx_kernel<OP_REFLECT_REFRACT>",
-                            "rlGgx reflect+refract VNDF sampling, mixed params (SURVEY 8d config 2)")
-        out = (ctx.empty(3, n), ctx.empty(3, n), ctx.empty(n), ctx.empty(n))
-        return Workload(name, 1, (17 + 8) * 4, lambda: g.sampleEvalPdf(xi[0], xi[1], out=out),
-                        "ggx_kernel<OP_FUSED>", "rlGgx reflect triple, mixed params")
-    if name == "disney_integrate":
+            wl = Workload(name, 2, (19 + 12) * 4, lambda: g.reflectRefract(xi[0], xi[1], xi[2], xi[3], out=out),
+                          "ggx_kernel<OP_REFLECT_REFRACT>",
+                          "rlGgx reflect+refract VNDF sampling, mixed params (SURVEY 8d config 2)")
+        else:
+            out = (A.planes(3), A.planes(3), A.plane(), A.plane())
+            wl = Workload(name, 1, (17 + 8) * 4, lambda: g.sampleEvalPdf(xi[0], xi[1], out=out),
+                          "ggx_kernel<OP_FUSED>", "rlGgx reflect triple, mixed params")
+    elif name == "disney_integrate":
+        base = u3(S_KS)
         sc = {k: u(S_PARAM0 + j) for j, k in enumerate(R._capi.DISNEY_SCALARS)}
-        d = R.DisneySampler(ctx, wo, N, T, base_color=u3(S_KS), **sc)
-        out = {"diffuse_sum": ctx.empty(3, n), "diffuse_count": ctx.empty(n),
-               "specular_sum": ctx.empty(3, n), "specular_count": ctx.empty(n)}
-        return Workload(name, 128, (22 + 8) * 4, lambda: d.integrate(8, SEED, out=out),
-                        "disney_integrate_kernel<1>",
-                        "rlDisney both lobes x 64 spp, reduced mode (SURVEY 8d config 3, mode R; VALU-bound)")
-    if name == "sss_probe":
+        d = R.DisneySampler(ctx, wo, N, T, base_color=base, **sc)
+        out = {"diffuse_sum": A.planes(3), "diffuse_count": A.plane(),
+               "specular_sum": A.planes(3), "specular_count": A.plane()}
+        wl = Workload(name, 128, (22 + 8) * 4, lambda: d.integrate(8, SEED, out=out),
+                      "disney_integrate_kernel<1>",
+                      "rlDisney both lobes x 64 spp, reduced mode (SURVEY 8d config 3, mode R; VALU-bound)")
+    elif name == "sss_probe":
         s = R.SssSampler(ctx, N, T, albedo=u3(S_KS), dist=u3(S_PARAM0, 0.1, 2.1))
         xi = [u(S_XI0 + j) for j in range(2)]
-        out = {"r": ctx.empty(n), "origin": ctx.empty(3, n), "dir": ctx.empty(3, n), "maxdist": ctx.empty(n),
-               "pdf": ctx.empty(n), "profile": ctx.empty(3, n)}
-        return Workload(name, 1, (14 + 12) * 4, lambda: s.getProbeRay(xi[0], xi[1], out=out),
-                        "sss_kernel<OP_PROBE>", "rlSss ND probe ray + pdf + profile (SURVEY 8d config 4)")
-    if name == "sss_scatter":
+        out = {"r": A.plane(), "origin": A.planes(3), "dir": A.planes(3), "maxdist": A.plane(),
+               "pdf": A.plane(), "profile": A.planes(3)}
+        wl = Workload(name, 1, (14 + 12) * 4, lambda: s.getProbeRay(xi[0], xi[1], out=out),
+                      "sss_kernel<OP_PROBE>", "rlSss ND probe ray + pdf + profile (SURVEY 8d config 4)")
+    elif name == "sss_scatter":
         # shading points on the unit sphere (P = geometric normal), 16 probe rays each
         s = R.SssSampler(ctx, N, T, albedo=u3(S_KS), dist=u3(S_PARAM0, 0.02, 0.3))
         scene = R.make_scene("sphere", sphere_radius=1.0, light_dir=(0.0, 0.6, 0.8), use_cavity_fade=True)
-        out = ctx.empty(3, n)
-        return Workload(name, 16, (15 + 3) * 4, lambda: s.integrateScatter(N, scene, 4, SEED, out=out),
-                        "sss_scatter_kernel<1>",
-                        "rlSss integrateScatter, 16 probe rays per point on an analytic sphere (SURVEY 8f rank 3; "
-                        "VALU-bound)")
-    if name == "skin":
+        out = A.planes(3)
+        wl = Workload(name, 16, (15 + 3) * 4, lambda: s.integrateScatter(N, scene, 4, SEED, out=out),
+                      "sss_scatter_kernel<1>",
+                      "rlSss integrateScatter, 16 probe rays per point on an analytic sphere (SURVEY 8f rank 3; "
+                      "VALU-bound)")
+    elif name == "skin":
         p = dict(sss_color=u3(S_PARAM0), sss_weight=u(S_PARAM0 + 3), sss_dist_multiplier=u(S_PARAM0 + 4, 0.5, 1.5),
                  sss_scatter_dist=u3(S_PARAM0 + 5, 0.1, 2.1),
                  specular_color=u3(S_PARAM0 + 8), specular_weight=u(S_PARAM0 + 11),
@@ -115,11 +133,16 @@ def make_workload(R, ctx, name: str, n: int, first: int):
                  sheen_color=u3(S_PARAM0 + 14), sheen_weight=u(S_PARAM0 + 17),
                  sheen_roughness=u(S_PARAM0 + 18, 0.05, 1.0), sheen_ior=u(S_PARAM0 + 19, 1.05, 2.55))
         sk = R.SkinShader(ctx, wo, N, T, **p)
-        xi = torch.stack([u(S_XI0 + j) for j in range(6)])
-        out = sk.alloc_out()
-        return Workload(name, 3, (35 + 24) * 4, lambda: sk.sampleEvalPdf(xi, out=out),
-                        "skin_kernel", "rlSkin sheen GGX + specular GGX + SSS (SURVEY 8d config 5)")
-    raise ValueError(name)
+        xi = A.planes(6)
+        for j in range(6):
+            R.gen_uniform(ctx, SEED, first, n, S_XI0 + j, out=xi[j])
+        out = sk.alloc_out(arena=A)
+        wl = Workload(name, 3, (35 + 24) * 4, lambda: sk.sampleEvalPdf(xi, out=out),
+                      "skin_kernel", "rlSkin sheen GGX + specular GGX + SSS (SURVEY 8d config 5)")
+    else:
+        raise ValueError(name)
+    wl.arena = A
+    return wl
 
 
 # ------------------------------------------------------------------------------------------------
@@ -213,7 +236,7 @@ def main():
     # weak scaling: the job is world * n points, rank g owns the index range [g*n, (g+1)*n)
     first, count = shard_range(world * n, rank, world)
     assert count == n
-    wl = make_workload(R, ctx, args.workload, n, first=first)
+    wl = make_workload(R, ctx, args.workload, n, first=first, candidates=args.arena_candidates)
     torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -263,7 +286,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": wl.desc, "name": wl.name, "math": args.math, "points_per_gpu": n,
-                       "samples_per_point": wl.samples_per_point, "sharding": f"index-range x{world}, no collective"},
+                       "samples_per_point": wl.samples_per_point, "sharding": f"index-range x{world}, no collective",
+                       "placement": wl.arena.info()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": tr["hbm_bytes_per_launch"] if tr else None,

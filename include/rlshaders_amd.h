@@ -113,6 +113,21 @@ rls_status  rls_device_free(rls_context *ctx, void *p);
 rls_status  rls_copy_to_device(rls_context *ctx, void *dst, const void *src_host, size_t bytes);
 rls_status  rls_copy_to_host(rls_context *ctx, void *dst_host, const void *src, size_t bytes);
 
+/* Plane arenas.  Where in HBM the planes of a batch live matters: the closure kernels stream ~31 planes at once,
+ * and (a) planes carved from ONE allocation run the reflect+refract kernel 7 % faster than 31 separate
+ * allocations do (page-table reach), (b) equally sized blocks differ by up to 18 % in the bandwidth that plane
+ * pattern reaches on them, stably for the life of the allocation ("Placement").  An arena is one
+ * device allocation carved into `planes` planes of n floats; with candidates > 1 that many blocks are allocated,
+ * each timed with an arithmetic-free copy of the kernels' access pattern, and the fastest is kept.
+ * rls_probe_block times a caller-owned block the same way (its contents are overwritten).  Both synchronise. */
+typedef struct rls_arena rls_arena;
+rls_status  rls_arena_create(rls_context *ctx, int64_t n, int planes, int candidates, rls_arena **out);
+float      *rls_arena_plane(const rls_arena *arena, int k);                    /* NULL if k is out of range */
+rls_status  rls_arena_info(const rls_arena *arena, size_t *bytes, int *candidates_probed, float *probe_gb_per_s,
+                           float *probe_min, float *probe_max);
+void        rls_arena_destroy(rls_arena *arena);
+rls_status  rls_probe_block(rls_context *ctx, void *block, size_t bytes, float *gb_per_s);
+
 /* HIP-event stopwatch on the context's stream (what bench.py times kernels with). */
 rls_status  rls_timer_start(rls_context *ctx);
 rls_status  rls_timer_stop(rls_context *ctx);

@@ -152,6 +152,12 @@ PROTOTYPES = {
     "rls_timer_start": (C.c_int, [_ctx]),
     "rls_timer_stop": (C.c_int, [_ctx]),
     "rls_timer_elapsed_ms": (C.c_int, [_ctx, C.POINTER(C.c_float)]),
+    "rls_arena_create": (C.c_int, [_ctx, _i64, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "rls_arena_plane": (_vp, [_vp, C.c_int]),
+    "rls_arena_info": (C.c_int, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_float),
+                                 C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "rls_arena_destroy": (None, [_vp]),
+    "rls_probe_block": (C.c_int, [_ctx, _vp, C.c_size_t, C.POINTER(C.c_float)]),
     "rls_libm_eval": (C.c_int, [_ctx, C.c_int, _i64, _vp, _vp, _vp]),
     "rls_graph_begin_capture": (C.c_int, [_ctx]),
     "rls_graph_end_capture": (C.c_int, [_ctx, C.POINTER(_vp)]),

@@ -95,6 +95,64 @@ class Context:
         return torch.empty(*shape, dtype=torch.float32, device=self.torch_device)
 
 
+class Arena:
+    """All the planes of a batch in ONE device allocation -- and, with ``candidates`` > 1, in the fastest of that
+    many equally sized blocks (each is timed with an arithmetic-free copy of the kernels' plane pattern,
+    rls_probe_block; see "Placement" in DESIGN.md).  The memory is a torch tensor; ``plane()`` / ``planes(rows)``
+    hand out consecutive [n] / [rows, n] views of it."""
+
+    def __init__(self, ctx: Context, n: int, planes: int, candidates: int = 1):
+        self.ctx, self.n, self.count = ctx, int(n), int(planes)
+        self.stride = ((self.n * 4 + 255) // 256 * 256) // 4          # planes start on 256-byte boundaries
+        self.bytes = self.count * self.stride * 4
+        self.used = 0
+        self.probe_gbs, self.chosen_gbs = [], None
+        self.block = None
+        if candidates <= 0:        # comparison mode: every request is its own allocation, as without an arena
+            return
+        free, _ = torch.cuda.mem_get_info(ctx.torch_device)
+        candidates = max(1, min(int(candidates), int(0.8 * free // max(self.bytes, 1))))
+        blocks = []
+        for _ in range(candidates):
+            try:
+                b = torch.empty(self.count * self.stride, dtype=torch.float32, device=ctx.torch_device)
+            except torch.OutOfMemoryError:
+                break
+            blocks.append(b)
+            if candidates > 1:
+                torch.cuda.synchronize(ctx.torch_device)
+                g = C.c_float()
+                check(ctx.lib.rls_probe_block(ctx.handle, C.c_void_p(b.data_ptr()), self.bytes, C.byref(g)))
+                self.probe_gbs.append(float(g.value))
+        if not blocks:
+            raise torch.OutOfMemoryError(f"Arena: cannot allocate {self.bytes} bytes")
+        best = max(range(len(blocks)), key=lambda k: self.probe_gbs[k]) if self.probe_gbs else 0
+        self.block = blocks[best]
+        self.chosen_gbs = self.probe_gbs[best] if self.probe_gbs else None
+        del blocks
+        torch.cuda.empty_cache()
+        self.block.zero_()
+
+    def planes(self, rows: int) -> torch.Tensor:
+        if self.block is None:
+            self.used += rows
+            return torch.empty(rows, self.n, dtype=torch.float32, device=self.ctx.torch_device)
+        if self.used + rows > self.count:
+            raise RuntimeError(f"Arena: {self.count} planes, {self.used} handed out, {rows} more requested")
+        t = self.block[self.used * self.stride:].as_strided((rows, self.n), (self.stride, 1))
+        self.used += rows
+        return t
+
+    def plane(self) -> torch.Tensor:
+        return self.planes(1)[0]
+
+    def info(self) -> dict:
+        if self.block is None:
+            return {"arena": False, "planes": self.used}
+        return {"arena": True, "bytes": self.bytes, "planes": self.count, "candidates_probed": len(self.probe_gbs),
+                "probe_gb_per_s": [round(g, 1) for g in self.probe_gbs], "chosen_gb_per_s": self.chosen_gbs}
+
+
 class GraphCapture:
     """A recorded sequence of closure launches (rls_graph)."""
 
@@ -603,8 +661,12 @@ class SkinShader:
                 c.sss_scatter_dist[k] = capi.Param(None, float(d[k]))
         self.c = c
 
-    def alloc_out(self) -> dict:
+    def alloc_out(self, arena: Optional["Arena"] = None) -> dict:
         n, ctx = self.n, self.ctx
+        if arena is not None:
+            out = {k: arena.planes(3) for k in SKIN_OUT_VEC}
+            out.update({k: arena.plane() for k in SKIN_OUT_SCALAR})
+            return out
         out = {k: ctx.empty(3, n) for k in SKIN_OUT_VEC}
         out.update({k: ctx.empty(n) for k in SKIN_OUT_SCALAR})
         return out
@@ -625,9 +687,9 @@ class SkinShader:
 
 
 # ================================================================================================
-def gen_frame(ctx: Context, seed: int, first: int, n: int):
+def gen_frame(ctx: Context, seed: int, first: int, n: int, out=None):
     """Synthetic (wo, N, T) planes (DESIGN.md "Synthetic inputs")."""
-    wo, N, T = ctx.empty(3, n), ctx.empty(3, n), ctx.empty(3, n)
+    wo, N, T = out if out is not None else (ctx.empty(3, n), ctx.empty(3, n), ctx.empty(3, n))
     check(ctx.lib.rls_gen_frame(ctx.handle, seed, first, n, vec3(wo, n, "wo"), vec3(N, n, "N"), vec3(T, n, "T")))
     return wo, N, T
 
@@ -639,8 +701,8 @@ def gen_uniform(ctx: Context, seed: int, first: int, n: int, stream: int, lo: fl
     return out
 
 
-def gen_aniso(ctx: Context, seed: int, first: int, n: int):
-    out = ctx.empty(n)
+def gen_aniso(ctx: Context, seed: int, first: int, n: int, out: Optional[torch.Tensor] = None):
+    out = ctx.empty(n) if out is None else out
     check(ctx.lib.rls_gen_aniso(ctx.handle, seed, first, n, plane(out, n, "out")))
     return out
 

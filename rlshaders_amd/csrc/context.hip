@@ -397,9 +397,147 @@ __global__ __launch_bounds__(rlsh::kBlock) void checksum_kernel(int64_t n, const
     if ((threadIdx.x & 63) == 0) atomicAdd(acc, local);
 }
 
+// Placement probe: the access pattern of the closure kernels -- 19 planes read, 12 written, one float per
+// lane per plane, XCD-contiguous tiles -- with no arithmetic, over a block treated as 31 equal sub-planes.
+struct ProbePlanes { const float *in[19]; float *out[12]; };
+__global__ __launch_bounds__(rlsh::kBlock) void placement_probe_kernel(ProbePlanes p, int64_t n)
+{
+    const rlsd::TileRange tiles = rlsd::tile_range(n);
+    for (int64_t base = tiles.first; base < tiles.end; base += tiles.step) {
+        const int64_t i = base + threadIdx.x;
+        if (i >= n) continue;
+        float a = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 19; j++) a += __builtin_nontemporal_load(p.in[j] + i);
+#pragma unroll
+        for (int j = 0; j < 12; j++) __builtin_nontemporal_store(a + (float)j, p.out[j] + i);
+    }
+}
+
+rls_status probe_block(rls_context *ctx, void *block, size_t bytes, float *gbs)
+{
+    const int64_t n = (int64_t)(bytes / (31 * sizeof(float))) / 64 * 64;   // sub-planes on 256-byte boundaries
+    *gbs = 0.0f;
+    if (n < rlsh::kBlock) return RLS_OK;
+    ProbePlanes p;
+    float *base = (float *)block;
+    for (int j = 0; j < 19; j++) p.in[j] = base + (int64_t)j * n;
+    for (int j = 0; j < 12; j++) p.out[j] = base + (int64_t)(19 + j) * n;
+    const dim3 grid = rlsh::grid_for(ctx, n);
+    for (int w = 0; w < 2; w++) hipLaunchKernelGGL(placement_probe_kernel, grid, dim3(rlsh::kBlock), 0, ctx->stream, p, n);
+    RLS_HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
+    const int reps = 5;
+    for (int r = 0; r < reps; r++) hipLaunchKernelGGL(placement_probe_kernel, grid, dim3(rlsh::kBlock), 0, ctx->stream, p, n);
+    RLS_HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
+    rls_status st = rlsh::check_launch("placement_probe_kernel");
+    if (st != RLS_OK) return st;
+    RLS_HIP_TRY(hipEventSynchronize(ctx->ev_stop));
+    float ms = 0.0f;
+    RLS_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+    if (ms > 0.0f) *gbs = (float)(31.0 * sizeof(float) * (double)n * reps / (ms * 1e-3) / 1e9);
+    return RLS_OK;
+}
+
 } // namespace
 
+struct rls_arena {
+    int device;
+    void *block;
+    size_t bytes, plane_bytes;
+    int planes, candidates;
+    float probe_gbs, probe_gbs_min, probe_gbs_max;
+};
+
 extern "C" {
+
+rls_status rls_probe_block(rls_context *ctx, void *block, size_t bytes, float *gb_per_s)
+{
+    RLS_REQUIRE(ctx != nullptr && block != nullptr && gb_per_s != nullptr, "NULL argument");
+    RLS_REQUIRE(!ctx->capturing, "not allowed while a launch graph is being recorded");
+    RLS_HIP_TRY(hipSetDevice(ctx->device));
+    RLS_HIP_TRY(hipMemsetAsync(block, 0, bytes, ctx->stream));
+    return probe_block(ctx, block, bytes, gb_per_s);
+}
+
+rls_status rls_arena_create(rls_context *ctx, int64_t n, int planes, int candidates, rls_arena **out)
+{
+    RLS_REQUIRE(ctx != nullptr && out != nullptr, "NULL argument");
+    RLS_REQUIRE(!ctx->capturing, "not allowed while a launch graph is being recorded");
+    RLS_REQUIRE(n > 0 && planes > 0, "n and planes must be positive");
+    RLS_REQUIRE(candidates >= 1 && candidates <= 16, "candidates must be in [1, 16]");
+    *out = nullptr;
+    RLS_HIP_TRY(hipSetDevice(ctx->device));
+    // planes start on 256-byte boundaries
+    const size_t plane_bytes = ((size_t)n * sizeof(float) + 255) / 256 * 256;
+    const size_t bytes = plane_bytes * (size_t)planes;
+    void *blocks[16] = {nullptr};
+    float gbs[16] = {0.0f};
+    int got = 0;
+    rls_status st = RLS_OK;
+    for (int k = 0; k < candidates; k++) {
+        hipError_t e = hipMalloc(&blocks[k], bytes);
+        if (e != hipSuccess) {                      // fewer candidates than asked for is fine, none is not
+            (void)hipGetLastError();
+            if (k == 0) st = rlsh::hip_fail(e, "hipMalloc(arena)");
+            break;
+        }
+        got++;
+        hipError_t m = hipMemsetAsync(blocks[k], 0, bytes, ctx->stream);
+        if (m != hipSuccess) { st = rlsh::hip_fail(m, "hipMemsetAsync(arena)"); break; }
+        if (candidates > 1) {
+            st = probe_block(ctx, blocks[k], bytes, &gbs[k]);
+            if (st != RLS_OK) break;
+        }
+    }
+    int best = 0;
+    float lo = gbs[0], hi = gbs[0];
+    for (int k = 1; k < got; k++) {
+        if (gbs[k] > gbs[best]) best = k;
+        lo = gbs[k] < lo ? gbs[k] : lo;
+        hi = gbs[k] > hi ? gbs[k] : hi;
+    }
+    rls_arena *a = (st == RLS_OK && got > 0) ? (rls_arena *)calloc(1, sizeof(rls_arena)) : nullptr;
+    for (int k = 0; k < got; k++) {
+        if (!a || k != best) (void)hipFree(blocks[k]);
+    }
+    if (!a) {
+        if (st == RLS_OK) { rlsh::set_error("rls_arena_create: out of host memory"); st = RLS_ERR_OUT_OF_MEMORY; }
+        return st;
+    }
+    if (candidates > 1) RLS_HIP_TRY(hipMemsetAsync(blocks[best], 0, bytes, ctx->stream));   // the probe wrote into it
+    RLS_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    a->device = ctx->device; a->block = blocks[best]; a->bytes = bytes; a->plane_bytes = plane_bytes;
+    a->planes = planes; a->candidates = got;
+    a->probe_gbs = gbs[best]; a->probe_gbs_min = lo; a->probe_gbs_max = hi;
+    *out = a;
+    return RLS_OK;
+}
+
+float *rls_arena_plane(const rls_arena *arena, int k)
+{
+    if (!arena || k < 0 || k >= arena->planes) return nullptr;
+    return (float *)((char *)arena->block + (size_t)k * arena->plane_bytes);
+}
+
+rls_status rls_arena_info(const rls_arena *arena, size_t *bytes, int *candidates_probed, float *probe_gb_per_s,
+                          float *probe_min, float *probe_max)
+{
+    RLS_REQUIRE(arena != nullptr, "arena is NULL");
+    if (bytes) *bytes = arena->bytes;
+    if (candidates_probed) *candidates_probed = arena->candidates;
+    if (probe_gb_per_s) *probe_gb_per_s = arena->probe_gbs;
+    if (probe_min) *probe_min = arena->probe_gbs_min;
+    if (probe_max) *probe_max = arena->probe_gbs_max;
+    return RLS_OK;
+}
+
+void rls_arena_destroy(rls_arena *arena)
+{
+    if (!arena) return;
+    (void)hipSetDevice(arena->device);
+    (void)hipFree(arena->block);
+    free(arena);
+}
 
 rls_status rls_gen_frame(rls_context *ctx, uint32_t seed, uint64_t first_index, int64_t n,
                          rls_vec3 wo, rls_vec3 N, rls_vec3 T)

@@ -1,6 +1,7 @@
 """Experiment: is the run-to-run spread of the FAST reflect+refract kernel tied to the allocation
 (physical placement) or to time (clocks)?  Three independent 8.3 GB layouts A, B, C of the same data,
-timed round-robin."""
+timed round-robin.
+usage: exp_placement.py [exact|fast] [pad floats] [layouts]"""
 import sys
 sys.path.insert(0, ".")
 import torch
@@ -26,7 +27,8 @@ def layout():
     out = (v3(19), v3(22), pl[25], pl[26], v3(27), pl[30])
     return big, (lambda: g.reflectRefract(pl[15], pl[16], pl[17], pl[18], out=out))
 
-L = [layout() for _ in range(3)]
+K = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+L = [layout() for _ in range(K)]
 def t(fn, reps=10):
     fn(); torch.cuda.synchronize()
     ctx.timer_start()
@@ -34,5 +36,5 @@ def t(fn, reps=10):
         fn()
     ctx.timer_stop()
     return ctx.timer_elapsed_ms() / reps
-for rnd in range(4):
-    print("round", rnd, " ".join(f"{'ABC'[k]} {t(L[k][1]):.3f}" for k in range(3)), "| ptrs", [hex(b.data_ptr()) for b, _ in L] if rnd == 0 else "", flush=True)
+for rnd in range(3):
+    print("round", rnd, " ".join(f"{chr(65 + k)} {t(L[k][1]):.3f}" for k in range(K)), flush=True)

@@ -1,0 +1,58 @@
+// Micro-benchmark: is the speed of the 19-in / 12-out plane pattern a property of WHERE in HBM the planes
+// live?  K arenas of 31 planes each are allocated in one process and timed in turn, several rounds.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+struct Planes { const float *in[19]; float *out[12]; };
+
+__global__ __launch_bounds__(256) void k(Planes p, long n)
+{
+    const long per_xcd = n / 8, x = blockIdx.x % 8, b = blockIdx.x / 8;
+    const long step = (long)(gridDim.x / 8) * 256, end = (x + 1) * per_xcd;
+    for (long i = x * per_xcd + b * 256 + threadIdx.x; i < end; i += step) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 19; j++) a += __builtin_nontemporal_load(p.in[j] + i);
+#pragma unroll
+        for (int j = 0; j < 12; j++) __builtin_nontemporal_store(a + (float)j, p.out[j] + i);
+    }
+}
+
+float run(const Planes &p, long n)
+{
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    for (int w = 0; w < 2; w++) hipLaunchKernelGGL(k, dim3(256 * 64), dim3(256), 0, 0, p, n);
+    CHECK(hipEventRecord(a));
+    for (int r = 0; r < 10; r++) hipLaunchKernelGGL(k, dim3(256 * 64), dim3(256), 0, 0, p, n);
+    CHECK(hipEventRecord(b));
+    CHECK(hipEventSynchronize(b));
+    float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+    return ms / 10;
+}
+
+int main(int argc, char **argv)
+{
+    const long n = 1L << 26;
+    const int K = argc > 1 ? atoi(argv[1]) : 6;
+    const int separate = argc > 2 ? atoi(argv[2]) : 0;     // 1: 31 hipMallocs per arena, 0: one block per arena
+    Planes ar[16];
+    for (int a = 0; a < K; a++) {
+        if (separate) {
+            for (int j = 0; j < 19; j++) { void *q; CHECK(hipMalloc(&q, n * 4)); CHECK(hipMemset(q, 0, n * 4)); ar[a].in[j] = (const float *)q; }
+            for (int j = 0; j < 12; j++) { void *q; CHECK(hipMalloc(&q, n * 4)); ar[a].out[j] = (float *)q; }
+        } else {
+            float *base; CHECK(hipMalloc((void **)&base, 31 * n * 4)); CHECK(hipMemset(base, 0, 31 * n * 4));
+            for (int j = 0; j < 19; j++) ar[a].in[j] = base + j * n;
+            for (int j = 0; j < 12; j++) ar[a].out[j] = base + (19 + j) * n;
+        }
+    }
+    for (int round = 0; round < 3; round++) {
+        printf("round %d (%s):", round, separate ? "31 allocations per arena" : "one allocation per arena");
+        for (int a = 0; a < K; a++) { float t = run(ar[a], n); printf("  %c %.3f ms %4.0f GB/s", 'A' + a, t, 124.0 * n / t / 1e6); }
+        printf("\n");
+    }
+    return 0;
+}

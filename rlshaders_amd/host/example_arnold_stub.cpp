@@ -88,6 +88,29 @@ int main(int argc, char **argv)
         for (size_t i = 0; i < hp.size(); i++)
             if (hp[i] != hp3[i]) { std::fprintf(stderr, "graph replay pdf != direct at %zu\n", i); return 1; }
 
+        // --- batch buffers as one arena, the fastest of three candidate blocks; a direct C-ABI call on its planes ----
+        rlsb::Arena arena(dev, n, 10, 3);
+        {
+            rls_ggx_closure c = {};
+            std::vector<float> w = pts.planar(pts.wo), nn = pts.planar(pts.N), tt = pts.planar(pts.T);
+            // planes of an arena are padded to 256 bytes: copy plane by plane
+            for (int k = 0; k < 3; k++) {
+                rlsb::check(rls_copy_to_device(dev.ctx(), arena.plane(k), w.data() + (size_t)k * n, sizeof(float) * (size_t)n));
+                rlsb::check(rls_copy_to_device(dev.ctx(), arena.plane(3 + k), nn.data() + (size_t)k * n, sizeof(float) * (size_t)n));
+                rlsb::check(rls_copy_to_device(dev.ctx(), arena.plane(6 + k), tt.data() + (size_t)k * n, sizeof(float) * (size_t)n));
+            }
+            c.wo = arena.cvec3(0); c.N = arena.cvec3(3); c.T = arena.cvec3(6);
+            c.KsColor = rlsb::ParamRGB(1, 1, 1).c();
+            c.specularRoughness = rlsb::Param(std::sqrt(0.3f)).c(); c.ior = rlsb::Param(1.5f).c();
+            c.anisotropic = rlsb::Param(0.0f).c();
+            rlsb::check(rls_ggx_pdf(dev.ctx(), n, &c, L.cvec3(), arena.plane(9)));
+            std::vector<float> pa((size_t)n);
+            rlsb::check(rls_copy_to_host(dev.ctx(), pa.data(), arena.plane(9), sizeof(float) * (size_t)n));
+            for (int i = 0; i < n; i++)
+                if (pa[(size_t)i] != hp[(size_t)i]) { std::fprintf(stderr, "arena pdf != direct at %d\n", i); return 1; }
+            if (!(arena.probeGBs() > 0.0f)) { std::fprintf(stderr, "arena was not probed\n"); return 1; }
+        }
+
         // --- rlSkin on the same shading points (defaults of src/rlSkin.cpp:109-128, sheen switched on) ---
         rlsb::SkinParams sp;
         sp.sheen_weight = rlsb::Param(0.25f);

@@ -82,6 +82,34 @@ private:
     rls_graph *g_ = nullptr;
 };
 
+// The batch buffers of a stub: `planes` planes of n floats in ONE device allocation -- with candidates > 1 the
+// fastest of that many equally sized blocks (rls_arena_create; DESIGN.md, "Placement").
+class Arena {
+public:
+    Arena(const Device &d, int64_t n, int planes, int candidates = 1) { check(rls_arena_create(d.ctx(), n, planes, candidates, &a_)); }
+    ~Arena() { rls_arena_destroy(a_); }
+    Arena(const Arena &) = delete;
+    Arena &operator=(const Arena &) = delete;
+    float *plane(int k) const
+    {
+        float *p = rls_arena_plane(a_, k);
+        if (!p) throw Error(RLS_ERR_INVALID_ARGUMENT, "Arena::plane: index out of range");
+        return p;
+    }
+    rls_cvec3 cvec3(int first) const { return rls_cvec3{plane(first), plane(first + 1), plane(first + 2)}; }
+    rls_vec3 vec3(int first) const { return rls_vec3{plane(first), plane(first + 1), plane(first + 2)}; }
+    rls_rgb rgb(int first) const { return rls_rgb{plane(first), plane(first + 1), plane(first + 2)}; }
+    float probeGBs() const
+    {
+        float g = 0.0f;
+        check(rls_arena_info(a_, nullptr, nullptr, &g, nullptr, nullptr));
+        return g;
+    }
+
+private:
+    rls_arena *a_ = nullptr;
+};
+
 // n x planes floats in device memory, planar (plane p occupies [p*n, (p+1)*n)).
 class Planes {
 public:

@@ -4,9 +4,19 @@ profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc.json, profiles/<tag>_<worklo
 usage: summarize_profile.py <tag> [workload] [kernel-substring]"""
 import collections, csv, glob, json, os, shutil, sys
 
+def fresh(files):
+    """gpurun merges each call's files into the same local tree: keep only the newest run's (within 30 minutes of
+    the newest file)"""
+    files = list(files)
+    if not files:
+        return files
+    newest = max(os.path.getmtime(f) for f in files)
+    return [f for f in files if newest - os.path.getmtime(f) < 1800]
+
+
 def pmc(dirname, sub):
     acc = collections.defaultdict(list)
-    for f in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
+    for f in fresh(glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(f)):
             if sub in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -22,7 +32,7 @@ def main():
     src = os.path.join(root, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(root, "profiles")
     os.makedirs(dst, exist_ok=True)
-    for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    for f in fresh(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)):
         shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats.csv"))
     bench = {}
     for name in ("bench_unprofiled.json", "bench_trace.json"):

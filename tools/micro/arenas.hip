@@ -49,6 +49,8 @@ int main(int argc, char **argv)
             for (int j = 0; j < 12; j++) ar[a].out[j] = base + (19 + j) * n;
         }
     }
+    for (int a = 0; a < K; a++) printf("arena %c base %p (mod 1 GiB: %4lu MiB, mod 2 MiB: %4lu KiB)\n", 'A' + a, (const void *)ar[a].in[0],
+                                       ((unsigned long)ar[a].in[0] >> 20) & 1023, ((unsigned long)ar[a].in[0] >> 10) & 2047);
     for (int round = 0; round < 3; round++) {
         printf("round %d (%s):", round, separate ? "31 allocations per arena" : "one allocation per arena");
         for (int a = 0; a < K; a++) { float t = run(ar[a], n); printf("  %c %.3f ms %4.0f GB/s", 'A' + a, t, 124.0 * n / t / 1e6); }

@@ -5,7 +5,9 @@ Default workload = BASELINE.json configs[1]: rlGgx reflect + refract visible-nor
 2^26 SoA shading points per GPU, fp32, mixed per-point parameters.  One
 "step" is one pass of the fused kernel (`rls_ggx_reflect_refract`) over the batch = 2 samples per
 point (a reflect sample->eval->pdf triple and a refract sample->weight).  Inputs are generated on
-the device before the timed region; nothing crosses PCIe inside it.
+the device before the timed region; nothing crosses PCIe inside it.  All planes of the workload live
+in one arena, the fastest of `--arena-candidates` equally sized HBM blocks (DESIGN.md, "Placement");
+the JSON line records the probe results under config.placement.
 
 Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.  For N > 1
 it runs under `python -m torch.distributed.run --nproc-per-node N ...` (one rank per GPU); the

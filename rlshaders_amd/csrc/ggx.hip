@@ -1,8 +1,8 @@
 // ggx.hip -- rlGgx closure kernels (rls::GgxSamplerT<VNDFKernel>, src/rlGgx.h:92-373 and
 // src/rlGgx.cpp:14-99 of the reference) and their C-ABI entry points.  gfx950, wave64, one
-// shading point per lane, planar SoA streams, grid-stride over the batch.
+// shading point per lane, planar SoA streams, XCD-contiguous tiles strided over the batch.
 //
-// Roofline: HBM.  Algorithmic bytes per point (all planes streamed): reflect triple 64 B in
+// Roofline: HBM nominally (EXACT arithmetic makes the kernels VALU-issue-bound: DESIGN.md section 5).  Algorithmic bytes per point (all planes streamed): reflect triple 64 B in
 // (wo3 N3 T3 Ks3 rough ior xi2) + 32 B out (wi3 f3 pdf F) = 96 B; reflect+refract 72 B in +
 // 48 B out = 120 B; +4 B when `anisotropic` is a stream.
 #include "rls_internal.hpp"

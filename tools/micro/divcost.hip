@@ -73,6 +73,39 @@ __global__ __launch_bounds__(256) void k(const float *a, const float *b, float *
     }
     o[i] = acc;
 }
+// constant numerator (2 / x), varying denominator: nothing hoistable.  V 0: IEEE, 1: guard on b only + core
+template <int V>
+__global__ __launch_bounds__(256) void kc(const float *a, float *o, long n, int reps)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = fabsf(a[i]) + 1.0f, acc = 0.f;
+    for (int r = 0; r < reps; r++) {
+        float q;
+        if (V == 0) q = 2.0f / x;
+        else {
+            const bool ok = ((__float_as_uint(x) >> 23) & 0xffu) - 80u <= 94u;
+            if (__builtin_amdgcn_ballot_w64(!ok) == 0) q = div_core(2.0f, x); else q = 2.0f / x;
+        }
+        acc += q;
+        x = q * 0.37f + 1.0f;
+    }
+    o[i] = acc;
+}
+template <int V>
+void timeit_c(const char *name, const float *da, float *d0, long n)
+{
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int w = 0; w < 2; w++) hipLaunchKernelGGL(kc<V>, dim3(n / 256), dim3(256), 0, 0, da, d0, n, 256);
+    CHECK(hipEventRecord(e0));
+    for (int r = 0; r < 5; r++) hipLaunchKernelGGL(kc<V>, dim3(n / 256), dim3(256), 0, 0, da, d0, n, 256);
+    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
+    double waves = (double)n / 64 * 256;
+    printf("%-34s %.3f ms  %7.1f G div/s   ~%.1f SIMD-cycles per wave-division (incl. 2 chain ops)\n", name, ms, n * 256.0 / ms / 1e6,
+           ms * 1e-3 * 2.1e9 * 1024 / waves);
+}
+
 template <int V>
 __global__ __launch_bounds__(256) void one(const float *a, const float *b, float *o, long n)
 {
@@ -144,5 +177,7 @@ int main()
     timeit<4>("guarded core, select", da, db, d0, n);
     timeit<6>("wave-uniform guarded core", da, db, d0, n);
     timeit<5>("a * rcp(b)  (not exact)", da, db, d0, n);
+    timeit_c<0>("2 / x, IEEE", da, d0, n);
+    timeit_c<1>("2 / x, guard on x + core", da, d0, n);
     return 0;
 }

@@ -77,6 +77,12 @@ typedef struct { const float *r, *g, *b; float ur, ug, ub; } rls_param_rgb;
 /* ------------------------------------------------------------------------------------------
  * Context, memory, timing
  * ---------------------------------------------------------------------------------------- */
+/* Visible HIP devices (0 when there is none or the runtime cannot initialise). */
+int         rls_device_count(void);
+/* The contiguous shard [first, first + count) of rank `rank` of `world` over `total` shading points; the shards
+ * tile [0, total) exactly.  Points are independent, so a batch shards by index range with no collective on the
+ * data path (one context per device). */
+rls_status  rls_shard_range(int64_t total, int rank, int world, int64_t *first, int64_t *count);
 rls_status  rls_context_create(int device_ordinal, rls_context **out);
 void        rls_context_destroy(rls_context *ctx);
 /* Launch on an existing hipStream_t (e.g. the framework's current stream).  The handle is taken

@@ -131,6 +131,8 @@ _vp = C.c_void_p
 # name -> (restype, argtypes).  Every symbol include/rlshaders_amd.h declares is listed here;
 # tests/test_capi_symbols.py checks the two stay in step.
 PROTOTYPES = {
+    "rls_device_count": (C.c_int, []),
+    "rls_shard_range": (C.c_int, [_i64, C.c_int, C.c_int, C.POINTER(_i64), C.POINTER(_i64)]),
     "rls_context_create": (C.c_int, [C.c_int, C.POINTER(_ctx)]),
     "rls_context_destroy": (None, [_ctx]),
     "rls_context_set_stream": (C.c_int, [_ctx, _vp]),

@@ -113,6 +113,24 @@ void rls_context_destroy(rls_context *ctx)
     free(ctx);
 }
 
+int rls_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+rls_status rls_shard_range(int64_t total, int rank, int world, int64_t *first, int64_t *count)
+{
+    RLS_REQUIRE(first != nullptr && count != nullptr, "NULL argument");
+    RLS_REQUIRE(world >= 1 && rank >= 0 && rank < world && total >= 0, "bad shard request");
+    // 128-bit products: total * (rank + 1) can exceed 63 bits for absurd totals only, but cost nothing to get right
+    const __int128 lo = (__int128)total * rank / world, hi = (__int128)total * (rank + 1) / world;
+    *first = (int64_t)lo;
+    *count = (int64_t)(hi - lo);
+    return RLS_OK;
+}
+
 rls_status rls_context_set_stream(rls_context *ctx, void *hip_stream)
 {
     RLS_REQUIRE(ctx != nullptr, "ctx is NULL");

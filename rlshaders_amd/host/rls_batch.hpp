@@ -40,6 +40,17 @@ inline void check(rls_status s)
     }
 }
 
+// Index-range shard of rank `rank` of `world` over `total` shading points (rls_shard_range): one Device per GPU, one
+// shard each, no collective on the data path.
+struct Shard { int64_t first = 0, count = 0; };
+inline Shard shardRange(int64_t total, int rank, int world)
+{
+    Shard s;
+    check(rls_shard_range(total, rank, world, &s.first, &s.count));
+    return s;
+}
+inline int deviceCount() { return rls_device_count(); }
+
 // One GPU + the stream the closures launch on.
 class Device {
 public:

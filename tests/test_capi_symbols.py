@@ -82,3 +82,29 @@ def test_product_never_touches_oracle():
         assert "oracle_lib" not in t and "librls_oracle" not in t and "rls_oracle.h" not in t, p
     out = subprocess.run(["ldd", str(pkg / "lib" / "librlshaders_amd.so")], capture_output=True, text=True).stdout
     assert "rls_oracle" not in out
+
+
+def test_shard_range_matches_the_python_sharding():
+    """rls_shard_range (what a C++ host shards with) == rlshaders_amd.sharding.shard_range (what bench.py shards
+    with); touches no device."""
+    import ctypes as C
+    import random
+    from rlshaders_amd import _capi
+    from rlshaders_amd.sharding import shard_range
+    lib = _capi.load()
+    f, c = C.c_int64(), C.c_int64()
+    rng = random.Random(1)
+    for _ in range(5000):
+        total = rng.choice([0, 1, 7, 2 ** 26, 2 ** 30, 10 ** 9, rng.randrange(0, 2 ** 40), 2 ** 62 + 12345])
+        world = rng.choice([1, 2, 3, 4, 7, 8, 64])
+        rank = rng.randrange(world)
+        assert lib.rls_shard_range(total, rank, world, C.byref(f), C.byref(c)) == 0
+        assert (f.value, c.value) == shard_range(total, rank, world), (total, rank, world)
+    covered = 0
+    for rank in range(8):
+        assert lib.rls_shard_range(10 ** 9, rank, 8, C.byref(f), C.byref(c)) == 0
+        assert f.value == covered
+        covered += c.value
+    assert covered == 10 ** 9
+    assert lib.rls_shard_range(10, 3, 3, C.byref(f), C.byref(c)) == 1 and lib.rls_shard_range(-1, 0, 1, C.byref(f), C.byref(c)) == 1
+    assert lib.rls_device_count() >= 0

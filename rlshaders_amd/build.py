@@ -97,22 +97,23 @@ def build_library(force: bool = False, verbose: bool = False, variant: str = "",
 
 def build_host_examples(verbose: bool = False) -> Path:
     """Compile-check the C++ host mirror (header-only) and its example against the C ABI."""
-    hipcc = _hipcc()
-    src = PKG / "host" / "example_arnold_stub.cpp"
-    out = OBJDIR / "example_arnold_stub"
-    if not src.exists():
-        return out
     OBJDIR.mkdir(exist_ok=True)
-    if _stale(out, [src, PKG / "host" / "rls_batch.hpp", LIB, *HEADERS]):
-        cmd = ["g++", "-std=c++14", "-O2", "-Wall", f"-I{PKG.parent / 'include'}", f"-I{PKG / 'host'}",
-               str(src), "-o", str(out), f"-L{LIBDIR}", "-lrlshaders_amd", f"-Wl,-rpath,{LIBDIR}",
-               "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        p = subprocess.run(cmd, capture_output=True, text=True)
-        if p.returncode != 0:
-            raise RuntimeError(f"host example failed to build:\n{p.stdout}\n{p.stderr}")
-    return out
+    first = OBJDIR / "example_arnold_stub"
+    for name in ("example_arnold_stub", "example_multi_gpu"):
+        src = PKG / "host" / f"{name}.cpp"
+        out = OBJDIR / name
+        if not src.exists():
+            continue
+        if _stale(out, [src, PKG / "host" / "rls_batch.hpp", LIB, *HEADERS]):
+            cmd = ["g++", "-std=c++14", "-O2", "-Wall", "-pthread", f"-I{PKG.parent / 'include'}", f"-I{PKG / 'host'}",
+                   str(src), "-o", str(out), f"-L{LIBDIR}", "-lrlshaders_amd", f"-Wl,-rpath,{LIBDIR}",
+                   "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            p = subprocess.run(cmd, capture_output=True, text=True)
+            if p.returncode != 0:
+                raise RuntimeError(f"host example {name} failed to build:\n{p.stdout}\n{p.stderr}")
+    return first
 
 
 if __name__ == "__main__":

@@ -33,3 +33,19 @@ def test_arnold_stub_example_matches_survey_kat():
     for d, a, e, m in zip(dist, albedo, light, got["scatter_mean"]):
         want = a * e / math.pi * (1 - (math.exp(-rmax / d) + 3 * math.exp(-rmax / (3 * d))) / 4)
         assert abs(m / want - 1) < 0.03
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("log2n,shards", [(20, 3), (22, 2), (16, 8)])
+def test_multi_gpu_example_shards_add_up(log2n, shards):
+    """the C++ sharded runtime: one thread + context + arena per shard (several per device on a one-GPU box); the
+    shard checksums of the GGX reflect+refract outputs add up to the single-shard checksum"""
+    from rlshaders_amd import build
+    build.build_library()
+    build.build_host_examples()
+    exe = ROOT / "rlshaders_amd" / "build" / "example_multi_gpu"
+    p = subprocess.run([str(exe), str(log2n), str(shards)], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout, p.stderr)
+    got = json.loads(p.stdout.strip().splitlines()[-1])
+    assert got["points"] == 1 << log2n and got["shards"] == shards and got["devices"] >= 1
+    assert got["sharded_checksum"] == got["single_checksum"] != 0

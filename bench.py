@@ -49,7 +49,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2-points", type=int, default=26, help="points per GPU = 2^this (config: 26)")
     ap.add_argument("--workload", default="ggx_reflect_refract",
-                    choices=["ggx_reflect_refract", "ggx_reflect", "disney_integrate", "sss_probe", "sss_scatter", "skin"])
+                    choices=["ggx_reflect_refract", "ggx_reflect", "ggx_direct", "disney_integrate", "sss_probe", "sss_scatter", "skin"])
     ap.add_argument("--math", default="exact", choices=["exact", "fast"],
                     help="arithmetic of the measured kernels: exact (default, bit-faithful to the CPU closures) "
                          "or fast (RLS_MATH_FAST)")
@@ -72,7 +72,7 @@ class Workload:
 
 # planes (n floats each) a workload reads and writes: sizes its arena
 PLANES = {"ggx_reflect_refract": 19 + 12, "ggx_reflect": 17 + 8, "disney_integrate": 22 + 8, "sss_probe": 17 + 12,
-          "sss_scatter": 15 + 3, "skin": 35 + 24}     # (the generator's wo planes included where the closure ignores them)
+          "sss_scatter": 15 + 3, "skin": 35 + 24, "ggx_direct": 15 + 3 + 6 + 6}     # (the generator's wo planes included where the closure ignores them)
 
 
 def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1):
@@ -102,6 +102,19 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1):
             out = (A.planes(3), A.planes(3), A.plane(), A.plane())
             wl = Workload(name, 1, (17 + 8) * 4, lambda: g.sampleEvalPdf(xi[0], xi[1], out=out),
                           "ggx_kernel<OP_FUSED>", "rlGgx reflect triple, mixed params")
+    elif name == "ggx_direct":
+        # the light loop of rlGgx (direct diffuse + direct specular): 16 light samples + 16 BSDF samples per lobe
+        g = R.GgxSampler(ctx, wo, N, T, specColor=u3(S_KS), ior=u(S_IOR, 1.05, 2.55),
+                         roughness=u(S_ROUGH, 0.05, 1.0), anisotropic=R.gen_aniso(ctx, SEED, first, n, out=A.plane()))
+        P = u3(S_PARAM0 + 8, 0.0, 4.0)
+        kdc, kd, kdr, ks = u3(S_PARAM0), u(S_PARAM0 + 3), u(S_PARAM0 + 4), u(S_PARAM0 + 5)
+        light = R.make_light(center=(2.0, 2.0, 6.0), radius=1.25, radiance=(3.0, 2.0, 1.0))
+        out = (A.planes(3), A.planes(3))
+        wl = Workload(name, 48, (15 + 3 + 6 + 6) * 4,
+                      lambda: g.directLighting(P, light, 4, SEED, KdColor=kdc, Kd=kd, diffuseRoughness=kdr, Ks=ks, out=out),
+                      "ggx_direct_kernel<1>",
+                      "rlGgx light loop: Oren-Nayar + GGX under a spherical light, 16 light + 2 x 16 BSDF samples per "
+                      "point, power-heuristic MIS (SURVEY 8f rank 2; VALU-bound)")
     elif name == "disney_integrate":
         base = u3(S_KS)
         sc = {k: u(S_PARAM0 + j) for j, k in enumerate(R._capi.DISNEY_SCALARS)}

@@ -27,6 +27,12 @@
  * All pointers are DEVICE pointers owned by the caller; a plane holds n floats; planes of a
  * vec3/rgb need not be adjacent.  The library allocates nothing per call.
  * All arithmetic is fp32.  Launches go to the context's stream and are asynchronous.
+ *
+ * Threading: a context is a (device, stream, math mode) triple with no internal locking -- use one
+ * context per host thread (any number per device; rlshaders_amd/host/example_multi_gpu.cpp runs eight
+ * on one GPU concurrently).  Closure structs, arenas and graphs are plain data / handles and may be
+ * shared between threads as long as the device memory they name is not written concurrently.
+ * rls_last_error() is per thread.
  */
 #ifndef RLSHADERS_AMD_H
 #define RLSHADERS_AMD_H

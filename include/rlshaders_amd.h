@@ -126,8 +126,8 @@ rls_status  rls_copy_to_device(rls_context *ctx, void *dst, const void *src_host
 rls_status  rls_copy_to_host(rls_context *ctx, void *dst_host, const void *src, size_t bytes);
 
 /* Plane arenas.  Where in HBM the planes of a batch live matters: the closure kernels stream ~31 planes at once,
- * and (a) planes carved from ONE allocation run the reflect+refract kernel 7 % faster than 31 separate
- * allocations do (page-table reach), (b) equally sized blocks differ by up to 18 % in the bandwidth that plane
+ * and (a) planes carved from ONE allocation run the reflect+refract kernel 1-2 % faster than 31 separate
+ * allocations do, (b) equally sized blocks differ by up to 18 % in the bandwidth that plane
  * pattern reaches on them, stably for the life of the allocation ("Placement").  An arena is one
  * device allocation carved into `planes` planes of n floats; with candidates > 1 that many blocks are allocated,
  * each timed with an arithmetic-free copy of the kernels' access pattern, and the fastest is kept.
@@ -385,6 +385,10 @@ rls_status rls_skin_sample_eval_pdf(rls_context *ctx, int64_t n, const rls_skin_
  * ---------------------------------------------------------------------------------------- */
 rls_status rls_util_directions(rls_context *ctx, int64_t n, const float *a, const float *b,
                                rls_vec3 spherical, rls_vec3 disk);
+/* reflected = reflectDirection(i, nrm) = 2 |i.nrm| nrm - i (src/rlUtil.h:31-34; note the ABS),
+ * luminance = colorToLuminance(color) (src/rlUtil.h:36-39) */
+rls_status rls_util_reflect_luminance(rls_context *ctx, int64_t n, rls_cvec3 i, rls_cvec3 nrm, rls_cvec3 color,
+                                      rls_vec3 reflected, float *luminance);
 
 /* ------------------------------------------------------------------------------------------
  * Synthetic shading-point generator (bench / tests): counter-based, value = f(seed, index,

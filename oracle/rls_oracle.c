@@ -1490,6 +1490,14 @@ void orc_batch_util(int64_t n, const float *a, const float *b, orc_v3p spherical
     parallel_for(n, nthreads, util_range, &j);
 }
 
+void orc_batch_reflect_luminance(int64_t n, orc_cv3p i, orc_cv3p nrm, orc_cv3p color, orc_v3p reflected, float *luminance)
+{
+    for (int64_t k = 0; k < n; k++) {
+        st3(reflected, k, orc_reflect_direction(ld3(i, k), ld3(nrm, k)));
+        luminance[k] = orc_color_to_luminance(ldc(color, k));
+    }
+}
+
 /* ========================= integrateScatter over an analytic scene ====================== */
 /* src/rlSss.h:167-280 (sample loop + MIS combine), 293-356 (traceProbe), 361-424
  * (shadeProbeSample), 439-454 (evalLightSample).  See orc_scene in rls_oracle.h for what stands

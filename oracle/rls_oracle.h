@@ -342,6 +342,8 @@ void  orc_batch_ggx_direct_lighting(int64_t n, const orc_ggx_soa *in, const orc_
 
 /* utility closures, batch form (a2-a5) */
 void orc_batch_util(int64_t n, const float *a, const float *b, orc_v3p spherical, orc_v3p disk, int nthreads);
+/* a3 reflectDirection, a4 colorToLuminance */
+void orc_batch_reflect_luminance(int64_t n, orc_cv3p i, orc_cv3p nrm, orc_cv3p color, orc_v3p reflected, float *luminance);
 
 /* ---- synthetic input generator; bit-identical to the device
  *      generator in rlshaders_amd/csrc/gen.hip: only + - * / sqrt and integer hashing. ---- */

@@ -7,10 +7,10 @@ classes; it fails loudly when the HIP library is missing -- there is no CPU path
 """
 from ._capi import (RLS_KERNEL_NDF, RLS_KERNEL_VNDF, RLS_RAY_DIFFUSE, RLS_RAY_GLOSSY, RlsError, load)
 from .closures import (Arena, Context, DisneySampler, GaussianProfile, GgxSampler, NDProfile, SkinShader, SssSampler, checksum,
-                       gen_aniso, gen_frame, gen_uniform, make_light, make_scene, util_directions)
+                       gen_aniso, gen_frame, gen_uniform, make_light, make_scene, util_directions, util_reflect_luminance)
 
 __all__ = [
     "Context", "Arena", "GgxSampler", "DisneySampler", "NDProfile", "GaussianProfile", "SssSampler", "SkinShader",
     "RLS_RAY_DIFFUSE", "RLS_RAY_GLOSSY", "RLS_KERNEL_VNDF", "RLS_KERNEL_NDF",
-    "RlsError", "load", "gen_frame", "gen_uniform", "gen_aniso", "checksum", "util_directions", "make_scene", "make_light",
+    "RlsError", "load", "gen_frame", "gen_uniform", "gen_aniso", "checksum", "util_directions", "util_reflect_luminance", "make_scene", "make_light",
 ]

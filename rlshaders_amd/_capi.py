@@ -205,6 +205,7 @@ PROTOTYPES = {
     "rls_skin_sample_eval_pdf": (C.c_int, [_ctx, _i64, C.POINTER(SkinClosure), C.POINTER(_vp), C.POINTER(SkinOut)]),
     # rlUtil, generator, checksum
     "rls_util_directions": (C.c_int, [_ctx, _i64, _vp, _vp, Vec3, Vec3]),
+    "rls_util_reflect_luminance": (C.c_int, [_ctx, _i64, CVec3, CVec3, CVec3, Vec3, _vp]),
     "rls_gen_frame": (C.c_int, [_ctx, C.c_uint32, C.c_uint64, _i64, Vec3, Vec3, Vec3]),
     "rls_gen_uniform": (C.c_int, [_ctx, C.c_uint32, C.c_uint64, _i64, C.c_uint32, C.c_float, C.c_float, _vp]),
     "rls_gen_aniso": (C.c_int, [_ctx, C.c_uint32, C.c_uint64, _i64, _vp]),

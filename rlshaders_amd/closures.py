@@ -687,6 +687,15 @@ class SkinShader:
 
 
 # ================================================================================================
+def util_reflect_luminance(ctx: Context, i, nrm, color):
+    """reflectDirection(i, nrm) and colorToLuminance(color) (src/rlUtil.h:31-39) -> ([3,n], [n])"""
+    n = int(i.shape[-1])
+    r, lum = ctx.empty(3, n), ctx.empty(n)
+    check(ctx.lib.rls_util_reflect_luminance(ctx.handle, n, cvec3(i, n, "i"), cvec3(nrm, n, "nrm"), cvec3(color, n, "color"),
+                                             vec3(r, n, "reflected"), plane(lum, n, "luminance")))
+    return r, lum
+
+
 def gen_frame(ctx: Context, seed: int, first: int, n: int, out=None):
     """Synthetic (wo, N, T) planes (DESIGN.md "Synthetic inputs")."""
     wo, N, T = out if out is not None else (ctx.empty(3, n), ctx.empty(3, n), ctx.empty(3, n))

@@ -65,7 +65,7 @@ struct SssIO {
     rls_rgb profile;
     int64_t n;
 };
-enum MiscOp { MOP_CAVITY, MOP_DIFFUSE_DIR, MOP_UTIL };
+enum MiscOp { MOP_CAVITY, MOP_DIFFUSE_DIR, MOP_UTIL, MOP_REFLECT_LUM };
 struct MiscIO {
     rls_cvec3 a, b, c;
     const float *rx, *ry;

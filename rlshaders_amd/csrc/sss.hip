@@ -15,7 +15,8 @@ using rlsh::SssIO;
 using rlsh::MiscIO;
 enum { OP_ND = rlsh::SOP_ND, OP_ND_PDF = rlsh::SOP_ND_PDF, OP_ND_EVAL = rlsh::SOP_ND_EVAL, OP_PROBE = rlsh::SOP_PROBE,
        OP_MIS = rlsh::SOP_MIS };
-enum { OP_CAVITY = rlsh::MOP_CAVITY, OP_DIFFUSE_DIR = rlsh::MOP_DIFFUSE_DIR, OP_UTIL = rlsh::MOP_UTIL };
+enum { OP_CAVITY = rlsh::MOP_CAVITY, OP_DIFFUSE_DIR = rlsh::MOP_DIFFUSE_DIR, OP_UTIL = rlsh::MOP_UTIL,
+       OP_REFLECT_LUM = rlsh::MOP_REFLECT_LUM };
 
 template <class I>
 __device__ __forceinline__ NdProfile load_profile(const rls_sss_closure &c, I i)
@@ -88,6 +89,10 @@ __global__ __launch_bounds__(rlsh::kBlock) void misc_kernel(MiscIO a)
             fr.U = ld3(a.b, i);
             fr.V = cross(fr.N, fr.U);
             st3(a.v0, i, cosine_hemisphere(fr, ldg(a.rx, i), ldg(a.ry, i)));
+        } else if (OP == OP_REFLECT_LUM) {
+            st3(a.v0, i, reflect_direction(ld3(a.a, i), ld3(a.b, i)));
+            V3 c = ld3(a.c, i);
+            stg(a.out, i, luminance(c.x, c.y, c.z));
         } else {
             float u = ldg(a.rx, i), v = ldg(a.ry, i);
             st3(a.v0, i, spherical_direction(2.0f * u - 1.0f, kTwoPi * v));
@@ -137,6 +142,7 @@ RLS_HIDDEN rls_status rls_fast_misc(rls_context *ctx, int op, const rlsh::MiscIO
     switch (op) {
     case OP_CAVITY: return launch_misc_kernel<OP_CAVITY>(ctx, *io, "rls_sss_cavity_fade[fast]");
     case OP_DIFFUSE_DIR: return launch_misc_kernel<OP_DIFFUSE_DIR>(ctx, *io, "rls_sss_sample_diffuse_direction[fast]");
+    case OP_REFLECT_LUM: return launch_misc_kernel<OP_REFLECT_LUM>(ctx, *io, "rls_util_reflect_luminance[fast]");
     default: return launch_misc_kernel<OP_UTIL>(ctx, *io, "rls_util_directions[fast]");
     }
 }
@@ -252,6 +258,18 @@ rls_status rls_util_directions(rls_context *ctx, int64_t n, const float *a, cons
     MiscIO io = {};
     io.rx = a; io.ry = b; io.v0 = spherical; io.v1 = disk; io.n = n;
     return launch_misc<OP_UTIL>(ctx, io, "rls_util_directions");
+}
+
+rls_status rls_util_reflect_luminance(rls_context *ctx, int64_t n, rls_cvec3 i, rls_cvec3 nrm, rls_cvec3 color,
+                                      rls_vec3 reflected, float *luminance)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_REQUIRE(n >= 0, "n < 0");
+    if (n == 0) return RLS_OK;
+    RLS_REQUIRE(rlsh::has3(i) && rlsh::has3(nrm) && rlsh::has3(color) && rlsh::has3(reflected) && luminance, "NULL plane");
+    MiscIO io = {};
+    io.a = i; io.b = nrm; io.c = color; io.v0 = reflected; io.out = luminance; io.n = n;
+    return launch_misc<OP_REFLECT_LUM>(ctx, io, "rls_util_reflect_luminance");
 }
 
 } // extern "C"

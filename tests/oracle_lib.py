@@ -439,6 +439,14 @@ def sample_diffuse_direction(normal, T, rx, ry, nthreads=1):
     return wi
 
 
+def reflect_luminance(i, nrm, color):
+    n = i.shape[1]
+    i, nrm, color = f32(i), f32(nrm), f32(color)
+    r, lum = np.empty((3, n), np.float32), np.empty(n, np.float32)
+    lib().orc_batch_reflect_luminance(C.c_int64(n), _v(i), _v(nrm), _v(color), _v(r), _p(lum))
+    return r, lum
+
+
 def util_directions(a, b, nthreads=1):
     a, b = f32(a), f32(b)
     n = a.shape[0]

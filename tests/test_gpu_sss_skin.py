@@ -128,6 +128,17 @@ def _skin_check(gpu, oracle, wo, N, T, params, xi, tag):
     return got, ref
 
 
+def test_reflect_direction_and_luminance(gpu, oracle, mixed):
+    """a3 / a4 through the ABI: arbitrary (not normalised, not front-facing) vectors and colours"""
+    c, _ = mixed
+    i = (cases.xi(cases.SEED_EDGE, N, 3) * 2 - 1).astype(np.float32)
+    col = cases.xi(cases.SEED_PARITY, N, 3)
+    r_ref, l_ref = oracle.reflect_luminance(i, c["N"], col)
+    r, lum = (host(t) for t in R.util_reflect_luminance(gpu, dev(i), dev(c["N"]), dev(col)))
+    assert np.array_equal(r.view(np.uint32), r_ref.view(np.uint32))
+    assert np.array_equal(lum.view(np.uint32), l_ref.view(np.uint32))
+
+
 def test_skin_mixed(gpu, oracle):
     c = cases.skin_mixed(cases.SEED_PARITY, N)
     xi = cases.xi(cases.SEED_PARITY, N, 6)

@@ -177,3 +177,20 @@ def test_generator_statistics():
     # counter-based: a shard generated with an index offset equals the slice of the whole
     w2, _, _ = O.gen_frame(1234, 1000, 500)
     assert np.array_equal(w2, wo[:, 1000:1500])
+
+
+def test_reflect_direction_and_luminance_closed_forms():
+    """a3 reflectDirection = 2 |i.n| n - i (src/rlUtil.h:31-34: with the ABS a back-facing normal does NOT give the
+    mirror direction), a4 colorToLuminance (src/rlUtil.h:36-39: Rec.709 weights as written)"""
+    import numpy as np
+    import oracle_lib as O
+    i = np.array([[0.6, 0.0, 0.3], [0.0, 0.6, -0.4], [0.8, 0.8, 0.5]], np.float32)
+    n = np.array([[0.0, 0.0, 0.0], [0.0, 0.0, 0.0], [1.0, -1.0, 1.0]], np.float32)
+    c = np.array([[1.0, 0.0, 0.25], [0.0, 1.0, 0.5], [0.0, 0.0, 0.75]], np.float32)
+    r, lum = O.reflect_luminance(i, n, c)
+    # column 0: mirror about +z; column 1: normal flipped -> 2 * 0.8 * (0,0,-1) - i, not the mirror direction
+    assert np.allclose(r[:, 0], [-0.6, 0.0, 0.8]) and np.allclose(r[:, 1], [0.0, -0.6, -2.4])
+    assert np.allclose(r[:, 2], [-0.3, 0.4, 0.5])
+    w = np.array([0.212671, 0.715160, 0.072169])
+    assert abs(lum[0] - w[0]) < 1e-7 and abs(lum[1] - w[1]) < 1e-7
+    assert abs(lum[2] - float(w @ [0.25, 0.5, 0.75])) < 1e-7

@@ -197,7 +197,16 @@ def cpu_baseline(workload: str, target_seconds: float) -> dict | None:
     n = 1 << (n.bit_length() - 1)
     times = run(n, target_seconds)
     best, mean = min(times), sum(times) / len(times)
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {"value": round(2 * n / best / 1e9, 6), "unit": "Gsamples/s", "cores": threads, "kind": "port",
+            "per_core_msamples": round(2 * n / best / 1e6 / threads, 3), "cpu_model": model,
             "mean_value": round(2 * n / mean / 1e9, 6),
             "sample": f"{n} points (2 samples each) of the same seeded workload, best of {len(times)} passes "
                       f"({sum(times):.1f} s of CPU work), oracle/rls_oracle.c orc_batch_ggx_reflect_refract "

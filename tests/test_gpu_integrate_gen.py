@@ -118,7 +118,7 @@ def test_full_size_properties(gpu, oracle):
 def test_large_parity_sweep(gpu, oracle):
     """2^22 device-generated points per closure family against the oracle: how many output WORDS differ at all.
     (Expected: none, or a handful from glibc's FMA-contracted fp64 polynomials, ~1e-8 per sinf/cosf/expf/powf call.)
-    tools/parity_soak.py runs the same sweep at 2^24 points x 4 seeds; profiles/r01_parity_soak.json."""
+    tools/parity_soak.py runs the same sweep at 2^25 points x 8 seeds; profiles/r01_parity_soak.json."""
     import parity_sweep
     report = parity_sweep.sweep(gpu, 1 << 22, 4242)
     assert len(report) == 8

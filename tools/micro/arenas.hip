@@ -20,6 +20,42 @@ __global__ __launch_bounds__(256) void k(Planes p, long n)
     }
 }
 
+// one plane at a time, read only: does the speed belong to a place in HBM, or to the combination of planes?
+__global__ __launch_bounds__(256) void read1(const float *p, float *sink, long n)
+{
+    const long per_xcd = n / 8, x = blockIdx.x % 8, b = blockIdx.x / 8;
+    const long step = (long)(gridDim.x / 8) * 256, end = (x + 1) * per_xcd;
+    float a = 0.f;
+    for (long i = x * per_xcd + b * 256 + threadIdx.x; i < end; i += step) a += __builtin_nontemporal_load(p + i);
+    if (a == 12345.678f) sink[0] = a;
+}
+// k planes read together (k = 2, 4, 8, 16): where does the interference start?
+template <int K>
+__global__ __launch_bounds__(256) void readk(Planes p, float *sink, long n)
+{
+    const long per_xcd = n / 8, x = blockIdx.x % 8, b = blockIdx.x / 8;
+    const long step = (long)(gridDim.x / 8) * 256, end = (x + 1) * per_xcd;
+    float a = 0.f;
+    for (long i = x * per_xcd + b * 256 + threadIdx.x; i < end; i += step) {
+#pragma unroll
+        for (int j = 0; j < K; j++) a += __builtin_nontemporal_load(p.in[j] + i);
+    }
+    if (a == 12345.678f) sink[0] = a;
+}
+template <typename F>
+float timeit(F launch)
+{
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    launch(); launch();
+    CHECK(hipEventRecord(a));
+    for (int r = 0; r < 10; r++) launch();
+    CHECK(hipEventRecord(b));
+    CHECK(hipEventSynchronize(b));
+    float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+    return ms / 10;
+}
+
 float run(const Planes &p, long n)
 {
     hipEvent_t a, b;
@@ -55,6 +91,27 @@ int main(int argc, char **argv)
         printf("round %d (%s):", round, separate ? "31 allocations per arena" : "one allocation per arena");
         for (int a = 0; a < K; a++) { float t = run(ar[a], n); printf("  %c %.3f ms %4.0f GB/s", 'A' + a, t, 124.0 * n / t / 1e6); }
         printf("\n");
+    }
+    // dissect the slowest and the fastest arena
+    int lo = 0, hi = 0; float tlo = 0, thi = 1e9;
+    for (int a = 0; a < K; a++) { float t = run(ar[a], n); if (t > tlo) { tlo = t; lo = a; } if (t < thi) { thi = t; hi = a; } }
+    float *sink; CHECK(hipMalloc((void **)&sink, 4));
+    for (int which = 0; which < 2; which++) {
+        const int a = which ? hi : lo;
+        printf("%s arena %c (%.3f ms on the full pattern)\n  single planes, GB/s:", which ? "fastest" : "slowest", 'A' + a, which ? thi : tlo);
+        for (int j = 0; j < 19; j++) {
+            const float *pl = ar[a].in[j];
+            float t = timeit([&] { hipLaunchKernelGGL(read1, dim3(256 * 64), dim3(256), 0, 0, pl, sink, n); });
+            printf(" %4.0f", 4.0 * n / t / 1e6);
+        }
+        printf("\n  k planes read together, GB/s:");
+        float t2 = timeit([&] { hipLaunchKernelGGL(readk<2>, dim3(256 * 64), dim3(256), 0, 0, ar[a], sink, n); });
+        float t4 = timeit([&] { hipLaunchKernelGGL(readk<4>, dim3(256 * 64), dim3(256), 0, 0, ar[a], sink, n); });
+        float t8 = timeit([&] { hipLaunchKernelGGL(readk<8>, dim3(256 * 64), dim3(256), 0, 0, ar[a], sink, n); });
+        float t16 = timeit([&] { hipLaunchKernelGGL(readk<16>, dim3(256 * 64), dim3(256), 0, 0, ar[a], sink, n); });
+        float t19 = timeit([&] { hipLaunchKernelGGL(readk<19>, dim3(256 * 64), dim3(256), 0, 0, ar[a], sink, n); });
+        printf("  k=2 %4.0f  k=4 %4.0f  k=8 %4.0f  k=16 %4.0f  k=19 %4.0f\n", 8.0 * n / t2 / 1e6, 16.0 * n / t4 / 1e6, 32.0 * n / t8 / 1e6,
+               64.0 * n / t16 / 1e6, 76.0 * n / t19 / 1e6);
     }
     return 0;
 }

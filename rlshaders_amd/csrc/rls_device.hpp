@@ -92,6 +92,8 @@ RLS_DEV float refined_div(float a, float b)
 }
 #define R_DIVH(a, b) refined_div(a, b)
 #define R_SQRTH(x) rlm::sqrt32(x)
+#define R_SQRT1P(y) __builtin_amdgcn_sqrtf(1.0f + (y))
+#define R_SQRTH1P(y) rlm::sqrt32_1p(y)
 RLS_DEV void t_sincos(float x, float *s, float *c) { *s = __sinf(x); *c = __cosf(x); }
 RLS_DEV void t_sincos_any(float x, float *s, float *c) { t_sincos(x, s, c); }
 RLS_DEV void stage_libm_tables() {}
@@ -101,6 +103,9 @@ RLS_DEV void stage_libm_tables() {}
 #define R_SQRT(x) rlm::sqrt32(x)
 #define R_DIVH(a, b) ((a) / (b))
 #define R_SQRTH(x) rlm::sqrt32(x)
+// sqrtf(1 + y): no small-argument guard needed (rls_libm.hpp, sqrt32<false>)
+#define R_SQRT1P(y) rlm::sqrt32_1p(y)
+#define R_SQRTH1P(y) rlm::sqrt32_1p(y)
 // exp / log / pow: the host libm's table-driven fp64 algorithms (rls_libm.hpp).  The tables live
 // in LDS (640 B per workgroup; each table is at most one 256-byte bank row, so the per-lane
 // lookups are conflict-free); a kernel that evaluates any of the three calls
@@ -233,7 +238,7 @@ RLS_DEV VndfView vndf_view_from(V3 local, float ax, float ay)
     float B = flat ? 0.0f : R_DIVH(h, cz);                 // tan(theta') = |(sx,sy)| / cz
     w.B = B;
     w.B2 = sqr(B);
-    w.G1 = R_DIVH(2.0f, 1.0f + R_SQRTH(1.0f + w.B2));
+    w.G1 = R_DIVH(2.0f, 1.0f + R_SQRTH1P(w.B2));
     w.invB = R_RCP(B);
     return w;
 }
@@ -264,7 +269,7 @@ RLS_DEV VndfView vndf_view_from(V3 local, float ax, float ay)
     float B = t_tan(theta);
     w.B = B;
     w.B2 = sqr(B);
-    w.G1 = R_DIV(2.0f, 1.0f + R_SQRT(1.0f + w.B2));
+    w.G1 = R_DIV(2.0f, 1.0f + R_SQRT1P(w.B2));
     w.invB = R_RCP(B);
     return w;
 }
@@ -314,7 +319,7 @@ RLS_DEV V3 vndf_microfacet(const VndfView &w, const Frame &fr, float rx, float r
         }
         float z = R_DIVH(u * (u * (u * 0.27385f - 0.73369f) + 0.46341f),
                         u * (u * (u * 0.093073f + 0.309420f) - 1.0f) + 0.597999f);
-        slope.y = sign * z * R_SQRTH(1.0f + sqr(slope.x));
+        slope.y = sign * z * R_SQRTH1P(sqr(slope.x));
     }
     V3 omega;
     omega.x = -(w.cosPhi * slope.x - w.sinPhi * slope.y) * w.ax;
@@ -358,7 +363,7 @@ RLS_DEV Ggx ggx_make(V3 wo, V3 N, V3 T, bool exiting, float ksR, float ksG, floa
     {
         float cosSqr = sqr(g.vn);
         float tanSqr = R_RCP(cosSqr) - 1.0f;
-        g.g1v = R_DIV(2.0f, 1.0f + R_SQRT(1.0f + sqr(g.rough) * tanSqr));
+        g.g1v = R_DIV(2.0f, 1.0f + R_SQRT1P(sqr(g.rough) * tanSqr));
     }
     return g;
 }
@@ -393,7 +398,7 @@ RLS_DEV float ggx_G1(const Ggx &g, V3 v, V3 m, V3 n)
     if (vm * vn < 0.0f) return 0.0f;
     float cosSqr = sqr(vn);
     float tanSqr = R_RCP(cosSqr) - 1.0f;
-    float den = 1.0f + R_SQRT(1.0f + sqr(g.rough) * tanSqr);
+    float den = 1.0f + R_SQRT1P(sqr(g.rough) * tanSqr);
     return R_DIV(2.0f, den);
 }
 

@@ -60,12 +60,16 @@ RLM_FN float fabs32(float x) { return u2f(f2u(x) & 0x7fffffffu); }
 // its final +-1 ulp correction stay normal; the closures' radicands are never that small, so the
 // common path here is the same v_sqrt_f32 + correction without the rescaling, and arguments
 // below 2^-96 (never seen in practice) take the compiler's full sequence.  Identical results.
+// GUARDED = false: for radicands of the form 1 + y.  The sum of 1 and an fp32 number is a multiple of 2^-24 (or
+// exceeds 2), so it is never in (0, 2^-96) and the rescaling branch below is dead whatever y is; leaving the
+// test out saves three vector instructions and a branch per call.
+template <bool GUARDED = true>
 RLM_FN float sqrt32(float x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
 #ifndef RLS_SQRT_NO_FALLBACK
     // |x| < 2^-96, x != 0 (negative subnormals included: v_sqrt_f32 would flush them to -0 instead of NaN)
-    if (__builtin_expect((f2u(x) & 0x7fffffffu) - 1u < 0x0f800000u - 1u, 0)) return sqrtf(x);
+    if (GUARDED && __builtin_expect((f2u(x) & 0x7fffffffu) - 1u < 0x0f800000u - 1u, 0)) return sqrtf(x);
 #endif
     float s = __builtin_amdgcn_sqrtf(x);
     const float sm = __uint_as_float(__float_as_uint(s) - 1u);
@@ -79,6 +83,7 @@ RLM_FN float sqrt32(float x)
     return sqrtf(x);
 #endif
 }
+RLM_FN float sqrt32_1p(float y) { return sqrt32<false>(1.0f + y); }   // sqrtf(1 + y)
 
 // ---- atanf: fdlibm s_atanf.c ---------------------------------------------------------------------
 RLM_FN float atan32(float x)

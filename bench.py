@@ -53,7 +53,7 @@ def parse_args():
     ap.add_argument("--math", default="exact", choices=["exact", "fast"],
                     help="arithmetic of the measured kernels: exact (default, bit-faithful to the CPU closures) "
                          "or fast (RLS_MATH_FAST)")
-    ap.add_argument("--arena-candidates", type=int, default=10,
+    ap.add_argument("--arena-candidates", type=int, default=16,
                     help="equally sized blocks probed for the workload's plane arena (the fastest is kept); 1 = one arena, no "
                          "probing; 0 = no arena, every plane group its own allocation (for comparison)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

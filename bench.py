@@ -96,12 +96,12 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1):
             out = (A.planes(3), A.planes(3), A.plane(), A.plane(), A.planes(3), A.plane())
             # in: wo3 N3 T3 Ks3 rough ior aniso xi4 = 19 f; out: wi3 f3 pdf F wt3 weight = 12 f
             wl = Workload(name, 2, (19 + 12) * 4, lambda: g.reflectRefract(xi[0], xi[1], xi[2], xi[3], out=out),
-                          "ggx_kernel<OP_REFLECT_REFRACT>",
+                          "ggx_kernel<5, {m}, true>",
                           "rlGgx reflect+refract VNDF sampling, mixed params (SURVEY 8d config 2)")
         else:
             out = (A.planes(3), A.planes(3), A.plane(), A.plane())
             wl = Workload(name, 1, (17 + 8) * 4, lambda: g.sampleEvalPdf(xi[0], xi[1], out=out),
-                          "ggx_kernel<OP_FUSED>", "rlGgx reflect triple, mixed params")
+                          "ggx_kernel<3, {m}, true>", "rlGgx reflect triple, mixed params")
     elif name == "ggx_direct":
         # the light loop of rlGgx (direct diffuse + direct specular): 16 light samples + 16 BSDF samples per lobe
         g = R.GgxSampler(ctx, wo, N, T, specColor=u3(S_KS), ior=u(S_IOR, 1.05, 2.55),
@@ -112,7 +112,7 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1):
         out = (A.planes(3), A.planes(3))
         wl = Workload(name, 48, (15 + 3 + 6 + 6) * 4,
                       lambda: g.directLighting(P, light, 4, SEED, KdColor=kdc, Kd=kd, diffuseRoughness=kdr, Ks=ks, out=out),
-                      "ggx_direct_kernel<1>",
+                      "ggx_direct_kernel<1, {m}>",
                       "rlGgx light loop: Oren-Nayar + GGX under a spherical light, 16 light + 2 x 16 BSDF samples per "
                       "point, power-heuristic MIS (SURVEY 8f rank 2; VALU-bound)")
     elif name == "disney_integrate":
@@ -122,7 +122,7 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1):
         out = {"diffuse_sum": A.planes(3), "diffuse_count": A.plane(),
                "specular_sum": A.planes(3), "specular_count": A.plane()}
         wl = Workload(name, 128, (22 + 8) * 4, lambda: d.integrate(8, SEED, out=out),
-                      "disney_integrate_kernel<1>",
+                      "disney_integrate_kernel<1, {m}>",
                       "rlDisney both lobes x 64 spp, reduced mode (SURVEY 8d config 3, mode R; VALU-bound)")
     elif name == "sss_probe":
         s = R.SssSampler(ctx, N, T, albedo=u3(S_KS), dist=u3(S_PARAM0, 0.1, 2.1))
@@ -130,14 +130,14 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1):
         out = {"r": A.plane(), "origin": A.planes(3), "dir": A.planes(3), "maxdist": A.plane(),
                "pdf": A.plane(), "profile": A.planes(3)}
         wl = Workload(name, 1, (14 + 12) * 4, lambda: s.getProbeRay(xi[0], xi[1], out=out),
-                      "sss_kernel<OP_PROBE>", "rlSss ND probe ray + pdf + profile (SURVEY 8d config 4)")
+                      "sss_kernel<3, {m}>", "rlSss ND probe ray + pdf + profile (SURVEY 8d config 4)")
     elif name == "sss_scatter":
         # shading points on the unit sphere (P = geometric normal), 16 probe rays each
         s = R.SssSampler(ctx, N, T, albedo=u3(S_KS), dist=u3(S_PARAM0, 0.02, 0.3))
         scene = R.make_scene("sphere", sphere_radius=1.0, light_dir=(0.0, 0.6, 0.8), use_cavity_fade=True)
         out = A.planes(3)
         wl = Workload(name, 16, (15 + 3) * 4, lambda: s.integrateScatter(N, scene, 4, SEED, out=out),
-                      "sss_scatter_kernel<1>",
+                      "sss_scatter_kernel<1, {m}>",
                       "rlSss integrateScatter, 16 probe rays per point on an analytic sphere (SURVEY 8f rank 3; "
                       "VALU-bound)")
     elif name == "skin":
@@ -153,7 +153,7 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1):
             R.gen_uniform(ctx, SEED, first, n, S_XI0 + j, out=xi[j])
         out = sk.alloc_out(arena=A)
         wl = Workload(name, 3, (35 + 24) * 4, lambda: sk.sampleEvalPdf(xi, out=out),
-                      "skin_kernel", "rlSkin sheen GGX + specular GGX + SSS (SURVEY 8d config 5)")
+                      "skin_kernel<{m}, true>", "rlSkin sheen GGX + specular GGX + SSS (SURVEY 8d config 5)")
     else:
         raise ValueError(name)
     wl.arena = A
@@ -315,7 +315,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": tr["hbm_bytes_per_launch"] if tr else None,
-                         "kernel": wl.kernel, "kernel_ms": round(kernel_ms, 5),
+                         "kernel": wl.kernel.format(m=1 if args.math == "fast" else 0),   # as rocprofv3 --kernel-trace names it
+                         "kernel_ms": round(kernel_ms, 5),
                          "algorithmic_bytes_per_point": wl.bytes_per_point,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }

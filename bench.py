@@ -45,8 +45,10 @@ S_PARAM0 = 32
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # the first ~10 launches of the VALU-bound EXACT kernel run up to 40 % slower while the GPU leaves its idle power state
+    # (3.3, 2.9, 2.7, 2.6, 2.55, 2.5 ... 2.38 ms; tools/exp_warmup.py), hence ten warm-up steps by default
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--log2-points", type=int, default=26, help="points per GPU = 2^this (config: 26)")
     ap.add_argument("--workload", default="ggx_reflect_refract",
                     choices=["ggx_reflect_refract", "ggx_reflect", "ggx_direct", "disney_integrate", "sss_probe", "sss_scatter", "skin"])

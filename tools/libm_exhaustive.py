@@ -25,6 +25,22 @@ FN = dict(sqrtf=0, div=1, atan2f=2, acosf=3, tanf=4, sinf=5, cosf=6, expf=7, log
 BINARY = {"div", "atan2f", "powf"}
 # the forms the closure kernels call: specified for |x| < 120 and NaN only (include/rlshaders_amd.h)
 BOUNDED = {"tanf_bounded", "sinf_bounded", "cosf_bounded"}
+# exhaustive slices of the two-argument functions: every fp32 value of one argument against a fixed other one
+# (name -> (function id, which argument sweeps, the fixed value))
+SLICES = {
+    "powf(x, 5)": (9, 0, 5.0),            # the Schlick weights of rlDisney (src/rlDisney.cpp:576)
+    "powf(x, 0.5)": (9, 0, 0.5),
+    "powf(0.25, y)": (9, 1, 0.25),        # a2^(1 - xi) of sampleGTR1Direction (src/rlDisney.cpp:399)
+    "atan2f(y, 1)": (2, 0, 1.0),
+    "atan2f(y, -0.3)": (2, 0, -0.3),
+    "atan2f(0.7, x)": (2, 1, 0.7),
+    "atan2f(-1e-3, x)": (2, 1, -1e-3),
+    "x / 3": (1, 0, 3.0),
+    "x / 0.3333": (1, 0, 0.3333),
+    "1 / y": (1, 1, 1.0),
+    "2 / y": (1, 1, 2.0),
+    "0.31830988 / y": (1, 1, 0.31830988),
+}
 
 
 def host_lib() -> C.CDLL:
@@ -67,6 +83,8 @@ def main():
     ap.add_argument("--log2-chunk", type=int, default=26)
     ap.add_argument("--quick", action="store_true", help="every 64th chunk only")
     ap.add_argument("--only", default="")
+    ap.add_argument("--slices", action="store_true", help="also sweep the exhaustive one-argument slices of powf / atan2f / division")
+    ap.add_argument("--slices-only", action="store_true")
     ap.add_argument("--math", default="exact", choices=["exact", "fast"],
                     help="fast: characterise the RLS_MATH_FAST (hardware) forms -- error in ulp against the host libm on "
                          "the arguments closures produce")
@@ -78,11 +96,16 @@ def main():
     chunk = 1 << args.log2_chunk
     fp = C.POINTER(C.c_float)
     res = {}
-    for name, fn in FN.items():
+    work = ([] if args.slices_only else list(FN.items())) + \
+        ([(k, v[0]) for k, v in SLICES.items()] if (args.slices or args.slices_only) else [])
+    for name, fn in work:
         if args.only and name not in args.only.split(","):
             continue
+        sl = SLICES.get(name)
         binary = name in BINARY
-        total_chunks = (1 << 32) // chunk if not binary else (1 << 30) // chunk
+        total_chunks = (1 << 32) // chunk if (not binary or sl is not None) else (1 << 30) // chunk
+        if sl is not None:
+            binary = False          # reported as exhaustive over the swept argument
         bad_port = bad_libm = 0
         max_port = max_libm = 0
         first = None
@@ -94,7 +117,12 @@ def main():
         for c in range(total_chunks):
             if args.quick and c % 64:
                 continue
-            if binary:
+            if sl is not None:
+                base = c * chunk - 2 ** 31
+                sweep = (torch.arange(chunk, device="cuda", dtype=torch.int64) + base).to(torch.int32).view(torch.float32)
+                fixed = torch.full((chunk,), sl[2], device="cuda", dtype=torch.float32)
+                x, y = (sweep, fixed) if sl[1] == 0 else (fixed, sweep)
+            elif binary:
                 # raw bit patterns for both arguments: every exponent, signs, denormals, NaN/Inf included
                 xb = torch.randint(-2 ** 31, 2 ** 31, (chunk,), device="cuda", dtype=torch.int32, generator=gen)
                 yb = torch.randint(-2 ** 31, 2 ** 31, (chunk,), device="cuda", dtype=torch.int32, generator=gen)
@@ -107,13 +135,14 @@ def main():
                 x = (torch.arange(chunk, device="cuda", dtype=torch.int64) + base).to(torch.int32).view(torch.float32)
                 y = None
             out = torch.empty(chunk, device="cuda", dtype=torch.float32)
-            R._capi.check(ctx.lib.rls_libm_eval(ctx.handle, fn, chunk, x.data_ptr(), y.data_ptr() if binary else None,
+            two = binary or sl is not None
+            R._capi.check(ctx.lib.rls_libm_eval(ctx.handle, fn, chunk, x.data_ptr(), y.data_ptr() if two else None,
                                                 out.data_ptr()))
             torch.cuda.synchronize()
             xd, od = x.cpu().numpy(), out.cpu().numpy()
-            yd = y.cpu().numpy() if binary else None
+            yd = y.cpu().numpy() if two else None
             port, libm = np.empty(chunk, np.float32), np.empty(chunk, np.float32)
-            hl.libm_host_eval(fn, chunk, xd.ctypes.data_as(fp), yd.ctypes.data_as(fp) if binary else None,
+            hl.libm_host_eval(fn, chunk, xd.ctypes.data_as(fp), yd.ctypes.data_as(fp) if two else None,
                               port.ctypes.data_as(fp), libm.ctypes.data_as(fp), nthreads)
             if args.math == "fast":
                 # the domain the closures use each function on (normal, finite, moderate magnitudes)

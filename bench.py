@@ -33,6 +33,7 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+VALU_PEAK_TFLOPS = 157.3  # fp32 vector peak of the same guide (packed-fp32 FMA rate; the integrators' bound)
 SEED = 1234               # throughput seed, SURVEY.md 8(d)
 
 # stream ids (shared with oracle/rls_oracle.h)
@@ -51,7 +52,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--log2-points", type=int, default=26, help="points per GPU = 2^this (config: 26)")
     ap.add_argument("--workload", default="ggx_reflect_refract",
-                    choices=["ggx_reflect_refract", "ggx_reflect", "ggx_direct", "disney_integrate", "sss_probe", "sss_scatter", "skin"])
+                    choices=["ggx_reflect_refract", "ggx_reflect", "ggx_direct", "disney_integrate", "disney_stream", "sss_probe",
+                             "sss_scatter", "skin"])
+    ap.add_argument("--chunk-log2", type=int, default=20, help="disney_stream: points per chunk = 2^this")
     ap.add_argument("--math", default="exact", choices=["exact", "fast"],
                     help="arithmetic of the measured kernels: exact (default, bit-faithful to the CPU closures) "
                          "or fast (RLS_MATH_FAST)")
@@ -67,17 +70,22 @@ def parse_args():
 class Workload:
     """name, samples per point, algorithmic bytes per point, a launch() closure"""
 
-    def __init__(self, name, samples_per_point, bytes_per_point, launch, kernel, desc):
+    def __init__(self, name, samples_per_point, bytes_per_point, launch, kernel, desc, bound="hbm", launches_per_step=1):
         self.name, self.samples_per_point, self.bytes_per_point = name, samples_per_point, bytes_per_point
         self.launch, self.kernel, self.desc = launch, kernel, desc
+        # "hbm": the pointwise streaming kernels; "valu": the n^2-spp integrators, which read ~100 B per point for
+        # tens of triples of arithmetic (SURVEY.md 8(d): "VALU-bound, not HBM-bound ... must be stated as such")
+        self.bound = bound
+        self.launches_per_step = launches_per_step     # kernel launches one step() issues (chunked streaming)
 
 
 # planes (n floats each) a workload reads and writes: sizes its arena
-PLANES = {"ggx_reflect_refract": 19 + 12, "ggx_reflect": 17 + 8, "disney_integrate": 22 + 8, "sss_probe": 17 + 12,
+PLANES = {"ggx_reflect_refract": 19 + 12, "ggx_reflect": 17 + 8, "disney_integrate": 22 + 8, "disney_stream": 22 + 8,
+          "sss_probe": 17 + 12,
           "sss_scatter": 15 + 3, "skin": 35 + 24, "ggx_direct": 15 + 3 + 6 + 6}     # (the generator's wo planes included where the closure ignores them)
 
 
-def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1):
+def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, chunk_log2: int = 20):
     """All planes of the workload live in one arena (R.Arena): one allocation, and with candidates > 1 the
     fastest of that many equally sized blocks ("Placement")."""
     A = R.Arena(ctx, n, PLANES[name], candidates)
@@ -113,19 +121,33 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1):
         light = R.make_light(center=(2.0, 2.0, 6.0), radius=1.25, radiance=(3.0, 2.0, 1.0))
         out = (A.planes(3), A.planes(3))
         wl = Workload(name, 48, (15 + 3 + 6 + 6) * 4,
-                      lambda: g.directLighting(P, light, 4, SEED, KdColor=kdc, Kd=kd, diffuseRoughness=kdr, Ks=ks, out=out),
+                      lambda: g.directLighting(P, light, 4, SEED, KdColor=kdc, Kd=kd, diffuseRoughness=kdr, Ks=ks, out=out,
+                                               first_index=first),
                       "ggx_direct_kernel<1, {m}>",
                       "rlGgx light loop: Oren-Nayar + GGX under a spherical light, 16 light + 2 x 16 BSDF samples per "
-                      "point, power-heuristic MIS (SURVEY 8f rank 2; VALU-bound)")
-    elif name == "disney_integrate":
+                      "point, power-heuristic MIS (SURVEY 8f rank 2; VALU-bound)", bound="valu")
+    elif name in ("disney_integrate", "disney_stream"):
         base = u3(S_KS)
         sc = {k: u(S_PARAM0 + j) for j, k in enumerate(R._capi.DISNEY_SCALARS)}
         d = R.DisneySampler(ctx, wo, N, T, base_color=base, **sc)
         out = {"diffuse_sum": A.planes(3), "diffuse_count": A.plane(),
                "specular_sum": A.planes(3), "specular_count": A.plane()}
-        wl = Workload(name, 128, (22 + 8) * 4, lambda: d.integrate(8, SEED, out=out),
-                      "disney_integrate_kernel<1, {m}>",
-                      "rlDisney both lobes x 64 spp, reduced mode (SURVEY 8d config 3, mode R; VALU-bound)")
+        if name == "disney_integrate":
+            wl = Workload(name, 128, (22 + 8) * 4, lambda: d.integrate(8, SEED, out=out, first_index=first),
+                          "disney_integrate_kernel<1, {m}>",
+                          "rlDisney both lobes x 64 spp, reduced mode (SURVEY 8d config 3, mode R; VALU-bound)", bound="valu")
+        else:
+            # mode S: every sample's (wi, f, pdf) = 28 B per triple goes to HBM; the 241 GB of a whole 2^26-point batch
+            # are produced chunk by chunk into one chunk-sized set of sample-major planes (what a consumer would read
+            # before the next chunk overwrites them: rls_disney_integrate_chunked)
+            cp = min(n, 1 << chunk_log2)
+            m = 2 * 64 * cp
+            chunk = dict(wi=ctx.empty(3, m), f=ctx.empty(3, m), pdf=ctx.empty(m))
+            wl = Workload(name, 128, (22 + 8) * 4 + 128 * 28,
+                          lambda: d.integrateChunked(8, SEED, cp, out=out, chunk=chunk, first_index=first),
+                          "disney_integrate_kernel<1, {m}>",
+                          f"rlDisney both lobes x 64 spp, streamed mode in chunks of {cp} points (SURVEY 8d config 3, "
+                          "mode S: 88 B in + 32 B sums + 128 x 28 B samples per point)", launches_per_step=(n + cp - 1) // cp)
     elif name == "sss_probe":
         s = R.SssSampler(ctx, N, T, albedo=u3(S_KS), dist=u3(S_PARAM0, 0.1, 2.1))
         xi = [u(S_XI0 + j) for j in range(2)]
@@ -138,10 +160,10 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1):
         s = R.SssSampler(ctx, N, T, albedo=u3(S_KS), dist=u3(S_PARAM0, 0.02, 0.3))
         scene = R.make_scene("sphere", sphere_radius=1.0, light_dir=(0.0, 0.6, 0.8), use_cavity_fade=True)
         out = A.planes(3)
-        wl = Workload(name, 16, (15 + 3) * 4, lambda: s.integrateScatter(N, scene, 4, SEED, out=out),
+        wl = Workload(name, 16, (15 + 3) * 4, lambda: s.integrateScatter(N, scene, 4, SEED, out=out, first_index=first),
                       "sss_scatter_kernel<1, {m}>",
                       "rlSss integrateScatter, 16 probe rays per point on an analytic sphere (SURVEY 8f rank 3; "
-                      "VALU-bound)")
+                      "VALU-bound)", bound="valu")
     elif name == "skin":
         p = dict(sss_color=u3(S_PARAM0), sss_weight=u(S_PARAM0 + 3), sss_dist_multiplier=u(S_PARAM0 + 4, 0.5, 1.5),
                  sss_scatter_dist=u3(S_PARAM0 + 5, 0.1, 2.1),
@@ -163,13 +185,59 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1):
 
 
 # ------------------------------------------------------------------------------------------------
-def cpu_baseline(workload: str, target_seconds: float) -> dict | None:
-    """The CPU oracle on a bounded sample of the same synthetic workload, all host cores."""
-    if workload != "ggx_reflect_refract":
-        return None
+def _cpu_leg(workload: str, n: int, threads: int):
+    """(run, samples_per_point, what): one pass of the CPU oracle over n points of the same seeded workload."""
     import numpy as np
     import oracle_lib as O
     import cases
+    u = lambda stream, lo=0.0, hi=1.0: O.gen_uniform(SEED, 0, n, stream, lo, hi)
+    u3 = lambda stream, lo=0.0, hi=1.0: np.stack([u(stream + j, lo, hi) for j in range(3)])
+    if workload in ("ggx_reflect_refract", "ggx_reflect", "ggx_direct"):
+        c = cases.ggx_mixed(SEED, n)
+        g = O.Ggx(c["wo"], c["N"], c["T"], KsColor=c["KsColor"], ior=c["ior"], roughness=c["roughness"],
+                  anisotropic=c["anisotropic"], nthreads=threads)
+        x = cases.xi(SEED, n, 4)
+        if workload == "ggx_reflect_refract":
+            out = g.reflect_refract(x[0], x[1], x[2], x[3])
+            return (lambda: g.reflect_refract(x[0], x[1], x[2], x[3], out=out)), 2, "orc_batch_ggx_reflect_refract"
+        if workload == "ggx_reflect":
+            return (lambda: g.sample_eval_pdf(x[0], x[1])), 1, "orc_batch_ggx_sample_eval_pdf"
+        P = u3(S_PARAM0 + 8, 0.0, 4.0)
+        lt = O.make_light(center=(2.0, 2.0, 6.0), radius=1.25, radiance=(3.0, 2.0, 1.0))
+        kdc, kd, kdr, ks = u3(S_PARAM0), u(S_PARAM0 + 3), u(S_PARAM0 + 4), u(S_PARAM0 + 5)
+        return (lambda: g.direct_lighting(P, lt, 4, SEED, Kd_color=kdc, Kd=kd, Kd_roughness=kdr, Ks=ks)), 48, \
+            "orc_batch_ggx_direct_lighting"
+    if workload in ("disney_integrate", "disney_stream"):
+        c = cases.disney_mixed(SEED, n)
+        sc = {k: c[k] for k in O.DISNEY_SCALARS}
+        d = O.Disney(c["wo"], c["N"], c["T"], base_color=c["base_color"], nthreads=threads, **sc)
+        streamed = workload == "disney_stream"
+        return (lambda: d.integrate(8, SEED, streamed=streamed)), 128, "orc_batch_disney_integrate"
+    if workload in ("sss_probe", "sss_scatter"):
+        _, N, T = cases.frame(SEED, n)
+        if workload == "sss_probe":
+            s = O.Sss(n, u3(S_PARAM0, 0.1, 2.1), u3(S_KS), N=N, T=T, nthreads=threads)
+            x = cases.xi(SEED, n, 2)
+            return (lambda: s.probe(x[0], x[1])), 1, "orc_batch_sss_probe"
+        s = O.Sss(n, u3(S_PARAM0, 0.02, 0.3), u3(S_KS), N=N, T=T, nthreads=threads)
+        scene = O.make_scene("sphere", sphere_radius=1.0, light_dir=(0.0, 0.6, 0.8), use_cavity_fade=True)
+        return (lambda: O.integrate_scatter(s, N, scene, 4, SEED)), 16, "orc_batch_sss_integrate_scatter"
+    if workload == "skin":
+        wo, N, T = cases.frame(SEED, n)
+        p = dict(sss_color=u3(S_PARAM0), sss_weight=u(S_PARAM0 + 3), sss_dist_multiplier=u(S_PARAM0 + 4, 0.5, 1.5),
+                 sss_scatter_dist=u3(S_PARAM0 + 5, 0.1, 2.1),
+                 specular_color=u3(S_PARAM0 + 8), specular_weight=u(S_PARAM0 + 11),
+                 specular_roughness=u(S_PARAM0 + 12, 0.05, 1.0), specular_ior=u(S_PARAM0 + 13, 1.05, 2.55),
+                 sheen_color=u3(S_PARAM0 + 14), sheen_weight=u(S_PARAM0 + 17),
+                 sheen_roughness=u(S_PARAM0 + 18, 0.05, 1.0), sheen_ior=u(S_PARAM0 + 19, 1.05, 2.55))
+        x = cases.xi(SEED, n, 6)
+        return (lambda: O.skin(wo, N, T, p, x, nthreads=threads)), 3, "orc_batch_skin"
+    raise ValueError(workload)
+
+
+def cpu_baseline(workload: str, target_seconds: float) -> dict | None:
+    """The CPU oracle on a bounded sample of the same synthetic workload, all host cores."""
+    import oracle_lib as O
     threads = O.hardware_threads()            # CPUs this process may run on (sched_getaffinity)
     try:                                      # ... capped by a cgroup CPU quota, if the box sets one
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -179,25 +247,22 @@ def cpu_baseline(workload: str, target_seconds: float) -> dict | None:
         pass
 
     def run(n, seconds):
-        c = cases.ggx_mixed(SEED, n)
-        x = cases.xi(SEED, n, 4)
-        g = O.Ggx(c["wo"], c["N"], c["T"], KsColor=c["KsColor"], ior=c["ior"], roughness=c["roughness"],
-                  anisotropic=c["anisotropic"], nthreads=threads)
-        out = g.reflect_refract(x[0], x[1], x[2], x[3])          # touch pages
+        fn, spp, what = _cpu_leg(workload, n, threads)
+        fn()                                                      # touch pages
         times = []
         t_end = time.perf_counter() + seconds
         while len(times) < 3 or time.perf_counter() < t_end:
             t0 = time.perf_counter()
-            g.reflect_refract(x[0], x[1], x[2], x[3], out=out)
+            fn()
             times.append(time.perf_counter() - t0)
-        return times
+        return times, spp, what
 
-    n0 = 1 << 18
-    t = min(run(n0, 0.0))
-    # one pass of about a second (bounded by 2^24 points = 2 GB of planes), repeated for target_seconds
+    n0 = 1 << 12
+    t = min(run(n0, 0.0)[0])
+    # one pass of about a second (bounded by 2^24 points), repeated for target_seconds
     n = int(min(1 << 24, max(n0, n0 * 1.0 / max(t, 1e-6))))
     n = 1 << (n.bit_length() - 1)
-    times = run(n, target_seconds)
+    times, spp, what = run(n, target_seconds)
     best, mean = min(times), sum(times) / len(times)
     model = ""
     try:
@@ -207,12 +272,11 @@ def cpu_baseline(workload: str, target_seconds: float) -> dict | None:
                 break
     except OSError:
         pass
-    return {"value": round(2 * n / best / 1e9, 6), "unit": "Gsamples/s", "cores": threads, "kind": "port",
-            "per_core_msamples": round(2 * n / best / 1e6 / threads, 3), "cpu_model": model,
-            "mean_value": round(2 * n / mean / 1e9, 6),
-            "sample": f"{n} points (2 samples each) of the same seeded workload, best of {len(times)} passes "
-                      f"({sum(times):.1f} s of CPU work), oracle/rls_oracle.c orc_batch_ggx_reflect_refract "
-                      f"on {threads} threads"}
+    return {"value": round(spp * n / best / 1e9, 6), "unit": "Gsamples/s", "cores": threads, "kind": "port",
+            "per_core_msamples": round(spp * n / best / 1e6 / threads, 3), "cpu_model": model,
+            "mean_value": round(spp * n / mean / 1e9, 6),
+            "sample": f"{n} points ({spp} samples each) of the same seeded workload, best of {len(times)} passes "
+                      f"({sum(times):.1f} s of CPU work), oracle/rls_oracle.c {what} on {threads} threads"}
 
 
 def traffic_bytes(workload: str):

@@ -206,9 +206,12 @@ rls_status rls_ggx_ndf_pdf(rls_context *ctx, int64_t n, const rls_ggx_closure *c
 /* spp_n^2 stratified samples per point drawn in-kernel (stand-in for AiSampler(spp_n, 2),
  * src/rlGgx.cpp:148): sum_f_over_pdf = sum over samples of eval/pdf (what AiBRDFIntegrate
  * accumulates before radiance), avg_reflect_weight = getAvgReflectWeight (src/rlGgx.h:181-184).
- * One wavefront per point group, lanes = strata, wave-shuffle reduction. */
+ * One wavefront per point group, lanes = strata, wave-shuffle reduction.
+ * first_index (here and in every other in-kernel-sampling entry point): the global index of point 0 of
+ * this call.  The per-point scrambles are hash(seed, first_index + i), so a batch split with
+ * rls_shard_range -- or walked in chunks -- draws exactly the numbers of the unsplit batch. */
 rls_status rls_ggx_integrate(rls_context *ctx, int64_t n, const rls_ggx_closure *c,
-                             int spp_n, uint32_t seed,
+                             int spp_n, uint32_t seed, uint64_t first_index,
                              rls_rgb sum_f_over_pdf, float *avg_reflect_weight);
 
 /* Direct lighting of the rlGgx node: the light loop of shader_evaluate (src/rlGgx.cpp:274-299) --
@@ -239,7 +242,7 @@ typedef struct rls_ggx_shader {
 } rls_ggx_shader;
 rls_status rls_ggx_direct_lighting(rls_context *ctx, int64_t n, const rls_ggx_closure *c, const rls_ggx_shader *sh,
                                    rls_cvec3 P, const rls_sphere_light *light, int spp_n, uint32_t seed,
-                                   rls_rgb direct_diffuse, rls_rgb direct_specular);
+                                   uint64_t first_index, rls_rgb direct_diffuse, rls_rgb direct_specular);
 
 /* ------------------------------------------------------------------------------------------
  * rlDisney closure: DisneySampler (src/rlDisney.cpp:105-602)
@@ -268,10 +271,27 @@ rls_status rls_disney_sample_eval_pdf(rls_context *ctx, int64_t n, const rls_dis
  * additionally every sample's (wi, f, pdf) at index  lobe*n*spp + s*n + i  (sample-major planes). */
 typedef struct rls_disney_stream_out { rls_vec3 wi; rls_rgb f; float *pdf; } rls_disney_stream_out;
 rls_status rls_disney_integrate(rls_context *ctx, int64_t n, const rls_disney_closure *c,
-                                int spp_n, uint32_t seed,
+                                int spp_n, uint32_t seed, uint64_t first_index,
                                 rls_rgb diffuse_sum, float *diffuse_count,
                                 rls_rgb specular_sum, float *specular_count,
                                 const rls_disney_stream_out *stream /* optional */);
+/* Streamed mode over a batch whose samples do not fit in memory at once (BASELINE config 3: 2^26 points x
+ * 2 x 64 triples x 28 B = 241 GB).  The point range is walked in chunks of chunk_points; every chunk writes
+ * its samples to the SAME chunk buffers (index lobe*count*spp + s*count + k, k = point - first point of the
+ * chunk, count = points in this chunk) and the reduced sums to their place in the whole-batch planes.
+ * `consume` plays the part of the loop body that uses each sample in the reference (the AiTrace of the
+ * explicit sample loop, src/rlDisney.cpp:299-312): it is called on the host right after a chunk's kernel has
+ * been enqueued; work it enqueues on the context's stream runs after the chunk is complete and before the
+ * next chunk overwrites the buffers.  NULL discards the samples (measurement).  A non-zero return stops the
+ * walk.  The samples are those of the unchunked rls_disney_integrate call. */
+typedef int (*rls_disney_chunk_fn)(void *user, int64_t first_point, int64_t count,
+                                   const rls_disney_stream_out *chunk);
+rls_status rls_disney_integrate_chunked(rls_context *ctx, int64_t n, const rls_disney_closure *c,
+                                        int spp_n, uint32_t seed, uint64_t first_index,
+                                        rls_rgb diffuse_sum, float *diffuse_count,
+                                        rls_rgb specular_sum, float *specular_count,
+                                        int64_t chunk_points, const rls_disney_stream_out *chunk,
+                                        rls_disney_chunk_fn consume /* optional */, void *user);
 
 /* Alternates the reference compiles but never selects (mSampleFromVisibleNormal is hard-wired to
  * true, src/rlDisney.cpp:191): the plain-NDF microfacet samplers, the matching pdf branch and D_GTR2. */
@@ -350,7 +370,7 @@ typedef struct rls_sss_scene {
 /* P: sg->P per shading point; result: integrateScatter's return value; mean_depth (optional):
  * shaded probe hits per probe ray (msgData->probeDepth averaged over the samples). */
 rls_status rls_sss_integrate_scatter(rls_context *ctx, int64_t n, const rls_sss_closure *c, rls_cvec3 P,
-                                     const rls_sss_scene *scene, int spp_n, uint32_t seed,
+                                     const rls_sss_scene *scene, int spp_n, uint32_t seed, uint64_t first_index,
                                      rls_rgb result, float *mean_depth);
 
 /* ------------------------------------------------------------------------------------------

@@ -1397,7 +1397,7 @@ void orc_sample_02(uint32_t seed, uint64_t index, uint32_t dim_pair, uint32_t s,
 }
 
 typedef struct {
-    const orc_ggx_soa *gin; const orc_disney_soa *din; int spp; uint32_t seed; int64_t n;
+    const orc_ggx_soa *gin; const orc_disney_soa *din; int spp; uint32_t seed; uint64_t first; int64_t n;
     orc_v3p sum, sum2; float *avg, *cnt, *cnt2; orc_v3p s_wi, s_f; float *s_pdf;
 } int_job;
 
@@ -1410,7 +1410,7 @@ static void ggx_int_range(int64_t lo, int64_t hi, void *ctx)
         float aR = 0.0f, aG = 0.0f, aB = 0.0f;
         for (int s = 0; s < j->spp; s++) {
             float rx, ry;
-            orc_sample_02(j->seed, (uint64_t)i, 0, (uint32_t)s, &rx, &ry);
+            orc_sample_02(j->seed, j->first + (uint64_t)i, 0, (uint32_t)s, &rx, &ry);
             orc_v3 L = orc_ggx_eval_sample(&g, rx, ry);
             orc_rgb f = orc_ggx_eval_brdf(&g, L);
             float pdf = orc_ggx_eval_pdf(&g, L);
@@ -1421,10 +1421,10 @@ static void ggx_int_range(int64_t lo, int64_t hi, void *ctx)
     }
 }
 
-void orc_batch_ggx_integrate(int64_t n, const orc_ggx_soa *in, int spp_n, uint32_t seed,
+void orc_batch_ggx_integrate(int64_t n, const orc_ggx_soa *in, int spp_n, uint32_t seed, uint64_t first_index,
                              orc_v3p sum_f_over_pdf, float *avg_reflect_weight, int nthreads)
 {
-    int_job j = { .gin = in, .spp = spp_n * spp_n, .seed = seed, .n = n, .sum = sum_f_over_pdf, .avg = avg_reflect_weight };
+    int_job j = { .gin = in, .spp = spp_n * spp_n, .seed = seed, .first = first_index, .n = n, .sum = sum_f_over_pdf, .avg = avg_reflect_weight };
     parallel_for(n, nthreads, ggx_int_range, &j);
 }
 
@@ -1441,7 +1441,7 @@ static void disney_int_range(int64_t lo, int64_t hi, void *ctx)
             for (int lobe = 0; lobe < 2; lobe++) {
                 d.sampleType = lobe == 0 ? ORC_RAY_DIFFUSE : ORC_RAY_GLOSSY;
                 float rx, ry;
-                orc_sample_02(j->seed, (uint64_t)i, (uint32_t)lobe, (uint32_t)s, &rx, &ry);
+                orc_sample_02(j->seed, j->first + (uint64_t)i, (uint32_t)lobe, (uint32_t)s, &rx, &ry);
                 orc_v3 L = orc_disney_eval_sample(&d, rx, ry);
                 orc_rgb f = orc_disney_eval_brdf(&d, L);
                 float pdf = orc_disney_eval_pdf(&d, L);
@@ -1460,11 +1460,11 @@ static void disney_int_range(int64_t lo, int64_t hi, void *ctx)
     }
 }
 
-void orc_batch_disney_integrate(int64_t n, const orc_disney_soa *in, int spp_n, uint32_t seed,
+void orc_batch_disney_integrate(int64_t n, const orc_disney_soa *in, int spp_n, uint32_t seed, uint64_t first_index,
                                 orc_v3p dsum, float *dcount, orc_v3p ssum, float *scount,
                                 orc_v3p s_wi, orc_v3p s_f, float *s_pdf, int nthreads)
 {
-    int_job j = { .din = in, .spp = spp_n * spp_n, .seed = seed, .n = n, .sum = dsum, .cnt = dcount,
+    int_job j = { .din = in, .spp = spp_n * spp_n, .seed = seed, .first = first_index, .n = n, .sum = dsum, .cnt = dcount,
                   .sum2 = ssum, .cnt2 = scount, .s_wi = s_wi, .s_f = s_f, .s_pdf = s_pdf };
     parallel_for(n, nthreads, disney_int_range, &j);
 }
@@ -1538,7 +1538,7 @@ int orc_scene_trace(const orc_scene *sc, orc_v3 O, orc_v3 D, float maxdist, floa
 }
 
 typedef struct {
-    const orc_sss_soa *in; int has_dPdu; orc_cv3p P; const orc_scene *sc; int spp; uint32_t seed;
+    const orc_sss_soa *in; int has_dPdu; orc_cv3p P; const orc_scene *sc; int spp; uint32_t seed; uint64_t first;
     orc_v3p result; float *depth;
 } scatter_job;
 
@@ -1555,7 +1555,7 @@ static void scatter_range(int64_t lo, int64_t hi, void *ctx)
         float accR = 0.0f, accG = 0.0f, accB = 0.0f, accD = 0.0f;
         for (int s = 0; s < j->spp; s++) {
             float rx, ry;
-            orc_sample_02(j->seed, (uint64_t)i, 0, (uint32_t)s, &rx, &ry);
+            orc_sample_02(j->seed, j->first + (uint64_t)i, 0, (uint32_t)s, &rx, &ry);
             orc_v3 off, dir; float maxdist;
             (void)orc_sss_get_probe_ray(&S, rx, ry, &off, &dir, &maxdist);          /* :228 */
             float t[2]; orc_v3 hp[2], hn[2];
@@ -1599,10 +1599,10 @@ static void scatter_range(int64_t lo, int64_t hi, void *ctx)
 }
 
 void orc_batch_sss_integrate_scatter(int64_t n, const orc_sss_soa *in, int has_dPdu, orc_cv3p P,
-                                     const orc_scene *sc, int spp_n, uint32_t seed,
+                                     const orc_scene *sc, int spp_n, uint32_t seed, uint64_t first_index,
                                      orc_v3p result, float *mean_depth, int nthreads)
 {
-    scatter_job j = { in, has_dPdu, P, sc, spp_n * spp_n, seed, result, mean_depth };
+    scatter_job j = { in, has_dPdu, P, sc, spp_n * spp_n, seed, first_index, result, mean_depth };
     parallel_for(n, nthreads, scatter_range, &j);
 }
 
@@ -1680,6 +1680,7 @@ static inline float power_heuristic(float pa, float pb) { return (pa * pa) / (pa
 
 typedef struct {
     const orc_ggx_soa *in; const orc_ggx_shader_soa *sh; orc_cv3p P; const orc_light *lt; int spp; uint32_t seed;
+    uint64_t first;
     orc_v3p dd, ds;
 } light_job;
 
@@ -1698,7 +1699,7 @@ static void light_range(int64_t lo, int64_t hi, void *ctx)
         for (int s = 0; s < j->spp && c.valid; s++) {
             float rx, ry;
             if (mode != 2) {                                   /* one light sample, both lobes */
-                orc_sample_02(j->seed, (uint64_t)i, 0, (uint32_t)s, &rx, &ry);
+                orc_sample_02(j->seed, j->first + (uint64_t)i, 0, (uint32_t)s, &rx, &ry);
                 orc_v3 L = cone_sample(&c, rx, ry);
                 if (v3dot(L, N) > 0.0f) {
                     orc_rgb f = orc_ggx_eval_brdf(&g, L);
@@ -1711,7 +1712,7 @@ static void light_range(int64_t lo, int64_t hi, void *ctx)
                 }
             }
             if (mode != 1) {                                   /* one BSDF sample per lobe */
-                orc_sample_02(j->seed, (uint64_t)i, 1, (uint32_t)s, &rx, &ry);
+                orc_sample_02(j->seed, j->first + (uint64_t)i, 1, (uint32_t)s, &rx, &ry);
                 orc_v3 L = orc_ggx_eval_sample(&g, rx, ry);
                 if (!v3iszero(L) && v3dot(L, N) > 0.0f && cone_hit(&c, L)) {
                     orc_rgb f = orc_ggx_eval_brdf(&g, L);
@@ -1719,7 +1720,7 @@ static void light_range(int64_t lo, int64_t hi, void *ctx)
                     float w = mode == 2 ? 1.0f : power_heuristic(pb, c.pdf);
                     sR += f.r * w / pb; sG += f.g * w / pb; sB += f.b * w / pb;
                 }
-                orc_sample_02(j->seed, (uint64_t)i, 2, (uint32_t)s, &rx, &ry);
+                orc_sample_02(j->seed, j->first + (uint64_t)i, 2, (uint32_t)s, &rx, &ry);
                 orc_v3 Ld = orc_sss_sample_diffuse_direction(rx, ry, N, T);
                 float pd = orc_oren_nayar_pdf(&on, Ld);
                 if (pd > 0.0f && cone_hit(&c, Ld)) {
@@ -1740,10 +1741,10 @@ static void light_range(int64_t lo, int64_t hi, void *ctx)
 }
 
 void orc_batch_ggx_direct_lighting(int64_t n, const orc_ggx_soa *in, const orc_ggx_shader_soa *sh, orc_cv3p P,
-                                   const orc_light *light, int spp_n, uint32_t seed,
+                                   const orc_light *light, int spp_n, uint32_t seed, uint64_t first_index,
                                    orc_v3p direct_diffuse, orc_v3p direct_specular, int nthreads)
 {
-    light_job j = { in, sh, P, light, spp_n * spp_n, seed, direct_diffuse, direct_specular };
+    light_job j = { in, sh, P, light, spp_n * spp_n, seed, first_index, direct_diffuse, direct_specular };
     parallel_for(n, nthreads, light_range, &j);
 }
 

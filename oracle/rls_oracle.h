@@ -283,10 +283,11 @@ void orc_batch_skin(int64_t n, const orc_skin_soa *in, const orc_skin_out_soa *o
  * callback triple (explicit form: src/rlDisney.cpp:299-312), samples from the per-point scrambled
  * (0,2)-sequence below (stand-in for the closed AiSampler(n,2)); sums in ascending sample order. */
 void orc_sample_02(uint32_t seed, uint64_t index, uint32_t dim_pair, uint32_t s, float *rx, float *ry);
-void orc_batch_ggx_integrate(int64_t n, const orc_ggx_soa *in, int spp_n, uint32_t seed,
+/* first_index: global index of point 0 (scrambles hash first_index + i) */
+void orc_batch_ggx_integrate(int64_t n, const orc_ggx_soa *in, int spp_n, uint32_t seed, uint64_t first_index,
                              orc_v3p sum_f_over_pdf, float *avg_reflect_weight, int nthreads);
 /* s_wi/s_f/s_pdf: optional streamed per-sample planes, index lobe*n*spp + s*n + i (lobe 0 = diffuse) */
-void orc_batch_disney_integrate(int64_t n, const orc_disney_soa *in, int spp_n, uint32_t seed,
+void orc_batch_disney_integrate(int64_t n, const orc_disney_soa *in, int spp_n, uint32_t seed, uint64_t first_index,
                                 orc_v3p dsum, float *dcount, orc_v3p ssum, float *scount,
                                 orc_v3p s_wi, orc_v3p s_f, float *s_pdf, int nthreads);
 
@@ -310,7 +311,7 @@ typedef struct {
 /* up to two probe hits of (O, D, maxdist) in ascending t; returns the count */
 int  orc_scene_trace(const orc_scene *sc, orc_v3 O, orc_v3 D, float maxdist, float t[2], orc_v3 hitP[2], orc_v3 hitN[2]);
 void orc_batch_sss_integrate_scatter(int64_t n, const orc_sss_soa *in, int has_dPdu, orc_cv3p P,
-                                     const orc_scene *sc, int spp_n, uint32_t seed,
+                                     const orc_scene *sc, int spp_n, uint32_t seed, uint64_t first_index,
                                      orc_v3p result, float *mean_depth, int nthreads);
 
 /* Direct lighting of the rlGgx node (shader_evaluate's light loop, src/rlGgx.cpp:274-299): per light
@@ -337,7 +338,7 @@ void  orc_oren_nayar_init(orc_oren_nayar *o, orc_v3 N, orc_v3 T, float sigma);
 float orc_oren_nayar_brdf(const orc_oren_nayar *o, orc_v3 wo, orc_v3 wi);   /* BRDF x cos(theta_i) */
 float orc_oren_nayar_pdf(const orc_oren_nayar *o, orc_v3 wi);
 void  orc_batch_ggx_direct_lighting(int64_t n, const orc_ggx_soa *in, const orc_ggx_shader_soa *sh, orc_cv3p P,
-                                    const orc_light *light, int spp_n, uint32_t seed,
+                                    const orc_light *light, int spp_n, uint32_t seed, uint64_t first_index,
                                     orc_v3p direct_diffuse, orc_v3p direct_specular, int nthreads);
 
 /* utility closures, batch form (a2-a5) */

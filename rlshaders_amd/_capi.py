@@ -71,6 +71,10 @@ class DisneyStreamOut(C.Structure):
     _fields_ = [("wi", Vec3), ("f", Rgb), ("pdf", C.c_void_p)]
 
 
+# int consume(void *user, int64_t first_point, int64_t count, const rls_disney_stream_out *chunk)
+DisneyChunkFn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(DisneyStreamOut))
+
+
 class SssClosure(C.Structure):
     _fields_ = [("sss_color", ParamRgb),
                 ("sss_dist_multiplier", Param),
@@ -176,16 +180,19 @@ PROTOTYPES = {
     "rls_ggx_microfacet": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), C.c_int, _vp, _vp, Vec3]),
     "rls_ggx_ndf_pdf": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), CVec3, _vp]),
     "rls_ggx_direct_lighting": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), C.POINTER(GgxShader), CVec3,
-                                          C.POINTER(SphereLight), C.c_int, C.c_uint32, Rgb, Rgb]),
-    "rls_ggx_integrate": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), C.c_int, C.c_uint32, Rgb, _vp]),
+                                          C.POINTER(SphereLight), C.c_int, C.c_uint32, C.c_uint64, Rgb, Rgb]),
+    "rls_ggx_integrate": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), C.c_int, C.c_uint32, C.c_uint64, Rgb, _vp]),
     # rlDisney
     "rls_disney_sample": (C.c_int, [_ctx, _i64, C.POINTER(DisneyClosure), C.c_int, _vp, _vp, Vec3]),
     "rls_disney_eval": (C.c_int, [_ctx, _i64, C.POINTER(DisneyClosure), C.c_int, CVec3, Rgb]),
     "rls_disney_pdf": (C.c_int, [_ctx, _i64, C.POINTER(DisneyClosure), C.c_int, CVec3, _vp]),
     "rls_disney_sample_eval_pdf": (C.c_int, [_ctx, _i64, C.POINTER(DisneyClosure), C.c_int, _vp, _vp,
                                              Vec3, Rgb, _vp]),
-    "rls_disney_integrate": (C.c_int, [_ctx, _i64, C.POINTER(DisneyClosure), C.c_int, C.c_uint32,
+    "rls_disney_integrate": (C.c_int, [_ctx, _i64, C.POINTER(DisneyClosure), C.c_int, C.c_uint32, C.c_uint64,
                                        Rgb, _vp, Rgb, _vp, C.POINTER(DisneyStreamOut)]),
+    "rls_disney_integrate_chunked": (C.c_int, [_ctx, _i64, C.POINTER(DisneyClosure), C.c_int, C.c_uint32, C.c_uint64,
+                                               Rgb, _vp, Rgb, _vp, _i64, C.POINTER(DisneyStreamOut),
+                                               DisneyChunkFn, C.c_void_p]),
     "rls_disney_alt_sample": (C.c_int, [_ctx, _i64, C.POINTER(DisneyClosure), C.c_int, _vp, _vp, Vec3]),
     "rls_disney_alt_pdf": (C.c_int, [_ctx, _i64, C.POINTER(DisneyClosure), CVec3, _vp]),
     "rls_disney_d_gtr2": (C.c_int, [_ctx, _i64, C.POINTER(DisneyClosure), CVec3, _vp]),
@@ -200,7 +207,7 @@ PROTOTYPES = {
     "rls_sss_cavity_fade": (C.c_int, [_ctx, _i64, CVec3, CVec3, CVec3, _vp]),
     "rls_sss_sample_diffuse_direction": (C.c_int, [_ctx, _i64, CVec3, CVec3, _vp, _vp, Vec3]),
     "rls_sss_integrate_scatter": (C.c_int, [_ctx, _i64, C.POINTER(SssClosure), CVec3, C.POINTER(SssScene),
-                                            C.c_int, C.c_uint32, Rgb, _vp]),
+                                            C.c_int, C.c_uint32, C.c_uint64, Rgb, _vp]),
     # rlSkin
     "rls_skin_sample_eval_pdf": (C.c_int, [_ctx, _i64, C.POINTER(SkinClosure), C.POINTER(_vp), C.POINTER(SkinOut)]),
     # rlUtil, generator, checksum

@@ -323,7 +323,7 @@ class GgxSampler:
         return out
 
     def directLighting(self, P, light: "capi.SphereLight", spp_n: int, seed: int, KdColor: Color = (1.0, 1.0, 1.0),
-                       Kd: Scalar = 0.5, diffuseRoughness: Scalar = 0.0, Ks: Scalar = 0.5, out=None):
+                       Kd: Scalar = 0.5, diffuseRoughness: Scalar = 0.0, Ks: Scalar = 0.5, out=None, first_index: int = 0):
         """The light loop of rlGgx's shader_evaluate (src/rlGgx.cpp:274-299) under one spherical light ->
         (direct_diffuse [3,n], direct_specular [3,n]); parameter names and defaults of src/rlGgx.cpp:170-175."""
         n, ctx = self.n, self.ctx
@@ -331,7 +331,7 @@ class GgxSampler:
         sh = capi.GgxShader(param_rgb(KdColor, n, "KdColor"), param(Kd, n, "Kd"),
                             param(diffuseRoughness, n, "diffuseRoughness"), param(Ks, n, "Ks"))
         check(ctx.lib.rls_ggx_direct_lighting(ctx.handle, n, C.byref(self.c), C.byref(sh), cvec3(P, n, "P"),
-                                              C.byref(light), int(spp_n), int(seed) & 0xFFFFFFFF,
+                                              C.byref(light), int(spp_n), int(seed) & 0xFFFFFFFF, int(first_index),
                                               rgb(dd, n, "direct_diffuse"), rgb(ds, n, "direct_specular")))
         return dd, ds
 
@@ -349,12 +349,13 @@ class GgxSampler:
         check(ctx.lib.rls_ggx_ndf_pdf(ctx.handle, n, C.byref(self.c), cvec3(indir, n, "indir"), plane(pdf, n, "pdf")))
         return pdf
 
-    def integrate(self, spp_n: int, seed: int, out=None):
-        """spp_n^2 in-kernel samples -> (sum of f/pdf [3,n], getAvgReflectWeight [n]) (src/rlGgx.h:181-184)."""
+    def integrate(self, spp_n: int, seed: int, out=None, first_index: int = 0):
+        """spp_n^2 in-kernel samples -> (sum of f/pdf [3,n], getAvgReflectWeight [n]) (src/rlGgx.h:181-184).
+        first_index: global index of point 0 (a shard of a larger batch draws the batch's numbers)."""
         n, ctx = self.n, self.ctx
         s, a = out if out is not None else (ctx.empty(3, n), ctx.empty(n))
         check(ctx.lib.rls_ggx_integrate(ctx.handle, n, C.byref(self.c), int(spp_n), int(seed) & 0xFFFFFFFF,
-                                        rgb(s, n, "sum"), plane(a, n, "avg")))
+                                        int(first_index), rgb(s, n, "sum"), plane(a, n, "avg")))
         return s, a
 
 
@@ -436,7 +437,7 @@ class DisneySampler:
         check(ctx.lib.rls_disney_d_gtr2(ctx.handle, n, C.byref(self.c), cvec3(m, n, "m"), plane(d, n, "d")))
         return d
 
-    def integrate(self, spp_n: int, seed: int, streamed: bool = False, out=None):
+    def integrate(self, spp_n: int, seed: int, streamed: bool = False, out=None, first_index: int = 0):
         """Both lobes, spp_n^2 samples each -> dict(diffuse_sum, diffuse_count, specular_sum,
         specular_count[, wi, f, pdf as [3, 2*spp*n] / [2*spp*n] sample-major planes])."""
         n, ctx = self.n, self.ctx
@@ -451,11 +452,48 @@ class DisneySampler:
             m = 2 * spp_n * spp_n * n
             so = capi.DisneyStreamOut(vec3(out["wi"], m, "wi"), rgb(out["f"], m, "f"), plane(out["pdf"], m, "pdf"))
         check(ctx.lib.rls_disney_integrate(
-            ctx.handle, n, C.byref(self.c), int(spp_n), int(seed) & 0xFFFFFFFF,
+            ctx.handle, n, C.byref(self.c), int(spp_n), int(seed) & 0xFFFFFFFF, int(first_index),
             rgb(out["diffuse_sum"], n, "diffuse_sum"), plane(out["diffuse_count"], n, "diffuse_count"),
             rgb(out["specular_sum"], n, "specular_sum"), plane(out["specular_count"], n, "specular_count"),
             C.byref(so) if so is not None else None))
         return out
+
+    def integrateChunked(self, spp_n: int, seed: int, chunk_points: int, consume=None, out=None, chunk=None,
+                         first_index: int = 0):
+        """Streamed mode in chunks of the point range (rls_disney_integrate_chunked): every chunk's samples land in the
+        same chunk buffers (``chunk`` = dict(wi [3,m], f [3,m], pdf [m]), m = 2*spp*chunk_points, sample-major within
+        the chunk) and ``consume(first_point, count, chunk)`` is called after each chunk has been enqueued -- it
+        stands for the per-sample loop body of the reference (src/rlDisney.cpp:299-312).  Returns (sums, chunk)."""
+        n, ctx = self.n, self.ctx
+        spp = spp_n * spp_n
+        chunk_points = min(int(chunk_points), n)
+        m = 2 * spp * chunk_points
+        if out is None:
+            out = {"diffuse_sum": ctx.empty(3, n), "diffuse_count": ctx.empty(n),
+                   "specular_sum": ctx.empty(3, n), "specular_count": ctx.empty(n)}
+        if chunk is None:
+            chunk = dict(wi=ctx.empty(3, m), f=ctx.empty(3, m), pdf=ctx.empty(m))
+        so = capi.DisneyStreamOut(vec3(chunk["wi"], m, "wi"), rgb(chunk["f"], m, "f"), plane(chunk["pdf"], m, "pdf"))
+        err = []
+
+        def _cb(_user, first_point, count, _chunk):
+            try:
+                consume(int(first_point), int(count), chunk)
+                return 0
+            except Exception as e:      # never unwind through the C frames
+                err.append(e)
+                return 1
+
+        cb = capi.DisneyChunkFn(_cb) if consume is not None else capi.DisneyChunkFn()
+        st = ctx.lib.rls_disney_integrate_chunked(
+            ctx.handle, n, C.byref(self.c), int(spp_n), int(seed) & 0xFFFFFFFF, int(first_index),
+            rgb(out["diffuse_sum"], n, "diffuse_sum"), plane(out["diffuse_count"], n, "diffuse_count"),
+            rgb(out["specular_sum"], n, "specular_sum"), plane(out["specular_count"], n, "specular_count"),
+            chunk_points, C.byref(so), cb, None)
+        if err:
+            raise err[0]
+        check(st)
+        return out, chunk
 
 
 # ================================================================================================
@@ -559,7 +597,8 @@ class SssSampler:
                                       cvec3(sampleN, n, "sampleN"), 1 if literal_matrix else 0, plane(pdf, n, "pdf")))
         return pdf
 
-    def integrateScatter(self, P, scene: "capi.SssScene", spp_n: int, seed: int, want_depth: bool = False, out=None):
+    def integrateScatter(self, P, scene: "capi.SssScene", spp_n: int, seed: int, want_depth: bool = False, out=None,
+                         first_index: int = 0):
         """src/rlSss.h:167-280 over an analytic scene (see rls_sss_integrate_scatter) -> result [3,n]
         (and the mean number of shaded probe hits per probe ray)."""
         n, ctx = self.n, self.ctx
@@ -567,7 +606,7 @@ class SssSampler:
         depth = ctx.empty(n) if want_depth else None
         check(ctx.lib.rls_sss_integrate_scatter(
             ctx.handle, n, C.byref(self.c), cvec3(P, n, "P"), C.byref(scene), int(spp_n), int(seed) & 0xFFFFFFFF,
-            rgb(result, n, "result"), plane(depth, n, "mean_depth") if want_depth else None))
+            int(first_index), rgb(result, n, "result"), plane(depth, n, "mean_depth") if want_depth else None))
         return (result, depth) if want_depth else result
 
     @staticmethod

@@ -87,8 +87,8 @@ __global__ __launch_bounds__(rlsh::kBlock) void ggx_integrate_kernel(GgxIntIO a)
         Ggx g = ggx_make(wo, N, T, exiting, kr, kg, kb, ldp(c.ior, ii), ldp(c.specularRoughness, ii),
                          ldp(c.anisotropic, ii));
         VndfView w = vndf_view(g.view, g.fr, g.ax, g.ay);
-        const uint32_t sx = hash_u32(a.seed, (uint64_t)ii, kScrambleStream);
-        const uint32_t sy = hash_u32(a.seed, (uint64_t)ii, kScrambleStream + 1);
+        const uint32_t sx = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream);
+        const uint32_t sy = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream + 1);
 
         float accR = 0.0f, accG = 0.0f, accB = 0.0f, accF = 0.0f;
         for (int s = sub; s < a.spp; s += G) {
@@ -140,10 +140,10 @@ __global__ __launch_bounds__(rlsh::kBlock) void disney_integrate_kernel(DisneyIn
         sc[9] = ldp(c.clearcoat_gloss, ii);
         Disney d = disney_make(wo, N, T, br, bg, bb, sc);
         VndfView w = vndf_view(d.view, d.fr, d.ax, d.ay);
-        const uint32_t dx = hash_u32(a.seed, (uint64_t)ii, kScrambleStream);
-        const uint32_t dy = hash_u32(a.seed, (uint64_t)ii, kScrambleStream + 1);
-        const uint32_t sx = hash_u32(a.seed, (uint64_t)ii, kScrambleStream + 2);
-        const uint32_t sy = hash_u32(a.seed, (uint64_t)ii, kScrambleStream + 3);
+        const uint32_t dx = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream);
+        const uint32_t dy = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream + 1);
+        const uint32_t sx = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream + 2);
+        const uint32_t sy = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream + 3);
 
         float dR = 0.0f, dG = 0.0f, dB = 0.0f, dC = 0.0f;
         float sR = 0.0f, sG = 0.0f, sB = 0.0f, sC = 0.0f;
@@ -226,8 +226,8 @@ __global__ __launch_bounds__(rlsh::kBlock) void sss_scatter_kernel(ScatterIO a)
         const V3 Po = ld3(a.P, ii);
         float br, bg, bb;
         ldrgb(c.sss_color, ii, br, bg, bb);
-        const uint32_t sx = hash_u32(a.seed, (uint64_t)ii, kScrambleStream);
-        const uint32_t sy = hash_u32(a.seed, (uint64_t)ii, kScrambleStream + 1);
+        const uint32_t sx = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream);
+        const uint32_t sy = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream + 1);
 
         float accR = 0.0f, accG = 0.0f, accB = 0.0f, accD = 0.0f;
         for (int s = sub; s < a.spp; s += G) {
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(rlsh::kBlock) void ggx_direct_kernel(LightIO a)
         LightCone cone = cone_make(center, a.light.radius, ld3(a.P, ii));
         uint32_t scr[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) scr[k] = hash_u32(a.seed, (uint64_t)ii, kScrambleStream + k);
+        for (int k = 0; k < 6; k++) scr[k] = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream + k);
 
         float sR = 0.0f, sG = 0.0f, sB = 0.0f, dA = 0.0f;
         for (int s = sub; s < a.spp && cone.valid; s += G) {
@@ -406,6 +406,12 @@ rls_status launch_g(rls_context *ctx, K k1, K k4, K k16, K k64, int g, const IO 
     return rlsh::check_launch(name);
 }
 
+// plane pointers advanced by k points (chunked / sharded calls)
+inline rls_param adv(rls_param p, int64_t k) { if (p.v) p.v += k; return p; }
+inline rls_param_rgb adv(rls_param_rgb p, int64_t k) { if (p.r) { p.r += k; p.g += k; p.b += k; } return p; }
+inline rls_cvec3 adv(rls_cvec3 v, int64_t k) { v.x += k; v.y += k; v.z += k; return v; }
+inline rls_rgb adv(rls_rgb v, int64_t k) { v.r += k; v.g += k; v.b += k; return v; }
+
 } // namespace
 
 #if RLS_FAST
@@ -438,7 +444,8 @@ RLS_HIDDEN rls_status rls_fast_ggx_direct(rls_context *ctx, int g, const rlsh::L
 extern "C" {
 
 rls_status rls_ggx_integrate(rls_context *ctx, int64_t n, const rls_ggx_closure *c,
-                             int spp_n, uint32_t seed, rls_rgb sum_f_over_pdf, float *avg_reflect_weight)
+                             int spp_n, uint32_t seed, uint64_t first_index,
+                             rls_rgb sum_f_over_pdf, float *avg_reflect_weight)
 {
     RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
     RLS_REQUIRE(n >= 0, "n < 0");
@@ -449,7 +456,7 @@ rls_status rls_ggx_integrate(rls_context *ctx, int64_t n, const rls_ggx_closure 
     RLS_REQUIRE(rlsh::ok_rgb(c->KsColor), "KsColor planes must be all set or all NULL");
     RLS_REQUIRE(rlsh::has3(sum_f_over_pdf) && avg_reflect_weight, "NULL output plane");
     GgxIntIO io = {};
-    io.c = *c; io.sum = sum_f_over_pdf; io.avgF = avg_reflect_weight; io.n = n; io.spp = spp_n * spp_n; io.seed = seed;
+    io.c = *c; io.sum = sum_f_over_pdf; io.avgF = avg_reflect_weight; io.n = n; io.spp = spp_n * spp_n; io.seed = seed; io.first = first_index;
     int g = pick_group(ctx, n, io.spp);
     if (ctx->fast) return rls_fast_ggx_integrate(ctx, g, &io);
     return launch_g(ctx, ggx_integrate_kernel<1>, ggx_integrate_kernel<4>, ggx_integrate_kernel<16>,
@@ -457,7 +464,7 @@ rls_status rls_ggx_integrate(rls_context *ctx, int64_t n, const rls_ggx_closure 
 }
 
 rls_status rls_disney_integrate(rls_context *ctx, int64_t n, const rls_disney_closure *c,
-                                int spp_n, uint32_t seed,
+                                int spp_n, uint32_t seed, uint64_t first_index,
                                 rls_rgb diffuse_sum, float *diffuse_count,
                                 rls_rgb specular_sum, float *specular_count,
                                 const rls_disney_stream_out *stream)
@@ -473,7 +480,7 @@ rls_status rls_disney_integrate(rls_context *ctx, int64_t n, const rls_disney_cl
                 "NULL output plane");
     DisneyIntIO io = {};
     io.c = *c; io.dsum = diffuse_sum; io.dcount = diffuse_count; io.ssum = specular_sum; io.scount = specular_count;
-    io.n = n; io.spp = spp_n * spp_n; io.seed = seed;
+    io.n = n; io.spp = spp_n * spp_n; io.seed = seed; io.first = first_index;
     if (stream) {
         RLS_REQUIRE(rlsh::has3(stream->wi) && rlsh::has3(stream->f) && stream->pdf, "NULL streamed-output plane");
         io.st = *stream;
@@ -486,8 +493,48 @@ rls_status rls_disney_integrate(rls_context *ctx, int64_t n, const rls_disney_cl
                     disney_integrate_kernel<64>, g, io, "rls_disney_integrate");
 }
 
+// Streamed mode in chunks of the point range (2^26 points x 128 triples x 28 B = 241 GB does not fit beside the
+// inputs): each chunk is one launch over [p0, p0 + count) with every plane pointer advanced by p0 and the sampler's
+// first_index by p0, so the samples are those of the unchunked call.
+rls_status rls_disney_integrate_chunked(rls_context *ctx, int64_t n, const rls_disney_closure *c,
+                                        int spp_n, uint32_t seed, uint64_t first_index,
+                                        rls_rgb diffuse_sum, float *diffuse_count,
+                                        rls_rgb specular_sum, float *specular_count,
+                                        int64_t chunk_points, const rls_disney_stream_out *chunk,
+                                        rls_disney_chunk_fn consume, void *user)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_REQUIRE(n >= 0, "n < 0");
+    RLS_REQUIRE(chunk_points >= 1, "chunk_points < 1");
+    RLS_REQUIRE(chunk != nullptr, "chunk buffers are NULL");
+    if (n == 0) return RLS_OK;
+    RLS_REQUIRE(c != nullptr, "closure is NULL");
+    for (int64_t p0 = 0; p0 < n; p0 += chunk_points) {
+        const int64_t count = n - p0 < chunk_points ? n - p0 : chunk_points;
+        rls_disney_closure cc = *c;
+        cc.wo = adv(c->wo, p0); cc.N = adv(c->N, p0); cc.T = adv(c->T, p0);
+        cc.base_color = adv(c->base_color, p0);
+        cc.subsurface = adv(c->subsurface, p0); cc.metallic = adv(c->metallic, p0); cc.specular = adv(c->specular, p0);
+        cc.specular_tint = adv(c->specular_tint, p0); cc.roughness = adv(c->roughness, p0);
+        cc.anisotropic = adv(c->anisotropic, p0); cc.sheen = adv(c->sheen, p0); cc.sheen_tint = adv(c->sheen_tint, p0);
+        cc.clearcoat = adv(c->clearcoat, p0); cc.clearcoat_gloss = adv(c->clearcoat_gloss, p0);
+        rls_status st = rls_disney_integrate(ctx, count, &cc, spp_n, seed, first_index + (uint64_t)p0,
+                                             adv(diffuse_sum, p0), diffuse_count ? diffuse_count + p0 : nullptr,
+                                             adv(specular_sum, p0), specular_count ? specular_count + p0 : nullptr, chunk);
+        if (st != RLS_OK) return st;
+        if (consume) {
+            int rc = consume(user, p0, count, chunk);
+            if (rc != 0) {
+                rlsh::set_error("rls_disney_integrate_chunked: consumer returned %d at point %lld", rc, (long long)p0);
+                return RLS_ERR_INVALID_ARGUMENT;
+            }
+        }
+    }
+    return RLS_OK;
+}
+
 rls_status rls_sss_integrate_scatter(rls_context *ctx, int64_t n, const rls_sss_closure *c, rls_cvec3 P,
-                                     const rls_sss_scene *scene, int spp_n, uint32_t seed,
+                                     const rls_sss_scene *scene, int spp_n, uint32_t seed, uint64_t first_index,
                                      rls_rgb result, float *mean_depth)
 {
     RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
@@ -501,7 +548,7 @@ rls_status rls_sss_integrate_scatter(rls_context *ctx, int64_t n, const rls_sss_
     RLS_REQUIRE(rlsh::has3(result), "NULL output plane");
     ScatterIO io = {};
     io.c = *c; io.P = P; io.scene = *scene; io.result = result; io.depth = mean_depth;
-    io.n = n; io.spp = spp_n * spp_n; io.seed = seed;
+    io.n = n; io.spp = spp_n * spp_n; io.seed = seed; io.first = first_index;
     int g = pick_group(ctx, n, io.spp);
     if (ctx->fast) return rls_fast_sss_scatter(ctx, g, &io);
     return launch_g(ctx, sss_scatter_kernel<1>, sss_scatter_kernel<4>, sss_scatter_kernel<16>,
@@ -510,7 +557,7 @@ rls_status rls_sss_integrate_scatter(rls_context *ctx, int64_t n, const rls_sss_
 
 rls_status rls_ggx_direct_lighting(rls_context *ctx, int64_t n, const rls_ggx_closure *c, const rls_ggx_shader *sh,
                                    rls_cvec3 P, const rls_sphere_light *light, int spp_n, uint32_t seed,
-                                   rls_rgb direct_diffuse, rls_rgb direct_specular)
+                                   uint64_t first_index, rls_rgb direct_diffuse, rls_rgb direct_specular)
 {
     RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
     RLS_REQUIRE(n >= 0, "n < 0");
@@ -524,7 +571,7 @@ rls_status rls_ggx_direct_lighting(rls_context *ctx, int64_t n, const rls_ggx_cl
     RLS_REQUIRE(rlsh::has3(direct_diffuse) && rlsh::has3(direct_specular), "NULL output plane");
     LightIO io = {};
     io.c = *c; io.sh = *sh; io.P = P; io.light = *light; io.dd = direct_diffuse; io.ds = direct_specular;
-    io.n = n; io.spp = spp_n * spp_n; io.seed = seed;
+    io.n = n; io.spp = spp_n * spp_n; io.seed = seed; io.first = first_index;
     int g = pick_group(ctx, n, io.spp);
     if (ctx->fast) return rls_fast_ggx_direct(ctx, g, &io);
     return launch_g(ctx, ggx_direct_kernel<1>, ggx_direct_kernel<4>, ggx_direct_kernel<16>,

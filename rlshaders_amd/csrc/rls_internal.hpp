@@ -101,6 +101,7 @@ struct GgxIntIO {
     int64_t n;
     int spp;
     uint32_t seed;
+    uint64_t first;         // global index of point 0 (the sampler scrambles hash first + i)
 };
 struct DisneyIntIO {
     rls_disney_closure c;
@@ -111,6 +112,7 @@ struct DisneyIntIO {
     int64_t n;
     int spp;
     uint32_t seed;
+    uint64_t first;         // global index of point 0 (the sampler scrambles hash first + i)
 };
 
 struct LightIO {
@@ -122,6 +124,7 @@ struct LightIO {
     int64_t n;
     int spp;
     uint32_t seed;
+    uint64_t first;         // global index of point 0 (the sampler scrambles hash first + i)
 };
 
 struct ScatterIO {
@@ -133,6 +136,7 @@ struct ScatterIO {
     int64_t n;
     int spp;
     uint32_t seed;
+    uint64_t first;         // global index of point 0 (the sampler scrambles hash first + i)
 };
 
 void set_error(const char *fmt, ...);

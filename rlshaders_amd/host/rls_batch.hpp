@@ -272,19 +272,22 @@ public:
         check(rls_ggx_refract_sample(dev_.ctx(), n_, &c_, rx.plane(0), ry.plane(0), dir.vec3(), weight.plane(0), nullptr));
     }
     // integrateGlossy's sample loop with spp_n^2 samples + getAvgReflectWeight  (src/rlGgx.h:172-184)
-    void integrateGlossy(int spp_n, uint32_t seed, Planes &sum_f_over_pdf, Planes &avgReflectWeight) const
+    // first_index: global index of this batch's point 0 (a shard draws the numbers of the whole batch)
+    void integrateGlossy(int spp_n, uint32_t seed, Planes &sum_f_over_pdf, Planes &avgReflectWeight,
+                         uint64_t first_index = 0) const
     {
-        check(rls_ggx_integrate(dev_.ctx(), n_, &c_, spp_n, seed, sum_f_over_pdf.rgb(), avgReflectWeight.plane(0)));
+        check(rls_ggx_integrate(dev_.ctx(), n_, &c_, spp_n, seed, first_index, sum_f_over_pdf.rgb(),
+                                avgReflectWeight.plane(0)));
     }
     // the light loop of shader_evaluate (src/rlGgx.cpp:274-299) under one spherical area light:
     // direct_diffuse (Oren-Nayar, KdColor * Kd) and direct_specular (this closure, Ks)
     void directLighting(const Planes &P, const rls_sphere_light &light, int spp_n, uint32_t seed, ParamRGB KdColor,
                         Param Kd, Param diffuseRoughness, Param Ks, Planes &direct_diffuse,
-                        Planes &direct_specular) const
+                        Planes &direct_specular, uint64_t first_index = 0) const
     {
         rls_ggx_shader sh{KdColor.c(), Kd.c(), diffuseRoughness.c(), Ks.c()};
-        check(rls_ggx_direct_lighting(dev_.ctx(), n_, &c_, &sh, P.cvec3(), &light, spp_n, seed, direct_diffuse.rgb(),
-                                      direct_specular.rgb()));
+        check(rls_ggx_direct_lighting(dev_.ctx(), n_, &c_, &sh, P.cvec3(), &light, spp_n, seed, first_index,
+                                      direct_diffuse.rgb(), direct_specular.rgb()));
     }
 
 private:
@@ -332,6 +335,25 @@ public:
     void evalPdf(const Planes &indir, Planes &pdf) const
     {
         check(rls_disney_pdf(dev_.ctx(), n_, &c_, mSampleType, indir.cvec3(), pdf.plane(0)));
+    }
+    // integrateDiffuse + integrateGlossy sample loops (src/rlDisney.cpp:240-315), spp_n^2 samples per lobe:
+    // per point and lobe the sum of eval/pdf over the valid samples and their count
+    void integrate(int spp_n, uint32_t seed, Planes &diffuse_sum, Planes &diffuse_count, Planes &specular_sum,
+                   Planes &specular_count, uint64_t first_index = 0) const
+    {
+        check(rls_disney_integrate(dev_.ctx(), n_, &c_, spp_n, seed, first_index, diffuse_sum.rgb(), diffuse_count.plane(0),
+                                   specular_sum.rgb(), specular_count.plane(0), nullptr));
+    }
+    // the same with every sample handed to `consume` chunk by chunk (the loop body of src/rlDisney.cpp:299-312);
+    // chunk_wi / chunk_f: 3 x (2 * spp * chunk_points) planes, chunk_pdf: 1 x the same
+    void integrateStreamed(int spp_n, uint32_t seed, Planes &diffuse_sum, Planes &diffuse_count, Planes &specular_sum,
+                           Planes &specular_count, int64_t chunk_points, Planes &chunk_wi, Planes &chunk_f,
+                           Planes &chunk_pdf, rls_disney_chunk_fn consume, void *user, uint64_t first_index = 0) const
+    {
+        rls_disney_stream_out so{chunk_wi.vec3(), chunk_f.rgb(), chunk_pdf.plane(0)};
+        check(rls_disney_integrate_chunked(dev_.ctx(), n_, &c_, spp_n, seed, first_index, diffuse_sum.rgb(),
+                                           diffuse_count.plane(0), specular_sum.rgb(), specular_count.plane(0),
+                                           chunk_points, &so, consume, user));
     }
     int64_t size() const { return n_; }
 
@@ -403,9 +425,11 @@ public:
         check(rls_sss_mis_pdf(dev_.ctx(), n_, &c_, disp.cvec3(), sampleN.cvec3(), literal_matrix ? 1 : 0, pdf.plane(0)));
     }
     // AtColor integrateScatter(sg, data)  (src/rlSss.h:167-280) over an analytic scene
-    void integrateScatter(const Planes &P, const rls_sss_scene &scene, int spp_n, uint32_t seed, Planes &result) const
+    void integrateScatter(const Planes &P, const rls_sss_scene &scene, int spp_n, uint32_t seed, Planes &result,
+                          uint64_t first_index = 0) const
     {
-        check(rls_sss_integrate_scatter(dev_.ctx(), n_, &c_, P.cvec3(), &scene, spp_n, seed, result.rgb(), nullptr));
+        check(rls_sss_integrate_scatter(dev_.ctx(), n_, &c_, P.cvec3(), &scene, spp_n, seed, first_index, result.rgb(),
+                                        nullptr));
     }
 
 private:

@@ -3,6 +3,7 @@ import numpy as np
 import torch
 
 import rlshaders_amd as R
+from gpu_util_cpu import disney_oracle, ggx_oracle  # noqa: F401  (re-exported)
 
 
 def dev(a):
@@ -22,18 +23,7 @@ def ggx_sampler(ctx, case, exiting=None):
                         exiting=None if exiting is None else torch.from_numpy(exiting).cuda())
 
 
-def ggx_oracle(O, case, exiting=None, nthreads=4):
-    return O.Ggx(case["wo"], case["N"], case["T"], KsColor=case["KsColor"], ior=case["ior"],
-                 roughness=case["roughness"], anisotropic=case["anisotropic"], exiting=exiting, nthreads=nthreads)
-
-
 def disney_sampler(ctx, case):
     sc = {k: dev(case[k]) for k in R._capi.DISNEY_SCALARS if k in case}
     return R.DisneySampler(ctx, dev(case["wo"]), dev(case["N"]), dev(case["T"]),
                            base_color=dev(case.get("base_color", (1.0, 1.0, 1.0))), **sc)
-
-
-def disney_oracle(O, case, nthreads=4):
-    sc = {k: case[k] for k in O.DISNEY_SCALARS if k in case}
-    return O.Disney(case["wo"], case["N"], case["T"], base_color=case.get("base_color", (1.0, 1.0, 1.0)),
-                    nthreads=nthreads, **sc)

@@ -231,7 +231,8 @@ class Ggx:
         lib().orc_batch_ggx_ndf_pdf(C.c_int64(n), C.byref(self.soa), _v(wi), _p(pdf), self.nthreads)
         return pdf
 
-    def direct_lighting(self, P, light: "Light", spp_n, seed, Kd_color=(1, 1, 1), Kd=1.0, Kd_roughness=0.0, Ks=1.0):
+    def direct_lighting(self, P, light: "Light", spp_n, seed, Kd_color=(1, 1, 1), Kd=1.0, Kd_roughness=0.0, Ks=1.0,
+                        first_index=0):
         """orc_batch_ggx_direct_lighting -> (direct_diffuse [3,n], direct_specular [3,n])"""
         n = self.n
         P = f32(P)
@@ -239,14 +240,15 @@ class Ggx:
         sh = GgxShaderSoa(_v(kdc), _p(kd), _p(kdr), _p(ks))
         dd, ds = np.empty((3, n), np.float32), np.empty((3, n), np.float32)
         lib().orc_batch_ggx_direct_lighting(C.c_int64(n), C.byref(self.soa), C.byref(sh), _v(P), C.byref(light),
-                                            int(spp_n), C.c_uint32(seed), _v(dd), _v(ds), self.nthreads)
+                                            int(spp_n), C.c_uint32(seed), C.c_uint64(first_index), _v(dd), _v(ds),
+                                            self.nthreads)
         return dd, ds
 
-    def integrate(self, spp_n, seed):
+    def integrate(self, spp_n, seed, first_index=0):
         n = self.n
         s, a = np.empty((3, n), np.float32), np.empty(n, np.float32)
         lib().orc_batch_ggx_integrate(C.c_int64(n), C.byref(self.soa), int(spp_n), C.c_uint32(seed),
-                                      _v(s), _p(a), self.nthreads)
+                                      C.c_uint64(first_index), _v(s), _p(a), self.nthreads)
         return s, a
 
 
@@ -299,7 +301,7 @@ class Disney:
                                    _p(out1), self.nthreads)
         return out3 if kind < 2 else out1
 
-    def integrate(self, spp_n, seed, streamed=False):
+    def integrate(self, spp_n, seed, streamed=False, first_index=0):
         n = self.n
         spp = spp_n * spp_n
         out = dict(diffuse_sum=np.empty((3, n), np.float32), diffuse_count=np.empty(n, np.float32),
@@ -311,7 +313,7 @@ class Disney:
         else:
             swi, sf, spdf = CV3P(), CV3P(), None
         lib().orc_batch_disney_integrate(C.c_int64(n), C.byref(self.soa), int(spp_n), C.c_uint32(seed),
-                                         _v(out["diffuse_sum"]), _p(out["diffuse_count"]),
+                                         C.c_uint64(first_index), _v(out["diffuse_sum"]), _p(out["diffuse_count"]),
                                          _v(out["specular_sum"]), _p(out["specular_count"]), swi, sf, spdf,
                                          self.nthreads)
         return out
@@ -413,13 +415,14 @@ def scene_trace(scene: Scene, O, D, maxdist):
         [(hn[i].x, hn[i].y, hn[i].z) for i in range(k)]
 
 
-def integrate_scatter(sss: "Sss", P, scene: Scene, spp_n, seed):
+def integrate_scatter(sss: "Sss", P, scene: Scene, spp_n, seed, first_index=0):
     """orc_batch_sss_integrate_scatter -> (result [3,n], mean_depth [n])"""
     n = sss.n
     P = f32(P)
     result, depth = np.empty((3, n), np.float32), np.empty(n, np.float32)
     lib().orc_batch_sss_integrate_scatter(C.c_int64(n), C.byref(sss.soa), sss.has_dPdu, _v(P), C.byref(scene),
-                                          int(spp_n), C.c_uint32(seed), _v(result), _p(depth), sss.nthreads)
+                                          int(spp_n), C.c_uint32(seed), C.c_uint64(first_index), _v(result), _p(depth),
+                                          sss.nthreads)
     return result, depth
 
 

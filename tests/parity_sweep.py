@@ -80,6 +80,13 @@ def sweep(ctx, n: int, seed: int, spp_n: int = 2, verbose: bool = True) -> dict:
     for lobe, nm in ((R.RLS_RAY_DIFFUSE, "diffuse"), (R.RLS_RAY_GLOSSY, "glossy")):
         d.setSampleType(lobe)
         tally(f"disney {nm}", [hostf(t) for t in d.sampleEvalPdf(xi[0], xi[1])], od.sample_eval_pdf(lobe, hxi[0], hxi[1]))
+    os.environ["RLS_INTEGRATE_GROUP"] = "1"
+    try:                                              # BASELINE config 3's loop: spp_n^2 samples per lobe, both lobes
+        keys = ("diffuse_sum", "diffuse_count", "specular_sum", "specular_count")
+        gi, ri = d.integrate(spp_n, seed), od.integrate(spp_n, seed)
+        tally("disney integrate", [hostf(gi[k]) for k in keys], [ri[k] for k in keys])
+    finally:
+        del os.environ["RLS_INTEGRATE_GROUP"]
     # --- rlSss probe
     dist = torch.stack([u(32 + j, 0.1, 2.1) for j in range(3)])
     s = R.SssSampler(ctx, N, T, Ks, dist)

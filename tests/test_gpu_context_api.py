@@ -89,7 +89,7 @@ def test_error_paths():
     c = capi.DisneyClosure()
     v = capi.Vec3(None, None, None)
     assert lib.rls_disney_sample(h, 8, C.byref(c), 3, None, None, v) == 1 and b"lobe" in lib.rls_last_error()
-    assert lib.rls_ggx_integrate(h, 8, None, 0, 1, capi.Rgb(None, None, None), None) == 1
+    assert lib.rls_ggx_integrate(h, 8, None, 0, 1, 0, capi.Rgb(None, None, None), None) == 1
     assert lib.rls_status_string(4) == b"out of device memory"
     assert lib.rls_version() == 1
     lib.rls_context_destroy(h)

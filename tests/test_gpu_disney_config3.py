@@ -1,0 +1,181 @@
+"""GPU: BASELINE config 3 as it is stated -- rlDisney, both lobes, 8 x 8 = 64 stratified samples per point and
+lobe (the sample loops of src/rlDisney.cpp:240-315) -- against the oracle at a size the oracle finishes in
+seconds, through size-independent properties at the full 2^26 points, and in streamed mode walked in chunks."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+import rlshaders_amd as R
+from gpu_util import dev, disney_oracle, disney_sampler, host
+
+pytestmark = pytest.mark.gpu
+
+SUMS = ("diffuse_sum", "specular_sum")
+COUNTS = ("diffuse_count", "specular_count")
+
+
+def _with_group(g, fn):
+    os.environ["RLS_INTEGRATE_GROUP"] = str(g)
+    try:
+        return fn()
+    finally:
+        del os.environ["RLS_INTEGRATE_GROUP"]
+
+
+def test_integrate_8x8_against_oracle(gpu, oracle):
+    """64 spp per lobe (LDS table of 2 x 64 words, the G-lane split at spp 64): G = 1 adds in the reference's order
+    and must match the oracle bit for bit; G = 4 / 16 / 64 differ by the summation order only."""
+    n, spp_n, seed = 1 << 11, 8, 4321
+    c = cases.disney_mixed(cases.SEED_PARITY, n)
+    ref = disney_oracle(oracle, c).integrate(spp_n, seed)
+    s = disney_sampler(gpu, c)
+    base = _with_group(1, lambda: {k: host(v) for k, v in s.integrate(spp_n, seed).items()})
+    for k in COUNTS:
+        assert (base[k] != ref[k]).sum() <= 1, k
+        assert base[k].min() >= 0 and base[k].max() <= spp_n * spp_n
+    for k in SUMS:
+        st = cases.summarize(cases.rel_err(base[k], ref[k]))
+        print("disney 8x8", k, st, "words differing", int((base[k].view(np.uint32) != ref[k].view(np.uint32)).sum()))
+        cases.assert_tight(st, k)
+    for g in (4, 16, 64):
+        alt = _with_group(g, lambda: {k: host(v) for k, v in s.integrate(spp_n, seed).items()})
+        for k in COUNTS:
+            assert np.array_equal(alt[k], base[k]), (g, k)
+        for k in SUMS:
+            e = cases.rel_err(alt[k], base[k])
+            assert np.quantile(e, 0.999) <= 1e-4, (g, k, float(e.max()))
+    # the automatic width (small batch -> several lanes per point)
+    auto = {k: host(v) for k, v in s.integrate(spp_n, seed).items()}
+    for k in COUNTS:
+        assert np.array_equal(auto[k], base[k]), k
+
+
+def test_streamed_chunked_equals_unchunked(gpu, oracle):
+    """rls_disney_integrate_chunked: ragged last chunk, every chunk handed to the consumer; the samples and the
+    sums are those of the unchunked streamed call (and of the oracle)."""
+    n, spp_n, seed, first = 1000, 8, 99, (1 << 33) + 17
+    spp = spp_n * spp_n
+    c = cases.disney_mixed(cases.SEED_PARITY, n)
+    s = disney_sampler(gpu, c)
+    whole = _with_group(1, lambda: {k: host(v) for k, v in s.integrate(spp_n, seed, streamed=True, first_index=first).items()})
+    ref = disney_oracle(oracle, c).integrate(spp_n, seed, streamed=True, first_index=first)
+    for k in ("wi", "f", "pdf"):
+        cases.assert_tight(cases.summarize(cases.rel_err(whole[k], ref[k])), ("streamed", k))
+    got = {k: np.zeros_like(whole[k]) for k in ("wi", "f", "pdf")}
+    seen = []
+
+    def consume(p0, count, chunk):
+        torch.cuda.synchronize()
+        seen.append((p0, count))
+        for k in ("wi", "f", "pdf"):
+            a = host(chunk[k])[..., : 2 * spp * count]
+            a = a.reshape(a.shape[:-1] + (2 * spp, count))
+            dst = got[k].reshape(got[k].shape[:-1] + (2 * spp, n))
+            dst[..., p0:p0 + count] = a
+
+    sums, _ = _with_group(1, lambda: s.integrateChunked(spp_n, seed, 300, consume=consume, first_index=first))
+    assert seen == [(0, 300), (300, 300), (600, 300), (900, 100)]
+    for k in ("wi", "f", "pdf"):
+        assert np.array_equal(got[k].view(np.uint32), whole[k].view(np.uint32)), k
+    for k in SUMS + COUNTS:
+        assert np.array_equal(host(sums[k]).view(np.uint32), whole[k].view(np.uint32)), k
+    # a consumer that fails stops the walk with an error, not a crash
+    def bad(p0, count, chunk):
+        raise RuntimeError("consumer failed")
+    with pytest.raises(RuntimeError, match="consumer failed"):
+        s.integrateChunked(spp_n, seed, 300, consume=bad)
+    # no consumer: samples discarded, sums unchanged
+    sums2, _ = _with_group(1, lambda: s.integrateChunked(spp_n, seed, 256, first_index=first))
+    for k in SUMS + COUNTS:
+        assert np.array_equal(host(sums2[k]).view(np.uint32), whole[k].view(np.uint32)), k
+
+
+def test_full_size_config3(gpu, oracle):
+    """2^26 points x 64 spp x 2 lobes in reduced mode: counts, finiteness, lane-width independence, a second launch
+    gives the same bits, and oracle spot checks on windows of the very same device-generated inputs."""
+    n, spp_n, seed = 1 << 26, 8, 1234
+    ctx = gpu
+    wo, N, T = R.gen_frame(ctx, seed, 0, n)
+    u = lambda stream, lo=0.0, hi=1.0: R.gen_uniform(ctx, seed, 0, n, stream, lo, hi)
+    base = torch.stack([u(8 + j) for j in range(3)])
+    sc = {k: u(32 + j) for j, k in enumerate(R._capi.DISNEY_SCALARS)}
+    d = R.DisneySampler(ctx, wo, N, T, base_color=base, **sc)
+    out = _with_group(1, lambda: d.integrate(spp_n, seed))
+    spp = spp_n * spp_n
+    for k in COUNTS:
+        cnt = out[k]
+        assert (cnt >= 0).all() and (cnt <= spp).all() and (cnt == cnt.round()).all(), k
+    # the cosine lobe is valid wherever the direction has cos > pi * 1e-4: nearly every sample
+    assert out["diffuse_count"].mean().item() > 0.99 * spp
+    assert out["specular_count"].mean().item() > 0.5 * spp
+    for k in SUMS:
+        fin = torch.isfinite(out[k]).all(dim=0)
+        assert fin.float().mean().item() > 0.99999, k
+        assert (out[k][:, fin] >= 0).all(), k
+    ck = {k: R.checksum(ctx, out[k]) for k in SUMS + COUNTS}
+    again = _with_group(1, lambda: d.integrate(spp_n, seed))
+    assert ck == {k: R.checksum(ctx, again[k]) for k in SUMS + COUNTS}
+    del again
+    alt = _with_group(4, lambda: d.integrate(spp_n, seed))
+    for k in COUNTS:
+        assert torch.equal(alt[k], out[k]), k
+    for k in SUMS:
+        rel = (alt[k] - out[k]).abs() / out[k].abs().clamp_min(1e-20)
+        assert torch.quantile(rel.flatten()[:: 257].float(), 0.999).item() <= 1e-4, k
+    del alt
+    # oracle on eight windows of 256 points; first_index aligns the oracle's scrambles with the batch's
+    for w in range(8):
+        p0 = w * (n // 8) + 4099 * w
+        sl = slice(p0, p0 + 256)
+        sub = lambda t: t[..., sl].contiguous().cpu().numpy()
+        c = dict(wo=sub(wo), N=sub(N), T=sub(T), base_color=sub(base), **{k: sub(v) for k, v in sc.items()})
+        ref = disney_oracle(oracle, c).integrate(spp_n, seed, first_index=p0)
+        for k in COUNTS:
+            assert (sub(out[k]) != ref[k]).sum() <= 1, (w, k)
+        for k in SUMS:
+            cases.assert_tight(cases.summarize(cases.rel_err(sub(out[k]), ref[k])), ("window", w, k))
+
+
+def test_sharded_integrators_draw_the_batch_numbers(gpu, oracle):
+    """first_index: two shards of a batch reproduce the unsplit call bit for bit, for every in-kernel-sampling
+    entry point (rls_ggx_integrate, rls_ggx_direct_lighting, rls_disney_integrate, rls_sss_integrate_scatter)."""
+    n, h, spp_n, seed = 4096, 1500, 4, 31
+    cut = lambda a, sl: a[..., sl] if isinstance(a, np.ndarray) else a
+    parts = (slice(0, h), slice(h, n))
+
+    def run(fn_whole, fn_part):
+        whole = _with_group(1, fn_whole)
+        pieces = [_with_group(1, lambda sl=sl: fn_part(sl)) for sl in parts]
+        for j, w in enumerate(whole):
+            joined = np.concatenate([p[j] for p in pieces], axis=-1)
+            assert np.array_equal(joined.view(np.uint32), w.view(np.uint32)), j
+
+    # rlGgx integrate + direct lighting
+    c = cases.ggx_mixed(cases.SEED_PARITY, n)
+    from gpu_util import ggx_sampler
+    P = np.stack([oracle.gen_uniform(seed, 0, n, 40 + j, 0.0, 4.0) for j in range(3)])
+    lt = R.make_light(center=(2.0, 2.0, 6.0), radius=1.25, radiance=(3.0, 2.0, 1.0))
+    mk = lambda sl: ggx_sampler(gpu, {k: cut(v, sl) for k, v in c.items()})
+    run(lambda: [host(t) for t in mk(slice(0, n)).integrate(spp_n, seed)],
+        lambda sl: [host(t) for t in mk(sl).integrate(spp_n, seed, first_index=sl.start)])
+    run(lambda: [host(t) for t in mk(slice(0, n)).directLighting(dev(P), lt, spp_n, seed)],
+        lambda sl: [host(t) for t in mk(sl).directLighting(dev(np.ascontiguousarray(P[:, sl])), lt, spp_n, seed,
+                                                           first_index=sl.start)])
+    # rlDisney
+    cd = cases.disney_mixed(cases.SEED_PARITY, n)
+    keys = SUMS + COUNTS
+    mkd = lambda sl: disney_sampler(gpu, {k: cut(v, sl) for k, v in cd.items()})
+    run(lambda: [host(mkd(slice(0, n)).integrate(spp_n, seed)[k]) for k in keys],
+        lambda sl: [host(mkd(sl).integrate(spp_n, seed, first_index=sl.start)[k]) for k in keys])
+    # rlSss integrateScatter on the unit sphere
+    dist = np.stack([oracle.gen_uniform(seed, 0, n, 32 + j, 0.02, 0.3) for j in range(3)])
+    scene = R.make_scene("sphere", sphere_radius=1.0, light_dir=(0.0, 0.6, 0.8), use_cavity_fade=True)
+    Nn, Tt = c["N"], c["T"]
+    mks = lambda sl: R.SssSampler(gpu, dev(np.ascontiguousarray(Nn[:, sl])), dev(np.ascontiguousarray(Tt[:, sl])),
+                                  (0.8, 0.5, 0.3), dev(np.ascontiguousarray(dist[:, sl])))
+    run(lambda: [host(mks(slice(0, n)).integrateScatter(dev(Nn), scene, spp_n, seed))],
+        lambda sl: [host(mks(sl).integrateScatter(dev(np.ascontiguousarray(Nn[:, sl])), scene, spp_n, seed,
+                                                  first_index=sl.start))])

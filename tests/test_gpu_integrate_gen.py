@@ -121,6 +121,6 @@ def test_large_parity_sweep(gpu, oracle):
     tools/parity_soak.py runs the same sweep at 2^25 points x 8 seeds; profiles/r01_parity_soak.json."""
     import parity_sweep
     report = parity_sweep.sweep(gpu, 1 << 22, 4242)
-    assert len(report) == 8
+    assert len(report) == 9
     for name, r in report.items():
         assert r["words_differing"] <= 64 and r["beyond_1e5"] <= 4, (name, r)

@@ -279,15 +279,18 @@ def cpu_baseline(workload: str, target_seconds: float) -> dict | None:
                       f"({sum(times):.1f} s of CPU work), oracle/rls_oracle.c {what} on {threads} threads"}
 
 
-def traffic_bytes(workload: str):
-    """HBM bytes per launch from committed PMC profiles (profiles/*_traffic.json), or None."""
+def profile_record(workload: str, math: str, suffix: str, key: str):
+    """The newest committed PMC record for this workload and arithmetic mode (profiles/*_<suffix>.json), or None.
+    Counters come from separate `rocprofv3 --pmc` passes of this very command (tools/profile_round.sh); they cannot
+    be collected inside an un-profiled run, so the line says which file each one comes from."""
     best = None
-    for p in sorted((ROOT / "profiles").glob("*_traffic.json")):
+    for p in sorted((ROOT / "profiles").glob(f"*_{suffix}.json")):
         try:
             d = json.loads(p.read_text())
         except Exception:
             continue
-        if d.get("workload") == workload and d.get("hbm_bytes_per_launch"):
+        if d.get("workload") == workload and d.get("math", "exact") == math and d.get(key):
+            d["file"] = f"profiles/{p.name}"
             best = d
     return best
 
@@ -326,7 +329,8 @@ def main():
     # weak scaling: the job is world * n points, rank g owns the index range [g*n, (g+1)*n)
     first, count = shard_range(world * n, rank, world)
     assert count == n
-    wl = make_workload(R, ctx, args.workload, n, first=first, candidates=args.arena_candidates)
+    wl = make_workload(R, ctx, args.workload, n, first=first, candidates=args.arena_candidates,
+                       chunk_log2=args.chunk_log2)
     torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -359,9 +363,33 @@ def main():
     if rank == 0:
         samples = world * n * wl.samples_per_point * args.steps
         value = samples / elapsed / 1e9
-        bytes_per_launch = n * wl.bytes_per_point
-        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        tr = traffic_bytes(args.workload)
+        launches = wl.launches_per_step
+        bytes_per_step = n * wl.bytes_per_point                       # algorithmic bytes of one pass over the shard
+        bytes_per_launch = bytes_per_step / launches
+        launch_ms = kernel_ms / launches                              # average duration of one kernel launch
+        achieved_gbs = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+        tr = profile_record(args.workload, args.math, "traffic", "hbm_bytes_per_launch")
+        if wl.bound == "hbm":
+            roof = {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
+                    "traffic": tr["hbm_bytes_per_launch"] if tr else None}
+        else:
+            # the integrators run tens of triples per 100-odd bytes: bounded by fp32 vector issue.  Executed flops per
+            # point come from the PMC instruction mix of this kernel (add + mul + 2 fma + transcendental, fp64 counted
+            # once each), see tools/pmc_flops.py
+            fl = profile_record(args.workload, args.math, "flops", "flops_per_point")
+            tflops = fl["flops_per_point"] * n / (kernel_ms * 1e-3) / 1e12 if fl else None
+            roof = {"bound": "valu", "achieved": round(tflops, 3) if fl else None, "peak": VALU_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(tflops / VALU_PEAK_TFLOPS, 4) if fl else None,
+                    "traffic": tr["hbm_bytes_per_launch"] if tr else None,
+                    "flops_per_point": fl["flops_per_point"] if fl else None,
+                    "flops_source": fl["file"] if fl else None,
+                    "hbm_gbs": round(achieved_gbs, 2), "hbm_frac": round(achieved_gbs / HBM_PEAK_GBS, 4)}
+        roof.update({"traffic_source": (tr["file"] + " (rocprofv3 --pmc passes of this command, not this run)") if tr else None,
+                     "kernel": wl.kernel.format(m=1 if args.math == "fast" else 0),   # as rocprofv3 --kernel-trace names it
+                     "kernel_ms": round(launch_ms, 5), "launches_per_step": launches,
+                     "algorithmic_bytes_per_point": wl.bytes_per_point,
+                     "algorithmic_bytes_per_launch": int(bytes_per_launch)})
         line = {
             "metric": "BSDF Gsamples/sec (eval+sample+pdf)",
             "value": round(value, 4),
@@ -377,21 +405,18 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl.desc, "name": wl.name, "math": args.math, "points_per_gpu": n,
                        "samples_per_point": wl.samples_per_point, "sharding": f"index-range x{world}, no collective",
-                       "placement": wl.arena.info()},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": tr["hbm_bytes_per_launch"] if tr else None,
-                         "kernel": wl.kernel.format(m=1 if args.math == "fast" else 0),   # as rocprofv3 --kernel-trace names it
-                         "kernel_ms": round(kernel_ms, 5),
-                         "algorithmic_bytes_per_point": wl.bytes_per_point,
-                         "algorithmic_bytes_per_launch": bytes_per_launch},
+                       "placement": wl.arena.info(),
+                       # the EXACT kernels are vector-ALU-bound: the first ~10 launches after idle run up to 40 % slower
+                       # while the clocks ramp ("Warm-up"); fewer warm-up steps under-report
+                       "warmup_note": None if args.warmup >= 10 else
+                       f"warmup {args.warmup} < 10: the clock ramp of the first launches is inside the timed region "
+                       "(under-reports by ~4 % at 5, ~15 % at 1)"},
+            "roofline": roof,
         }
-        if tr:
-            line["roofline"]["traffic_source"] = tr.get("source")
         other = "exact" if args.math == "fast" else "fast"
         line["other_math_mode"] = {"math": other, "kernel_ms": round(other_ms, 5),
                                    "value": round(world * n * wl.samples_per_point / (other_ms * 1e-3) / 1e9, 4),
-                                   "roofline_frac": round(bytes_per_launch / (other_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                                   "hbm_frac": round(bytes_per_step / (other_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(args.workload, args.cpu_seconds)
             if cb:

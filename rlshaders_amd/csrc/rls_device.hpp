@@ -98,10 +98,10 @@ RLS_DEV void t_sincos(float x, float *s, float *c) { *s = __sinf(x); *c = __cosf
 RLS_DEV void t_sincos_any(float x, float *s, float *c) { t_sincos(x, s, c); }
 RLS_DEV void stage_libm_tables() {}
 #else
-#define R_DIV(a, b) ((a) / (b))
-#define R_RCP(b) (1.0f / (b))
+#define R_DIV(a, b) rlm::div32((a), (b))
+#define R_RCP(b) rlm::div32(1.0f, (b))
 #define R_SQRT(x) rlm::sqrt32(x)
-#define R_DIVH(a, b) ((a) / (b))
+#define R_DIVH(a, b) rlm::div32((a), (b))
 #define R_SQRTH(x) rlm::sqrt32(x)
 // sqrtf(1 + y): no small-argument guard needed (rls_libm.hpp, sqrt32<false>)
 #define R_SQRT1P(y) rlm::sqrt32_1p(y)
@@ -266,7 +266,14 @@ RLS_DEV VndfView vndf_view_from(V3 local, float ax, float ay)
     }
     t_sincos(phi, &w.sinPhi, &w.cosPhi);
     w.nearNormal = theta < kEps;
+#ifdef RLS_TAN_NEARNORMAL   // experiment
+    // theta is either exactly 0 (the branch above not taken) or >= acos(1 - 1e-4) = 0.0141: lanes at 0 would drag
+    // their whole wavefront through tanf's |x| < 2^-13 special case (two divisions); tanf(0) = 0
+    float B = t_tan(w.nearNormal ? 1.0f : theta);
+    B = theta == 0.0f ? 0.0f : B;
+#else
     float B = t_tan(theta);
+#endif
     w.B = B;
     w.B2 = sqr(B);
     w.G1 = R_DIV(2.0f, 1.0f + R_SQRT1P(w.B2));

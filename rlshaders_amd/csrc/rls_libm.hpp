@@ -55,6 +55,48 @@ RLM_FN float u2f(uint32_t u)
 }
 RLM_FN float fabs32(float x) { return u2f(f2u(x) & 0x7fffffffu); }
 
+// ---- experiment switch RLS_DIV_CORE: a / b through the compiler's own Newton sequence without its range handling
+// (v_div_scale / v_div_fmas); v_div_fixup keeps NaN / inf / zero operands right
+RLM_FN float div32(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && defined(RLS_DIV_CORE)
+    float r = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float q = a * r;
+    float t = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(t, r, q);
+    t = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(t, r, q);
+    return __builtin_amdgcn_div_fixupf(q, b, a);
+#else
+    return a / b;
+#endif
+}
+
+// ---- which build of glibc's fp64-polynomial routines to reproduce --------------------------------------------
+// glibc >= 2.28 compiles sinf / cosf / sincosf / expf / logf / powf twice on x86-64: a baseline SSE2 build and
+// an -mfma -mavx2 build (sysdeps/x86_64/fpu/multiarch/s_sinf-fma.c, e_expf-fma.c, ...) and an ifunc picks the FMA
+// build on every CPU that has AVX2 + FMA -- every x86 server since 2013, the GPU box's EPYC host included.  That
+// is the code the reference's CPU closures (and the oracle) actually execute there.  GCC contracts every
+// `a * b + c` of those sources; the pattern below was read from the disassembly of the FMA entry points of
+// glibc 2.35 (the resolvers of sinf / cosf / expf / logf / powf in libm.so.6 name them): each polynomial step is one
+// fma, the pi/2 reduction is x - n*hpi as one fma, and expf forms both kd = InvLn2N*x + Shift and
+// r = InvLn2N*x - kd as fmas of the unrounded product.  RLM_GLIBC_FMA = 1 (default) follows that build,
+// 0 the uncontracted SSE2 build (a host without FMA); the two differ in the last fp32 bit on ~1e-8 of arguments.
+// tanf / atanf / atan2f / acosf are fdlibm fp32 code, built once, never contracted.
+#ifndef RLM_GLIBC_FMA
+#define RLM_GLIBC_FMA 1
+#endif
+RLM_FN double mad(double a, double b, double c)
+{
+#if RLM_GLIBC_FMA
+    return __builtin_fma(a, b, c);
+#else
+    return a * b + c;
+#endif
+}
+
 // Correctly rounded fp32 square root.  Host: libm's sqrtf.  Device: the compiler's expansion of
 // sqrtf spends 7 of its 16 instructions rescaling arguments below 2^-96 so that the residuals of
 // its final +-1 ulp correction stay normal; the closures' radicands are never that small, so the
@@ -69,7 +111,11 @@ RLM_FN float sqrt32(float x)
 #if defined(__HIP_DEVICE_COMPILE__)
 #ifndef RLS_SQRT_NO_FALLBACK
     // |x| < 2^-96, x != 0 (negative subnormals included: v_sqrt_f32 would flush them to -0 instead of NaN)
+#ifdef RLS_SQRT_CMP1   // experiment: one compare (|x| < 2^-96, zeros included) instead of and + add + compare
+    if (GUARDED && __builtin_expect(__builtin_fabsf(x) < 0x1p-96f, 0)) return sqrtf(x);
+#else
     if (GUARDED && __builtin_expect((f2u(x) & 0x7fffffffu) - 1u < 0x0f800000u - 1u, 0)) return sqrtf(x);
+#endif
 #endif
     float s = __builtin_amdgcn_sqrtf(x);
     const float sm = __uint_as_float(__float_as_uint(s) - 1u);
@@ -314,7 +360,7 @@ RLM_FN void sincos32(float y, float *sinp, float *cosp)
     } else if (top < 0x42fu) {                                            // |y| < 120
         const double r = x * hpi_inv;
         n = ((int32_t)r + 0x800000) >> 24;
-        x = x - (double)n * hpi;
+        x = mad(-(double)n, hpi, x);
     } else if (top < 0x7f8u) {                                            // |y| >= 120, finite
         x = reduce_large(f2u(y), &n);
         m = n + (int)(f2u(y) >> 31);                                      // signs include the argument's
@@ -331,17 +377,17 @@ RLM_FN void sincos32(float y, float *sinp, float *cosp)
     const double x2 = x * x;
     // sine polynomial in xs
     const double x3 = xs * x2;
-    const double s1 = S2 + x2 * S3;
+    const double s1 = mad(x2, S3, S2);
     const double x7 = x3 * x2;
-    const double sv = xs + x3 * S1;
-    const double sres = sv + x7 * s1;
+    const double sv = mad(x3, S1, xs);
+    const double sres = mad(x7, s1, sv);
     // cosine polynomial (table[1] negates every coefficient)
     const double x4 = x2 * x2;
-    const double c2 = (cs * C3) + x2 * (cs * C4);
-    const double c1 = (cs * C0) + x2 * (cs * C1);
+    const double c2 = mad(x2, cs * C4, cs * C3);
+    const double c1 = mad(x2, cs * C1, cs * C0);
     const double x6 = x4 * x2;
-    const double cv = c1 + x4 * (cs * C2);
-    const double cres = cv + x6 * c2;
+    const double cv = mad(x4, cs * C2, c1);
+    const double cres = mad(x6, c2, cv);
     // sinf(y): quadrant n -> sine poly if n even else cosine poly; cosf(y): uses n ^ 1
     // Note the sign conventions of s_sinf.c / s_cosf.c: both multiply x by sign[n & 3] and select
     // the second table on n & 2; the polynomial is chosen by the parity of n (sin) or n ^ 1 (cos).
@@ -409,20 +455,16 @@ RLM_FN double u2d(uint64_t u)
 #endif
 }
 
-// 2^(x/32-scaled) core shared by expf and powf: s * (C0 r^3 + C1 r^2 + C2 r + 1)
-RLM_FN float exp2_core(double z, double shift, double c0, double c1, double c2, const Tables &t, uint64_t sign_bias)
+// s * (C0 r^3 + C1 r^2 + C2 r + 1) with s = 2^(k/32) from the table: the tail shared by expf and powf
+RLM_FN float exp2_tail(double r, uint64_t ki, double c0, double c1, double c2, const Tables &t, uint64_t sign_bias)
 {
-    double kd = z + shift;
-    const uint64_t ki = d2u(kd);
-    kd -= shift;
-    const double r = z - kd;
     uint64_t tt = t.exp2t[ki % 32];
     tt += (ki + sign_bias) << (52 - 5);
     const double s = u2d(tt);
-    const double zz = c0 * r + c1;
+    const double zz = mad(c0, r, c1);
     const double r2 = r * r;
-    double y = c2 * r + 1.0;
-    y = zz * r2 + y;
+    double y = mad(c2, r, 1.0);
+    y = mad(zz, r2, y);
     y = y * s;
     return (float)y;
 }
@@ -437,8 +479,22 @@ RLM_FN float exp32(float x, const Tables &t)
         if (x < -0x1.9fe368p6f) return 0.0f;                            // underflow
     }
     const double N = 32.0;
-    const double z = (0x1.71547652b82fep+0 * N) * (double)x;
-    return exp2_core(z, 0x1.8p+52, 0x1.c6af84b912394p-5 / N / N / N, 0x1.ebfce50fac4f3p-3 / N / N,
+    const double InvLn2N = 0x1.71547652b82fep+0 * N, Shift = 0x1.8p+52;
+    const double xd = (double)x;
+#if RLM_GLIBC_FMA
+    // the FMA build never rounds z = InvLn2N * x on its own: kd and r are fmas of the exact product
+    double kd = __builtin_fma(InvLn2N, xd, Shift);
+    const uint64_t ki = d2u(kd);
+    kd -= Shift;
+    const double r = __builtin_fma(InvLn2N, xd, -kd);
+#else
+    const double z = InvLn2N * xd;
+    double kd = z + Shift;
+    const uint64_t ki = d2u(kd);
+    kd -= Shift;
+    const double r = z - kd;
+#endif
+    return exp2_tail(r, ki, 0x1.c6af84b912394p-5 / N / N / N, 0x1.ebfce50fac4f3p-3 / N / N,
                      0x1.62e42ff0c52d6p-1 / N, t, 0);
 }
 
@@ -459,12 +515,12 @@ RLM_FN float log32(float x, const Tables &t)
     const uint32_t iz = ix - (tmp & (0x1ffu << 23));
     const double invc = t.invc[i], logc = t.logc[i];
     const double z = (double)u2f(iz);
-    const double r = z * invc - 1.0;
-    const double y0 = logc + (double)k * 0x1.62e42fefa39efp-1;
+    const double r = mad(z, invc, -1.0);
+    const double y0 = mad((double)k, 0x1.62e42fefa39efp-1, logc);
     const double r2 = r * r;
-    double y = 0x1.5575b0be00b6ap-2 * r + -0x1.ffffef20a4123p-2;
-    y = -0x1.00ea348b88334p-2 * r2 + y;
-    y = y * r2 + (y0 + r);
+    double y = mad(0x1.5575b0be00b6ap-2, r, -0x1.ffffef20a4123p-2);
+    y = mad(-0x1.00ea348b88334p-2, r2, y);
+    y = mad(y, r2, y0 + r);
     return (float)y;
 }
 
@@ -520,22 +576,27 @@ RLM_FN float pow32(float x, float y, const Tables &t)
     const int k = (int32_t)top >> 23;
     const double invc = t.invc[i], logc = t.log2c[i];
     const double z = (double)u2f(iz);
-    const double r = z * invc - 1.0;
+    const double r = mad(z, invc, -1.0);
     const double y0 = logc + (double)k;
     const double r2 = r * r;
-    double yy = 0x1.27616c9496e0bp-2 * r + -0x1.71969a075c67ap-2;
-    const double p = 0x1.ec70a6ca7baddp-2 * r + -0x1.7154748bef6c8p-1;
+    double yy = mad(0x1.27616c9496e0bp-2, r, -0x1.71969a075c67ap-2);
+    const double p = mad(0x1.ec70a6ca7baddp-2, r, -0x1.7154748bef6c8p-1);
     const double r4 = r2 * r2;
-    double q = 0x1.71547652ab82bp0 * r + y0;
-    q = p * r2 + q;
-    yy = yy * r4 + q;
+    double q = mad(0x1.71547652ab82bp0, r, y0);
+    q = mad(p, r2, q);
+    yy = mad(yy, r4, q);
     const double ylogx = (double)y * yy;
     if (((d2u(ylogx) >> 47) & 0xffffu) >= (d2u(126.0) >> 47)) {         // |y log2 x| >= 126
         if (ylogx > 0x1.fffffffd1d571p+6) return u2f(sign_bias ? 0xff800000u : 0x7f800000u);
         if (ylogx <= -150.0) return sign_bias ? -0.0f : 0.0f;
     }
-    return exp2_core(ylogx, 0x1.8p+52 / 32.0, 0x1.c6af84b912394p-5, 0x1.ebfce50fac4f3p-3, 0x1.62e42ff0c52d6p-1, t,
-                     sign_bias);
+    // exp2_inline: the argument is already a double, nothing to contract in the reduction
+    const double Shift = 0x1.8p+52 / 32.0;
+    double kd = ylogx + Shift;
+    const uint64_t ki = d2u(kd);
+    kd -= Shift;
+    const double rr = ylogx - kd;
+    return exp2_tail(rr, ki, 0x1.c6af84b912394p-5, 0x1.ebfce50fac4f3p-3, 0x1.62e42ff0c52d6p-1, t, sign_bias);
 }
 
 // =================================================================================================
@@ -565,7 +626,7 @@ RLM_FN float atan32_v(float x)
     const float den = r0 ? 1.0f : r1 ? (2.0f + ax) : r2 ? (ax + 1.0f) : r3 ? (1.0f + 1.5f * ax) : ax;
     const float hi = r1 ? u2f(0x3eed6338u) : r2 ? u2f(0x3f490fdau) : r3 ? u2f(0x3f7b985eu) : u2f(0x3fc90fdau);
     const float lo = r1 ? u2f(0x31ac3769u) : r2 ? u2f(0x33222168u) : r3 ? u2f(0x33140fb4u) : u2f(0x33a22168u);
-    const float t = num / den;
+    const float t = div32(num, den);
     const float z = t * t;
     const float w = z * z;
     const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
@@ -591,7 +652,7 @@ RLM_FN float atan2_32_v(float y, float x)
     const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
     if (__builtin_expect(ix >= 0x7f800000 || iy >= 0x7f800000, 0)) return atan2_32(y, x);
     const int32_t k = (iy - ix) >> 23;
-    float z = atan32_v(fabs32(y / x));
+    float z = atan32_v(fabs32(div32(y, x)));
     z = (k > 60) ? (pi_o_2 + 0.5f * pi_lo) : z;
     z = (hx < 0 && k < -60) ? 0.0f : z;
     const float zl = z - pi_lo;
@@ -617,13 +678,13 @@ RLM_FN float acos32_v(float x)
     const float z = mid ? x * x : (neg ? (1.0f + x) * 0.5f : (1.0f - x) * 0.5f);
     const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
     const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
-    const float r = p / q;
+    const float r = div32(p, q);
     const float r_mid = pio2_hi - (x - (pio2_lo - x * r));
     float res = r_mid;
     if (!mid) {
         const float s = sqrt32(z);
         const float df = u2f(f2u(s) & 0xfffff000u);
-        const float c = (z - df * df) / (s + df);
+        const float c = div32(z - df * df, s + df);
         const float r_pos = 2.0f * (df + (r * s + c));
         const float r_neg = pi - 2.0f * (s + (r * s - pio2_lo));
         res = neg ? r_neg : r_pos;
@@ -639,7 +700,7 @@ RLM_FN float acos32_v(float x)
 // FULL = false drops the branch for |y| >= 120: the form the closure kernels use, whose angles are bounded by
 // construction (results of atan2f / acosf, or 2 pi xi with xi in [0, 1)); NaN still propagates.  The branch is
 // never taken there, but its presence costs 1.7 % of the reflect+refract kernel.
-template <bool FULL>
+template <bool FULL, bool CONTRACT>
 RLM_FN double reduce_pio2(float y, int *np, bool *large_negative)
 {
     const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
@@ -653,7 +714,8 @@ RLM_FN double reduce_pio2(float y, int *np, bool *large_negative)
     const double r = x * hpi_inv;
     const int n = ((int32_t)r + 0x800000) >> 24;
     *np = n;
-    return x - (double)n * hpi;
+    // sinf / cosf (FMA build: one fma); tanf's __ieee754_rem_pio2f is built once, uncontracted
+    return CONTRACT ? mad(-(double)n, hpi, x) : x - (double)n * hpi;
 }
 
 // sinf and cosf of the same argument (one reduction, both polynomials)
@@ -665,21 +727,21 @@ RLM_FN void sincos32_v(float y, float *sinp, float *cosp)
     const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
     int n;
     bool lneg;
-    const double x = reduce_pio2<FULL>(y, &n, &lneg);   // n == 0 and x == y whenever |y| < pi/4
+    const double x = reduce_pio2<FULL, true>(y, &n, &lneg);   // n == 0 and x == y whenever |y| < pi/4
     const int m = n + (lneg ? 1 : 0);             // s_sinf.c / s_cosf.c: signs from n + sign beyond 120
     const double xs = ((m & 3) == 1 || (m & 3) == 2) ? -x : x;
     const double x2 = x * x;
     const double x3 = xs * x2;
-    const double s1 = S2 + x2 * S3;
+    const double s1 = mad(x2, S3, S2);
     const double x5 = x3 * x2;
-    const double sv = xs + x3 * S1;
-    double sres = sv + x5 * s1;
+    const double sv = mad(x3, S1, xs);
+    double sres = mad(x5, s1, sv);
     const double x4 = x2 * x2;
-    const double c2 = C3 + x2 * C4;
-    const double c1 = C0 + x2 * C1;
+    const double c2 = mad(x2, C4, C3);
+    const double c1 = mad(x2, C1, C0);
     const double x6 = x4 * x2;
-    const double cv = c1 + x4 * C2;
-    double cres = cv + x6 * c2;
+    const double cv = mad(x4, C2, c1);
+    double cres = mad(x6, c2, cv);
     cres = (m & 2) ? -cres : cres;                // second table: every cosine coefficient negated
     float sf = (float)((n & 1) ? cres : sres);
     float cf = (float)((n & 1) ? sres : cres);
@@ -702,7 +764,7 @@ RLM_FN float tan32_v(float xin)
     // y1 = 0 there, so it is applied unconditionally
     int n;
     bool lneg;
-    double dx = reduce_pio2<FULL>(xin, &n, &lneg);
+    double dx = reduce_pio2<FULL, false>(xin, &n, &lneg);
     if (lneg) { dx = -dx; n = -n; }
     float x = (float)dx;
     float y = (float)(dx - (double)x);
@@ -734,7 +796,7 @@ RLM_FN float tan32_v(float xin)
     r += T0 * s;
     w = x + r;
     // one division: w*w/(w+iy) in the big case, -1/w when the cotangent is wanted
-    const float q = (big ? w * w : -1.0f) / (big ? w + fiy : w);
+    const float q = div32(big ? w * w : -1.0f, big ? w + fiy : w);
     const float r_big = sgn * (fiy - 2.0f * (x - (q - r)));
     const float zt = u2f(f2u(w) & 0xfffff000u);
     const float vt = r - (zt - x);

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 CSVs of tools/profile_workload.sh into the committed per-workload summaries:
+  profiles/<tag>_<workload>_bench.json          the un-profiled bench line (and the traced one)
+  profiles/<tag>_<workload>_kernel_stats.csv    rocprofv3 --kernel-trace --stats
+  profiles/<tag>_<workload>_traffic.json        HBM bytes per launch (FETCH_SIZE x calibrated factor + WRITE_SIZE)
+  profiles/<tag>_<workload>_flops.json          executed flops per point from the dynamic instruction mix
+usage: summarize_workload.py <tag> <workload>"""
+import csv, glob, json, os, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def pmc(dirname, sub):
+    """mean counter value per dispatch of kernels whose name contains `sub` (sum over the XCD/SE dimensions rocprofv3
+    has already aggregated)"""
+    acc = {}
+    for f in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
+        per_dispatch = {}
+        for r in csv.DictReader(open(f)):
+            if sub in r["Kernel_Name"]:
+                per_dispatch.setdefault((r["Counter_Name"], r["Dispatch_Id"]), 0.0)
+                per_dispatch[(r["Counter_Name"], r["Dispatch_Id"])] += float(r["Counter_Value"])
+        for (c, _), v in per_dispatch.items():
+            acc.setdefault(c, []).append(v)
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+def main():
+    tag, workload = sys.argv[1], sys.argv[2]
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{workload}")
+    dst = os.path.join(ROOT, "profiles")
+    line = None
+    for name in ("bench.json", "bench_trace.json"):
+        p = os.path.join(src, name)
+        lines = [l for l in open(p).read().splitlines() if l.startswith("{")] if os.path.exists(p) else []
+        if lines and name == "bench.json":
+            line = json.loads(lines[-1])
+        if lines:
+            json.dump(json.loads(lines[-1]), open(os.path.join(dst, f"{tag}_{workload}_{name}"), "w"), indent=1)
+    if line is None:
+        raise SystemExit(f"no bench line under {src}")
+    ksub = line["roofline"]["kernel"]
+    n = line["config"]["points_per_gpu"]
+    math = line["config"]["math"]
+    launches = line["roofline"].get("launches_per_step", 1)
+    points_per_launch = n / launches
+    for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
+        shutil.copy(f, os.path.join(dst, f"{tag}_{workload}_kernel_stats.csv"))
+        for r in csv.DictReader(open(f)):
+            if ksub in r["Name"]:
+                print(f"rocprofv3: {r['Name'][:60]} calls {r['Calls']} avg {float(r['AverageNs']) / 1e6:.4f} ms "
+                      f"(bench line: {line['roofline']['kernel_ms']} ms)")
+    fetch, write = pmc(os.path.join(src, "fetch"), ksub), pmc(os.path.join(src, "write"), ksub)
+    calib = pmc(os.path.join(src, "calib"), "checksum_kernel")
+    # FETCH_SIZE / WRITE_SIZE count KiB; gfx950's FETCH_SIZE under-reports streaming reads (MI355X_MICROARCH.md, HBM
+    # section): the factor is re-measured on rls_checksum, a kernel of known size in the same one-dword-per-lane pattern
+    factor = (4 * (1 << 28)) / (calib["FETCH_SIZE"] * 1024.0) if calib.get("FETCH_SIZE") else 2.0
+    if "FETCH_SIZE" in fetch and "WRITE_SIZE" in write:
+        rd, wr = fetch["FETCH_SIZE"] * 1024.0 * factor, write["WRITE_SIZE"] * 1024.0
+        alg = line["roofline"]["algorithmic_bytes_per_launch"]
+        t = {"workload": workload, "math": math, "kernel": ksub, "hbm_bytes_per_launch": int(round(rd + wr)),
+             "read": int(round(rd)), "write": int(round(wr)), "algorithmic_bytes_per_launch": alg,
+             "ratio_to_algorithmic": round((rd + wr) / alg, 4), "fetch_size_factor": round(factor, 4),
+             "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/profile_workload.sh); FETCH_SIZE x "
+                       "the factor measured on rls_checksum (known byte count) in the same session"}
+        json.dump(t, open(os.path.join(dst, f"{tag}_{workload}_traffic.json"), "w"), indent=1)
+        print("traffic", t["hbm_bytes_per_launch"], "ratio", t["ratio_to_algorithmic"])
+    mix = {}
+    for d in ("mix_a", "mix_b", "mix_c", "mix_d"):
+        mix.update(pmc(os.path.join(src, d), ksub))
+    if mix:
+        waves = points_per_launch / 64.0          # one point per lane: counters per wave-instruction -> per point
+        per = {k: round(v / waves, 2) for k, v in mix.items() if k.startswith("SQ_INSTS")}
+        g = lambda k: per.get(k, 0.0)
+        flops = (g("SQ_INSTS_VALU_ADD_F32") + g("SQ_INSTS_VALU_MUL_F32") + 2 * g("SQ_INSTS_VALU_FMA_F32")
+                 + g("SQ_INSTS_VALU_TRANS_F32") + g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64")
+                 + 2 * g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_TRANS_F64"))
+        f = {"workload": workload, "math": math, "kernel": ksub, "flops_per_point": round(flops, 1),
+             "instructions_per_point": per,
+             "note": "wave-instructions per wave of 64 points = instructions per point (G = 1: one lane per point); flops = "
+                     "add + mul + 2 fma + transcendental, fp32 and fp64 alike; divergent lanes count as executed",
+             "source": "rocprofv3 --pmc SQ_INSTS_VALU_* in four passes (tools/profile_workload.sh)"}
+        json.dump(f, open(os.path.join(dst, f"{tag}_{workload}_flops.json"), "w"), indent=1)
+        print("flops/point", f["flops_per_point"], "VALU/point", per.get("SQ_INSTS_VALU"))
+
+
+if __name__ == "__main__":
+    main()

@@ -41,7 +41,14 @@ __global__ RLS_KERNEL_ATTR void ggx_kernel(GgxIO a)
             float rx = ldg(a.rx, i), ry = ldg(a.ry, i);
             VndfView w = vndf_view(g.view, g.fr, g.ax, g.ay);
             // evalSample: src/rlGgx.h:97-107
-            V3 M = vndf_microfacet(w, g.fr, rx, ry);
+            V3 M, M2;
+            if (OP == OP_REFLECT_REFRACT) {
+                // second sample on the same closure: the view analysis is reused, the uniform fallback shared
+                float rx2 = ldg(a.rx2, i), ry2 = ldg(a.ry2, i);
+                vndf_microfacet_pair(w, g.fr, rx, ry, w, g.fr, rx2, ry2, M, M2);
+            } else {
+                M = vndf_microfacet(w, g.fr, rx, ry);
+            }
             V3 L = reflect_direction(g.view, M);
             float F = ggx_fresnel(g, L, M);
             st3(a.wi, i, L);
@@ -53,9 +60,6 @@ __global__ RLS_KERNEL_ATTR void ggx_kernel(GgxIO a)
                 stg(a.pdf, i, pdf);
             }
             if (OP == OP_REFLECT_REFRACT) {
-                // second sample on the same closure: the view analysis is reused
-                float rx2 = ldg(a.rx2, i), ry2 = ldg(a.ry2, i);
-                V3 M2 = vndf_microfacet(w, g.fr, rx2, ry2);
                 V3 dir;
                 ggx_refract(g, M2, dir);
                 st3(a.wt, i, dir);

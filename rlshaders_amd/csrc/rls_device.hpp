@@ -301,38 +301,107 @@ RLS_DEV V2 uniform_slope(float rx, float ry)
     return slope;
 }
 
-// Per-sample part of sampleSlope + evalSample: src/rlGgx.cpp:36-60, 89-98
-RLS_DEV V3 vndf_microfacet(const VndfView &w, const Frame &fr, float rx, float ry)
+// Per-sample part of sampleSlope + evalSample: src/rlGgx.cpp:36-60, 89-98.
+// vndf_slope_closed: the closed-form slopes (36-60); returns true where the reference takes the uniform fallback
+// instead (27: theta < eps, 38: |A^2 - 1| < eps) -- the slopes it writes are then unused.
+RLS_DEV bool vndf_slope_closed(const VndfView &w, float rx, float ry, V2 &slope)
 {
-    V2 slope;
     float A = R_DIVH(2.0f * rx, w.G1) - 1.0f;
     float A2 = sqr(A);
-    if (w.nearNormal || absf(A2 - 1.0f) < kEps) {
-        slope = uniform_slope(rx, ry);
-    } else {
-        float tmp = R_DIVH(1.0f, A2 - 1.0f);
-        float D = R_SQRTH(maxf(0.0f, w.B2 * sqr(tmp) - (A2 - w.B2) * tmp));
-        float slopeX1 = w.B * tmp - D;
-        float slopeX2 = w.B * tmp + D;
-        slope.x = (A < 0.0f || slopeX2 > w.invB) ? slopeX1 : slopeX2;
+    float tmp = R_DIVH(1.0f, A2 - 1.0f);
+    float D = R_SQRTH(maxf(0.0f, w.B2 * sqr(tmp) - (A2 - w.B2) * tmp));
+    float slopeX1 = w.B * tmp - D;
+    float slopeX2 = w.B * tmp + D;
+    slope.x = (A < 0.0f || slopeX2 > w.invB) ? slopeX1 : slopeX2;
 
-        float sign = 1.0f;
-        float u;
-        if (ry > 0.5f) {
-            u = 2.0f * (ry - 0.5f);
-        } else {
-            sign = -1.0f;
-            u = 2.0f * (0.5f - ry);
-        }
-        float z = R_DIVH(u * (u * (u * 0.27385f - 0.73369f) + 0.46341f),
-                        u * (u * (u * 0.093073f + 0.309420f) - 1.0f) + 0.597999f);
-        slope.y = sign * z * R_SQRTH1P(sqr(slope.x));
+    float sign = 1.0f;
+    float u;
+    if (ry > 0.5f) {
+        u = 2.0f * (ry - 0.5f);
+    } else {
+        sign = -1.0f;
+        u = 2.0f * (0.5f - ry);
     }
+    float z = R_DIVH(u * (u * (u * 0.27385f - 0.73369f) + 0.46341f),
+                    u * (u * (u * 0.093073f + 0.309420f) - 1.0f) + 0.597999f);
+    slope.y = sign * z * R_SQRTH1P(sqr(slope.x));
+    return w.nearNormal || absf(A2 - 1.0f) < kEps;
+}
+
+// rotate by the view azimuth, unstretch, to world, normalise: src/rlGgx.cpp:89-98
+RLS_DEV V3 vndf_from_slope(const VndfView &w, const Frame &fr, V2 slope)
+{
     V3 omega;
     omega.x = -(w.cosPhi * slope.x - w.sinPhi * slope.y) * w.ax;
     omega.y = -(w.sinPhi * slope.x + w.cosPhi * slope.y) * w.ay;
     omega.z = 1.0f;
     return normalize_h(to_frame(omega, fr.U, fr.V, fr.N));
+}
+
+RLS_DEV V3 vndf_microfacet(const VndfView &w, const Frame &fr, float rx, float ry)
+{
+    V2 slope;
+    if (w.nearNormal) {           // whole wavefronts of near-normal points (low roughness) skip the closed form
+        slope = uniform_slope(rx, ry);
+    } else if (vndf_slope_closed(w, rx, ry, slope)) {
+        slope = uniform_slope(rx, ry);
+    }
+    return vndf_from_slope(w, fr, slope);
+}
+
+// Two microfacet samples per lane (reflect + refract on one closure; the two lobes of rlSkin) with ONE pass of
+// the uniform fallback for the whole wavefront.  A few lanes per wavefront need the fallback (near-normal stretched
+// view: ~7 % of the points of the mixed-roughness workload) and drag all 64 through uniform_slope's exact division,
+// square root and fp64 sincosf -- once per sample.  Here the (rx, ry) pairs of the lanes that need it are packed into
+// the low lanes with ds_permute, evaluated once, and handed back with ds_bpermute: the same function on the same
+// arguments, on another lane.  Falls back to the per-sample form when the wavefront is not fully active or more
+// than 63 evaluations are wanted.
+RLS_DEV void vndf_microfacet_pair(const VndfView &w1, const Frame &fr1, float rx1, float ry1,
+                                  const VndfView &w2, const Frame &fr2, float rx2, float ry2, V3 &M1, V3 &M2)
+{
+#if RLS_FAST || defined(RLS_NO_PAIR_COMPACTION)
+    M1 = vndf_microfacet(w1, fr1, rx1, ry1);
+    M2 = vndf_microfacet(w2, fr2, rx2, ry2);
+#else
+    if (__builtin_amdgcn_ballot_w64(true) != ~0ull) {
+        M1 = vndf_microfacet(w1, fr1, rx1, ry1);
+        M2 = vndf_microfacet(w2, fr2, rx2, ry2);
+        return;
+    }
+    V2 s1, s2;
+    const bool n1 = vndf_slope_closed(w1, rx1, ry1, s1);
+    const bool n2 = vndf_slope_closed(w2, rx2, ry2, s2);
+    const uint64_t m1 = __builtin_amdgcn_ballot_w64(n1), m2 = __builtin_amdgcn_ballot_w64(n2);
+    const int c1 = __builtin_popcountll(m1), tot = c1 + __builtin_popcountll(m2);
+    if (tot != 0) {
+        if (tot <= 63) {
+            const int lane = (int)(threadIdx.x & 63u);
+            const int k1 = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+            const int k2 = c1 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u));
+            // lanes without a request push to lane 63, which holds no request (tot <= 63)
+            const int d1 = (n1 ? k1 : 63) * 4, d2 = (n2 ? k2 : 63) * 4;
+            const int ax = __builtin_amdgcn_ds_permute(d1, (int)__float_as_uint(rx1));
+            const int ay = __builtin_amdgcn_ds_permute(d1, (int)__float_as_uint(ry1));
+            const int bx = __builtin_amdgcn_ds_permute(d2, (int)__float_as_uint(rx2));
+            const int by = __builtin_amdgcn_ds_permute(d2, (int)__float_as_uint(ry2));
+            const float qx = __uint_as_float((uint32_t)(lane < c1 ? ax : bx));
+            const float qy = __uint_as_float((uint32_t)(lane < c1 ? ay : by));
+            V2 u = { 0.0f, 0.0f };
+            if (lane < tot) u = uniform_slope(qx, qy);
+            const float u1x = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(k1 * 4, (int)__float_as_uint(u.x)));
+            const float u1y = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(k1 * 4, (int)__float_as_uint(u.y)));
+            const float u2x = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(k2 * 4, (int)__float_as_uint(u.x)));
+            const float u2y = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(k2 * 4, (int)__float_as_uint(u.y)));
+            if (n1) { s1.x = u1x; s1.y = u1y; }
+            if (n2) { s2.x = u2x; s2.y = u2y; }
+        } else {
+            if (n1) s1 = uniform_slope(rx1, ry1);
+            if (n2) s2 = uniform_slope(rx2, ry2);
+        }
+    }
+    M1 = vndf_from_slope(w1, fr1, s1);
+    M2 = vndf_from_slope(w2, fr2, s2);
+#endif
 }
 
 // ---- rlGgx closure state, src/rlGgx.h:130-156 ---------------------------------------------------

@@ -53,7 +53,7 @@ def parse_args():
     ap.add_argument("--log2-points", type=int, default=26, help="points per GPU = 2^this (config: 26)")
     ap.add_argument("--workload", default="ggx_reflect_refract",
                     choices=["ggx_reflect_refract", "ggx_reflect", "ggx_direct", "disney_integrate", "disney_stream", "sss_probe",
-                             "sss_scatter", "skin"])
+                             "sss_scatter", "skin", "skin_integrate"])
     ap.add_argument("--chunk-log2", type=int, default=20, help="disney_stream: points per chunk = 2^this")
     ap.add_argument("--math", default="exact", choices=["exact", "fast"],
                     help="arithmetic of the measured kernels: exact (default, bit-faithful to the CPU closures) "
@@ -82,7 +82,7 @@ class Workload:
 # planes (n floats each) a workload reads and writes: sizes its arena
 PLANES = {"ggx_reflect_refract": 19 + 12, "ggx_reflect": 17 + 8, "disney_integrate": 22 + 8, "disney_stream": 22 + 8,
           "sss_probe": 17 + 12,
-          "sss_scatter": 15 + 3, "skin": 35 + 24, "ggx_direct": 15 + 3 + 6 + 6}     # (the generator's wo planes included where the closure ignores them)
+          "sss_scatter": 15 + 3, "skin": 35 + 24, "skin_integrate": 29 + 3 + 15, "ggx_direct": 15 + 3 + 6 + 6}     # (the generator's wo planes included where the closure ignores them)
 
 
 def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, chunk_log2: int = 20):
@@ -164,7 +164,7 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
                       "sss_scatter_kernel<1, {m}>",
                       "rlSss integrateScatter, 16 probe rays per point on an analytic sphere (SURVEY 8f rank 3; "
                       "VALU-bound)", bound="valu")
-    elif name == "skin":
+    elif name in ("skin", "skin_integrate"):
         p = dict(sss_color=u3(S_PARAM0), sss_weight=u(S_PARAM0 + 3), sss_dist_multiplier=u(S_PARAM0 + 4, 0.5, 1.5),
                  sss_scatter_dist=u3(S_PARAM0 + 5, 0.1, 2.1),
                  specular_color=u3(S_PARAM0 + 8), specular_weight=u(S_PARAM0 + 11),
@@ -172,6 +172,20 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
                  sheen_color=u3(S_PARAM0 + 14), sheen_weight=u(S_PARAM0 + 17),
                  sheen_roughness=u(S_PARAM0 + 18, 0.05, 1.0), sheen_ior=u(S_PARAM0 + 19, 1.05, 2.55))
         sk = R.SkinShader(ctx, wo, N, T, **p)
+        if name == "skin_integrate":
+            # shader_evaluate with 16 samples per layer: 2 x 16 GGX triples + 16 probe rays per point, shading points on
+            # the unit sphere (P = N); in 29 parameter planes + P3, out 4 AOVs x 3 + 3 layer scalars
+            scene = R.make_scene("sphere", sphere_radius=1.0, light_dir=(0.0, 0.6, 0.8), use_cavity_fade=True)
+            out = {k: A.planes(3) for k in ("sheen", "specular", "sss", "out")}
+            out.update({k: A.plane() for k in ("sheenFresnel", "specularFresnel", "sssWeight")})
+            wl = Workload(name, 48, (29 + 3 + 15) * 4,
+                          lambda: sk.integrate(N, scene, 4, SEED, env=(1.0, 0.9, 0.8), out=out, first_index=first),
+                          "skin_integrate_kernel<1, {m}>",
+                          "rlSkin shader_evaluate, 16 samples per layer: sheen + specular integrateGlossy with the mean-"
+                          "Fresnel hand-down, integrateScatter on an analytic sphere (src/rlSkin.cpp:174-254; VALU-bound)",
+                          bound="valu")
+            wl.arena = A
+            return wl
         xi = A.planes(6)
         for j in range(6):
             R.gen_uniform(ctx, SEED, first, n, S_XI0 + j, out=xi[j])
@@ -222,7 +236,7 @@ def _cpu_leg(workload: str, n: int, threads: int):
         s = O.Sss(n, u3(S_PARAM0, 0.02, 0.3), u3(S_KS), N=N, T=T, nthreads=threads)
         scene = O.make_scene("sphere", sphere_radius=1.0, light_dir=(0.0, 0.6, 0.8), use_cavity_fade=True)
         return (lambda: O.integrate_scatter(s, N, scene, 4, SEED)), 16, "orc_batch_sss_integrate_scatter"
-    if workload == "skin":
+    if workload in ("skin", "skin_integrate"):
         wo, N, T = cases.frame(SEED, n)
         p = dict(sss_color=u3(S_PARAM0), sss_weight=u(S_PARAM0 + 3), sss_dist_multiplier=u(S_PARAM0 + 4, 0.5, 1.5),
                  sss_scatter_dist=u3(S_PARAM0 + 5, 0.1, 2.1),
@@ -230,6 +244,10 @@ def _cpu_leg(workload: str, n: int, threads: int):
                  specular_roughness=u(S_PARAM0 + 12, 0.05, 1.0), specular_ior=u(S_PARAM0 + 13, 1.05, 2.55),
                  sheen_color=u3(S_PARAM0 + 14), sheen_weight=u(S_PARAM0 + 17),
                  sheen_roughness=u(S_PARAM0 + 18, 0.05, 1.0), sheen_ior=u(S_PARAM0 + 19, 1.05, 2.55))
+        if workload == "skin_integrate":
+            scene = O.make_scene("sphere", sphere_radius=1.0, light_dir=(0.0, 0.6, 0.8), use_cavity_fade=True)
+            return (lambda: O.skin_integrate(wo, N, T, p, N, scene, 4, SEED, env=(1.0, 0.9, 0.8), nthreads=threads)), 48, \
+                "orc_batch_skin_integrate"
         x = cases.xi(SEED, n, 6)
         return (lambda: O.skin(wo, N, T, p, x, nthreads=threads)), 3, "orc_batch_skin"
     raise ValueError(workload)

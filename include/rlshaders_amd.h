@@ -214,6 +214,17 @@ rls_status rls_ggx_integrate(rls_context *ctx, int64_t n, const rls_ggx_closure 
                              int spp_n, uint32_t seed, uint64_t first_index,
                              rls_rgb sum_f_over_pdf, float *avg_reflect_weight);
 
+/* integrateRefract (src/rlGgx.h:205-245).  traced != 0: the sample loop of 228-244 -- per sample a microfacet
+ * normal, the refraction of the view about it (Snell, Walter et al. eq. 40; the mirror direction on total
+ * internal reflection, 234-237), radiance x getSampleWeight (294-301), the sum x AiSamplerGetSampleInvCount.
+ * traced == 0: the branch of 213-222 -- one refraction about the shading normal, radiance x SQR(iorOut / iorIn)
+ * x |Nf . dir|, black on total internal reflection.  AiTrace / AiTraceBackground are closed: the radiance is that
+ * of a uniform environment, env[3] (parity unpinned).  tir_fraction (optional): the share of samples that were
+ * totally internally reflected. */
+rls_status rls_ggx_integrate_refract(rls_context *ctx, int64_t n, const rls_ggx_closure *c, int traced,
+                                     const float env[3], int spp_n, uint32_t seed, uint64_t first_index,
+                                     rls_rgb result, float *tir_fraction);
+
 /* Direct lighting of the rlGgx node: the light loop of shader_evaluate (src/rlGgx.cpp:274-299) --
  *     diffuse  += AiEvaluateLightSample(sg, diffData, AiOrenNayarMISSample, ..BRDF, ..PDF)
  *     specular += sampler.evalLightSample(sg)        (AiEvaluateLightSample over the GGX triple,
@@ -398,6 +409,27 @@ typedef struct rls_skin_out {
 /* xi: six planes {sheen rx, ry, specular rx, ry, sss rx, ry} */
 rls_status rls_skin_sample_eval_pdf(rls_context *ctx, int64_t n, const rls_skin_closure *c,
                                     const float *const xi[6], const rls_skin_out *out);
+
+/* shader_evaluate of rlSkin over spp_n^2 samples per layer (src/rlSkin.cpp:174-254).  Per GGX lobe (sheen, then
+ * specular; skipped when its weight <= AI_EPSILON, 191/214) integrateGlossy's sample loop; every evalSample of it
+ * adds its Fresnel term to the closure (src/rlGgx.h:103) and getAvgReflectWeight (181-184) -- the mean over ALL the
+ * samples of the lobe, 1 when none were drawn -- is what the layer hands down:
+ *     sheenFresnel    = avg_sheen * sheen_weight                      (204)    sheen    *= sheen_weight        (207)
+ *     specularFresnel = avg_spec  * specular_weight                   (228)    specular *= specular_weight * (1 - sheenFresnel)   (231)
+ *     sssWeight       = sss_weight * (1 - specularFresnel * (1 - sheenFresnel))   (238)
+ *     sss = sssWeight < AI_EPSILON ? black : integrateScatter(scatterDist = sss_scatter_dist * sss_dist_multiplier) * sssWeight   (244-246)
+ * The mean is a wave-shuffle reduction over the lanes that share a shading point (a17).  What the reference gets
+ * from the closed renderer is supplied as for the single-closure integrators (parity unpinned): AiBRDFIntegrate ->
+ * the mean of evalBrdf / evalPdf over the samples times the radiance env[3] of a uniform environment; the light
+ * loops of 195-200 / 218-223 draw no samples; integrateScatter -> rls_sss_integrate_scatter's analytic scene. */
+typedef struct rls_skin_integrate_out {
+    rls_rgb sheen, specular, sss;                          /* the three AOVs (src/rlSkin.cpp:249-251)            */
+    rls_rgb out;                                           /* optional: sg->out.RGB = their sum (254)            */
+    float  *sheenFresnel, *specularFresnel, *sssWeight;    /* optional: the hand-down scalars (204, 228, 238)    */
+} rls_skin_integrate_out;
+rls_status rls_skin_integrate(rls_context *ctx, int64_t n, const rls_skin_closure *c, rls_cvec3 P,
+                              const rls_sss_scene *scene, const float env[3], int spp_n, uint32_t seed,
+                              uint64_t first_index, const rls_skin_integrate_out *out);
 
 /* ------------------------------------------------------------------------------------------
  * rlUtil closures (src/rlUtil.h:21-29, src/rlUtil.cpp:3-27), batch form for parity checks:

@@ -1327,6 +1327,22 @@ void orc_batch_sss_sample_diffuse(int64_t n, orc_cv3p normal, orc_cv3p T, const 
 
 typedef struct { const orc_skin_soa *in; const orc_skin_out_soa *out; } skin_job;
 
+static void skin_load(const orc_skin_soa *in, int64_t i, orc_skin_params *p)
+{
+    p->sss_color = ldc(in->sss_color, i);
+    p->sss_weight = in->sss_weight[i];
+    p->sss_dist_multiplier = in->sss_dist_multiplier[i];
+    p->sss_scatter_dist = ld3(in->sss_scatter_dist, i);
+    p->specular_color = ldc(in->specular_color, i);
+    p->specular_weight = in->specular_weight[i];
+    p->specular_roughness = in->specular_roughness[i];
+    p->specular_ior = in->specular_ior[i];
+    p->sheen_color = ldc(in->sheen_color, i);
+    p->sheen_weight = in->sheen_weight[i];
+    p->sheen_roughness = in->sheen_roughness[i];
+    p->sheen_ior = in->sheen_ior[i];
+}
+
 static void skin_range(int64_t lo, int64_t hi, void *ctx)
 {
     skin_job *j = (skin_job *)ctx;
@@ -1334,18 +1350,7 @@ static void skin_range(int64_t lo, int64_t hi, void *ctx)
     const orc_skin_out_soa *o = j->out;
     for (int64_t i = lo; i < hi; i++) {
         orc_skin_params p;
-        p.sss_color = ldc(in->sss_color, i);
-        p.sss_weight = in->sss_weight[i];
-        p.sss_dist_multiplier = in->sss_dist_multiplier[i];
-        p.sss_scatter_dist = ld3(in->sss_scatter_dist, i);
-        p.specular_color = ldc(in->specular_color, i);
-        p.specular_weight = in->specular_weight[i];
-        p.specular_roughness = in->specular_roughness[i];
-        p.specular_ior = in->specular_ior[i];
-        p.sheen_color = ldc(in->sheen_color, i);
-        p.sheen_weight = in->sheen_weight[i];
-        p.sheen_roughness = in->sheen_roughness[i];
-        p.sheen_ior = in->sheen_ior[i];
+        skin_load(in, i, &p);
         float xi[6];
         for (int k = 0; k < 6; k++) xi[k] = in->xi[k][i];
         orc_skin_out r;
@@ -1542,58 +1547,68 @@ typedef struct {
     orc_v3p result; float *depth;
 } scatter_job;
 
+/* the probe-ray loop of integrateScatter (src/rlSss.h:224-270) for one shading point: sums of irradiance / pdf
+ * (before albedo and 1 / count) and of the shaded-hit count; samples from dimension pair `dim_pair` */
+void orc_sss_scatter_point(const orc_sss *Sp, orc_v3 Po, const orc_scene *sc, int spp, uint32_t seed, uint64_t index,
+                           uint32_t dim_pair, float acc[3], float *depth_sum)
+{
+    const orc_sss S = *Sp;
+    const orc_v3 Ldir = arr3(sc->light_dir), No = S.axisN;
+    float accR = 0.0f, accG = 0.0f, accB = 0.0f, accD = 0.0f;
+    for (int s = 0; s < spp; s++) {
+        float rx, ry;
+        orc_sample_02(seed, index, dim_pair, (uint32_t)s, &rx, &ry);
+        orc_v3 off, dir; float maxdist;
+        (void)orc_sss_get_probe_ray(&S, rx, ry, &off, &dir, &maxdist);          /* :228 */
+        float t[2]; orc_v3 hp[2], hn[2];
+        int nh = orc_scene_trace(sc, v3add(Po, off), dir, maxdist, t, hp, hn);  /* AiTraceProbe, :293 */
+        /* probeSampleArray, :245 */
+        orc_rgb irr[2]; orc_v3 disp[2], sN[2];
+        int depth = 0;
+        orc_v3 prev = Po;
+        for (int k = 0; k < nh; k++) {
+            if (!(v3length(v3sub(prev, hp[k])) > AI_EPSILON)) continue;         /* :316-317 */
+            prev = hp[k];
+            /* shadeProbeSample, :379-420 */
+            orc_v3 d = v3sub(hp[k], Po);
+            float r = v3length(d);
+            if (r > S.profile.maxRadius) continue;
+            float fade = 1.0f;
+            if (sc->use_cavity_fade) fade = orc_sss_cavity_fade(d, r, hn[k], No);
+            if (fade > AI_EPSILON) {
+                /* evalLightSample, :439-454: Lambert (Oren-Nayar, sigma 0) under one distant light */
+                float w = AI_ONEOVERPI * MAXf(0.0f, v3dot(hn[k], Ldir));
+                if (sc->has_gate &&
+                    !(v3dot(v3sub(hp[k], arr3(sc->gate_point)), arr3(sc->gate_normal)) > 0.0f)) w = 0.0f;
+                orc_rgb prof = orc_nd_eval_profile(&S.profile, r);
+                irr[depth] = rgb(sc->light_color[0] * w * prof.r * fade, sc->light_color[1] * w * prof.g * fade,
+                                 sc->light_color[2] * w * prof.b * fade);
+                disp[depth] = d; sN[depth] = hn[k];
+                depth++;
+            }
+        }
+        for (int k = 0; k < depth; k++) {                                        /* :246-268 */
+            if (irr[k].r == 0.0f && irr[k].g == 0.0f && irr[k].b == 0.0f) continue;
+            float pdf = orc_sss_mis_pdf(&S, disp[k], sN[k], sc->literal_matrix);
+            accR += irr[k].r / pdf; accG += irr[k].g / pdf; accB += irr[k].b / pdf;
+        }
+        accD += (float)depth;
+    }
+    acc[0] = accR; acc[1] = accG; acc[2] = accB;
+    *depth_sum = accD;
+}
+
 static void scatter_range(int64_t lo, int64_t hi, void *ctx)
 {
     scatter_job *j = (scatter_job *)ctx;
-    const orc_scene *sc = j->sc;
-    const orc_v3 Ldir = arr3(sc->light_dir);
     for (int64_t i = lo; i < hi; i++) {
         orc_rgb albedo = j->in->sss_color.x ? ldc(j->in->sss_color, i) : RGB_WHITE;
         orc_sss S;
         orc_sss_init(&S, ld3(j->in->N, i), ld3(j->in->T, i), j->has_dPdu, albedo, sss_dist(j->in, i));
-        const orc_v3 Po = ld3(j->P, i), No = S.axisN;
-        float accR = 0.0f, accG = 0.0f, accB = 0.0f, accD = 0.0f;
-        for (int s = 0; s < j->spp; s++) {
-            float rx, ry;
-            orc_sample_02(j->seed, j->first + (uint64_t)i, 0, (uint32_t)s, &rx, &ry);
-            orc_v3 off, dir; float maxdist;
-            (void)orc_sss_get_probe_ray(&S, rx, ry, &off, &dir, &maxdist);          /* :228 */
-            float t[2]; orc_v3 hp[2], hn[2];
-            int nh = orc_scene_trace(sc, v3add(Po, off), dir, maxdist, t, hp, hn);  /* AiTraceProbe, :293 */
-            /* probeSampleArray, :245 */
-            orc_rgb irr[2]; orc_v3 disp[2], sN[2];
-            int depth = 0;
-            orc_v3 prev = Po;
-            for (int k = 0; k < nh; k++) {
-                if (!(v3length(v3sub(prev, hp[k])) > AI_EPSILON)) continue;         /* :316-317 */
-                prev = hp[k];
-                /* shadeProbeSample, :379-420 */
-                orc_v3 d = v3sub(hp[k], Po);
-                float r = v3length(d);
-                if (r > S.profile.maxRadius) continue;
-                float fade = 1.0f;
-                if (sc->use_cavity_fade) fade = orc_sss_cavity_fade(d, r, hn[k], No);
-                if (fade > AI_EPSILON) {
-                    /* evalLightSample, :439-454: Lambert (Oren-Nayar, sigma 0) under one distant light */
-                    float w = AI_ONEOVERPI * MAXf(0.0f, v3dot(hn[k], Ldir));
-                    if (sc->has_gate &&
-                        !(v3dot(v3sub(hp[k], arr3(sc->gate_point)), arr3(sc->gate_normal)) > 0.0f)) w = 0.0f;
-                    orc_rgb prof = orc_nd_eval_profile(&S.profile, r);
-                    irr[depth] = rgb(sc->light_color[0] * w * prof.r * fade, sc->light_color[1] * w * prof.g * fade,
-                                     sc->light_color[2] * w * prof.b * fade);
-                    disp[depth] = d; sN[depth] = hn[k];
-                    depth++;
-                }
-            }
-            for (int k = 0; k < depth; k++) {                                        /* :246-268 */
-                if (irr[k].r == 0.0f && irr[k].g == 0.0f && irr[k].b == 0.0f) continue;
-                float pdf = orc_sss_mis_pdf(&S, disp[k], sN[k], sc->literal_matrix);
-                accR += irr[k].r / pdf; accG += irr[k].g / pdf; accB += irr[k].b / pdf;
-            }
-            accD += (float)depth;
-        }
+        float acc[3], accD;
+        orc_sss_scatter_point(&S, ld3(j->P, i), j->sc, j->spp, j->seed, j->first + (uint64_t)i, 0, acc, &accD);
         float inv = 1.0f / (float)j->spp;                                            /* AiSamplerGetSampleInvCount */
-        stc(j->result, i, rgb(albedo.r * accR * inv, albedo.g * accG * inv, albedo.b * accB * inv));
+        stc(j->result, i, rgb(albedo.r * acc[0] * inv, albedo.g * acc[1] * inv, albedo.b * acc[2] * inv));
         if (j->depth) j->depth[i] = accD * inv;
     }
 }
@@ -1604,6 +1619,164 @@ void orc_batch_sss_integrate_scatter(int64_t n, const orc_sss_soa *in, int has_d
 {
     scatter_job j = { in, has_dPdu, P, sc, spp_n * spp_n, seed, first_index, result, mean_depth };
     parallel_for(n, nthreads, scatter_range, &j);
+}
+
+/* ============================ rlSkin over n^2 samples per layer ========================== */
+
+/* integrateGlossy (src/rlGgx.h:172-179) with the stand-in for the closed AiBRDFIntegrate: the mean of
+ * evalBrdf / evalPdf over the samples under a uniform environment of radiance env.  Every evalSample call adds
+ * its Fresnel term to the closure (src/rlGgx.h:103). */
+static orc_rgb ggx_integrate_glossy(orc_ggx *g, const float env[3], int spp, uint32_t seed, uint64_t index, uint32_t dim_pair)
+{
+    if (rgb_is_small(g->specColor)) {                                       /* src/rlGgx.h:174-176 */
+        return RGB_BLACK;
+    }
+    float aR = 0.0f, aG = 0.0f, aB = 0.0f;
+    for (int s = 0; s < spp; s++) {
+        float rx, ry;
+        orc_sample_02(seed, index, dim_pair, (uint32_t)s, &rx, &ry);
+        orc_v3 L = orc_ggx_eval_sample(g, rx, ry);
+        orc_rgb f = orc_ggx_eval_brdf(g, L);
+        float pdf = orc_ggx_eval_pdf(g, L);
+        aR += f.r / pdf; aG += f.g / pdf; aB += f.b / pdf;
+    }
+    float inv = 1.0f / (float)spp;
+    return rgb(aR * inv * env[0], aG * inv * env[1], aB * inv * env[2]);
+}
+
+/* shader_evaluate, src/rlSkin.cpp:174-254 */
+void orc_skin_integrate(const orc_skin_params *p, orc_v3 wo, orc_v3 Nf, orc_v3 T, orc_v3 P, const orc_scene *sc,
+                        const float env[3], int spp, uint32_t seed, uint64_t index, orc_skin_int_out *o)
+{
+    float sheenFresnel = 0.0f;
+    orc_rgb sheen = RGB_BLACK;
+    float specularFresnel = 0.0f;
+    orc_rgb specular = RGB_BLACK;
+
+    if (p->sheen_weight > AI_EPSILON) {                                      /* :191 */
+        orc_ggx g;
+        orc_ggx_init(&g, wo, Nf, T, 0, p->sheen_color, p->sheen_ior, p->sheen_roughness, 0.0f);
+        orc_rgb c = ggx_integrate_glossy(&g, env, spp, seed, index, 0);      /* :201-202 */
+        sheen = rgb(sheen.r + c.r, sheen.g + c.g, sheen.b + c.b);
+        sheenFresnel = orc_ggx_avg_reflect_weight(&g) * p->sheen_weight;     /* :204 */
+    }
+    sheen = rgb(sheen.r * p->sheen_weight, sheen.g * p->sheen_weight, sheen.b * p->sheen_weight);   /* :207 */
+
+    if (p->specular_weight > AI_EPSILON) {                                   /* :214 */
+        orc_ggx g;
+        orc_ggx_init(&g, wo, Nf, T, 0, p->specular_color, p->specular_ior, p->specular_roughness, 0.0f);
+        orc_rgb c = ggx_integrate_glossy(&g, env, spp, seed, index, 1);      /* :224-226 */
+        specular = rgb(specular.r + c.r, specular.g + c.g, specular.b + c.b);
+        specularFresnel = orc_ggx_avg_reflect_weight(&g) * p->specular_weight;   /* :228 */
+    }
+    {
+        float k = p->specular_weight * (1.0f - sheenFresnel);                /* :231 */
+        specular = rgb(specular.r * k, specular.g * k, specular.b * k);
+    }
+
+    orc_v3 scatterDist = v3scale(p->sss_scatter_dist, p->sss_dist_multiplier);   /* :236 */
+    float sssWeight = p->sss_weight;
+    sssWeight *= 1.0f - specularFresnel * (1.0f - sheenFresnel);             /* :238 */
+
+    orc_sss S;
+    orc_sss_init(&S, Nf, T, 1, p->sss_color, scatterDist);                   /* :241 */
+    orc_rgb sss = RGB_BLACK;
+    if (!(sssWeight < AI_EPSILON)) {                                         /* :244-246 */
+        float acc[3], depth;
+        orc_sss_scatter_point(&S, P, sc, spp, seed, index, 2, acc, &depth);
+        float inv = 1.0f / (float)spp;
+        sss = rgb(p->sss_color.r * acc[0] * inv * sssWeight, p->sss_color.g * acc[1] * inv * sssWeight,
+                  p->sss_color.b * acc[2] * inv * sssWeight);
+    }
+    o->sheen = sheen; o->specular = specular; o->sss = sss;
+    o->out = rgb(sheen.r + specular.r + sss.r, sheen.g + specular.g + sss.g, sheen.b + specular.b + sss.b);   /* :254 */
+    o->sheenFresnel = sheenFresnel; o->specularFresnel = specularFresnel; o->sssWeight = sssWeight;
+}
+
+typedef struct {
+    const orc_skin_soa *in; orc_cv3p P; const orc_scene *sc; const float *env; int spp; uint32_t seed; uint64_t first;
+    const orc_skin_int_out_soa *out;
+} skin_int_job;
+
+static void skin_int_range(int64_t lo, int64_t hi, void *ctx)
+{
+    skin_int_job *j = (skin_int_job *)ctx;
+    for (int64_t i = lo; i < hi; i++) {
+        orc_skin_params p;
+        skin_load(j->in, i, &p);
+        orc_skin_int_out o;
+        orc_skin_integrate(&p, ld3(j->in->wo, i), ld3(j->in->N, i), ld3(j->in->T, i), ld3(j->P, i), j->sc, j->env, j->spp,
+                           j->seed, j->first + (uint64_t)i, &o);
+        stc(j->out->sheen, i, o.sheen); stc(j->out->specular, i, o.specular); stc(j->out->sss, i, o.sss);
+        stc(j->out->out, i, o.out);
+        j->out->sheenFresnel[i] = o.sheenFresnel; j->out->specularFresnel[i] = o.specularFresnel;
+        j->out->sssWeight[i] = o.sssWeight;
+    }
+}
+
+void orc_batch_skin_integrate(int64_t n, const orc_skin_soa *in, orc_cv3p P, const orc_scene *sc, const float env[3],
+                              int spp_n, uint32_t seed, uint64_t first_index, const orc_skin_int_out_soa *out, int nthreads)
+{
+    skin_int_job j = { in, P, sc, env, spp_n * spp_n, seed, first_index, out };
+    parallel_for(n, nthreads, skin_int_range, &j);
+}
+
+/* ================================ rlGgx integrateRefract =============================== */
+
+/* src/rlGgx.h:205-245 with a uniform environment of radiance env standing in for AiTrace / AiTraceBackground */
+orc_rgb orc_ggx_integrate_refract(const orc_ggx *g, int traced, const float env[3], int spp, uint32_t seed,
+                                  uint64_t index, float *tir_fraction)
+{
+    float acc = 0.0f, tir = 0.0f;
+    if (!traced) {                                                           /* :213-222 */
+        orc_v3 i = g->viewDir, n = g->axisN;
+        float eta = g->iorIn / g->iorOut;
+        float c = v3dot(i, n);
+        float cosThetaTSqr = 1.0f - eta * eta * (1.0f - c * c);
+        if (!(cosThetaTSqr < 0.0f)) {
+            float sign = (float)SGNf(v3dot(i, g->axisN));
+            float k = eta * c - sign * sqrtf(cosThetaTSqr);
+            orc_v3 dir = v3sub(v3scale(n, k), v3scale(i, eta));
+            acc = SQRf(g->iorOut / g->iorIn) * ABSf(v3dot(n, dir));          /* :216 */
+        } else {
+            tir = 1.0f;                                                      /* :221 */
+        }
+    } else {
+        for (int s = 0; s < spp; s++) {                                      /* :228-242 */
+            float rx, ry;
+            orc_sample_02(seed, index, 0, (uint32_t)s, &rx, &ry);
+            orc_v3 dir; float w;
+            if (!orc_ggx_refract_sample(g, rx, ry, &dir, &w)) tir += 1.0f;
+            acc += w;
+        }
+        float inv = 1.0f / (float)spp;                                       /* :244 */
+        acc *= inv; tir *= inv;
+    }
+    if (tir_fraction) *tir_fraction = tir;
+    return rgb(env[0] * acc, env[1] * acc, env[2] * acc);
+}
+
+typedef struct {
+    const orc_ggx_soa *in; int traced; const float *env; int spp; uint32_t seed; uint64_t first; orc_v3p result; float *tir;
+} refr_int_job;
+
+static void refr_int_range(int64_t lo, int64_t hi, void *ctx)
+{
+    refr_int_job *j = (refr_int_job *)ctx;
+    for (int64_t i = lo; i < hi; i++) {
+        orc_ggx g;
+        ggx_load(j->in, i, &g);
+        float tir;
+        stc(j->result, i, orc_ggx_integrate_refract(&g, j->traced, j->env, j->spp, j->seed, j->first + (uint64_t)i, &tir));
+        if (j->tir) j->tir[i] = tir;
+    }
+}
+
+void orc_batch_ggx_integrate_refract(int64_t n, const orc_ggx_soa *in, int traced, const float env[3], int spp_n,
+                                     uint32_t seed, uint64_t first_index, orc_v3p result, float *tir_fraction, int nthreads)
+{
+    refr_int_job j = { in, traced, env, spp_n * spp_n, seed, first_index, result, tir_fraction };
+    parallel_for(n, nthreads, refr_int_range, &j);
 }
 
 /* ============================== rlGgx direct lighting ================================== */

@@ -314,6 +314,33 @@ void orc_batch_sss_integrate_scatter(int64_t n, const orc_sss_soa *in, int has_d
                                      const orc_scene *sc, int spp_n, uint32_t seed, uint64_t first_index,
                                      orc_v3p result, float *mean_depth, int nthreads);
 
+void orc_sss_scatter_point(const orc_sss *S, orc_v3 Po, const orc_scene *sc, int spp, uint32_t seed, uint64_t index,
+                           uint32_t dim_pair, float acc[3], float *depth_sum);
+
+/* shader_evaluate of rlSkin over spp samples per layer (src/rlSkin.cpp:174-254): integrateGlossy per GGX lobe with
+ * the Fresnel mean of getAvgReflectWeight (src/rlGgx.h:181-184) handed down, integrateScatter x sssWeight.
+ * AiBRDFIntegrate -> mean of evalBrdf / evalPdf x env (uniform environment); no light-loop samples; scene as above.
+ * Dimension pairs of the sampler: 0 sheen, 1 specular, 2 probe rays. */
+typedef struct {
+    orc_rgb sheen, specular, sss, out;
+    float sheenFresnel, specularFresnel, sssWeight;
+} orc_skin_int_out;
+void orc_skin_integrate(const orc_skin_params *p, orc_v3 wo, orc_v3 Nf, orc_v3 T, orc_v3 P, const orc_scene *sc,
+                        const float env[3], int spp, uint32_t seed, uint64_t index, orc_skin_int_out *out);
+typedef struct {
+    orc_v3p sheen, specular, sss, out;
+    float *sheenFresnel, *specularFresnel, *sssWeight;
+} orc_skin_int_out_soa;
+void orc_batch_skin_integrate(int64_t n, const orc_skin_soa *in, orc_cv3p P, const orc_scene *sc, const float env[3],
+                              int spp_n, uint32_t seed, uint64_t first_index, const orc_skin_int_out_soa *out, int nthreads);
+
+/* integrateRefract (src/rlGgx.h:205-245): traced -> the sample loop (228-244), else the single refraction about
+ * the shading normal (213-222); radiance of a uniform environment env */
+orc_rgb orc_ggx_integrate_refract(const orc_ggx *g, int traced, const float env[3], int spp, uint32_t seed,
+                                  uint64_t index, float *tir_fraction);
+void orc_batch_ggx_integrate_refract(int64_t n, const orc_ggx_soa *in, int traced, const float env[3], int spp_n,
+                                     uint32_t seed, uint64_t first_index, orc_v3p result, float *tir_fraction, int nthreads);
+
 /* Direct lighting of the rlGgx node (shader_evaluate's light loop, src/rlGgx.cpp:274-299): per light
  * sample `diffuse += AiEvaluateLightSample(sg, diffData, AiOrenNayarMIS*)` and `specular +=
  * sampler.evalLightSample(sg)` (= AiEvaluateLightSample over the GGX triple, src/rlGgx.h:167-170),

@@ -359,6 +359,21 @@ class GgxSampler:
         return s, a
 
 
+    def integrateRefract(self, spp_n: int, seed: int, traced: bool = True, env=(1.0, 1.0, 1.0), want_tir: bool = False,
+                         first_index: int = 0):
+        """integrateRefract (src/rlGgx.h:205-245) under a uniform environment of radiance ``env`` -> result [3,n]
+        (and the fraction of totally internally reflected samples).  traced=False: the single refraction about the
+        shading normal of lines 213-222."""
+        n, ctx = self.n, self.ctx
+        result = ctx.empty(3, n)
+        tir = ctx.empty(n) if want_tir else None
+        e = (C.c_float * 3)(*[float(v) for v in env])
+        check(ctx.lib.rls_ggx_integrate_refract(ctx.handle, n, C.byref(self.c), 1 if traced else 0, e, int(spp_n),
+                                                int(seed) & 0xFFFFFFFF, int(first_index), rgb(result, n, "result"),
+                                                plane(tir, n, "tir_fraction") if want_tir else None))
+        return (result, tir) if want_tir else result
+
+
 # ================================================================================================
 class DisneySampler:
     """Batched ``DisneySampler`` (src/rlDisney.cpp:105-602); parameter names from
@@ -722,6 +737,27 @@ class SkinShader:
             setattr(o, k, plane(out[k], n, k))
         xs = (C.c_void_p * 6)(*[xi[k].data_ptr() for k in range(6)])
         check(ctx.lib.rls_skin_sample_eval_pdf(ctx.handle, n, C.byref(self.c), xs, C.byref(o)))
+        return out
+
+
+    def integrate(self, P, scene: "capi.SssScene", spp_n: int, seed: int, env=(1.0, 1.0, 1.0), out=None,
+                  first_index: int = 0) -> dict:
+        """shader_evaluate over spp_n^2 samples per layer (src/rlSkin.cpp:174-254; rls_skin_integrate) -> dict(sheen,
+        specular, sss, out [3,n]; sheenFresnel, specularFresnel, sssWeight [n])."""
+        n, ctx = self.n, self.ctx
+        if out is None:
+            out = {k: ctx.empty(3, n) for k in ("sheen", "specular", "sss", "out")}
+            out.update({k: ctx.empty(n) for k in ("sheenFresnel", "specularFresnel", "sssWeight")})
+        o = capi.SkinIntegrateOut()
+        for k in ("sheen", "specular", "sss", "out"):
+            if k in out:
+                setattr(o, k, rgb(out[k], n, k))
+        for k in ("sheenFresnel", "specularFresnel", "sssWeight"):
+            if k in out:
+                setattr(o, k, plane(out[k], n, k))
+        e = (C.c_float * 3)(*[float(v) for v in env])
+        check(ctx.lib.rls_skin_integrate(ctx.handle, n, C.byref(self.c), cvec3(P, n, "P"), C.byref(scene), e, int(spp_n),
+                                         int(seed) & 0xFFFFFFFF, int(first_index), C.byref(o)))
         return out
 
 

@@ -61,6 +61,31 @@ __device__ __forceinline__ float group_sum(float v)
     return v;
 }
 
+// integrateGlossy's sample loop over one closure (src/rlGgx.h:172-179 -> AiBRDFIntegrate over the triple): lane `sub`
+// of a G-lane group takes samples sub, sub + G, ...; sums of f/pdf and of the Fresnel side effect of evalSample
+// (src/rlGgx.h:103), reduced over the group
+template <int G>
+__device__ __forceinline__ void ggx_glossy_loop(const Ggx &g, const VndfView &w, const uint32_t (*tab)[kMaxSpp], int spp,
+                                                int sub, uint32_t sx, uint32_t sy,
+                                                float &accR, float &accG, float &accB, float &accF)
+{
+    accR = 0.0f; accG = 0.0f; accB = 0.0f; accF = 0.0f;
+    for (int s = sub; s < spp; s += G) {
+        float rx = bits_u01(tab[0][s] ^ sx);
+        float ry = bits_u01(tab[1][s] ^ sy);
+        V3 M = vndf_microfacet(w, g.fr, rx, ry);
+        V3 L = reflect_direction(g.view, M);
+        accF += ggx_fresnel(g, L, M);                   // mReflectWeight, src/rlGgx.h:103
+        float fr, fg, fb, pdf;
+        ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pdf);
+        accR += fr / pdf; accG += fg / pdf; accB += fb / pdf;
+    }
+    if (G > 1) {
+        accR = group_sum<G>(accR); accG = group_sum<G>(accG);
+        accB = group_sum<G>(accB); accF = group_sum<G>(accF);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 using rlsh::GgxIntIO;
 using rlsh::DisneyIntIO;
@@ -90,21 +115,8 @@ __global__ __launch_bounds__(rlsh::kBlock) void ggx_integrate_kernel(GgxIntIO a)
         const uint32_t sx = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream);
         const uint32_t sy = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream + 1);
 
-        float accR = 0.0f, accG = 0.0f, accB = 0.0f, accF = 0.0f;
-        for (int s = sub; s < a.spp; s += G) {
-            float rx = bits_u01(tab[0][s] ^ sx);
-            float ry = bits_u01(tab[1][s] ^ sy);
-            V3 M = vndf_microfacet(w, g.fr, rx, ry);
-            V3 L = reflect_direction(g.view, M);
-            accF += ggx_fresnel(g, L, M);                   // mReflectWeight, src/rlGgx.h:103
-            float fr, fg, fb, pdf;
-            ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pdf);
-            accR += fr / pdf; accG += fg / pdf; accB += fb / pdf;
-        }
-        if (G > 1) {
-            accR = group_sum<G>(accR); accG = group_sum<G>(accG);
-            accB = group_sum<G>(accB); accF = group_sum<G>(accF);
-        }
+        float accR, accG, accB, accF;
+        ggx_glossy_loop<G>(g, w, tab, a.spp, sub, sx, sy, accR, accG, accB, accF);
         if (live && sub == 0) {
             strgb(a.sum, i, accR, accG, accB);
             // getAvgReflectWeight, src/rlGgx.h:181-184
@@ -202,16 +214,103 @@ __device__ __forceinline__ NdProfile scatter_profile(const rls_sss_closure &c, i
                    ldp(c.sss_scatter_dist[2], i) * m);
 }
 
+// the analytic scene in registers
+struct SceneRegs {
+    bool sphere, has_gate, cavity, literal;
+    V3 planeN, planeP, center, Ldir, gateP, gateN;
+    float radius, lc[3];
+};
+__device__ __forceinline__ SceneRegs scene_regs(const rls_sss_scene &sc)
+{
+    SceneRegs r;
+    r.sphere = sc.geometry == RLS_SCENE_SPHERE;
+    r.has_gate = sc.has_gate != 0; r.cavity = sc.use_cavity_fade != 0; r.literal = sc.literal_matrix != 0;
+    r.planeN = arr3(sc.plane_normal); r.planeP = arr3(sc.plane_point); r.center = arr3(sc.sphere_center);
+    r.Ldir = arr3(sc.light_dir); r.gateP = arr3(sc.gate_point); r.gateN = arr3(sc.gate_normal);
+    r.radius = sc.sphere_radius;
+    r.lc[0] = sc.light_color[0]; r.lc[1] = sc.light_color[1]; r.lc[2] = sc.light_color[2];
+    return r;
+}
+
+// the probe-ray loop of integrateScatter (src/rlSss.h:224-270) for one shading point: sums of irradiance / pdf and
+// of the shaded-hit count over the samples sub, sub + G, ..., reduced over the G-lane group
+template <int G>
+__device__ __forceinline__ void scatter_loop(const NdProfile &p, const Frame &fr, V3 Po, const SceneRegs &sc,
+                                             const uint32_t (*tab)[kMaxSpp], int spp, int sub, uint32_t sx, uint32_t sy,
+                                             float &accR, float &accG, float &accB, float &accD)
+{
+    accR = 0.0f; accG = 0.0f; accB = 0.0f; accD = 0.0f;
+    for (int s = sub; s < spp; s += G) {
+        float rx = bits_u01(tab[0][s] ^ sx);
+        float ry = bits_u01(tab[1][s] ^ sy);
+        V3 off, dir;
+        float maxdist;
+        sss_probe_ray(p, fr, rx, ry, off, dir, maxdist);                     // :228
+        const V3 O = Po + off;
+        // AiTraceProbe (:293): the roots of the ray against the plane / sphere, ascending
+        float cand[2];
+        bool has[2] = { false, false };
+        if (sc.sphere) {
+            V3 oc = O - sc.center;
+            float qa = dot(dir, dir);
+            float qb = dot(oc, dir);
+            float qc = dot(oc, oc) - sc.radius * sc.radius;
+            float disc = qb * qb - qa * qc;
+            if (!(disc < 0.0f) && qa != 0.0f) {
+                float sq = R_SQRT(disc);
+                cand[0] = R_DIV(-qb - sq, qa);
+                cand[1] = R_DIV(-qb + sq, qa);
+                has[0] = has[1] = true;
+            }
+        } else {
+            float denom = dot(sc.planeN, dir);
+            if (denom != 0.0f) {
+                cand[0] = R_DIV(dot(sc.planeN, sc.planeP - O), denom);
+                has[0] = true;
+            }
+        }
+        V3 prev = Po;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            if (!has[k] || !(cand[k] > 0.0f && cand[k] <= maxdist)) continue;
+            const V3 hp = O + dir * cand[k];
+            const V3 hn = sc.sphere ? normalize(hp - sc.center) : sc.planeN;
+            if (!(length(prev - hp) > kEps)) continue;                       // :316-317
+            prev = hp;
+            // shadeProbeSample, :379-420
+            const V3 d = hp - Po;
+            const float r = length(d);
+            if (r > p.maxR) continue;
+            float fade = 1.0f;
+            if (sc.cavity) fade = sss_cavity_fade(d, r, hn, fr.N);
+            if (!(fade > kEps)) continue;
+            accD += 1.0f;
+            // evalLightSample, :439-454
+            float w = kInvPi * maxf(0.0f, dot(hn, sc.Ldir));
+            if (sc.has_gate && !(dot(hp - sc.gateP, sc.gateN) > 0.0f)) w = 0.0f;
+            float pr, pg, pb;
+            nd_profile(p, r, pr, pg, pb);
+            const float iR = sc.lc[0] * w * pr * fade;
+            const float iG = sc.lc[1] * w * pg * fade;
+            const float iB = sc.lc[2] * w * pb * fade;
+            if (iR == 0.0f && iG == 0.0f && iB == 0.0f) continue;            // :249
+            const float pdf = sss_mis_pdf(p, fr, d, hn, sc.literal);
+            accR += R_DIV(iR, pdf); accG += R_DIV(iG, pdf); accB += R_DIV(iB, pdf);
+        }
+    }
+    if (G > 1) {
+        accR = group_sum<G>(accR); accG = group_sum<G>(accG);
+        accB = group_sum<G>(accB); accD = group_sum<G>(accD);
+    }
+}
+
 template <int G, int FAST_MATH = RLS_FAST>
 __global__ __launch_bounds__(rlsh::kBlock) void sss_scatter_kernel(ScatterIO a)
 {
     __shared__ uint32_t tab[2][kMaxSpp];
     stage_libm_tables();
     stage_table(tab, a.spp);
-    const rls_sss_scene &sc = a.scene;
-    const bool sphere = sc.geometry == RLS_SCENE_SPHERE;
-    const V3 planeN = arr3(sc.plane_normal), planeP = arr3(sc.plane_point), center = arr3(sc.sphere_center);
-    const V3 Ldir = arr3(sc.light_dir), gateP = arr3(sc.gate_point), gateN = arr3(sc.gate_normal);
+    const SceneRegs sc = scene_regs(a.scene);
     const int sub = threadIdx.x % G;
     const int64_t groups_per_block = rlsh::kBlock / G;
     const int64_t stride = (int64_t)gridDim.x * groups_per_block;
@@ -229,73 +328,164 @@ __global__ __launch_bounds__(rlsh::kBlock) void sss_scatter_kernel(ScatterIO a)
         const uint32_t sx = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream);
         const uint32_t sy = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream + 1);
 
-        float accR = 0.0f, accG = 0.0f, accB = 0.0f, accD = 0.0f;
-        for (int s = sub; s < a.spp; s += G) {
-            float rx = bits_u01(tab[0][s] ^ sx);
-            float ry = bits_u01(tab[1][s] ^ sy);
-            V3 off, dir;
-            float maxdist;
-            sss_probe_ray(p, fr, rx, ry, off, dir, maxdist);                     // :228
-            const V3 O = Po + off;
-            // AiTraceProbe (:293): the roots of the ray against the plane / sphere, ascending
-            float cand[2];
-            bool has[2] = { false, false };
-            if (sphere) {
-                V3 oc = O - center;
-                float qa = dot(dir, dir);
-                float qb = dot(oc, dir);
-                float qc = dot(oc, oc) - sc.sphere_radius * sc.sphere_radius;
-                float disc = qb * qb - qa * qc;
-                if (!(disc < 0.0f) && qa != 0.0f) {
-                    float sq = R_SQRT(disc);
-                    cand[0] = R_DIV(-qb - sq, qa);
-                    cand[1] = R_DIV(-qb + sq, qa);
-                    has[0] = has[1] = true;
-                }
-            } else {
-                float denom = dot(planeN, dir);
-                if (denom != 0.0f) {
-                    cand[0] = R_DIV(dot(planeN, planeP - O), denom);
-                    has[0] = true;
-                }
-            }
-            V3 prev = Po;
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                if (!has[k] || !(cand[k] > 0.0f && cand[k] <= maxdist)) continue;
-                const V3 hp = O + dir * cand[k];
-                const V3 hn = sphere ? normalize(hp - center) : planeN;
-                if (!(length(prev - hp) > kEps)) continue;                       // :316-317
-                prev = hp;
-                // shadeProbeSample, :379-420
-                const V3 d = hp - Po;
-                const float r = length(d);
-                if (r > p.maxR) continue;
-                float fade = 1.0f;
-                if (sc.use_cavity_fade) fade = sss_cavity_fade(d, r, hn, fr.N);
-                if (!(fade > kEps)) continue;
-                accD += 1.0f;
-                // evalLightSample, :439-454
-                float w = kInvPi * maxf(0.0f, dot(hn, Ldir));
-                if (sc.has_gate && !(dot(hp - gateP, gateN) > 0.0f)) w = 0.0f;
-                float pr, pg, pb;
-                nd_profile(p, r, pr, pg, pb);
-                const float iR = sc.light_color[0] * w * pr * fade;
-                const float iG = sc.light_color[1] * w * pg * fade;
-                const float iB = sc.light_color[2] * w * pb * fade;
-                if (iR == 0.0f && iG == 0.0f && iB == 0.0f) continue;            // :249
-                const float pdf = sss_mis_pdf(p, fr, d, hn, sc.literal_matrix != 0);
-                accR += R_DIV(iR, pdf); accG += R_DIV(iG, pdf); accB += R_DIV(iB, pdf);
-            }
-        }
-        if (G > 1) {
-            accR = group_sum<G>(accR); accG = group_sum<G>(accG);
-            accB = group_sum<G>(accB); accD = group_sum<G>(accD);
-        }
+        float accR, accG, accB, accD;
+        scatter_loop<G>(p, fr, Po, sc, tab, a.spp, sub, sx, sy, accR, accG, accB, accD);
         if (live && sub == 0) {
             const float inv = 1.0f / (float)a.spp;                               // AiSamplerGetSampleInvCount
             strgb(a.result, i, br * accR * inv, bg * accG * inv, bb * accB * inv);
             if (a.depth) stg(a.depth, i, accD * inv);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// rlSkin's shader_evaluate over spp_n^2 samples per layer (src/rlSkin.cpp:174-246): per GGX lobe integrateGlossy's
+// sample loop, whose evalSample calls build the mean Fresnel that getAvgReflectWeight (src/rlGgx.h:181-184) hands to
+// the next layer -- sheenFresnel = avg * sheen_weight (:204), specular *= specular_weight * (1 - sheenFresnel) (:231),
+// specularFresnel (:228), sssWeight *= 1 - specularFresnel * (1 - sheenFresnel) (:238) -- then integrateScatter *
+// sssWeight (:244-246).  AiBRDFIntegrate is closed: its stand-in is the mean of eval/pdf over the samples under a
+// uniform environment of radiance `env` (parity unpinned); the light loops of :195-200,218-223 contribute no samples.
+using rlsh::SkinIntIO;
+
+template <int G, int FAST_MATH = RLS_FAST>
+__global__ __launch_bounds__(rlsh::kBlock) void skin_integrate_kernel(SkinIntIO a)
+{
+    __shared__ uint32_t tab[2][kMaxSpp];
+    stage_libm_tables();
+    stage_table(tab, a.spp);
+    const SceneRegs sc = scene_regs(a.scene);
+    const int sub = threadIdx.x % G;
+    const int64_t groups_per_block = rlsh::kBlock / G;
+    const int64_t stride = (int64_t)gridDim.x * groups_per_block;
+    const int64_t rounds = (a.n + stride - 1) / stride;
+    const float inv = 1.0f / (float)a.spp;
+    int64_t i = (int64_t)blockIdx.x * groups_per_block + threadIdx.x / G;
+    for (int64_t it = 0; it < rounds; it++, i += stride) {
+        const bool live = i < a.n;
+        const int64_t ii = live ? i : a.n - 1;
+        const rls_skin_closure &c = a.c;
+        const V3 wo = ld3(c.wo, ii), N = ld3(c.N, ii), T = ld3(c.T, ii);
+        uint32_t scr[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) scr[k] = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream + k);
+        Frame gfr;
+        gfr.N = N; gfr.U = T; gfr.V = cross(N, T);
+        const V3 local = vndf_local(wo, gfr);       // shared by the two lobes (same frame, same view)
+
+        float sheenFresnel = 0.0f, specularFresnel = 0.0f;
+        float shR = 0.0f, shG = 0.0f, shB = 0.0f, spR = 0.0f, spG = 0.0f, spB = 0.0f;
+        const float sheenWeight = ldp(c.sheen_weight, ii);
+        // the group takes the branch together: the weights are per point, the G lanes of a group share the point
+        if (sheenWeight > kEps) {                                                     // :191
+            float cr, cg, cb;
+            ldrgb(c.sheen_color, ii, cr, cg, cb);
+            Ggx g = ggx_make(wo, N, T, false, cr, cg, cb, ldp(c.sheen_ior, ii), ldp(c.sheen_roughness, ii), 0.0f);
+            VndfView w = vndf_view_from(local, g.ax, g.ay);
+            float aF;
+            ggx_glossy_loop<G>(g, w, tab, a.spp, sub, scr[0], scr[1], shR, shG, shB, aF);
+            // integrateGlossy returns black for a small colour without sampling (src/rlGgx.h:174-176): no samples,
+            // getAvgReflectWeight = 1
+            const bool small = absf(cr) < kEps && absf(cg) < kEps && absf(cb) < kEps;
+            const float avg = small ? 1.0f : aF * inv;
+            if (small) { shR = 0.0f; shG = 0.0f; shB = 0.0f; }
+            sheenFresnel = avg * sheenWeight;                                         // :204
+            shR = shR * inv * a.env[0]; shG = shG * inv * a.env[1]; shB = shB * inv * a.env[2];
+        }
+        shR *= sheenWeight; shG *= sheenWeight; shB *= sheenWeight;                   // :207
+        const float specWeight = ldp(c.specular_weight, ii);
+        if (specWeight > kEps) {                                                      // :214
+            float cr, cg, cb;
+            ldrgb(c.specular_color, ii, cr, cg, cb);
+            Ggx g = ggx_make(wo, N, T, false, cr, cg, cb, ldp(c.specular_ior, ii), ldp(c.specular_roughness, ii), 0.0f);
+            VndfView w = vndf_view_from(local, g.ax, g.ay);
+            float aF;
+            ggx_glossy_loop<G>(g, w, tab, a.spp, sub, scr[2], scr[3], spR, spG, spB, aF);
+            const bool small = absf(cr) < kEps && absf(cg) < kEps && absf(cb) < kEps;
+            const float avg = small ? 1.0f : aF * inv;
+            if (small) { spR = 0.0f; spG = 0.0f; spB = 0.0f; }
+            specularFresnel = avg * specWeight;                                       // :228
+            spR = spR * inv * a.env[0]; spG = spG * inv * a.env[1]; spB = spB * inv * a.env[2];
+        }
+        const float sw = specWeight * (1.0f - sheenFresnel);                          // :231
+        spR *= sw; spG *= sw; spB *= sw;
+
+        const float mult = ldp(c.sss_dist_multiplier, ii);                            // :235-236
+        float sssWeight = ldp(c.sss_weight, ii);
+        sssWeight *= 1.0f - specularFresnel * (1.0f - sheenFresnel);                  // :238
+        float ssR = 0.0f, ssG = 0.0f, ssB = 0.0f;
+        if (!(sssWeight < kEps)) {                                                    // :244
+            NdProfile p = nd_make(ldp(c.sss_scatter_dist[0], ii) * mult, ldp(c.sss_scatter_dist[1], ii) * mult,
+                                  ldp(c.sss_scatter_dist[2], ii) * mult);
+            Frame fr = sss_frame(N, T, true);
+            float br, bg, bb, accD;
+            ldrgb(c.sss_color, ii, br, bg, bb);
+            scatter_loop<G>(p, fr, ld3(a.P, ii), sc, tab, a.spp, sub, scr[4], scr[5], ssR, ssG, ssB, accD);
+            ssR = br * ssR * inv * sssWeight; ssG = bg * ssG * inv * sssWeight; ssB = bb * ssB * inv * sssWeight;
+        }
+        if (live && sub == 0) {
+            strgb(a.sheen, i, shR, shG, shB);
+            strgb(a.specular, i, spR, spG, spB);
+            strgb(a.sss, i, ssR, ssG, ssB);
+            if (a.out.r) strgb(a.out, i, shR + spR + ssR, shG + spG + ssG, shB + spB + ssB);   // sg->out.RGB, :254
+            if (a.sheenFresnel) stg(a.sheenFresnel, i, sheenFresnel);
+            if (a.specularFresnel) stg(a.specularFresnel, i, specularFresnel);
+            if (a.sssWeight) stg(a.sssWeight, i, sssWeight);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// integrateRefract (src/rlGgx.h:205-245).  Traced branch (228-244): per sample a microfacet normal, the refraction
+// of the view about it (the mirror direction on total internal reflection), radiance x getSampleWeight, the sum
+// x AiSamplerGetSampleInvCount.  Untraced branch (213-222): one refraction about the shading normal, radiance x
+// SQR(iorOut / iorIn) x |Nf . dir|, black on total internal reflection.  AiTrace / AiTraceBackground are closed: the
+// radiance is that of a uniform environment, `env` (parity unpinned).
+using rlsh::RefractIntIO;
+
+template <int G, int FAST_MATH = RLS_FAST>
+__global__ __launch_bounds__(rlsh::kBlock) void ggx_refract_integrate_kernel(RefractIntIO a)
+{
+    __shared__ uint32_t tab[2][kMaxSpp];
+    stage_table(tab, a.spp);
+    const int sub = threadIdx.x % G;
+    const int64_t groups_per_block = rlsh::kBlock / G;
+    const int64_t stride = (int64_t)gridDim.x * groups_per_block;
+    const int64_t rounds = (a.n + stride - 1) / stride;
+    int64_t i = (int64_t)blockIdx.x * groups_per_block + threadIdx.x / G;
+    for (int64_t it = 0; it < rounds; it++, i += stride) {
+        const bool live = i < a.n;
+        const int64_t ii = live ? i : a.n - 1;
+        const rls_ggx_closure &c = a.c;
+        V3 wo = ld3(c.wo, ii), N = ld3(c.N, ii), T = ld3(c.T, ii);
+        float kr, kg, kb;
+        ldrgb(c.KsColor, ii, kr, kg, kb);
+        bool exiting = c.exiting ? (c.exiting[ii] != 0) : false;
+        Ggx g = ggx_make(wo, N, T, exiting, kr, kg, kb, ldp(c.ior, ii), ldp(c.specularRoughness, ii),
+                         ldp(c.anisotropic, ii));
+        float acc = 0.0f, tir = 0.0f;
+        if (a.traced) {
+            VndfView w = vndf_view(g.view, g.fr, g.ax, g.ay);
+            const uint32_t sx = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream);
+            const uint32_t sy = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream + 1);
+            for (int s = sub; s < a.spp; s += G) {
+                float rx = bits_u01(tab[0][s] ^ sx);
+                float ry = bits_u01(tab[1][s] ^ sy);
+                V3 M = vndf_microfacet(w, g.fr, rx, ry);
+                V3 dir;
+                if (!ggx_refract(g, M, dir)) tir += 1.0f;
+                acc += ggx_sample_weight(g, g.view, dir, M);                 // :241
+            }
+            if (G > 1) { acc = group_sum<G>(acc); tir = group_sum<G>(tir); }
+            const float inv = 1.0f / (float)a.spp;                           // AiSamplerGetSampleInvCount, :244
+            acc *= inv; tir *= inv;
+        } else {
+            V3 dir;
+            if (ggx_refract(g, g.fr.N, dir)) acc = g.eta2 * absf(dot(g.fr.N, dir));   // :216
+            else tir = 1.0f;
+        }
+        if (live && sub == 0) {
+            strgb(a.result, i, a.env[0] * acc, a.env[1] * acc, a.env[2] * acc);
+            if (a.tir) stg(a.tir, i, tir);
         }
     }
 }
@@ -430,6 +620,16 @@ RLS_HIDDEN rls_status rls_fast_ggx_direct(rls_context *ctx, int g, const rlsh::L
     return launch_g(ctx, ggx_direct_kernel<1>, ggx_direct_kernel<4>, ggx_direct_kernel<16>,
                     ggx_direct_kernel<64>, g, *io, "rls_ggx_direct_lighting[fast]");
 }
+RLS_HIDDEN rls_status rls_fast_skin_integrate(rls_context *ctx, int g, const rlsh::SkinIntIO *io)
+{
+    return launch_g(ctx, skin_integrate_kernel<1>, skin_integrate_kernel<4>, skin_integrate_kernel<16>,
+                    skin_integrate_kernel<64>, g, *io, "rls_skin_integrate[fast]");
+}
+RLS_HIDDEN rls_status rls_fast_ggx_refract_integrate(rls_context *ctx, int g, const rlsh::RefractIntIO *io)
+{
+    return launch_g(ctx, ggx_refract_integrate_kernel<1>, ggx_refract_integrate_kernel<4>, ggx_refract_integrate_kernel<16>,
+                    ggx_refract_integrate_kernel<64>, g, *io, "rls_ggx_integrate_refract[fast]");
+}
 RLS_HIDDEN rls_status rls_fast_sss_scatter(rls_context *ctx, int g, const rlsh::ScatterIO *io)
 {
     return launch_g(ctx, sss_scatter_kernel<1>, sss_scatter_kernel<4>, sss_scatter_kernel<16>,
@@ -440,8 +640,58 @@ RLS_HIDDEN rls_status rls_fast_ggx_integrate(rls_context *ctx, int g, const rlsh
 RLS_HIDDEN rls_status rls_fast_disney_integrate(rls_context *ctx, int g, const rlsh::DisneyIntIO *io);
 RLS_HIDDEN rls_status rls_fast_sss_scatter(rls_context *ctx, int g, const rlsh::ScatterIO *io);
 RLS_HIDDEN rls_status rls_fast_ggx_direct(rls_context *ctx, int g, const rlsh::LightIO *io);
+RLS_HIDDEN rls_status rls_fast_skin_integrate(rls_context *ctx, int g, const rlsh::SkinIntIO *io);
+RLS_HIDDEN rls_status rls_fast_ggx_refract_integrate(rls_context *ctx, int g, const rlsh::RefractIntIO *io);
 
 extern "C" {
+
+rls_status rls_skin_integrate(rls_context *ctx, int64_t n, const rls_skin_closure *c, rls_cvec3 P,
+                              const rls_sss_scene *scene, const float env[3], int spp_n, uint32_t seed,
+                              uint64_t first_index, const rls_skin_integrate_out *out)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_REQUIRE(n >= 0, "n < 0");
+    RLS_REQUIRE(spp_n >= 1 && spp_n * spp_n <= kMaxSpp, "spp_n must be in [1, 16]");
+    if (n == 0) return RLS_OK;
+    RLS_REQUIRE(c != nullptr && scene != nullptr && out != nullptr && env != nullptr, "closure, scene, env or out is NULL");
+    RLS_REQUIRE(rlsh::has3(c->wo) && rlsh::has3(c->N) && rlsh::has3(c->T) && rlsh::has3(P), "wo/N/T/P plane is NULL");
+    RLS_REQUIRE(rlsh::ok_rgb(c->sss_color) && rlsh::ok_rgb(c->specular_color) && rlsh::ok_rgb(c->sheen_color),
+                "colour planes must be all set or all NULL");
+    RLS_REQUIRE(scene->geometry == RLS_SCENE_PLANE || scene->geometry == RLS_SCENE_SPHERE, "unknown scene geometry");
+    RLS_REQUIRE(rlsh::has3(out->sheen) && rlsh::has3(out->specular) && rlsh::has3(out->sss), "NULL AOV plane");
+    RLS_REQUIRE(rlsh::has3(out->out) || (!out->out.r && !out->out.g && !out->out.b), "out planes must be all set or all NULL");
+    rlsh::SkinIntIO io = {};
+    io.c = *c; io.P = P; io.scene = *scene; io.env[0] = env[0]; io.env[1] = env[1]; io.env[2] = env[2];
+    io.sheen = out->sheen; io.specular = out->specular; io.sss = out->sss; io.out = out->out;
+    io.sheenFresnel = out->sheenFresnel; io.specularFresnel = out->specularFresnel; io.sssWeight = out->sssWeight;
+    io.n = n; io.spp = spp_n * spp_n; io.seed = seed; io.first = first_index;
+    int g = pick_group(ctx, n, io.spp);
+    if (ctx->fast) return rls_fast_skin_integrate(ctx, g, &io);
+    return launch_g(ctx, skin_integrate_kernel<1>, skin_integrate_kernel<4>, skin_integrate_kernel<16>,
+                    skin_integrate_kernel<64>, g, io, "rls_skin_integrate");
+}
+
+rls_status rls_ggx_integrate_refract(rls_context *ctx, int64_t n, const rls_ggx_closure *c, int traced,
+                                     const float env[3], int spp_n, uint32_t seed, uint64_t first_index,
+                                     rls_rgb result, float *tir_fraction)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_REQUIRE(n >= 0, "n < 0");
+    RLS_REQUIRE(spp_n >= 1 && spp_n * spp_n <= kMaxSpp, "spp_n must be in [1, 16]");
+    if (n == 0) return RLS_OK;
+    RLS_REQUIRE(c != nullptr && env != nullptr, "closure or env is NULL");
+    RLS_REQUIRE(rlsh::has3(c->wo) && rlsh::has3(c->N) && rlsh::has3(c->T), "wo/N/T plane is NULL");
+    RLS_REQUIRE(rlsh::ok_rgb(c->KsColor), "KsColor planes must be all set or all NULL");
+    RLS_REQUIRE(rlsh::has3(result), "NULL output plane");
+    rlsh::RefractIntIO io = {};
+    io.c = *c; io.env[0] = env[0]; io.env[1] = env[1]; io.env[2] = env[2]; io.traced = traced ? 1 : 0;
+    io.result = result; io.tir = tir_fraction;
+    io.n = n; io.spp = spp_n * spp_n; io.seed = seed; io.first = first_index;
+    int g = traced ? pick_group(ctx, n, io.spp) : 1;
+    if (ctx->fast) return rls_fast_ggx_refract_integrate(ctx, g, &io);
+    return launch_g(ctx, ggx_refract_integrate_kernel<1>, ggx_refract_integrate_kernel<4>, ggx_refract_integrate_kernel<16>,
+                    ggx_refract_integrate_kernel<64>, g, io, "rls_ggx_integrate_refract");
+}
 
 rls_status rls_ggx_integrate(rls_context *ctx, int64_t n, const rls_ggx_closure *c,
                              int spp_n, uint32_t seed, uint64_t first_index,

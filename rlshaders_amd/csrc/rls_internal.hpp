@@ -139,6 +139,30 @@ struct ScatterIO {
     uint64_t first;         // global index of point 0 (the sampler scrambles hash first + i)
 };
 
+struct SkinIntIO {
+    rls_skin_closure c;
+    rls_cvec3 P;
+    rls_sss_scene scene;
+    float env[3];
+    rls_rgb sheen, specular, sss, out;
+    float *sheenFresnel, *specularFresnel, *sssWeight;
+    int64_t n;
+    int spp;
+    uint32_t seed;
+    uint64_t first;
+};
+struct RefractIntIO {
+    rls_ggx_closure c;
+    float env[3];
+    int traced;
+    rls_rgb result;
+    float *tir;
+    int64_t n;
+    int spp;
+    uint32_t seed;
+    uint64_t first;
+};
+
 void set_error(const char *fmt, ...);
 rls_status hip_fail(hipError_t e, const char *what);
 

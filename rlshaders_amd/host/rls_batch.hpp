@@ -271,6 +271,14 @@ public:
     {
         check(rls_ggx_refract_sample(dev_.ctx(), n_, &c_, rx.plane(0), ry.plane(0), dir.vec3(), weight.plane(0), nullptr));
     }
+    // AtColor integrateRefract(sg, data)  (src/rlGgx.h:205-245) under a uniform environment of radiance env;
+    // traced = data->shouldTraceRefract(sg)
+    void integrateRefract(bool traced, const float env[3], int spp_n, uint32_t seed, Planes &result,
+                          uint64_t first_index = 0) const
+    {
+        check(rls_ggx_integrate_refract(dev_.ctx(), n_, &c_, traced ? 1 : 0, env, spp_n, seed, first_index, result.rgb(),
+                                        nullptr));
+    }
     // integrateGlossy's sample loop with spp_n^2 samples + getAvgReflectWeight  (src/rlGgx.h:172-184)
     // first_index: global index of this batch's point 0 (a shard draws the numbers of the whole batch)
     void integrateGlossy(int spp_n, uint32_t seed, Planes &sum_f_over_pdf, Planes &avgReflectWeight,
@@ -479,6 +487,17 @@ public:
         check(rls_skin_sample_eval_pdf(dev_.ctx(), n_, &c_, x, &o));
     }
     static constexpr int kOutPlanes = 24;
+    // shader_evaluate over spp_n^2 samples per layer  (src/rlSkin.cpp:174-254): the mean Fresnel of each GGX lobe
+    // (getAvgReflectWeight, src/rlGgx.h:181-184) handed down to the next, integrateScatter x sssWeight.
+    // aov: 12 planes {sheen3, specular3, sss3, out3}; layers (optional): 3 planes {sheenFresnel, specularFresnel, sssWeight}
+    void integrate(const Planes &P, const rls_sss_scene &scene, const float env[3], int spp_n, uint32_t seed, Planes &aov,
+                   Planes *layers = nullptr, uint64_t first_index = 0) const
+    {
+        rls_skin_integrate_out o{};
+        o.sheen = aov.rgb(0); o.specular = aov.rgb(3); o.sss = aov.rgb(6); o.out = aov.rgb(9);
+        if (layers) { o.sheenFresnel = layers->plane(0); o.specularFresnel = layers->plane(1); o.sssWeight = layers->plane(2); }
+        check(rls_skin_integrate(dev_.ctx(), n_, &c_, P.cvec3(), &scene, env, spp_n, seed, first_index, &o));
+    }
 
 private:
     const Device &dev_;

@@ -244,6 +244,15 @@ class Ggx:
                                             self.nthreads)
         return dd, ds
 
+    def integrate_refract(self, spp_n, seed, traced=True, env=(1.0, 1.0, 1.0), first_index=0):
+        """orc_batch_ggx_integrate_refract -> (result [3,n], tir_fraction [n])"""
+        n = self.n
+        res, tir = np.empty((3, n), np.float32), np.empty(n, np.float32)
+        e = (C.c_float * 3)(*[float(v) for v in env])
+        lib().orc_batch_ggx_integrate_refract(C.c_int64(n), C.byref(self.soa), 1 if traced else 0, e, int(spp_n),
+                                              C.c_uint32(seed), C.c_uint64(first_index), _v(res), _p(tir), self.nthreads)
+        return res, tir
+
     def integrate(self, spp_n, seed, first_index=0):
         n = self.n
         s, a = np.empty((3, n), np.float32), np.empty(n, np.float32)
@@ -463,6 +472,44 @@ SKIN_SCALAR = ("sheen_pdf", "sheen_fresnel", "spec_pdf", "spec_fresnel", "r", "r
                "sheenFresnel", "specularFresnel", "sssWeight")
 
 
+class SkinIntOutSoa(C.Structure):
+    _fields_ = [("sheen", CV3P), ("specular", CV3P), ("sss", CV3P), ("out", CV3P),
+                ("sheenFresnel", fp), ("specularFresnel", fp), ("sssWeight", fp)]
+
+
+def _skin_soa(wo, N, T, params: dict, xi):
+    n = wo.shape[1]
+    a = dict(wo=f32(wo), N=f32(N), T=f32(T),
+             sss_color=_full3(params["sss_color"], n), sss_weight=_full(params["sss_weight"], n),
+             mult=_full(params["sss_dist_multiplier"], n), dist=_full3(params["sss_scatter_dist"], n),
+             spec_color=_full3(params["specular_color"], n), spec_w=_full(params["specular_weight"], n),
+             spec_r=_full(params["specular_roughness"], n), spec_i=_full(params["specular_ior"], n),
+             sheen_color=_full3(params["sheen_color"], n), sheen_w=_full(params["sheen_weight"], n),
+             sheen_r=_full(params["sheen_roughness"], n), sheen_i=_full(params["sheen_ior"], n))
+    xs = [np.ascontiguousarray(f32(xi)[k]) for k in range(6)] if xi is not None else []
+    soa = SkinSoa(_v(a["wo"]), _v(a["N"]), _v(a["T"]), _v(a["sss_color"]), _p(a["sss_weight"]), _p(a["mult"]),
+                  _v(a["dist"]), _v(a["spec_color"]), _p(a["spec_w"]), _p(a["spec_r"]), _p(a["spec_i"]),
+                  _v(a["sheen_color"]), _p(a["sheen_w"]), _p(a["sheen_r"]), _p(a["sheen_i"]),
+                  (fp * 6)(*[_p(x) for x in xs]) if xs else (fp * 6)())
+    return soa, (a, xs)
+
+
+def skin_integrate(wo, N, T, params: dict, P, scene: "Scene", spp_n, seed, env=(1.0, 1.0, 1.0), first_index=0,
+                   nthreads=1) -> dict:
+    """orc_batch_skin_integrate -> dict(sheen, specular, sss, out [3,n]; sheenFresnel, specularFresnel, sssWeight [n])"""
+    n = wo.shape[1]
+    soa, keep = _skin_soa(wo, N, T, params, None)
+    P = f32(P)
+    out = {k: np.empty((3, n), np.float32) for k in ("sheen", "specular", "sss", "out")}
+    out.update({k: np.empty(n, np.float32) for k in ("sheenFresnel", "specularFresnel", "sssWeight")})
+    o = SkinIntOutSoa(_v(out["sheen"]), _v(out["specular"]), _v(out["sss"]), _v(out["out"]),
+                      _p(out["sheenFresnel"]), _p(out["specularFresnel"]), _p(out["sssWeight"]))
+    e = (C.c_float * 3)(*[float(v) for v in env])
+    lib().orc_batch_skin_integrate(C.c_int64(n), C.byref(soa), _v(P), C.byref(scene), e, int(spp_n), C.c_uint32(seed),
+                                   C.c_uint64(first_index), C.byref(o), nthreads)
+    return out
+
+
 def skin(wo, N, T, params: dict, xi, nthreads=1) -> dict:
     n = wo.shape[1]
     a = dict(wo=f32(wo), N=f32(N), T=f32(T),
@@ -486,6 +533,13 @@ def skin(wo, N, T, params: dict, xi, nthreads=1) -> dict:
                    _p(out["sheenFresnel"]), _p(out["specularFresnel"]), _p(out["sssWeight"]))
     lib().orc_batch_skin(C.c_int64(n), C.byref(soa), C.byref(o), nthreads)
     return out
+
+
+def sample_02(seed, index, dim_pair, s):
+    """sample s of point `index`'s scrambled (0,2)-sequence (orc_sample_02) -> (rx, ry)"""
+    rx, ry = C.c_float(), C.c_float()
+    lib().orc_sample_02(C.c_uint32(seed), C.c_uint64(index), C.c_uint32(dim_pair), C.c_uint32(s), C.byref(rx), C.byref(ry))
+    return rx.value, ry.value
 
 
 # ------------------------------------------------------------------------------------------------

@@ -99,12 +99,12 @@ def build_host_examples(verbose: bool = False) -> Path:
     """Compile-check the C++ host mirror (header-only) and its example against the C ABI."""
     OBJDIR.mkdir(exist_ok=True)
     first = OBJDIR / "example_arnold_stub"
-    for name in ("example_arnold_stub", "example_multi_gpu"):
+    for name in ("example_arnold_stub", "example_multi_gpu", "test_arnold_stub"):
         src = PKG / "host" / f"{name}.cpp"
         out = OBJDIR / name
         if not src.exists():
             continue
-        if _stale(out, [src, PKG / "host" / "rls_batch.hpp", LIB, *HEADERS]):
+        if _stale(out, [src, PKG / "host" / "rls_batch.hpp", PKG / "host" / "rl_arnold_stub.hpp", LIB, *HEADERS]):
             cmd = ["g++", "-std=c++14", "-O2", "-Wall", "-pthread", f"-I{PKG.parent / 'include'}", f"-I{PKG / 'host'}",
                    str(src), "-o", str(out), f"-L{LIBDIR}", "-lrlshaders_amd", f"-Wl,-rpath,{LIBDIR}",
                    "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"]

@@ -16,66 +16,84 @@ class Param(NamedTuple):
     name: str
     type: str                      # RGB | FLT | VEC | BOOL | STR
     default: Tuple
+    enum: str                      # the positional p_* enumerator the node's shader_evaluate reads it through
     closure: bool = True           # consumed by the batched closure layer
-    min: Optional[float] = None
+    min: Optional[float] = None    # UI ranges of rlShaders.mtd
     max: Optional[float] = None
     softmax: Optional[float] = None
+    meta: Tuple = ()               # metadata the node sets in code next to the declaration: ((key, value), ...)
 
 
-def _aov(name, default):
-    return Param(name, "STR", (default,), closure=False)
+def _aov(name, default, enum):
+    return Param(name, "STR", (default,), enum, closure=False, meta=(("aov.type", "AI_TYPE_RGB"),))
 
+
+def _d(name, enum, hard_max=False):
+    # src/rlDisney.cpp:612-620: min 0 and max 1 (specular, roughness, sheen) or softmax 1, set in code
+    return Param(name, "FLT", (0.0,), enum, meta=(("min", 0.0), ("max" if hard_max else "softmax", 1.0)))
+
+
+_LIN = (("always_linear", True),)
+
+# node_loader table, src/_PluginMain.cpp:8-46: (ShaderId enumerator, methods symbol, node name); every node is an
+# AI_NODE_SHADER with output type AI_TYPE_RGB
+NODE_LOADER = (("kGgx", "GgxMethod", "rlGgx"), ("kDisney", "DisneyMethod", "rlDisney"), ("kSkin", "SkinMethod", "rlSkin"))
 
 NODES: Dict[str, dict] = {
-    # src/rlGgx.cpp:172-197, src/rlShaders.mtd:1-29
+    # enum src/rlGgx.cpp:106-126, declarations src/rlGgx.cpp:172-197, ranges src/rlShaders.mtd:1-29
     "rlGgx": {"maya.id": "0x04700001", "params": [
-        Param("KdColor", "RGB", (1.0, 1.0, 1.0), closure=False),
-        Param("Kd", "FLT", (0.5,), closure=False, min=0.0, softmax=1.0),
-        Param("diffuseRoughness", "FLT", (0.0,), closure=False, min=0.0, softmax=1.0),
-        Param("KsColor", "RGB", (1.0, 1.0, 1.0)),
-        Param("Ks", "FLT", (0.5,), closure=False, min=0.0, softmax=1.0),
-        Param("specularRoughness", "FLT", (0.0,), min=0.0, softmax=1.0),
-        Param("KtColor", "RGB", (1.0, 1.0, 1.0), closure=False),
-        Param("Kt", "FLT", (0.0,), closure=False, min=0.0, softmax=1.0),
-        Param("ior", "FLT", (1.0,), min=0.0),
-        Param("anisotropic", "FLT", (0.0,), min=0.0, softmax=1.0),
-        Param("opacity", "FLT", (1.0,), closure=False, min=0.0, max=1.0),
-        Param("opacity_color", "RGB", (1.0, 1.0, 1.0), closure=False),
-        _aov("aov_direct_diffuse", "direct_diffuse"), _aov("aov_direct_specular", "direct_specular"),
-        _aov("aov_refract", "refraction"), _aov("aov_indirect_diffuse", "indirect_diffuse"),
-        _aov("aov_indirect_specular", "indirect_specular"),
+        Param("KdColor", "RGB", (1.0, 1.0, 1.0), "p_Kd_color", closure=False),
+        Param("Kd", "FLT", (0.5,), "p_Kd", closure=False, min=0.0, softmax=1.0),
+        Param("diffuseRoughness", "FLT", (0.0,), "p_Kd_roughness", closure=False, min=0.0, softmax=1.0),
+        Param("KsColor", "RGB", (1.0, 1.0, 1.0), "p_Ks_color"),
+        Param("Ks", "FLT", (0.5,), "p_Ks", closure=False, min=0.0, softmax=1.0),
+        Param("specularRoughness", "FLT", (0.0,), "p_Ks_roughness", min=0.0, softmax=1.0),
+        Param("KtColor", "RGB", (1.0, 1.0, 1.0), "p_Kt_Color", closure=False),
+        Param("Kt", "FLT", (0.0,), "p_Kt", closure=False, min=0.0, softmax=1.0),
+        Param("ior", "FLT", (1.0,), "p_ior", min=0.0),
+        Param("anisotropic", "FLT", (0.0,), "p_anisotropic", min=0.0, softmax=1.0),
+        Param("opacity", "FLT", (1.0,), "p_opacity", closure=False, min=0.0, max=1.0),
+        Param("opacity_color", "RGB", (1.0, 1.0, 1.0), "p_opacity_color", closure=False),
+        _aov("aov_direct_diffuse", "direct_diffuse", "p_aov_direct_diffuse"),
+        _aov("aov_direct_specular", "direct_specular", "p_aov_direct_specular"),
+        _aov("aov_refract", "refraction", "p_aov_refract"),
+        _aov("aov_indirect_diffuse", "indirect_diffuse", "p_aov_indirect_diffuse"),
+        _aov("aov_indirect_specular", "indirect_specular", "p_aov_indirect_specular"),
     ]},
-    # src/rlDisney.cpp:606-637 (ranges are set in code there, src/rlDisney.cpp:612-620), src/rlShaders.mtd:31-35
+    # enum src/rlDisney.cpp:24-46, declarations src/rlDisney.cpp:606-637, src/rlShaders.mtd:31-35
     "rlDisney": {"maya.id": "0x04700002", "params": [
-        Param("base_color", "RGB", (1.0, 1.0, 1.0)),
-        Param("subsurface", "FLT", (0.0,)), Param("metallic", "FLT", (0.0,)), Param("specular", "FLT", (0.0,)),
-        Param("specular_tint", "FLT", (0.0,)), Param("roughness", "FLT", (0.0,)), Param("anisotropic", "FLT", (0.0,)),
-        Param("sheen", "FLT", (0.0,)), Param("sheen_tint", "FLT", (0.0,)), Param("clearcoat", "FLT", (0.0,)),
-        Param("clearcoat_gloss", "FLT", (0.0,)),
-        Param("opacity", "RGB", (1.0, 1.0, 1.0), closure=False),
-        Param("indirectDiffuseScale", "FLT", (1.0,), closure=False),
-        Param("indirectSpecularScale", "FLT", (1.0,), closure=False),
-        _aov("aov_direct_diffuse", "direct_diffuse"), _aov("aov_direct_specular", "direct_specular"),
-        _aov("aov_indirect_diffuse", "indirect_diffuse"), _aov("aov_indirect_specular", "indirect_specular"),
+        Param("base_color", "RGB", (1.0, 1.0, 1.0), "p_base_color"),
+        _d("subsurface", "p_subsurface"), _d("metallic", "p_metallic"), _d("specular", "p_Ks", True),
+        _d("specular_tint", "p_specular_tint"), _d("roughness", "p_roughness", True), _d("anisotropic", "p_anisotropic"),
+        _d("sheen", "p_sheen", True), _d("sheen_tint", "p_sheen_tint"), _d("clearcoat", "p_clearcoat"),
+        _d("clearcoat_gloss", "p_clearcoat_gloss"),
+        Param("opacity", "RGB", (1.0, 1.0, 1.0), "p_opacity", closure=False),
+        Param("indirectDiffuseScale", "FLT", (1.0,), "p_indirect_diffuse", closure=False, meta=(("min", 0.0), ("max", 1.0))),
+        Param("indirectSpecularScale", "FLT", (1.0,), "p_indirect_specular", closure=False, meta=(("min", 0.0), ("max", 1.0))),
+        _aov("aov_direct_diffuse", "direct_diffuse", "p_aov_direct_diffuse"),
+        _aov("aov_direct_specular", "direct_specular", "p_aov_direct_specular"),
+        _aov("aov_indirect_diffuse", "indirect_diffuse", "p_aov_indirect_diffuse"),
+        _aov("aov_indirect_specular", "indirect_specular", "p_aov_indirect_specular"),
     ]},
-    # src/rlSkin.cpp:109-138, src/rlShaders.mtd:37-64
+    # enum src/rlSkin.cpp:11-35, declarations src/rlSkin.cpp:109-138, src/rlShaders.mtd:37-64
     "rlSkin": {"maya.id": "0x04700003", "params": [
-        Param("sss_color", "RGB", (1.0, 1.0, 1.0)),
-        Param("sss_weight", "FLT", (1.0,), min=0.0, softmax=1.0),
-        Param("sss_dist_multiplier", "FLT", (1.0,), min=0.0, softmax=3.0),
-        Param("sss_scatter_dist", "VEC", (1.0, 1.0, 1.0)),
-        Param("sss_cavity_fadeout", "BOOL", (True,), closure=False),
-        Param("specular_color", "RGB", (1.0, 1.0, 1.0)),
-        Param("specular_weight", "FLT", (0.6,), min=0.0, softmax=1.0),
-        Param("specular_roughness", "FLT", (0.5,), min=0.0, softmax=1.0),
-        Param("specular_ior", "FLT", (1.44,), min=0.0),
-        Param("sheen_color", "RGB", (1.0, 1.0, 1.0)),
-        Param("sheen_weight", "FLT", (0.0,), min=0.0, softmax=1.0),
-        Param("sheen_roughness", "FLT", (0.35,), min=0.0, max=1.0),
-        Param("sheen_ior", "FLT", (1.44,), min=0.0),
-        Param("opacity", "FLT", (1.0,), closure=False),
-        Param("opacity_color", "RGB", (1.0, 1.0, 1.0), closure=False),
-        _aov("aov_sheen", "sheen"), _aov("aov_specular", "specular"), _aov("aov_sss", "sss"),
+        Param("sss_color", "RGB", (1.0, 1.0, 1.0), "p_sss_color", meta=_LIN),
+        Param("sss_weight", "FLT", (1.0,), "p_sss_weight", min=0.0, softmax=1.0),
+        Param("sss_dist_multiplier", "FLT", (1.0,), "p_distance_multiplier", min=0.0, softmax=3.0),
+        Param("sss_scatter_dist", "VEC", (1.0, 1.0, 1.0), "p_scatter_distance"),
+        Param("sss_cavity_fadeout", "BOOL", (True,), "p_cavity_fadeout", closure=False, meta=(("linkable", False),)),
+        Param("specular_color", "RGB", (1.0, 1.0, 1.0), "p_specular_color", meta=_LIN),
+        Param("specular_weight", "FLT", (0.6,), "p_specular_weight", min=0.0, softmax=1.0),
+        Param("specular_roughness", "FLT", (0.5,), "p_specular_roughness", min=0.0, softmax=1.0),
+        Param("specular_ior", "FLT", (1.44,), "p_specular_ior", min=0.0),
+        Param("sheen_color", "RGB", (1.0, 1.0, 1.0), "p_sheen_color", meta=_LIN),
+        Param("sheen_weight", "FLT", (0.0,), "p_sheen_weight", min=0.0, softmax=1.0),
+        Param("sheen_roughness", "FLT", (0.35,), "p_sheen_roughness", min=0.0, max=1.0),
+        Param("sheen_ior", "FLT", (1.44,), "p_sheen_ior", min=0.0),
+        Param("opacity", "FLT", (1.0,), "p_opacity", closure=False),
+        Param("opacity_color", "RGB", (1.0, 1.0, 1.0), "p_opacity_color", closure=False),
+        _aov("aov_sheen", "sheen", "p_aov_sheen"), _aov("aov_specular", "specular", "p_aov_specular"),
+        _aov("aov_sss", "sss", "p_aov_sss"),
     ]},
 }
 

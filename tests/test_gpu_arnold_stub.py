@@ -1,0 +1,87 @@
+"""GPU: all three node paths of the generated Arnold-side stub (rl_arnold_stub.hpp: GgxNode, DisneyNode, SkinNode) --
+per shading point `add(globals, evaluator, xi)` with a table-lookup evaluator in the shape of AiShaderEvalParam*, one
+`flush()` per node through the C++ mirror and the C ABI -- against the oracle on the same shading points."""
+import json
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import cases
+from gpu_util_cpu import disney_oracle, ggx_oracle
+
+ROOT = Path(__file__).resolve().parent.parent
+FIX = json.loads((ROOT / "tests" / "golden" / "param_surface.json").read_text())["nodes"]
+
+
+def _table(node, n, values):
+    """3 rows per positional parameter id, in the reference's enum order (what AiShaderEvalParam*(pid) would return)"""
+    t = np.zeros((3 * len(FIX[node]["parameters"]), n), np.float32)
+    for pid, p in enumerate(FIX[node]["parameters"]):
+        if p["type"] == "STR":
+            continue
+        v = values.get(p["name"], p["default"])                      # parameters the test does not vary: node defaults
+        v = np.asarray(v, np.float32)
+        if v.ndim == 1 and v.shape[0] == n and p["type"] in ("FLT", "BOOL"):
+            t[3 * pid] = v
+        elif v.ndim == 2:
+            t[3 * pid:3 * pid + 3] = v
+        else:
+            for c in range(v.size):
+                t[3 * pid + c] = v.flat[c]
+    return t
+
+
+@pytest.mark.gpu
+def test_three_nodes_through_the_stub(oracle, tmp_path):
+    from rlshaders_amd import build
+    build.build_library()
+    build.build_host_examples()
+    exe = build.OBJDIR / "test_arnold_stub"
+    n = 3000
+    g = cases.ggx_mixed(cases.SEED_PARITY, n)
+    d = cases.disney_mixed(cases.SEED_PARITY, n)
+    s = cases.skin_mixed(cases.SEED_PARITY, n)
+    xi = cases.xi(cases.SEED_PARITY, n, 6)
+    wo, N, T = g["wo"], g["N"], g["T"]                  # the three case sets share their frames (same seed)
+    assert np.array_equal(wo, d["wo"]) and np.array_equal(wo, s["wo"])
+    geo = np.concatenate([-wo, N, N, T])                # sg->Rd = -wo, sg->N = sg->Nf = N, U = T
+    tg = _table("rlGgx", n, dict(KsColor=g["KsColor"], ior=g["ior"], specularRoughness=g["roughness"],
+                                 anisotropic=g["anisotropic"]))
+    td = _table("rlDisney", n, {k: d[k] for k in ("base_color",) + tuple(oracle.DISNEY_SCALARS)})
+    ts = _table("rlSkin", n, s["params"])
+    inp = tmp_path / "in.bin"
+    with open(inp, "wb") as f:
+        np.array([n], np.float32).tofile(f)
+        for a in (geo, xi, tg, td, ts):
+            np.ascontiguousarray(a, np.float32).tofile(f)
+    outp = tmp_path / "out.bin"
+    p = subprocess.run([str(exe), "run", str(inp), str(outp)], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr
+    info = json.loads(p.stdout.strip().splitlines()[-1])
+    assert info == {"n": n, "ggx_planes": 8, "disney_planes": 14, "skin_planes": 24}
+    out = np.fromfile(outp, np.float32).reshape(-1, n)
+    og, od, osk = out[:8], out[8:22], out[22:]
+    # rlGgx: evalSample -> evalBrdf -> evalPdf (+ the Fresnel side effect)
+    rwi, rf, rpdf, rF = ggx_oracle(oracle, g).sample_eval_pdf(xi[0], xi[1])
+    for name, a, b in (("wi", og[0:3], rwi), ("f", og[3:6], rf), ("pdf", og[6], rpdf), ("fresnel", og[7], rF)):
+        cases.assert_tight(cases.summarize(cases.rel_err(a, b)), ("rlGgx", name))
+    # rlDisney: both lobes
+    o = disney_oracle(oracle, d)
+    for l, lobe in enumerate((oracle.RAY_DIFFUSE, oracle.RAY_GLOSSY)):
+        rwi, rf, rpdf = o.sample_eval_pdf(lobe, xi[0], xi[1])
+        blk = od[7 * l:7 * l + 7]
+        for name, a, b in (("wi", blk[0:3], rwi), ("f", blk[3:6], rf), ("pdf", blk[6], rpdf)):
+            cases.assert_tight(cases.summarize(cases.rel_err(a, b)), ("rlDisney", lobe, name))
+    # rlSkin: the 24 planes of the composite
+    ref = oracle.skin(wo, N, T, s["params"], xi, nthreads=4)
+    order = ("sheen_wi", "sheen_f", "sheen_pdf", "sheen_fresnel", "spec_wi", "spec_f", "spec_pdf", "spec_fresnel",
+             "r", "r_pdf", "profile", "sheenFresnel", "specularFresnel", "sssWeight")
+    row = 0
+    for k in order:
+        rows = 3 if ref[k].ndim == 2 else 1
+        a = osk[row:row + rows] if rows == 3 else osk[row]
+        cases.assert_tight(cases.summarize(cases.rel_err(a, ref[k])), ("rlSkin", k))
+        row += rows
+    assert row == 24

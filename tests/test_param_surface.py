@@ -9,7 +9,8 @@ from pathlib import Path
 from rlshaders_amd import _capi as capi
 from rlshaders_amd.closures import SkinShader
 
-G = json.loads((Path(__file__).parent / "golden" / "param_surface.json").read_text())["nodes"]
+FIXTURE = json.loads((Path(__file__).parent / "golden" / "param_surface.json").read_text())
+G = FIXTURE["nodes"]
 
 # declared by the reference's nodes, consumed outside the closure layer
 OUT_OF_PATH = {
@@ -28,7 +29,7 @@ def check(node, struct, rename=None):
     f = fields(struct)
     for p in G[node]["parameters"]:
         name = p["name"]
-        if name in OUT_OF_PATH[node]:
+        if name in OUT_OF_PATH[node] or p["type"] == "STR":        # AOV names: renderer glue
             continue
         fld = rename.get(name, name)
         assert fld in f, f"{node}.{name} missing from the C-ABI closure struct"
@@ -56,7 +57,7 @@ def test_rldisney_parameters():
 def test_rlskin_parameters_and_defaults():
     check("rlSkin", capi.SkinClosure)
     for p in G["rlSkin"]["parameters"]:
-        if p["name"] in OUT_OF_PATH["rlSkin"]:
+        if p["name"] in OUT_OF_PATH["rlSkin"] or p["type"] == "STR":
             continue
         d = SkinShader.DEFAULTS[p["name"]]
         got = list(d) if isinstance(d, (tuple, list)) else [d]
@@ -71,25 +72,31 @@ def test_header_names_every_consumed_parameter():
     text = (Path(__file__).resolve().parent.parent / "include" / "rlshaders_amd.h").read_text()
     for node in G:
         for p in G[node]["parameters"]:
-            if p["name"] not in OUT_OF_PATH[node]:
+            if p["name"] not in OUT_OF_PATH[node] and p["type"] != "STR":
                 assert p["name"] in text, (node, p["name"])
 
 
 def test_product_parameter_table_matches_reference():
-    """rlshaders_amd.params.NODES (what a stub declares) == the reference's node_parameters + .mtd"""
+    """rlshaders_amd.params.NODES (what a stub declares) == the reference's node_parameters blocks, p_* enums,
+    in-code metadata, node_loader table and .mtd"""
     from rlshaders_amd import params
     for node, spec in G.items():
-        mine = [p for p in params.NODES[node]["params"] if p.type != "STR"]
+        mine = params.NODES[node]["params"]
         ref = spec["parameters"]
         assert [p.name for p in mine] == [p["name"] for p in ref], node           # declaration order
+        assert [p.enum for p in mine] == spec["enum"], node                       # = positional enum order
         for a, b in zip(mine, ref):
             assert a.type == b["type"] and list(a.default) == b["default"], (node, a.name)
-            assert a.closure == (a.name not in OUT_OF_PATH[node]), (node, a.name)
+            assert a.closure == (a.name not in OUT_OF_PATH[node] and a.type != "STR"), (node, a.name)
+            assert dict(a.meta) == b["meta"], (node, a.name, a.meta, b["meta"])
         assert params.NODES[node]["maya.id"] == spec["mtd"]["maya.id"]
         # UI ranges of rlShaders.mtd (rlDisney sets its ranges in code, so its .mtd block has none)
         for attr, r in spec["mtd"]["attrs"].items():
             p = next(p for p in mine if p.name == attr)
             assert {k: v for k, v in (("min", p.min), ("max", p.max), ("softmax", p.softmax)) if v is not None} == r
+    assert [(e["enumerator"], e["methods"], e["name"]) for e in FIXTURE["node_loader"]] == list(params.NODE_LOADER)
+    assert all(e["output_type"] == "AI_TYPE_RGB" and e["node_type"] == "AI_NODE_SHADER" for e in FIXTURE["node_loader"])
+    assert [e["id"] for e in FIXTURE["node_loader"]] == [0, 1, 2]
 
 
 def test_emitted_mtd_round_trips():

@@ -58,9 +58,11 @@ def parse_args():
     ap.add_argument("--math", default="exact", choices=["exact", "fast"],
                     help="arithmetic of the measured kernels: exact (default, bit-faithful to the CPU closures) "
                          "or fast (RLS_MATH_FAST)")
-    ap.add_argument("--arena-candidates", type=int, default=16,
+    ap.add_argument("--arena-candidates", type=int, default=2,
                     help="equally sized blocks probed for the workload's plane arena (the fastest is kept); 1 = one arena, no "
-                         "probing; 0 = no arena, every plane group its own allocation (for comparison)")
+                         "probing; 0 = no arena, every plane group its own allocation (for comparison).  Placement moves the "
+                         "vector-issue-bound EXACT kernels by < 1 % (profiles/r02_placement.txt): two candidates are a check, "
+                         "not a search; --math fast gains up to 15 % from 16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target seconds of CPU-baseline work")
     return ap.parse_args()
@@ -337,7 +339,8 @@ def main():
     backend = os.environ.get("RLS_DIST_BACKEND", "nccl")
     device_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(device_index)
-    ranks = Ranks(backend=backend if world > 1 else None,
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ        # under torchrun, also with one rank
+    ranks = Ranks(backend=backend if (world > 1 or launched) else None,
                   device=torch.device("cuda", device_index) if backend == "nccl" else torch.device("cpu"))
     rank = ranks.rank
 
@@ -423,6 +426,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl.desc, "name": wl.name, "math": args.math, "points_per_gpu": n,
                        "samples_per_point": wl.samples_per_point, "sharding": f"index-range x{world}, no collective",
+                       "control_plane": (f"torch.distributed {backend}" if ranks.dist is not None else "single process"),
                        "placement": wl.arena.info(),
                        # the EXACT kernels are vector-ALU-bound: the first ~10 launches after idle run up to 40 % slower
                        # while the clocks ramp ("Warm-up"); fewer warm-up steps under-report

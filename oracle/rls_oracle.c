@@ -459,6 +459,25 @@ static float D_GTR2Aniso(const orc_disney *d, orc_v3 m, float MdotN2)
     return AI_ONEOVERPI / denominator;
 }
 
+/* scalar access to the three static helpers above for known-answer tests (tests/test_oracle_closed_forms.py) */
+float orc_kat_smithG_GGX(float NdotV, float alphaG) { return smithG_GGX(NdotV, alphaG); }
+float orc_kat_D_GTR1(float clearcoat_gloss, float MdotN2)
+{
+    orc_disney d;
+    memset(&d, 0, sizeof d);
+    d.clearcoatGloss = clearcoat_gloss;
+    return D_GTR1(&d, MdotN2);
+}
+/* frame U = x, V = y, N = z */
+float orc_kat_D_GTR2Aniso(float alphaX, float alphaY, orc_v3 m)
+{
+    orc_disney d;
+    memset(&d, 0, sizeof d);
+    d.axisU = v3(1.0f, 0.0f, 0.0f); d.axisV = v3(0.0f, 1.0f, 0.0f); d.axisN = v3(0.0f, 0.0f, 1.0f);
+    d.alphaX = alphaX; d.alphaY = alphaY;
+    return D_GTR2Aniso(&d, m, m.z * m.z);
+}
+
 /* src/rlDisney.cpp:199-236 */
 orc_rgb orc_disney_eval_diffuse(const orc_disney *d, orc_v3 L)
 {

@@ -123,6 +123,10 @@ float   orc_disney_eval_pdf(const orc_disney *d, orc_v3 indir);
 orc_v3  orc_disney_sample_gtr2_aniso(const orc_disney *d, float rx, float ry);
 orc_v3  orc_disney_sample_gtr2(const orc_disney *d, float rx, float ry);
 float   orc_disney_D_GTR2(const orc_disney *d, orc_v3 m);
+/* scalar access to the file-local helpers smithG_GGX, D_GTR1, D_GTR2Aniso (src/rlDisney.cpp:545-577) for KATs */
+float   orc_kat_smithG_GGX(float NdotV, float alphaG);
+float   orc_kat_D_GTR1(float clearcoat_gloss, float MdotN2);
+float   orc_kat_D_GTR2Aniso(float alphaX, float alphaY, orc_v3 m);
 
 /* GaussianProfile (src/rlSss.h:63-97; not instantiated: src/rlSkin.cpp:242 is commented out).  Arnold's
  * closed fast_exp is replaced by expf: PARITY UNPINNED. */

@@ -35,16 +35,26 @@ class Context:
         check(self.lib.rls_context_create(self.device, C.byref(h)))
         self.handle = h
         self.torch_device = torch.device("cuda", self.device)
+        self._private_stream = not use_torch_stream          # a fresh rls_context launches on its own stream
         if use_torch_stream:
             self.use_stream(torch.cuda.current_stream(self.torch_device))
 
     def use_stream(self, stream: Optional["torch.cuda.Stream"]) -> None:
         """stream = a torch.cuda.Stream (its handle may be 0 = the null stream), or None for the
-        context's private stream"""
+        context's private stream.
+
+        On the private stream (``use_stream(None)`` / ``use_torch_stream=False``) the launches are NOT ordered with
+        torch's own work: torch fills and frees tensors on its current stream, the kernels read and write them on a
+        non-blocking stream.  The caller then orders the two -- ``torch.cuda.synchronize()`` (or an event) after the
+        inputs are produced and ``ctx.synchronize()`` before the outputs are read or any tensor a launch used is
+        dropped; tensors this class allocates for outputs are tagged with ``record_stream`` so that torch's caching
+        allocator does not hand their memory out again while a launch may still write to it."""
         if stream is None:
             check(self.lib.rls_context_use_own_stream(self.handle))
+            self._private_stream = True
         else:
             check(self.lib.rls_context_set_stream(self.handle, C.c_void_p(stream.cuda_stream)))
+            self._private_stream = False
 
     def set_math_mode(self, fast: bool) -> None:
         """False: RLS_MATH_EXACT (default, bit-faithful to the CPU closures); True: RLS_MATH_FAST."""
@@ -92,7 +102,12 @@ class Context:
 
     # -- helpers --------------------------------------------------------------------------------
     def empty(self, *shape) -> torch.Tensor:
-        return torch.empty(*shape, dtype=torch.float32, device=self.torch_device)
+        t = torch.empty(*shape, dtype=torch.float32, device=self.torch_device)
+        if getattr(self, "_private_stream", False):
+            # the launch stream is not torch's: keep the allocator from recycling the block under a running kernel
+            h = self.lib.rls_context_get_stream(self.handle)
+            t.record_stream(torch.cuda.ExternalStream(h or 0, device=self.torch_device))
+        return t
 
 
 class Arena:

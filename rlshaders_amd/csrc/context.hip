@@ -83,6 +83,8 @@ rls_status rls_context_create(int device_ordinal, rls_context **out)
     hipError_t e1 = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     hipError_t e2 = e1 == hipSuccess ? hipEventCreate(&ctx->ev_start) : e1;
     hipError_t e3 = e2 == hipSuccess ? hipEventCreate(&ctx->ev_stop) : e2;
+    if (e3 == hipSuccess) e3 = hipEventCreate(&ctx->ev_probe_start);
+    if (e3 == hipSuccess) e3 = hipEventCreate(&ctx->ev_probe_stop);
     hipError_t e4 = e3 == hipSuccess ? hipMalloc((void **)&ctx->scratch_u64, sizeof(unsigned long long)) : e3;
     if (e4 != hipSuccess) {
         rls_status st = rlsh::hip_fail(e4, "rls_context_create");
@@ -109,6 +111,8 @@ void rls_context_destroy(rls_context *ctx)
     if (ctx->scratch_u64) (void)hipFree(ctx->scratch_u64);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->ev_probe_start) (void)hipEventDestroy(ctx->ev_probe_start);
+    if (ctx->ev_probe_stop) (void)hipEventDestroy(ctx->ev_probe_stop);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     free(ctx);
 }
@@ -236,6 +240,7 @@ rls_status rls_copy_to_host(rls_context *ctx, void *dst_host, const void *src, s
 rls_status rls_timer_start(rls_context *ctx)
 {
     RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_REQUIRE(!ctx->capturing, "not allowed while a launch graph is being recorded");
     RLS_HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
     return RLS_OK;
 }
@@ -243,6 +248,7 @@ rls_status rls_timer_start(rls_context *ctx)
 rls_status rls_timer_stop(rls_context *ctx)
 {
     RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_REQUIRE(!ctx->capturing, "not allowed while a launch graph is being recorded");
     RLS_HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
     return RLS_OK;
 }
@@ -443,15 +449,16 @@ rls_status probe_block(rls_context *ctx, void *block, size_t bytes, float *gbs)
     for (int j = 0; j < 12; j++) p.out[j] = base + (int64_t)(19 + j) * n;
     const dim3 grid = rlsh::grid_for(ctx, n);
     for (int w = 0; w < 2; w++) hipLaunchKernelGGL(placement_probe_kernel, grid, dim3(rlsh::kBlock), 0, ctx->stream, p, n);
-    RLS_HIP_TRY(hipEventRecord(ctx->ev_start, ctx->stream));
+    // the probe's own event pair: rls_timer_start ... rls_timer_elapsed_ms of the caller stays intact across a probe
+    RLS_HIP_TRY(hipEventRecord(ctx->ev_probe_start, ctx->stream));
     const int reps = 5;
     for (int r = 0; r < reps; r++) hipLaunchKernelGGL(placement_probe_kernel, grid, dim3(rlsh::kBlock), 0, ctx->stream, p, n);
-    RLS_HIP_TRY(hipEventRecord(ctx->ev_stop, ctx->stream));
+    RLS_HIP_TRY(hipEventRecord(ctx->ev_probe_stop, ctx->stream));
     rls_status st = rlsh::check_launch("placement_probe_kernel");
     if (st != RLS_OK) return st;
-    RLS_HIP_TRY(hipEventSynchronize(ctx->ev_stop));
+    RLS_HIP_TRY(hipEventSynchronize(ctx->ev_probe_stop));
     float ms = 0.0f;
-    RLS_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+    RLS_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_probe_start, ctx->ev_probe_stop));
     if (ms > 0.0f) *gbs = (float)(31.0 * sizeof(float) * (double)n * reps / (ms * 1e-3) / 1e9);
     return RLS_OK;
 }
@@ -522,8 +529,14 @@ rls_status rls_arena_create(rls_context *ctx, int64_t n, int planes, int candida
         if (st == RLS_OK) { rlsh::set_error("rls_arena_create: out of host memory"); st = RLS_ERR_OUT_OF_MEMORY; }
         return st;
     }
-    if (candidates > 1) RLS_HIP_TRY(hipMemsetAsync(blocks[best], 0, bytes, ctx->stream));   // the probe wrote into it
-    RLS_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    hipError_t fin = hipSuccess;
+    if (candidates > 1) fin = hipMemsetAsync(blocks[best], 0, bytes, ctx->stream);          // the probe wrote into it
+    if (fin == hipSuccess) fin = hipStreamSynchronize(ctx->stream);
+    if (fin != hipSuccess) {                                                                // do not leak the block
+        (void)hipFree(blocks[best]);
+        free(a);
+        return rlsh::hip_fail(fin, "rls_arena_create: clearing the chosen block");
+    }
     a->device = ctx->device; a->block = blocks[best]; a->bytes = bytes; a->plane_bytes = plane_bytes;
     a->planes = planes; a->candidates = got;
     a->probe_gbs = gbs[best]; a->probe_gbs_min = lo; a->probe_gbs_max = hi;

@@ -14,7 +14,8 @@ struct rls_context {
     int blocks_per_cu;        // grid cap = compute_units * blocks_per_cu (RLS_BLOCKS_PER_CU)
     hipStream_t stream;       // stream launches go to
     hipStream_t own_stream;   // created by the context (may differ from `stream`)
-    hipEvent_t ev_start, ev_stop;
+    hipEvent_t ev_start, ev_stop;            // rls_timer_*
+    hipEvent_t ev_probe_start, ev_probe_stop;   // placement probes (never the caller's timer)
     unsigned long long *scratch_u64;   // device, 8 bytes (checksum accumulator)
     int fast;                 // RLS_MATH_FAST selected (rls_context_set_math_mode)
     int capturing;            // between rls_graph_begin_capture and rls_graph_end_capture
@@ -194,11 +195,19 @@ constexpr int kBlock = RLS_BLOCK;   // 4 wavefronts of 64
 
 // Pointwise streaming launches: enough workgroups to fill 256 CUs several times over, capped so
 // that very large batches grid-stride instead of queueing millions of workgroups.
+inline hipError_t &pending_device_error()
+{
+    static thread_local hipError_t e = hipSuccess;
+    return e;
+}
+
 inline dim3 grid_for(const rls_context *ctx, int64_t n, int points_per_block = kBlock)
 {
     // called right before every launch: make the context's device current for this host thread
     // (a host may drive several contexts, one per GPU, from one thread)
-    (void)hipSetDevice(ctx->device);
+    // a failure (lost device) is kept for check_launch(), which every launch path calls right after the launch
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) pending_device_error() = e;
     int64_t want = (n + points_per_block - 1) / points_per_block;
     int64_t cap = (int64_t)ctx->compute_units * ctx->blocks_per_cu;
     if (want < 1) want = 1;
@@ -211,6 +220,13 @@ inline dim3 grid_for(const rls_context *ctx, int64_t n, int points_per_block = k
 
 inline rls_status check_launch(const char *what)
 {
+    hipError_t &pend = pending_device_error();
+    if (pend != hipSuccess) {                       // hipSetDevice failed before the launch (grid_for)
+        hipError_t e0 = pend;
+        pend = hipSuccess;
+        (void)hipGetLastError();
+        return hip_fail(e0, "hipSetDevice");
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, what);
     return RLS_OK;

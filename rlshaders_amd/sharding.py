@@ -34,7 +34,11 @@ class Ranks:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.device = device if device is not None else torch.device("cpu")
         self.dist = None
-        if self.world > 1:
+        # under a launcher (torchrun exports RANK + MASTER_PORT) the process group is initialised even for one rank:
+        # the control path of an N-rank run -- init_process_group("nccl", device_id), barrier, device all_reduce --
+        # is then the one a single-GPU box exercises too
+        launched = "RANK" in os.environ and "MASTER_PORT" in os.environ
+        if self.world > 1 or launched:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if backend is None:

@@ -245,7 +245,8 @@ def test_ragged_and_empty(gpu, oracle):
         x = cases.xi(cases.SEED_PARITY, n, 2)
         ref = ggx_oracle(oracle, c, nthreads=1).sample_eval_pdf(x[0], x[1])
         got = ggx_sampler(gpu, c).sampleEvalPdf(dev(x[0]), dev(x[1]))
-        assert cases.summarize(cases.rel_err(host(got[0]), ref[0]))["max"] <= 1e-3
+        for name, a, b in zip(("wi", "f", "pdf", "fresnel"), got, ref):
+            cases.assert_tight(cases.summarize(cases.rel_err(host(a), b)), ("ragged", n, name))
     e3 = torch.empty(3, 0, device="cuda")
     e1 = torch.empty(0, device="cuda")
     s = R.GgxSampler(gpu, e3, e3, e3, roughness=0.3, ior=1.5)

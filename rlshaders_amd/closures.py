@@ -46,9 +46,9 @@ class Context:
         On the private stream (``use_stream(None)`` / ``use_torch_stream=False``) the launches are NOT ordered with
         torch's own work: torch fills and frees tensors on its current stream, the kernels read and write them on a
         non-blocking stream.  The caller then orders the two -- ``torch.cuda.synchronize()`` (or an event) after the
-        inputs are produced and ``ctx.synchronize()`` before the outputs are read or any tensor a launch used is
-        dropped; tensors this class allocates for outputs are tagged with ``record_stream`` so that torch's caching
-        allocator does not hand their memory out again while a launch may still write to it."""
+        inputs are produced and ``ctx.synchronize()`` before the outputs are read or any tensor a launch used (inputs,
+        and outputs this class allocated) is dropped: torch's caching allocator recycles a freed block for later work
+        on ITS stream without knowing that a kernel on the private stream may still be using it."""
         if stream is None:
             check(self.lib.rls_context_use_own_stream(self.handle))
             self._private_stream = True
@@ -102,12 +102,7 @@ class Context:
 
     # -- helpers --------------------------------------------------------------------------------
     def empty(self, *shape) -> torch.Tensor:
-        t = torch.empty(*shape, dtype=torch.float32, device=self.torch_device)
-        if getattr(self, "_private_stream", False):
-            # the launch stream is not torch's: keep the allocator from recycling the block under a running kernel
-            h = self.lib.rls_context_get_stream(self.handle)
-            t.record_stream(torch.cuda.ExternalStream(h or 0, device=self.torch_device))
-        return t
+        return torch.empty(*shape, dtype=torch.float32, device=self.torch_device)
 
 
 class Arena:

@@ -77,6 +77,8 @@ struct Frame { V3 U, V, N; };
 #if RLS_FAST
 #define R_DIV(a, b) ((a) * __builtin_amdgcn_rcpf(b))
 #define R_RCP(b) __builtin_amdgcn_rcpf(b)
+#define R_RCPW(b) __builtin_amdgcn_rcpf(b)
+#define R_TWO_OVER(den) (2.0f * __builtin_amdgcn_rcpf(den))
 #define R_SQRT(x) __builtin_amdgcn_sqrtf(x)
 #define R_EXP(x) __expf(x)
 #define R_LOG(x) __logf(x)
@@ -91,6 +93,8 @@ RLS_DEV float refined_div(float a, float b)
     return __builtin_fmaf(e, r, q);
 }
 #define R_DIVH(a, b) refined_div(a, b)
+#define R_RCPH(b) refined_div(1.0f, b)
+#define R_RCPG(b) refined_div(1.0f, b)
 #define R_SQRTH(x) rlm::sqrt32(x)
 #define R_SQRT1P(y) __builtin_amdgcn_sqrtf(1.0f + (y))
 #define R_SQRTH1P(y) rlm::sqrt32_1p(y)
@@ -99,9 +103,16 @@ RLS_DEV void t_sincos_any(float x, float *s, float *c) { t_sincos(x, s, c); }
 RLS_DEV void stage_libm_tables() {}
 #else
 #define R_DIV(a, b) rlm::div32((a), (b))
-#define R_RCP(b) rlm::div32(1.0f, (b))
+#define R_RCP(b) rlm::rcp32(b)
+// 1 / x for x that is 0, inf, NaN or in [2^-126, 2^126] by construction (rls_libm.hpp, rcp32_w): say why at the call
+#define R_RCPW(b) rlm::rcp32_w(b)
+// 2 / den for den = 1 + sqrtf(...) (Smith G1): den is NaN, inf or in [1, 2^64], 1 / den never subnormal, and doubling
+// is exact, so 2 * RN(1 / den) = RN(2 / den); all 2^32 arguments of 2 / (1 + sqrtf(1 + y)) checked in tools/micro/exact1.hip
+#define R_TWO_OVER(den) (2.0f * rlm::rcp32_w(den))
 #define R_SQRT(x) rlm::sqrt32(x)
 #define R_DIVH(a, b) rlm::div32((a), (b))
+#define R_RCPH(b) rlm::rcp32_w(b)            // of a square root (normalize_h)
+#define R_RCPG(b) rlm::rcp32_hi(b)           // of A^2 - 1: 0 or >= 2^-24 in magnitude (A^2 is near 1 or far from it), unbounded above
 #define R_SQRTH(x) rlm::sqrt32(x)
 // sqrtf(1 + y): no small-argument guard needed (rls_libm.hpp, sqrt32<false>)
 #define R_SQRT1P(y) rlm::sqrt32_1p(y)
@@ -138,7 +149,7 @@ RLS_DEV float length(V3 a) { return R_SQRT(a.x * a.x + a.y * a.y + a.z * a.z); }
 RLS_DEV V3 normalize(V3 a)
 {
     float t = length(a);
-    if (t != 0.0f) t = R_RCP(t);
+    if (t != 0.0f) t = R_RCPW(t);            // a square root: 0, inf, NaN or in [2^-75, 2^64]
     return mk(a.x * t, a.y * t, a.z * t);
 }
 // normalize() for vectors whose direction feeds a sharply peaked function (the microfacet normal
@@ -146,7 +157,7 @@ RLS_DEV V3 normalize(V3 a)
 RLS_DEV V3 normalize_h(V3 a)
 {
     float t = R_SQRTH(a.x * a.x + a.y * a.y + a.z * a.z);
-    if (t != 0.0f) t = R_DIVH(1.0f, t);
+    if (t != 0.0f) t = R_RCPH(t);
     return mk(a.x * t, a.y * t, a.z * t);
 }
 RLS_DEV float linearstep(float lo, float hi, float t) { return clampf(R_DIV(t - lo, hi - lo), 0.0f, 1.0f); }
@@ -276,8 +287,10 @@ RLS_DEV VndfView vndf_view_from(V3 local, float ax, float ay)
 #endif
     w.B = B;
     w.B2 = sqr(B);
-    w.G1 = R_DIV(2.0f, 1.0f + R_SQRT1P(w.B2));
-    w.invB = R_RCP(B);
+    w.G1 = R_TWO_OVER(1.0f + R_SQRT1P(w.B2));
+    // B = tanf(theta) with theta = 0 or in [acos(1 - 1e-4), pi] (or NaN): 0 or 8.7e-8 <= |B| <= 2.3e7 -- an fp32
+    // angle cannot come closer to pi/2 or pi than that
+    w.invB = R_RCPW(B);
     return w;
 }
 
@@ -308,7 +321,7 @@ RLS_DEV bool vndf_slope_closed(const VndfView &w, float rx, float ry, V2 &slope)
 {
     float A = R_DIVH(2.0f * rx, w.G1) - 1.0f;
     float A2 = sqr(A);
-    float tmp = R_DIVH(1.0f, A2 - 1.0f);
+    float tmp = R_RCPG(A2 - 1.0f);
     float D = R_SQRTH(maxf(0.0f, w.B2 * sqr(tmp) - (A2 - w.B2) * tmp));
     float slopeX1 = w.B * tmp - D;
     float slopeX2 = w.B * tmp + D;
@@ -439,7 +452,7 @@ RLS_DEV Ggx ggx_make(V3 wo, V3 N, V3 T, bool exiting, float ksR, float ksG, floa
     {
         float cosSqr = sqr(g.vn);
         float tanSqr = R_RCP(cosSqr) - 1.0f;
-        g.g1v = R_DIV(2.0f, 1.0f + R_SQRT1P(sqr(g.rough) * tanSqr));
+        g.g1v = R_TWO_OVER(1.0f + R_SQRT1P(sqr(g.rough) * tanSqr));
     }
     return g;
 }
@@ -475,7 +488,7 @@ RLS_DEV float ggx_G1(const Ggx &g, V3 v, V3 m, V3 n)
     float cosSqr = sqr(vn);
     float tanSqr = R_RCP(cosSqr) - 1.0f;
     float den = 1.0f + R_SQRT1P(sqr(g.rough) * tanSqr);
-    return R_DIV(2.0f, den);
+    return R_TWO_OVER(den);
 }
 
 // G1(mViewDir, m, mAxisN): the value depends on the view only, the zero test on m
@@ -1024,8 +1037,8 @@ RLS_DEV LightCone cone_make(V3 center, float radius, V3 P)
     c.valid = c.c2 > 0.0f;
     float sin2 = R_DIV(r2, dist2);
     c.cosMax = R_SQRT(maxf(0.0f, 1.0f - sin2));
-    c.pdf = R_DIV(1.0f, kTwoPi * R_DIV(sin2, 1.0f + c.cosMax));
-    float inv = R_DIV(1.0f, R_SQRT(dist2));
+    c.pdf = R_RCP(kTwoPi * R_DIV(sin2, 1.0f + c.cosMax));
+    float inv = R_RCPW(R_SQRT(dist2));            // of a square root
     c.w = c.d * inv;
     float sg = __builtin_copysignf(1.0f, c.w.z);
     float a = R_DIV(-1.0f, sg + c.w.z);

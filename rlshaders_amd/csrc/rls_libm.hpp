@@ -131,6 +131,47 @@ RLM_FN float sqrt32(float x)
 }
 RLM_FN float sqrt32_1p(float y) { return sqrt32<false>(1.0f + y); }   // sqrtf(1 + y)
 
+// Exactly rounded reciprocal.  v_rcp_f32 is accurate to 1 ulp; ONE Newton step e = 1 - x r, r' = r + e r (two fmas)
+// then rounds to the correctly rounded 1/x for EVERY x with 2^-126 <= |x| <= 2^126 -- checked by enumeration of all
+// 2^32 bit patterns on gfx950 (tools/micro/exact1.hip, profiles/r02_exact1.txt: 0 differences from the compiler's IEEE
+// division inside the window; outside it the reciprocal or its residual is subnormal and the sequence is wrong).
+// v_div_fixup_f32 supplies the IEEE results for x = +-0, +-inf and NaN.  4 instructions instead of the 11 of `1.0f / x`
+// (2 v_div_scale, v_rcp, 5 fma/mul, v_div_fmas, v_div_fixup), and none of them slow to issue.
+// rcp32_w: for arguments known to be 0, inf, NaN or inside the window (a square root, 1 + a square root, ...).
+// rcp32: any argument -- subnormal or huge ones (two compares) take the IEEE sequence.
+RLM_FN float rcp32_w(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RLS_NO_FAST_RCP)
+    float r = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    return __builtin_amdgcn_div_fixupf(r, x, 1.0f);
+#else
+    return 1.0f / x;
+#endif
+}
+RLM_FN float rcp32(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RLS_NO_FAST_RCP)
+    // +-subnormal (class bits 4 and 7), or beyond 2^126 (1/x subnormal; +-inf lands here too and is slow but right)
+    if (__builtin_expect(__builtin_amdgcn_classf(x, 0x90) || __builtin_fabsf(x) > 0x1p126f, 0)) return 1.0f / x;
+    return rcp32_w(x);
+#else
+    return 1.0f / x;
+#endif
+}
+
+// rcp32 for arguments that are 0, NaN or at least 2^-126 in magnitude by construction: only the upper end is tested
+RLM_FN float rcp32_hi(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RLS_NO_FAST_RCP)
+    if (__builtin_expect(!(__builtin_fabsf(x) <= 0x1p126f), 0)) return 1.0f / x;
+    return rcp32_w(x);
+#else
+    return 1.0f / x;
+#endif
+}
+
 // ---- atanf: fdlibm s_atanf.c ---------------------------------------------------------------------
 RLM_FN float atan32(float x)
 {

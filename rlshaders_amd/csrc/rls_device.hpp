@@ -95,8 +95,10 @@ RLS_DEV float refined_div(float a, float b)
 #define R_DIVH(a, b) refined_div(a, b)
 #define R_RCPH(b) refined_div(1.0f, b)
 #define R_RCPG(b) refined_div(1.0f, b)
+#define R_RCPHI(b) __builtin_amdgcn_rcpf(b)
 #define R_SQRTH(x) rlm::sqrt32(x)
 #define R_SQRT1P(y) __builtin_amdgcn_sqrtf(1.0f + (y))
+#define R_SQRT1M(t) __builtin_amdgcn_sqrtf(1.0f - (t))
 #define R_SQRTH1P(y) rlm::sqrt32_1p(y)
 RLS_DEV void t_sincos(float x, float *s, float *c) { *s = __sinf(x); *c = __cosf(x); }
 RLS_DEV void t_sincos_any(float x, float *s, float *c) { t_sincos(x, s, c); }
@@ -112,11 +114,14 @@ RLS_DEV void stage_libm_tables() {}
 #define R_SQRT(x) rlm::sqrt32(x)
 #define R_DIVH(a, b) rlm::div32((a), (b))
 #define R_RCPH(b) rlm::rcp32_w(b)            // of a square root (normalize_h)
+#define R_RCPHI(b) rlm::rcp32_hi(b)          // 1 / x for x that is 0, NaN or >= 2^-126 in magnitude by construction
 #define R_RCPG(b) rlm::rcp32_hi(b)           // of A^2 - 1: 0 or >= 2^-24 in magnitude (A^2 is near 1 or far from it), unbounded above
 #define R_SQRTH(x) rlm::sqrt32(x)
 // sqrtf(1 + y): no small-argument guard needed (rls_libm.hpp, sqrt32<false>)
 #define R_SQRT1P(y) rlm::sqrt32_1p(y)
 #define R_SQRTH1P(y) rlm::sqrt32_1p(y)
+// sqrtf(1 - t): no guard either (rls_libm.hpp, sqrt32_1m)
+#define R_SQRT1M(t) rlm::sqrt32_1m(t)
 // exp / log / pow: the host libm's table-driven fp64 algorithms (rls_libm.hpp).  The tables live
 // in LDS (640 B per workgroup; each table is at most one 256-byte bank row, so the per-lane
 // lookups are conflict-free); a kernel that evaluates any of the three calls
@@ -167,7 +172,7 @@ RLS_DEV float linearstep(float lo, float hi, float t) { return clampf(R_DIV(t - 
 template <bool BOUNDED_PHI = false>
 RLS_DEV V3 spherical_direction(float cosTheta, float phi)
 {
-    float r = R_SQRT(1.0f - sqr(cosTheta));
+    float r = R_SQRT1M(sqr(cosTheta));
     float s, c;
     if (BOUNDED_PHI) t_sincos(phi, &s, &c);
     else t_sincos_any(phi, &s, &c);
@@ -427,6 +432,7 @@ struct Ggx {
     float iorIn, iorOut;
     // values the reference recomputes in every call, hoisted (same expressions, same bits):
     float eta2;           // SQR(mIorOut / mIorIn), src/rlGgx.h:258
+    float etaIO;          // mIorIn / mIorOut (the eta of the refraction)
     float vn;             // dot(mViewDir, mAxisN)
     float g1v;            // G1(mViewDir, m, n) where it is not zero, src/rlGgx.h:353-356
 };
@@ -443,11 +449,15 @@ RLS_DEV Ggx ggx_make(V3 wo, V3 N, V3 T, bool exiting, float ksR, float ksG, floa
     g.fr.N = N;
     g.fr.U = T;
     g.fr.V = cross(N, T);
-    float aspect = R_SQRT(1.0f - anisotropic * 0.9f);
+    float aspect = R_SQRT1M(anisotropic * 0.9f);
     g.ax = maxf(1e-4f, R_DIV(sqr(roughness), aspect));
     g.ay = maxf(1e-4f, sqr(roughness) * aspect);
     g.rough = maxf(1e-5f, sqr(roughness));
-    g.eta2 = sqr(R_DIV(g.iorOut, g.iorIn));
+    // mIorOut / mIorIn (src/rlGgx.h:258) and mIorIn / mIorOut (refraction): one of the two iors is exactly 1, so one
+    // ratio is the other ior itself (x / 1 = x exactly) and the other its reciprocal; out >= 1e-4 (or it is 1e-4)
+    const float rout = R_RCPHI(out);
+    g.eta2 = sqr(exiting ? rout : out);
+    g.etaIO = exiting ? out : rout;
     g.vn = dot(wo, N);
     {
         float cosSqr = sqr(g.vn);
@@ -572,7 +582,7 @@ RLS_DEV float ggx_sample_weight(const Ggx &g, V3 i, V3 o, V3 m)
 RLS_DEV bool ggx_refract(const Ggx &g, V3 m, V3 &dir)
 {
     V3 i = g.view;
-    float eta = R_DIV(g.iorIn, g.iorOut);
+    float eta = g.etaIO;
     float c = dot(i, m);
     float k = 1.0f - eta * eta * (1.0f - c * c);
     bool refracted = !(k < 0.0f);
@@ -619,7 +629,7 @@ RLS_DEV Disney disney_make(V3 wo, V3 N, V3 T, float bR, float bG, float bB, cons
     d.fr.U = T;
     d.fr.V = cross(N, T);
 
-    float aspect = R_SQRT(1.0f - anisotropic * 0.9f);
+    float aspect = R_SQRT1M(anisotropic * 0.9f);
     d.ax = maxf(1e-2f, R_DIV(sqr(d.roughness), aspect));
     d.ay = maxf(1e-2f, sqr(d.roughness) * aspect);
     d.specRough = sqr(d.roughness);
@@ -723,7 +733,7 @@ RLS_DEV V3 disney_gtr1_microfacet(const Disney &d, float rx, float ry)
     float phiH = kTwoPi * rx;
     float a2 = sqr(d.roughness);
     float cosThetaH = a2 == 1.0f
-        ? R_SQRT(1.0f - ry)
+        ? R_SQRT1M(ry)
         : R_SQRT(R_DIV(1.0f - R_POW(a2, 1.0f - ry), 1.0f - a2));
     V3 omega = spherical_direction(cosThetaH, phiH);
     return normalize(to_frame(omega, d.fr.U, d.fr.V, d.fr.N));

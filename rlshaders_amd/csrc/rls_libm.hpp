@@ -130,6 +130,9 @@ RLM_FN float sqrt32(float x)
 #endif
 }
 RLM_FN float sqrt32_1p(float y) { return sqrt32<false>(1.0f + y); }   // sqrtf(1 + y)
+// sqrtf(1 - t): the difference is exact for t in [1/2, 2] (a multiple of ulp(t) >= 2^-25, or 0), at least 1/2 for smaller
+// t and negative beyond 2 -- never in (0, 2^-96) either, so no guard (all 2^32 arguments: tools/micro/exact1.hip)
+RLM_FN float sqrt32_1m(float t) { return sqrt32<false>(1.0f - t); }
 
 // Exactly rounded reciprocal.  v_rcp_f32 is accurate to 1 ulp; ONE Newton step e = 1 - x r, r' = r + e r (two fmas)
 // then rounds to the correctly rounded 1/x for EVERY x with 2^-126 <= |x| <= 2^126 -- checked by enumeration of all
@@ -723,7 +726,7 @@ RLM_FN float acos32_v(float x)
     const float r_mid = pio2_hi - (x - (pio2_lo - x * r));
     float res = r_mid;
     if (!mid) {
-        const float s = sqrt32(z);
+        const float s = sqrt32<false>(z);         // z = (1 -+ x) / 2: 0, >= 2^-26, or negative (|x| > 1 -> NaN)
         const float df = u2f(f2u(s) & 0xfffff000u);
         const float c = div32(z - df * df, s + df);
         const float r_pos = 2.0f * (df + (r * s + c));

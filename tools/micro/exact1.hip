@@ -83,6 +83,8 @@ __device__ __forceinline__ void eval(float x, float &got, float &ref)
         float B = rlm::tan32_v<false>(ok ? x : 1.0f);
         got = rlm::rcp32_w(B); ref = 1.0f / B;
     }
+    if (V == 15) { got = rlm::sqrt32_1m(x); ref = sqrtf(1.0f - x); }
+    if (V == 16) { float o = x > 1e-4f ? x : 1e-4f; got = rlm::rcp32_hi(o); ref = 1.0f / o; }          // 1 / max(ior, 1e-4)
     if (V == 12) { got = rlm::rcp32(x * x) - 1.0f; ref = 1.0f / (x * x) - 1.0f; }                     // tanSqr of G1
 }
 
@@ -139,6 +141,8 @@ int main()
     run<11>("2*rcp32_w(1+sqrt32_1p(y)) vs 2/(1+sqrtf(1+y))");
     run<12>("rcp32(x*x)-1 vs 1/(x*x)-1");
     run<13>("rcp32_hi(A*A-1) vs 1/(A*A-1)");
+    run<15>("sqrt32_1m(t) vs sqrtf(1-t)");
+    run<16>("rcp32_hi(max(ior,1e-4)) vs 1/max(ior,1e-4)");
     run<14>("rcp32_w(tanf(theta)) vs 1/tanf(theta), theta in {0} U [.0141, pi]");
     return 0;
 }

@@ -164,6 +164,25 @@ RLM_FN float rcp32(float x)
 #endif
 }
 
+// a / b inside the elementary functions below, where the denominator is a polynomial or sum that stays far inside
+// [2^-126, 2^126] for every argument whose result is not replaced afterwards: Markstein's short division -- the exactly
+// rounded reciprocal y (above), q0 = a y, the exact residual r = a - b q0, q = q0 + r y -- 6 instructions.  That it
+// rounds like IEEE division is not assumed from the theorem (q0 need not be faithful) but checked where it is used:
+// tools/libm_exhaustive.py runs atanf, acosf and tanf on all 2^32 arguments against the host libm.
+RLM_FN float div32_m(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RLS_NO_FAST_RCP)
+    float y = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, y, 1.0f);
+    y = __builtin_fmaf(e, y, y);
+    const float q0 = a * y;
+    const float r = __builtin_fmaf(-b, q0, a);
+    return __builtin_fmaf(r, y, q0);
+#else
+    return a / b;
+#endif
+}
+
 // rcp32 for arguments that are 0, NaN or at least 2^-126 in magnitude by construction: only the upper end is tested
 RLM_FN float rcp32_hi(float x)
 {
@@ -670,7 +689,7 @@ RLM_FN float atan32_v(float x)
     const float den = r0 ? 1.0f : r1 ? (2.0f + ax) : r2 ? (ax + 1.0f) : r3 ? (1.0f + 1.5f * ax) : ax;
     const float hi = r1 ? u2f(0x3eed6338u) : r2 ? u2f(0x3f490fdau) : r3 ? u2f(0x3f7b985eu) : u2f(0x3fc90fdau);
     const float lo = r1 ? u2f(0x31ac3769u) : r2 ? u2f(0x33222168u) : r3 ? u2f(0x33140fb4u) : u2f(0x33a22168u);
-    const float t = div32(num, den);
+    const float t = div32_m(num, den);          // den = 1 or in [1, 2^26]
     const float z = t * t;
     const float w = z * z;
     const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
@@ -722,13 +741,13 @@ RLM_FN float acos32_v(float x)
     const float z = mid ? x * x : (neg ? (1.0f + x) * 0.5f : (1.0f - x) * 0.5f);
     const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
     const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
-    const float r = div32(p, q);
+    const float r = div32_m(p, q);              // q in [0.3, 1.1] for z in [0, 1/2]
     const float r_mid = pio2_hi - (x - (pio2_lo - x * r));
     float res = r_mid;
     if (!mid) {
         const float s = sqrt32<false>(z);         // z = (1 -+ x) / 2: 0, >= 2^-26, or negative (|x| > 1 -> NaN)
         const float df = u2f(f2u(s) & 0xfffff000u);
-        const float c = div32(z - df * df, s + df);
+        const float c = div32_m(z - df * df, s + df);   // s + df >= 2^-12 (z >= 2^-26) unless |x| = 1, replaced below
         const float r_pos = 2.0f * (df + (r * s + c));
         const float r_neg = pi - 2.0f * (s + (r * s - pio2_lo));
         res = neg ? r_neg : r_pos;
@@ -840,7 +859,7 @@ RLM_FN float tan32_v(float xin)
     r += T0 * s;
     w = x + r;
     // one division: w*w/(w+iy) in the big case, -1/w when the cotangent is wanted
-    const float q = div32(big ? w * w : -1.0f, big ? w + fiy : w);
+    const float q = div32_m(big ? w * w : -1.0f, big ? w + fiy : w);   // w + fiy in [0.8, 1.2]; -1 / w is used for |w| >= 1e-8 only
     const float r_big = sgn * (fiy - 2.0f * (x - (q - r)));
     const float zt = u2f(f2u(w) & 0xfffff000u);
     const float vt = r - (zt - x);

@@ -319,6 +319,22 @@ RLS_DEV V2 uniform_slope(float rx, float ry)
     return slope;
 }
 
+// the rational fit of the inverse CDF in the second slope (src/rlGgx.cpp:52-56), u = 2 |ry - 1/2|
+RLS_DEV float slope_y_ratio(float u)
+{
+    const float num = u * (u * (u * 0.27385f - 0.73369f) + 0.46341f);
+    const float den = u * (u * (u * 0.093073f + 0.309420f) - 1.0f) + 0.597999f;
+#if RLS_FAST
+    return R_DIVH(num, den);
+#else
+    // for u in [0, 1] (ry in [0, 1]) the denominator falls from 0.598 to 4.9e-4: the short division of rls_libm.hpp
+    // rounds like IEEE division for every such u (all 2^32 bit patterns of ry: tools/micro/exact1.hip); other u
+    // (random numbers outside [0, 1], NaN) take the IEEE sequence
+    if (__builtin_expect(!(u <= 1.0f), 0)) return num / den;
+    return rlm::div32_m(num, den);
+#endif
+}
+
 // Per-sample part of sampleSlope + evalSample: src/rlGgx.cpp:36-60, 89-98.
 // vndf_slope_closed: the closed-form slopes (36-60); returns true where the reference takes the uniform fallback
 // instead (27: theta < eps, 38: |A^2 - 1| < eps) -- the slopes it writes are then unused.
@@ -340,8 +356,7 @@ RLS_DEV bool vndf_slope_closed(const VndfView &w, float rx, float ry, V2 &slope)
         sign = -1.0f;
         u = 2.0f * (0.5f - ry);
     }
-    float z = R_DIVH(u * (u * (u * 0.27385f - 0.73369f) + 0.46341f),
-                    u * (u * (u * 0.093073f + 0.309420f) - 1.0f) + 0.597999f);
+    float z = slope_y_ratio(u);
     slope.y = sign * z * R_SQRTH1P(sqr(slope.x));
     return w.nearNormal || absf(A2 - 1.0f) < kEps;
 }

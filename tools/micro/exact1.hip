@@ -85,6 +85,13 @@ __device__ __forceinline__ void eval(float x, float &got, float &ref)
     }
     if (V == 15) { got = rlm::sqrt32_1m(x); ref = sqrtf(1.0f - x); }
     if (V == 16) { float o = x > 1e-4f ? x : 1e-4f; got = rlm::rcp32_hi(o); ref = 1.0f / o; }          // 1 / max(ior, 1e-4)
+    if (V == 17) {                                                                                   // second-slope ratio, all ry
+        float u = x > 0.5f ? 2.0f * (x - 0.5f) : 2.0f * (0.5f - x);
+        const float num = u * (u * (u * 0.27385f - 0.73369f) + 0.46341f);
+        const float den = u * (u * (u * 0.093073f + 0.309420f) - 1.0f) + 0.597999f;
+        got = !(u <= 1.0f) ? num / den : rlm::div32_m(num, den);
+        ref = num / den;
+    }
     if (V == 12) { got = rlm::rcp32(x * x) - 1.0f; ref = 1.0f / (x * x) - 1.0f; }                     // tanSqr of G1
 }
 
@@ -142,6 +149,7 @@ int main()
     run<12>("rcp32(x*x)-1 vs 1/(x*x)-1");
     run<13>("rcp32_hi(A*A-1) vs 1/(A*A-1)");
     run<15>("sqrt32_1m(t) vs sqrtf(1-t)");
+    run<17>("slope ratio num(u)/den(u), u = 2|ry-1/2|: div32_m under u <= 1");
     run<16>("rcp32_hi(max(ior,1e-4)) vs 1/max(ior,1e-4)");
     run<14>("rcp32_w(tanf(theta)) vs 1/tanf(theta), theta in {0} U [.0141, pi]");
     return 0;

@@ -41,6 +41,7 @@ __global__ __launch_bounds__(rlsh::kBlock) void disney_kernel(DisneyIO a)
         const Idx i = make_idx(base);
         if (i.full() >= a.n) continue;
         Disney d = load_closure<STREAMED>(a.c, i);
+        disney_prepare(d);
         V3 L;
         if (OP == OP_SAMPLE || OP == OP_FUSED) {
             float rx = ldg(a.rx, i), ry = ldg(a.ry, i);
@@ -54,13 +55,11 @@ __global__ __launch_bounds__(rlsh::kBlock) void disney_kernel(DisneyIO a)
         } else {
             L = ld3(a.cwi, i);
         }
-        if (OP == OP_EVAL || OP == OP_FUSED) {
-            float r, g, b;
-            disney_eval<DIFFUSE>(d, L, r, g, b);
-            strgb(a.f, i, r, g, b);
-        }
-        if (OP == OP_PDF || OP == OP_FUSED) {
-            stg(a.pdf, i, disney_pdf<DIFFUSE>(d, L));
+        if (OP == OP_EVAL || OP == OP_PDF || OP == OP_FUSED) {
+            float r, g, b, pdf;
+            disney_eval_pdf<DIFFUSE, OP != OP_PDF, OP != OP_EVAL>(d, L, r, g, b, pdf);
+            if (OP != OP_PDF) strgb(a.f, i, r, g, b);
+            if (OP != OP_EVAL) stg(a.pdf, i, pdf);
         }
     }
 }

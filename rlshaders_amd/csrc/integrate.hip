@@ -26,6 +26,15 @@ using namespace rlsd;
 
 namespace {
 
+// Occupancy of the integrator kernels.  Left alone the register allocator takes 160-172 VGPRs (3 or 2 waves per SIMD,
+// changing with unrelated edits); these loops are chains of dependent arithmetic with LDS table reads in between, and
+// four waves hide that better than the extra registers help: measured 3 -> 4 waves: rlDisney 64 spp 102.7 -> 93.3 ms,
+// rlSkin shader_evaluate 107.3 -> 95.9 ms, the rlGgx light loop 25.6 -> 25.2 ms; 5, 6 and 8 are slower (spills).
+#ifndef RLS_INT_WAVES
+#define RLS_INT_WAVES 4
+#endif
+#define RLS_INT_ATTR __launch_bounds__(rlsh::kBlock) __attribute__((amdgpu_waves_per_eu(RLS_INT_WAVES, RLS_INT_WAVES)))
+
 constexpr int kMaxSpp = 256;   // spp_n <= 16
 
 // hash stream ids of the per-point scrambles (DESIGN.md "Synthetic inputs": streams 64..67)
@@ -91,7 +100,7 @@ using rlsh::GgxIntIO;
 using rlsh::DisneyIntIO;
 
 template <int G, int FAST_MATH = RLS_FAST>
-__global__ __launch_bounds__(rlsh::kBlock) void ggx_integrate_kernel(GgxIntIO a)
+__global__ RLS_INT_ATTR void ggx_integrate_kernel(GgxIntIO a)
 {
     __shared__ uint32_t tab[2][kMaxSpp];
     stage_table(tab, a.spp);
@@ -128,7 +137,7 @@ __global__ __launch_bounds__(rlsh::kBlock) void ggx_integrate_kernel(GgxIntIO a)
 // ---------------------------------------------------------------------------------------------
 
 template <int G, int FAST_MATH = RLS_FAST>
-__global__ __launch_bounds__(rlsh::kBlock) void disney_integrate_kernel(DisneyIntIO a)
+__global__ RLS_INT_ATTR void disney_integrate_kernel(DisneyIntIO a)
 {
     __shared__ uint32_t tab[2][kMaxSpp];
     stage_libm_tables();   // powf / logf tables -> LDS (EXACT mode)
@@ -151,6 +160,7 @@ __global__ __launch_bounds__(rlsh::kBlock) void disney_integrate_kernel(DisneyIn
         sc[6] = ldp(c.sheen, ii); sc[7] = ldp(c.sheen_tint, ii); sc[8] = ldp(c.clearcoat, ii);
         sc[9] = ldp(c.clearcoat_gloss, ii);
         Disney d = disney_make(wo, N, T, br, bg, bb, sc);
+        disney_prepare(d);        // what evalBrdf / evalPdf / evalSample recompute per call from the closure alone
         VndfView w = vndf_view(d.view, d.fr, d.ax, d.ay);
         const uint32_t dx = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream);
         const uint32_t dy = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream + 1);
@@ -164,9 +174,8 @@ __global__ __launch_bounds__(rlsh::kBlock) void disney_integrate_kernel(DisneyIn
             {
                 float rx = bits_u01(tab[0][s] ^ dx), ry = bits_u01(tab[1][s] ^ dy);
                 V3 L = cosine_hemisphere(d.fr, rx, ry);
-                float r, g, b;
-                disney_eval<true>(d, L, r, g, b);
-                float pdf = disney_pdf<true>(d, L);
+                float r, g, b, pdf;
+                disney_eval_pdf<true, true, true>(d, L, r, g, b, pdf);
                 if (pdf > kEps) { dR += r / pdf; dG += g / pdf; dB += b / pdf; dC += 1.0f; }
                 if (a.streamed && live) {
                     int64_t o = (int64_t)s * a.n + i;
@@ -177,9 +186,8 @@ __global__ __launch_bounds__(rlsh::kBlock) void disney_integrate_kernel(DisneyIn
             {
                 float rx = bits_u01(tab[0][s] ^ sx), ry = bits_u01(tab[1][s] ^ sy);
                 V3 L = disney_sample_specular(d, w, rx, ry);
-                float r, g, b;
-                disney_eval<false>(d, L, r, g, b);
-                float pdf = disney_pdf<false>(d, L);
+                float r, g, b, pdf;
+                disney_eval_pdf<false, true, true>(d, L, r, g, b, pdf);
                 if (pdf > kEps) { sR += r / pdf; sG += g / pdf; sB += b / pdf; sC += 1.0f; }   // :309
                 if (a.streamed && live) {
                     int64_t o = ((int64_t)a.spp + s) * a.n + i;
@@ -305,7 +313,7 @@ __device__ __forceinline__ void scatter_loop(const NdProfile &p, const Frame &fr
 }
 
 template <int G, int FAST_MATH = RLS_FAST>
-__global__ __launch_bounds__(rlsh::kBlock) void sss_scatter_kernel(ScatterIO a)
+__global__ RLS_INT_ATTR void sss_scatter_kernel(ScatterIO a)
 {
     __shared__ uint32_t tab[2][kMaxSpp];
     stage_libm_tables();
@@ -348,7 +356,7 @@ __global__ __launch_bounds__(rlsh::kBlock) void sss_scatter_kernel(ScatterIO a)
 using rlsh::SkinIntIO;
 
 template <int G, int FAST_MATH = RLS_FAST>
-__global__ __launch_bounds__(rlsh::kBlock) void skin_integrate_kernel(SkinIntIO a)
+__global__ RLS_INT_ATTR void skin_integrate_kernel(SkinIntIO a)
 {
     __shared__ uint32_t tab[2][kMaxSpp];
     stage_libm_tables();
@@ -443,7 +451,7 @@ __global__ __launch_bounds__(rlsh::kBlock) void skin_integrate_kernel(SkinIntIO 
 using rlsh::RefractIntIO;
 
 template <int G, int FAST_MATH = RLS_FAST>
-__global__ __launch_bounds__(rlsh::kBlock) void ggx_refract_integrate_kernel(RefractIntIO a)
+__global__ RLS_INT_ATTR void ggx_refract_integrate_kernel(RefractIntIO a)
 {
     __shared__ uint32_t tab[2][kMaxSpp];
     stage_table(tab, a.spp);
@@ -496,7 +504,7 @@ __global__ __launch_bounds__(rlsh::kBlock) void ggx_refract_integrate_kernel(Ref
 using rlsh::LightIO;
 
 template <int G, int FAST_MATH = RLS_FAST>
-__global__ __launch_bounds__(rlsh::kBlock) void ggx_direct_kernel(LightIO a)
+__global__ RLS_INT_ATTR void ggx_direct_kernel(LightIO a)
 {
     __shared__ uint32_t tab[2][kMaxSpp];
     stage_table(tab, a.spp);

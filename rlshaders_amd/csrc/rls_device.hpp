@@ -621,6 +621,15 @@ struct Disney {
     float roughness, subsurface, metallic, clearcoat, clearcoatGloss;
     float specRough;              // mSpecularRoughness
     float ax, ay;
+    // Per-point values of expressions the reference re-evaluates in every evalBrdf / evalPdf / evalSample call
+    // (same expressions on the same operands, so the same bits), filled by disney_prepare():
+    float vn;                     // dot(mViewDir, mAxisN)
+    float FV;                     // powf(clamp(1 - vn), 5), src/rlDisney.cpp:221
+    float gsV, grV;               // smithG_GGX(vn, mSpecularRoughness), smithG_GGX(vn, 0.25), src/rlDisney.cpp:345,350
+    float ccA2m1, ccLogA2;        // D_GTR1: a2 - 1 and logf(a2), a = LERP(gloss, .1, .001), src/rlDisney.cpp:547-549
+    float ccw, vnc;               // evalSpecularPdf: clearcoat / (clearcoat + 1), max(1e-4, vn), src/rlDisney.cpp:529,533
+    float gtr2Weight;             // sampleSpecularDirection: 1 / (clearcoat + 1), src/rlDisney.cpp:371
+    float om;                     // 1 - metallic
 };
 
 // s: subsurface, metallic, specular, specular_tint, roughness, anisotropic, sheen, sheen_tint,
@@ -686,6 +695,31 @@ RLS_DEV float D_GTR2Aniso(const Disney &d, V3 m, float mn2)
     float hv = dot(m, d.fr.V);
     float den = d.ax * d.ay * sqr(sqr(R_DIV(hu, d.ax)) + sqr(R_DIV(hv, d.ay)) + mn2);
     return R_DIV(kInvPi, den);
+}
+
+// D_GTR1 with the per-point part (alpha, a2, logf(a2)) taken from disney_prepare(): the same operations
+RLS_DEV float D_GTR1_prepared(const Disney &d, float mn2)
+{
+    float den = d.ccLogA2 * (1.0f + d.ccA2m1 * mn2);
+    return R_DIV(d.ccA2m1 * kInvPi, den);
+}
+
+// Everything the per-sample verbs compute from the closure alone.  Needs the libm tables (powf, logf): kernels call
+// stage_libm_tables() first.
+RLS_DEV void disney_prepare(Disney &d)
+{
+    d.vn = dot(d.view, d.fr.N);
+    d.FV = R_POW(clampf(1.0f - d.vn, 0.0f, 1.0f), 5.0f);
+    d.gsV = smithG_GGX(d.vn, d.specRough);
+    d.grV = smithG_GGX(d.vn, 0.25f);
+    float alpha = lerpf(d.clearcoatGloss, 0.1f, 0.001f);
+    float a2 = sqr(alpha);
+    d.ccA2m1 = a2 - 1.0f;
+    d.ccLogA2 = R_LOG(a2);
+    d.ccw = R_DIV(d.clearcoat, d.clearcoat + 1.0f);
+    d.vnc = maxf(1e-4f, d.vn);
+    d.gtr2Weight = R_RCP(d.clearcoat + 1.0f);
+    d.om = 1.0f - d.metallic;
 }
 
 // evalDiffuse, src/rlDisney.cpp:199-236 (BRDF without the cosine)
@@ -820,7 +854,7 @@ RLS_DEV float gauss_pdf(const GaussProfile &g, float r) { return R_DIV(gauss_pro
 RLS_DEV V3 disney_sample_specular(const Disney &d, const VndfView &w, float rx, float ry)
 {
     V3 M;
-    float gtr2Weight = R_RCP(d.clearcoat + 1.0f);
+    float gtr2Weight = d.gtr2Weight;                 // disney_prepare()
     if (rx < gtr2Weight) {
         rx = R_DIV(rx, gtr2Weight);
         M = vndf_microfacet(w, d.fr, rx, ry);
@@ -865,6 +899,69 @@ RLS_DEV float disney_pdf(const Disney &d, V3 L)
 {
     if (is_zero(L)) return 0.0f;
     return DIFFUSE ? disney_diffuse_pdf(d, L) : disney_specular_pdf(d, L);
+}
+
+// evalBrdf and evalPdf of one direction in one go, on a prepared closure (disney_prepare): what the two verbs share
+// -- the half vector normalize(L + V), D_GTR2Aniso and D_GTR1 of it -- is computed once, what depends on the closure
+// only comes from the Disney struct.  Every value is the one the separate verbs compute.
+template <bool DIFFUSE, bool WANT_F, bool WANT_PDF>
+RLS_DEV void disney_eval_pdf(const Disney &d, V3 L, float &r, float &g, float &b, float &pdf)
+{
+    r = 0.0f; g = 0.0f; b = 0.0f; pdf = 0.0f;
+    if (is_zero(L)) return;                                          // src/rlDisney.cpp:124-127,141-144
+    const float ln = dot(L, d.fr.N);                                 // == dot(N, L) of evalBrdf (136)
+    const float vn = d.vn;
+    // evalBrdf multiplies whatever evalDiffuse / evalSpecular return by N.L (136): their early "black" comes out as
+    // 0 * N.L -- -0 below the horizon, NaN for a NaN direction -- and so it does here
+    if (WANT_F) { r = 0.0f * ln; g = r; b = r; }
+    if (DIFFUSE) {
+        if (WANT_PDF) pdf = maxf(1e-4f, ln * kInvPi);                // evalDiffusePdf, 515-518
+        if (!WANT_F || ln < kEps || vn < kEps) return;
+        V3 H = normalize(L + d.view);
+        float lh = dot(L, H);
+        float vh = dot(d.view, H);
+        if (vh < kEps || lh < kEps) return;
+        float lh2 = sqr(lh);
+        float FL = R_POW(clampf(1.0f - ln, 0.0f, 1.0f), 5.0f);
+        float FV = d.FV;
+        float F90 = 0.5f + 2.0f * d.roughness * lh2;
+        float diffuseFactor = lerpf(FL, 1.0f, F90) * lerpf(FV, 1.0f, F90);
+        float Fss90 = d.roughness * lh2;
+        float Fss = lerpf(FL, 1.0f, Fss90) * lerpf(FV, 1.0f, Fss90);
+        float ssFactor = 1.25f * (Fss * (R_RCP(ln + vn) - 0.5f) + 0.5f);
+        float mix = lerpf(d.subsurface, diffuseFactor, ssFactor);
+        r = d.baseR * kInvPi * mix * d.om * ln;
+        g = d.baseG * kInvPi * mix * d.om * ln;
+        b = d.baseB * kInvPi * mix * d.om * ln;
+        return;
+    }
+    V3 M = normalize(L + d.view);                                    // 325 and 527: the same vector
+    const float lm = dot(L, M);
+    const float nm = dot(d.fr.N, M);
+    const float nm2 = sqr(nm);
+    const float Ds = D_GTR2Aniso(d, M, nm2);
+    const float Dr = D_GTR1_prepared(d, nm2);
+    if (WANT_PDF && !(nm < 0.0f)) {                                  // evalSpecularPdf, 520-543
+        float im = absf(lm);
+        float Dw = R_DIV(smithG_GGX(im, d.specRough) * Ds * 2.0f * im, d.vnc);
+        float D = lerpf(d.ccw, Dw, R_DIV(Dr * absf(nm), im));
+        pdf = D * 0.25f;
+    }
+    if (WANT_F) {                                                    // evalSpecular, 318-356
+        if (ln < kEps || vn < kEps) return;
+        if (nm < kEps || lm < kEps) return;
+        float FH = R_POW(clampf(1.0f - lm, 0.0f, 1.0f), 5.0f);
+        float FsR = lerpf(FH, d.f0R, 1.0f);
+        float FsG = lerpf(FH, d.f0G, 1.0f);
+        float FsB = lerpf(FH, d.f0B, 1.0f);
+        float Gs = smithG_GGX(ln, d.specRough) * d.gsV;
+        float Fr = lerpf(FH, 0.04f, 1.0f);
+        float Gr = smithG_GGX(ln, 0.25f) * d.grV;
+        float cc = d.clearcoat * Dr * Fr * Gr;
+        r = ((Ds * FsR * Gs + cc) + FH * d.shR * d.om) * ln;
+        g = ((Ds * FsG * Gs + cc) + FH * d.shG * d.om) * ln;
+        b = ((Ds * FsB * Gs + cc) + FH * d.shB * d.om) * ln;
+    }
 }
 
 // ---- rlSss: NDProfile, src/rlSss.h:27-61, src/rlSss.cpp:20-106 ---------------------------------

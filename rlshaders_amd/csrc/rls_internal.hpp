@@ -186,12 +186,13 @@ rls_status hip_fail(hipError_t e, const char *what);
 #endif
 constexpr int kBlock = RLS_BLOCK;   // 4 wavefronts of 64
 
-// occupancy hint for the closure kernels (waves per SIMD the register allocator must allow)
-#ifdef RLS_WAVES_PER_EU
-#define RLS_KERNEL_ATTR __launch_bounds__(rlsh::kBlock) __attribute__((amdgpu_waves_per_eu(RLS_WAVES_PER_EU, RLS_WAVES_PER_EU)))
-#else
-#define RLS_KERNEL_ATTR __launch_bounds__(rlsh::kBlock)
+// occupancy of the rlGgx kernels (waves per SIMD the register allocator must allow).  Left alone the reflect+refract
+// kernel takes 72 VGPRs (7 waves) and keeps its 31 plane pointers alive by spilling scalar registers into vector
+// lanes; at 6 waves (up to 80 VGPRs) it runs 1.8 % faster, at 4 or 8 slower (2.285 / 2.244 / 2.38 / 2.36 ms, one box)
+#ifndef RLS_WAVES_PER_EU
+#define RLS_WAVES_PER_EU 6
 #endif
+#define RLS_KERNEL_ATTR __launch_bounds__(rlsh::kBlock) __attribute__((amdgpu_waves_per_eu(RLS_WAVES_PER_EU, RLS_WAVES_PER_EU)))
 
 // Pointwise streaming launches: enough workgroups to fill 256 CUs several times over, capped so
 // that very large batches grid-stride instead of queueing millions of workgroups.

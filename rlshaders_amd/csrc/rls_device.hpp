@@ -1041,6 +1041,29 @@ RLS_DEV void nd_profile(const NdProfile &p, float r, float &R, float &G, float &
     R = out[0]; G = out[1]; B = out[2];
 }
 
+// getPdf and evalProfile at the same radius (the probe-ray sample of rlSss / rlSkin asks for both): e^(-r / d_i) is one
+// value in both -- getPdf divides by max(d_i, AI_EPSILON), evalProfile by d_i and only when d_i >= AI_EPSILON -- so
+// the three divisions and exponentials are done once.  Same results as nd_pdf() and nd_profile().
+RLS_DEV void nd_pdf_profile(const NdProfile &p, float r, float &pdf, float &R, float &G, float &B)
+{
+    if (p.maxR < kEps) { pdf = 1.0f; R = 0.0f; G = 0.0f; B = 0.0f; return; }
+    const float denom = 8.0f * kPi * r;
+    float acc = 0.0f;
+    float out[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float d = maxf(p.d[i], kEps);
+        const float q = R_DIV(-r, d);
+        const float p1 = R_EXP(q);
+        const float p2 = R_EXP(R_DIV(q, 3.0f));
+        acc += R_DIV(R_DIV(p1 + p2, d), p.c1[i] + p.c2[i] * 3.0f);
+        out[i] = p.d[i] < kEps ? 1.0f : R_DIV(p1 + R_EXP(R_DIV(-r, 3.0f * p.d[i])), denom * p.d[i]);
+    }
+    pdf = R_DIV(acc, kTwoPi * r * 3.0f);
+    const bool white = r < kEps;
+    R = white ? 1.0f : out[0]; G = white ? 1.0f : out[1]; B = white ? 1.0f : out[2];
+}
+
 // SssSampler frame, src/rlSss.h:149-158
 RLS_DEV Frame sss_frame(V3 Ns, V3 t, bool has_dPdu)
 {

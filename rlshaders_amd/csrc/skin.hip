@@ -86,8 +86,7 @@ __global__ __launch_bounds__(rlsh::kBlock) void skin_kernel(SkinIO a)
             V3 off, dir;
             float maxdist;
             r = sss_probe_ray(p, fr, rx2, ry2, off, dir, maxdist);
-            rpdf = nd_pdf(p, r);
-            nd_profile(p, r, R, G, B);
+            nd_pdf_profile(p, r, rpdf, R, G, B);
         }
 
         const rls_skin_out &o = a.o;

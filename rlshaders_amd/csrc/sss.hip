@@ -40,10 +40,10 @@ __global__ __launch_bounds__(rlsh::kBlock) void sss_kernel(SssIO a)
         NdProfile p = load_profile(a.c, i);
         if (OP == OP_ND) {
             float r = nd_radius(p, ldg(a.rx, i));
-            float R, G, B;
-            nd_profile(p, r, R, G, B);
+            float pdf, R, G, B;
+            nd_pdf_profile(p, r, pdf, R, G, B);
             stg(a.r, i, r);
-            stg(a.pdf, i, nd_pdf(p, r));
+            stg(a.pdf, i, pdf);
             strgb(a.profile, i, R, G, B);
         } else if (OP == OP_ND_PDF) {
             stg(a.pdf, i, nd_pdf(p, ldg(a.rin, i)));
@@ -57,13 +57,13 @@ __global__ __launch_bounds__(rlsh::kBlock) void sss_kernel(SssIO a)
             float maxdist;
             float r = sss_probe_ray(p, fr, ldg(a.rx, i), ldg(a.ry, i), off, dir, maxdist);
             if (a.P.x) off = ld3(a.P, i) + off;                       // ray.origin = origin + offset
-            float R, G, B;
-            nd_profile(p, r, R, G, B);
+            float pdf, R, G, B;
+            nd_pdf_profile(p, r, pdf, R, G, B);
             stg(a.r, i, r);
             st3(a.origin, i, off);
             st3(a.dir, i, dir);
             stg(a.maxdist, i, maxdist);
-            stg(a.pdf, i, nd_pdf(p, r));
+            stg(a.pdf, i, pdf);
             strgb(a.profile, i, R, G, B);
         } else if (OP == OP_MIS) {
             Frame fr = sss_frame(ld3(a.c.N, i), ld3(a.c.T, i), a.c.has_dPdu != 0);

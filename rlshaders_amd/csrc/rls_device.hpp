@@ -96,6 +96,7 @@ RLS_DEV float refined_div(float a, float b)
 #define R_RCPH(b) refined_div(1.0f, b)
 #define R_RCPG(b) refined_div(1.0f, b)
 #define R_RCPHI(b) __builtin_amdgcn_rcpf(b)
+#define R_DIVC(x, C) ((x) * (1.0f / (C)))
 #define R_SQRTH(x) rlm::sqrt32(x)
 #define R_SQRT1P(y) __builtin_amdgcn_sqrtf(1.0f + (y))
 #define R_SQRT1M(t) __builtin_amdgcn_sqrtf(1.0f - (t))
@@ -114,6 +115,8 @@ RLS_DEV void stage_libm_tables() {}
 #define R_SQRT(x) rlm::sqrt32(x)
 #define R_DIVH(a, b) rlm::div32((a), (b))
 #define R_RCPH(b) rlm::rcp32_w(b)            // of a square root (normalize_h)
+// x / C, C one of the compile-time constants checked in tools/micro/exact1.hip (3, 0.3333, 1 - 0.6666, 0.6666 - 0.3333)
+#define R_DIVC(x, C) rlm::div32_const((x), (C), 1.0f / (C))
 #define R_RCPHI(b) rlm::rcp32_hi(b)          // 1 / x for x that is 0, NaN or >= 2^-126 in magnitude by construction
 #define R_RCPG(b) rlm::rcp32_hi(b)           // of A^2 - 1: 0 or >= 2^-24 in magnitude (A^2 is near 1 or far from it), unbounded above
 #define R_SQRTH(x) rlm::sqrt32(x)
@@ -978,7 +981,7 @@ RLS_DEV NdProfile nd_make(float dx, float dy, float dz)
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         p.c1[i] = 1.0f - R_EXP(R_DIV(-p.maxR, p.d[i]));
-        p.c2[i] = 1.0f - R_EXP(R_DIV(R_DIV(-p.maxR, p.d[i]), 3.0f));
+        p.c2[i] = 1.0f - R_EXP(R_DIVC(R_DIV(-p.maxR, p.d[i]), 3.0f));
     }
     return p;
 }
@@ -988,14 +991,15 @@ RLS_DEV float nd_radius(const NdProfile &p, float rx)
 {
     if (p.maxR < kEps) return 0.0f;
     float d, w1, w2;
+    // LINEARSTEP(lo, hi, t) = CLAMP((t - lo) / (hi - lo), 0, 1) with constant bounds: division by a constant
     if (rx < 0.3333f) {
-        rx = linearstep(0.0f, 0.3333f, rx);
+        rx = clampf(R_DIVC(rx - 0.0f, 0.3333f - 0.0f), 0.0f, 1.0f);
         d = p.d[0]; w1 = p.c1[0]; w2 = p.c2[0];
     } else if (rx > 0.6666f) {
-        rx = linearstep(0.6666f, 1.0f, rx);
+        rx = clampf(R_DIVC(rx - 0.6666f, 1.0f - 0.6666f), 0.0f, 1.0f);
         d = p.d[2]; w1 = p.c1[2]; w2 = p.c2[2];
     } else {
-        rx = linearstep(0.3333f, 0.6666f, rx);
+        rx = clampf(R_DIVC(rx - 0.3333f, 0.6666f - 0.3333f), 0.0f, 1.0f);
         d = p.d[1]; w1 = p.c1[1]; w2 = p.c2[1];
     }
     if (d < kEps) return 0.0f;
@@ -1020,7 +1024,7 @@ RLS_DEV float nd_pdf(const NdProfile &p, float r)
     for (int i = 0; i < 3; i++) {
         float d = maxf(p.d[i], kEps);
         float p1 = R_EXP(R_DIV(-r, d));
-        float p2 = R_EXP(R_DIV(R_DIV(-r, d), 3.0f));
+        float p2 = R_EXP(R_DIVC(R_DIV(-r, d), 3.0f));
         pdf += R_DIV(R_DIV(p1 + p2, d), p.c1[i] + p.c2[i] * 3.0f);
     }
     return R_DIV(pdf, kTwoPi * r * 3.0f);
@@ -1055,7 +1059,7 @@ RLS_DEV void nd_pdf_profile(const NdProfile &p, float r, float &pdf, float &R, f
         const float d = maxf(p.d[i], kEps);
         const float q = R_DIV(-r, d);
         const float p1 = R_EXP(q);
-        const float p2 = R_EXP(R_DIV(q, 3.0f));
+        const float p2 = R_EXP(R_DIVC(q, 3.0f));
         acc += R_DIV(R_DIV(p1 + p2, d), p.c1[i] + p.c2[i] * 3.0f);
         out[i] = p.d[i] < kEps ? 1.0f : R_DIV(p1 + R_EXP(R_DIV(-r, 3.0f * p.d[i])), denom * p.d[i]);
     }

@@ -183,6 +183,23 @@ RLM_FN float div32_m(float a, float b)
 #endif
 }
 
+// x / C for a compile-time constant C: the short division with the reciprocal rounded at compile time, 3 instructions
+// for 2^-100 <= |x| <= 2^100 (the residual x - C q0 is then exact), IEEE division outside (zeros included: the
+// sign of -0 / C would be lost).  Used for the constants
+// tools/micro/exact1.hip has run over all 2^32 numerators: 3, 0.3333, 1 - 0.6666, 0.6666 - 0.3333.
+RLM_FN float div32_const(float x, float c, float rc)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RLS_NO_FAST_RCP)
+    if (__builtin_expect(!(__builtin_fabsf(x) >= 0x1p-100f && __builtin_fabsf(x) <= 0x1p100f), 0)) return x / c;   // 0, NaN too
+    const float q0 = x * rc;
+    const float r = __builtin_fmaf(-c, q0, x);
+    return __builtin_fmaf(r, rc, q0);
+#else
+    (void)rc;
+    return x / c;
+#endif
+}
+
 // rcp32 for arguments that are 0, NaN or at least 2^-126 in magnitude by construction: only the upper end is tested
 RLM_FN float rcp32_hi(float x)
 {

@@ -84,3 +84,57 @@ def test_sss_hostile_inputs(gpu, oracle):
     got = {k: host(v) for k, v in s.getProbeRay(dev(x[0]), dev(x[1])).items()}
     for k in ("r", "origin", "dir", "maxdist", "pdf", "profile"):
         _same(got[k], ref[k], f"sss probe {k}")
+
+
+def test_skin_hostile_inputs(gpu, oracle):
+    rng = np.random.default_rng(14)
+    c = cases.skin_mixed(cases.SEED_EDGE, N)
+    x = _poison(cases.xi(cases.SEED_EDGE, N, 6), rng)
+    for k in ("wo", "N", "T"):
+        c[k] = _poison(c[k], rng)
+    p = {k: _poison(v, rng) for k, v in c["params"].items()}
+    ref = oracle.skin(c["wo"], c["N"], c["T"], p, x, nthreads=4)
+    sk = R.SkinShader(gpu, dev(c["wo"]), dev(c["N"]), dev(c["T"]), **{k: dev(v) for k, v in p.items()})
+    got = {k: host(v) for k, v in sk.sampleEvalPdf(dev(x)).items()}
+    for k in ref:
+        _same(got[k], ref[k], f"skin {k}")
+
+
+def test_integrators_hostile_inputs(gpu, oracle):
+    """the n^2-spp integrators with one lane per point (the reference's summation order): rlGgx glossy and refraction,
+    rlDisney both lobes, rlSkin's shader_evaluate"""
+    import os
+    n, spp_n, seed = 1 << 12, 2, 5
+    rng = np.random.default_rng(15)
+    os.environ["RLS_INTEGRATE_GROUP"] = "1"
+    try:
+        c = cases.ggx_mixed(cases.SEED_EDGE, n)
+        for k in ("wo", "N", "T", "roughness", "ior", "anisotropic", "KsColor"):
+            c[k] = _poison(c[k], rng)
+        og, s = ggx_oracle(oracle, c, nthreads=4), ggx_sampler(gpu, c)
+        for nm, a, b in zip(("sum", "avg"), [host(t) for t in s.integrate(spp_n, seed)], og.integrate(spp_n, seed)):
+            _same(a, b, f"ggx integrate {nm}")
+        for traced in (True, False):
+            got = [host(t) for t in s.integrateRefract(spp_n, seed, traced=traced, want_tir=True)]
+            for nm, a, b in zip(("result", "tir"), got, og.integrate_refract(spp_n, seed, traced=traced)):
+                _same(a, b, f"integrateRefract {traced} {nm}")
+        d = cases.disney_mixed(cases.SEED_EDGE, n)
+        for k in ("wo", "N", "T", "base_color", "roughness", "metallic", "clearcoat", "clearcoat_gloss", "subsurface"):
+            d[k] = _poison(d[k], rng)
+        ref = disney_oracle(oracle, d).integrate(spp_n, seed)
+        got = {k: host(v) for k, v in disney_sampler(gpu, d).integrate(spp_n, seed).items()}
+        for k in ref:
+            _same(got[k], ref[k], f"disney integrate {k}")
+        sk = cases.skin_mixed(cases.SEED_EDGE, n)
+        for k in ("wo", "N", "T"):
+            sk[k] = _poison(sk[k], rng)
+        p = {k: _poison(v, rng) for k, v in sk["params"].items()}
+        kw = dict(geometry="sphere", sphere_radius=1.0, light_dir=(0.0, 0.6, 0.8), use_cavity_fade=True)
+        P = _poison(sk["N"], rng)
+        ref = oracle.skin_integrate(sk["wo"], sk["N"], sk["T"], p, P, oracle.make_scene(**kw), spp_n, seed, nthreads=4)
+        shader = R.SkinShader(gpu, dev(sk["wo"]), dev(sk["N"]), dev(sk["T"]), **{k: dev(v) for k, v in p.items()})
+        got = {k: host(v) for k, v in shader.integrate(dev(P), R.make_scene(**kw), spp_n, seed).items()}
+        for k in ref:
+            _same(got[k], ref[k], f"skin integrate {k}")
+    finally:
+        del os.environ["RLS_INTEGRATE_GROUP"]

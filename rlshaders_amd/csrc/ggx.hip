@@ -31,6 +31,8 @@ __device__ __forceinline__ Ggx load_closure(const rls_ggx_closure &c, Idx i)
 template <int OP, int FAST_MATH, bool STREAMED>
 __global__ RLS_KERNEL_ATTR void ggx_kernel(GgxIO a)
 {
+    if (OP == OP_SAMPLE || OP == OP_FUSED || OP == OP_REFLECT_REFRACT || OP == OP_REFRACT || OP == OP_MICROFACET)
+        stage_libm_tables();   // the range table of atanf -> LDS (visible-normal sampling calls atan2f twice)
     const TileRange tiles = tile_range(a.n);
     for (int64_t base = tiles.first; base < tiles.end; base += tiles.step) {
         const Idx i = make_idx(base);

@@ -103,6 +103,7 @@ template <int G, int FAST_MATH = RLS_FAST>
 __global__ RLS_INT_ATTR void ggx_integrate_kernel(GgxIntIO a)
 {
     __shared__ uint32_t tab[2][kMaxSpp];
+    stage_libm_tables();   // atanf range table (+ expf / logf / powf tables) -> LDS
     stage_table(tab, a.spp);
     const int sub = threadIdx.x % G;
     const int64_t groups_per_block = rlsh::kBlock / G;
@@ -454,6 +455,7 @@ template <int G, int FAST_MATH = RLS_FAST>
 __global__ RLS_INT_ATTR void ggx_refract_integrate_kernel(RefractIntIO a)
 {
     __shared__ uint32_t tab[2][kMaxSpp];
+    stage_libm_tables();   // atanf range table (+ expf / logf / powf tables) -> LDS
     stage_table(tab, a.spp);
     const int sub = threadIdx.x % G;
     const int64_t groups_per_block = rlsh::kBlock / G;
@@ -507,6 +509,7 @@ template <int G, int FAST_MATH = RLS_FAST>
 __global__ RLS_INT_ATTR void ggx_direct_kernel(LightIO a)
 {
     __shared__ uint32_t tab[2][kMaxSpp];
+    stage_libm_tables();   // atanf range table (+ expf / logf / powf tables) -> LDS
     stage_table(tab, a.spp);
     const int mode = a.light.mis_mode;
     const V3 center = arr3(a.light.center);

@@ -146,7 +146,11 @@ RLS_DEV void stage_libm_tables()
 // caller-supplied random numbers (2 pi xi); full domain, so that even numbers outside [0, 1) give what the CPU gives.
 RLS_DEV void t_sincos(float x, float *s, float *c) { rlm::sincos32_v<false>(x, s, c); }
 RLS_DEV void t_sincos_any(float x, float *s, float *c) { rlm::sincos32_v<true>(x, s, c); }
+#ifdef RLS_ATAN_SELECTS   // experiment switch: range constants by selects instead of the LDS table
 RLS_DEV float t_atan2(float y, float x) { return rlm::atan2_32_v(y, x); }
+#else
+RLS_DEV float t_atan2(float y, float x) { return rlm::atan2_32_t(y, x, s_libm_tables); }
+#endif
 RLS_DEV float t_acos(float x) { return rlm::acos32_v(x); }
 RLS_DEV float t_tan(float x) { return rlm::tan32_v<false>(x); }
 #endif

@@ -512,11 +512,18 @@ RLM_FN float tan32(float x)
 // =================================================================================================
 #include "rls_libm_tables.inc"
 
+// atan_k: the four reduction ranges of fdlibm's atanf beyond |x| < 7/16, one row each: t = (A|x| + B) / (C|x| + D),
+// atanhi, atanlo (s_atanf.c).  Row k is 7/16 <= |x| < 11/16, < 19/16, < 39/16, >= 39/16.
 struct Tables {
     uint64_t exp2t[32];
     double invc[16], logc[16], log2c[16];
+    float atan_k[4][8];
 };
-#define RLM_TABLES_INIT { RLM_EXP2_TABLE, RLM_LOG_INVC, RLM_LOG_LOGC, RLM_LOG_LOG2C }
+#define RLM_ATAN_K { { 2.0f, -1.0f, 1.0f, 2.0f, 0x1.dac670p-2f, 0x1.586ed2p-28f, 0.0f, 0.0f }, \
+                     { 1.0f, -1.0f, 1.0f, 1.0f, 0x1.921fb4p-1f, 0x1.4442d0p-25f, 0.0f, 0.0f }, \
+                     { 1.0f, -1.5f, 1.5f, 1.0f, 0x1.f730bcp-1f, 0x1.281f68p-25f, 0.0f, 0.0f }, \
+                     { 0.0f, -1.0f, 1.0f, 0.0f, 0x1.921fb4p+0f, 0x1.4442d0p-24f, 0.0f, 0.0f } }
+#define RLM_TABLES_INIT { RLM_EXP2_TABLE, RLM_LOG_INVC, RLM_LOG_LOGC, RLM_LOG_LOG2C, RLM_ATAN_K }
 
 RLM_FN uint64_t d2u(double x)
 {
@@ -740,6 +747,58 @@ RLM_FN float atan2_32_v(float y, float x)
     // y == +-0: +-0 for x >= 0 (sign of y), +-pi for x < 0
     res = (iy == 0) ? (hx < 0 ? (hy < 0 ? -pi : pi) : y) : res;
     // x == +-0, y != 0
+    res = (ix == 0 && iy != 0) ? (hy < 0 ? -pi_o_2 : pi_o_2) : res;
+    return res;
+}
+
+// The same atanf with the per-range constants read from a table (LDS on the device) instead of selected: the lanes of
+// a wavefront fall into all five ranges, and choosing numerator, denominator, atanhi and atanlo took 16 selects on
+// top of computing every candidate.  num = A|x| + B and den = C|x| + D are the same operations as the written forms
+// (2|x| - 1, |x| - 1.5, 1 + 1.5|x| ...: a product that is exact or the very product of the original, then one
+// addition), so the quotient is the same; all 2^32 arguments: tools/libm_exhaustive.py (atan2f(y, 1) slice).
+RLM_FN float atan32_t(float x, const Tables &tab)
+{
+    const float aT0 = u2f(0x3eaaaaabu), aT1 = u2f(0xbe4ccccdu), aT2 = u2f(0x3e124925u), aT3 = u2f(0xbde38e38u),
+                aT4 = u2f(0x3dba2e6eu), aT5 = u2f(0xbd9d8795u), aT6 = u2f(0x3d886b35u), aT7 = u2f(0xbd6ef16bu),
+                aT8 = u2f(0x3d4bda59u), aT9 = u2f(0xbd15a221u), aT10 = u2f(0x3c8569d7u);
+    const int32_t hx = (int32_t)f2u(x);
+    const int32_t ix = hx & 0x7fffffff;
+    const float ax = fabs32(x);
+    const bool r0 = ix < 0x3ee00000;      // |x| < 7/16: no reduction, signed x
+    const int id = (ix >= 0x3f300000) + (ix >= 0x3f980000) + (ix >= 0x401c0000);
+    const float *k = tab.atan_k[id];
+    const float A = k[0], B = k[1], C = k[2], D = k[3], hi = k[4], lo = k[5];
+    const float num = r0 ? x : A * ax + B;
+    const float den = r0 ? 1.0f : C * ax + D;
+    const float t = div32_m(num, den);
+    const float z = t * t;
+    const float w = z * z;
+    const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    const float ts = t * (s1 + s2);
+    const float small = t - ts;                                   // id < 0
+    float big = hi - ((ts - lo) - t);
+    big = hx < 0 ? -big : big;
+    float res = r0 ? small : big;
+    res = (ix < 0x31000000) ? x : res;                            // |x| < 2^-29
+    const float huge = u2f(0x3fc90fdau) + u2f(0x33a22168u);       // atanhi[3] + atanlo[3]
+    res = (ix >= 0x4c000000 && ix <= 0x7f800000) ? (hx > 0 ? huge : -huge) : res;
+    return res;
+}
+
+RLM_FN float atan2_32_t(float y, float x, const Tables &tab)
+{
+    const float pi_o_2 = u2f(0x3fc90fdbu), pi = u2f(0x40490fdbu), pi_lo = u2f(0xb3bbbd2eu);
+    const int32_t hx = (int32_t)f2u(x), hy = (int32_t)f2u(y);
+    const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    if (__builtin_expect(ix >= 0x7f800000 || iy >= 0x7f800000, 0)) return atan2_32(y, x);
+    const int32_t k = (iy - ix) >> 23;
+    float z = atan32_t(fabs32(div32(y, x)), tab);
+    z = (k > 60) ? (pi_o_2 + 0.5f * pi_lo) : z;
+    z = (hx < 0 && k < -60) ? 0.0f : z;
+    const float zl = z - pi_lo;
+    float res = hx < 0 ? (hy < 0 ? zl - pi : pi - zl) : (hy < 0 ? -z : z);
+    res = (iy == 0) ? (hx < 0 ? (hy < 0 ? -pi : pi) : y) : res;
     res = (ix == 0 && iy != 0) ? (hy < 0 ? -pi_o_2 : pi_o_2) : res;
     return res;
 }

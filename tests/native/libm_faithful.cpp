@@ -50,12 +50,12 @@ int main(int argc, char **argv)
         a_pow.add(rlm::pow32(pb2, pe2, tab), powf(pb2, pe2));
         // atanf over many magnitudes
         float m = exp2f(40.0f * u01() - 30.0f) * (rnd() & 1 ? 1.0f : -1.0f);
-        a_atan.add(rlm::atan32(m), atanf(m)); v_atan.add(rlm::atan32_v(m), atanf(m));
+        a_atan.add(rlm::atan32(m), atanf(m)); v_atan.add(rlm::atan32_v(m), atanf(m)); v_atan.add(rlm::atan32_t(m, tab), atanf(m));
         float t = 6.0f * u01() - 3.0f;
         a_atan.add(rlm::atan32(t), atanf(t)); v_atan.add(rlm::atan32_v(t), atanf(t));
         // atan2f: components of unit-ish vectors, plus scaled pairs
         float y = 2.0f * u01() - 1.0f, x = 2.0f * u01() - 1.0f;
-        a_atan2.add(rlm::atan2_32(y, x), atan2f(y, x)); v_atan2.add(rlm::atan2_32_v(y, x), atan2f(y, x));
+        a_atan2.add(rlm::atan2_32(y, x), atan2f(y, x)); v_atan2.add(rlm::atan2_32_v(y, x), atan2f(y, x)); v_atan2.add(rlm::atan2_32_t(y, x, tab), atan2f(y, x));
         float sc = exp2f(20.0f * u01() - 18.0f);
         a_atan2.add(rlm::atan2_32(y * sc, x), atan2f(y * sc, x)); v_atan2.add(rlm::atan2_32_v(y * sc, x), atan2f(y * sc, x));
         a_atan2.add(rlm::atan2_32(y, x * sc), atan2f(y, x * sc)); v_atan2.add(rlm::atan2_32_v(y, x * sc), atan2f(y, x * sc));

@@ -19,7 +19,7 @@ void range(int fn, int64_t lo, int64_t hi, const float *x, const float *y, float
         switch (fn) {
         case 0: p = rlm::sqrt32(a); l = sqrtf(a); break;
         case 1: p = a / b; l = a / b; break;
-        case 2: p = rlm::atan2_32_v(a, b); l = atan2f(a, b); break;
+        case 2: p = rlm::atan2_32_t(a, b, kTab); l = atan2f(a, b); break;
         case 3: p = rlm::acos32_v(a); l = acosf(a); break;
         case 4: case 10: p = rlm::tan32_v<true>(a); l = tanf(a); break;
         case 5: case 11: rlm::sincos32_v<true>(a, &p, &unused); l = sinf(a); break;

@@ -289,17 +289,7 @@ RLS_DEV VndfView vndf_view_from(V3 local, float ax, float ay)
     }
     t_sincos(phi, &w.sinPhi, &w.cosPhi);
     w.nearNormal = theta < kEps;
-#ifdef RLS_EXP_NO_FALLBACK   // timing experiment only (wrong results): how much do the integrators spend in the fallback?
-    w.nearNormal = false;
-#endif
-#ifdef RLS_TAN_NEARNORMAL   // experiment
-    // theta is either exactly 0 (the branch above not taken) or >= acos(1 - 1e-4) = 0.0141: lanes at 0 would drag
-    // their whole wavefront through tanf's |x| < 2^-13 special case (two divisions); tanf(0) = 0
-    float B = t_tan(w.nearNormal ? 1.0f : theta);
-    B = theta == 0.0f ? 0.0f : B;
-#else
     float B = t_tan(theta);
-#endif
     w.B = B;
     w.B2 = sqr(B);
     w.G1 = R_TWO_OVER(1.0f + R_SQRT1P(w.B2));

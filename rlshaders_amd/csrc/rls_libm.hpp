@@ -55,24 +55,10 @@ RLM_FN float u2f(uint32_t u)
 }
 RLM_FN float fabs32(float x) { return u2f(f2u(x) & 0x7fffffffu); }
 
-// ---- experiment switch RLS_DIV_CORE: a / b through the compiler's own Newton sequence without its range handling
-// (v_div_scale / v_div_fmas); v_div_fixup keeps NaN / inf / zero operands right
-RLM_FN float div32(float a, float b)
-{
-#if defined(__HIP_DEVICE_COMPILE__) && defined(RLS_DIV_CORE)
-    float r = __builtin_amdgcn_rcpf(b);
-    const float e = __builtin_fmaf(-b, r, 1.0f);
-    r = __builtin_fmaf(e, r, r);
-    float q = a * r;
-    float t = __builtin_fmaf(-b, q, a);
-    q = __builtin_fmaf(t, r, q);
-    t = __builtin_fmaf(-b, q, a);
-    q = __builtin_fmaf(t, r, q);
-    return __builtin_amdgcn_div_fixupf(q, b, a);
-#else
-    return a / b;
-#endif
-}
+// a / b: the compiler's exactly rounded IEEE sequence.  (Its arithmetic core without v_div_scale / v_div_fmas behind an
+// operand-window test was measured twice -- round 1 in isolation, round 2 in the kernels -- and is slower: the test costs
+// what the three special instructions cost.  profiles/r01_divcost.txt, profiles/r02_exact1.txt.)
+RLM_FN float div32(float a, float b) { return a / b; }
 
 // ---- which build of glibc's fp64-polynomial routines to reproduce --------------------------------------------
 // glibc >= 2.28 compiles sinf / cosf / sincosf / expf / logf / powf twice on x86-64: a baseline SSE2 build and
@@ -111,11 +97,7 @@ RLM_FN float sqrt32(float x)
 #if defined(__HIP_DEVICE_COMPILE__)
 #ifndef RLS_SQRT_NO_FALLBACK
     // |x| < 2^-96, x != 0 (negative subnormals included: v_sqrt_f32 would flush them to -0 instead of NaN)
-#ifdef RLS_SQRT_CMP1   // experiment: one compare (|x| < 2^-96, zeros included) instead of and + add + compare
-    if (GUARDED && __builtin_expect(__builtin_fabsf(x) < 0x1p-96f, 0)) return sqrtf(x);
-#else
     if (GUARDED && __builtin_expect((f2u(x) & 0x7fffffffu) - 1u < 0x0f800000u - 1u, 0)) return sqrtf(x);
-#endif
 #endif
     float s = __builtin_amdgcn_sqrtf(x);
     const float sm = __uint_as_float(__float_as_uint(s) - 1u);

@@ -126,3 +126,38 @@ def test_sss_and_skin(fast, oracle):
         st = cases.summarize(cases.rel_err(gotk[k], refk[k]))
         print("fast skin", k, st)
         assert st["nonfinite"] == 0 and st["median"] <= 3e-6 and st["frac_gt_1e5"] <= 5e-2, (k, st)
+
+
+def test_integrators_in_fast_mode(fast, oracle):
+    """the round-2 entry points run in FAST mode too (rlDisney n^2-spp loop incl. chunked streaming, rlSkin shader_evaluate,
+    integrateRefract): Monte-Carlo sums of many samples, held to the sums' own scale rather than per point"""
+    n, spp_n, seed = 1 << 12, 4, 17
+    d = cases.disney_mixed(cases.SEED_PARITY, n)
+    ref = disney_oracle(oracle, d).integrate(spp_n, seed)
+    ds = disney_sampler(fast, d)
+    got = {k: host(v) for k, v in ds.integrate(spp_n, seed).items()}
+    sums, _ = ds.integrateChunked(spp_n, seed, 1000)
+    for k in ("diffuse_sum", "specular_sum"):
+        a, b = got[k].astype(np.float64), ref[k].astype(np.float64)
+        assert np.isfinite(a).all()
+        assert abs(a.mean() / b.mean() - 1) < 2e-3, (k, a.mean(), b.mean())
+        assert np.quantile(cases.rel_err(got[k], ref[k]), 0.9) <= 1e-3, k
+        assert np.allclose(host(sums[k]), got[k], rtol=1e-4, atol=1e-6), k            # chunked == unchunked, same mode
+    for k in ("diffuse_count", "specular_count"):
+        assert np.mean(got[k] != ref[k]) < 0.02, k
+    sk = cases.skin_mixed(cases.SEED_PARITY, n)
+    kw = dict(geometry="sphere", sphere_radius=1.0, light_dir=(0.0, 0.6, 0.8), use_cavity_fade=True)
+    refk = oracle.skin_integrate(sk["wo"], sk["N"], sk["T"], sk["params"], sk["N"], oracle.make_scene(**kw), spp_n, seed, nthreads=4)
+    shader = R.SkinShader(fast, dev(sk["wo"]), dev(sk["N"]), dev(sk["T"]), **{k: dev(v) for k, v in sk["params"].items()})
+    gotk = {k: host(v) for k, v in shader.integrate(dev(sk["N"]), R.make_scene(**kw), spp_n, seed).items()}
+    for k in ("sheenFresnel", "specularFresnel", "sssWeight"):
+        st = cases.summarize(cases.rel_err(gotk[k], refk[k]))
+        assert st["nonfinite"] == 0 and st["median"] <= 1e-5 and st["p99"] <= 1e-3, (k, st)
+    for k in ("sheen", "specular", "sss", "out"):
+        a, b = gotk[k].astype(np.float64), refk[k].astype(np.float64)
+        assert np.isfinite(a).all() and abs(a.mean() / b.mean() - 1) < 5e-3, (k, a.mean(), b.mean())
+    g = cases.ggx_mixed(cases.SEED_PARITY, n)
+    res, tir = ggx_oracle(oracle, g).integrate_refract(spp_n, seed)
+    gr, gt = [host(t) for t in ggx_sampler(fast, g).integrateRefract(spp_n, seed, want_tir=True)]
+    assert np.array_equal(gt, tir)
+    assert abs(gr.astype(np.float64).mean() / res.astype(np.float64).mean() - 1) < 2e-3

@@ -306,10 +306,22 @@ RLS_DEV VndfView vndf_view(V3 view, const Frame &fr, float ax, float ay)
     return vndf_view_from(vndf_local(view, fr), ax, ay);
 }
 
+// rx / (1 - rx) of the uniform slope sample: a function of rx alone.  For 2^-60 <= rx < 1 the denominator is in
+// [2^-24, 1] and the short division of rls_libm.hpp rounds like IEEE division (every rx: tools/micro/exact1.hip)
+RLS_DEV float ratio_to_one_minus(float rx)
+{
+#if RLS_FAST
+    return R_DIV(rx, 1.0f - rx);
+#else
+    if (__builtin_expect(!(rx >= 0x1p-60f && rx < 1.0f), 0)) return rx / (1.0f - rx);
+    return rlm::div32_m(rx, 1.0f - rx);
+#endif
+}
+
 // uniformSample lambda, src/rlGgx.cpp:18-25
 RLS_DEV V2 uniform_slope(float rx, float ry)
 {
-    float r = R_SQRT(R_DIV(rx, 1.0f - rx));
+    float r = R_SQRT(ratio_to_one_minus(rx));
     float phi = kTwoPi * ry;
     float s, c;
     t_sincos_any(phi, &s, &c);

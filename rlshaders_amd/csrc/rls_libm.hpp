@@ -850,7 +850,8 @@ RLM_FN void sincos32_v(float y, float *sinp, float *cosp)
     bool lneg;
     const double x = reduce_pio2<FULL, true>(y, &n, &lneg);   // n == 0 and x == y whenever |y| < pi/4
     const int m = n + (lneg ? 1 : 0);             // s_sinf.c / s_cosf.c: signs from n + sign beyond 120
-    const double xs = ((m & 3) == 1 || (m & 3) == 2) ? -x : x;
+    // sign[m & 3] of s_sincosf.h = {+, -, -, +}: negative iff bit 1 of m + 1 is set; applied as an xor on the sign bit
+    const double xs = u2d(d2u(x) ^ ((uint64_t)(uint32_t)((m + 1) & 2) << 62));
     const double x2 = x * x;
     const double x3 = xs * x2;
     const double s1 = mad(x2, S3, S2);
@@ -863,9 +864,10 @@ RLM_FN void sincos32_v(float y, float *sinp, float *cosp)
     const double x6 = x4 * x2;
     const double cv = mad(x4, C2, c1);
     double cres = mad(x6, c2, cv);
-    cres = (m & 2) ? -cres : cres;                // second table: every cosine coefficient negated
-    float sf = (float)((n & 1) ? cres : sres);
-    float cf = (float)((n & 1) ? sres : cres);
+    cres = u2d(d2u(cres) ^ ((uint64_t)(uint32_t)(m & 2) << 62));   // second table: every cosine coefficient negated
+    const float fs = (float)sres, fc = (float)cres;               // round both, then pick (fp32 selects)
+    float sf = (n & 1) ? fc : fs;
+    float cf = (n & 1) ? fs : fc;
     const uint32_t top = (f2u(y) >> 20) & 0x7ffu;
     if (top < 0x398u) { sf = y; cf = 1.0f; }      // |y| < 2^-12
     *sinp = sf;

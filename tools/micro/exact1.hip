@@ -96,6 +96,7 @@ __device__ __forceinline__ void eval(float x, float &got, float &ref)
     if (V == 19) { got = rlm::div32_const(x, 0.3333f, 1.0f / 0.3333f); ref = x / 0.3333f; }
     if (V == 20) { const float c = 1.0f - 0.6666f; got = rlm::div32_const(x, c, 1.0f / c); ref = x / c; }
     if (V == 21) { const float c = 0.6666f - 0.3333f; got = rlm::div32_const(x, c, 1.0f / c); ref = x / c; }
+    if (V == 22) { got = !(x >= 0x1p-60f && x < 1.0f) ? x / (1.0f - x) : rlm::div32_m(x, 1.0f - x); ref = x / (1.0f - x); }
     if (V == 12) { got = rlm::rcp32(x * x) - 1.0f; ref = 1.0f / (x * x) - 1.0f; }                     // tanSqr of G1
 }
 
@@ -157,6 +158,7 @@ int main()
     run<19>("div32_const(x, 0.3333) vs x / 0.3333");
     run<20>("div32_const(x, 1 - 0.6666)");
     run<21>("div32_const(x, 0.6666 - 0.3333)");
+    run<22>("rx / (1 - rx): div32_m under 2^-60 <= rx < 1");
     run<17>("slope ratio num(u)/den(u), u = 2|ry-1/2|: div32_m under u <= 1");
     run<16>("rcp32_hi(max(ior,1e-4)) vs 1/max(ior,1e-4)");
     run<14>("rcp32_w(tanf(theta)) vs 1/tanf(theta), theta in {0} U [.0141, pi]");

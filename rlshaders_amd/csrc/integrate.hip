@@ -388,7 +388,7 @@ __global__ RLS_INT_ATTR void skin_integrate_kernel(SkinIntIO a)
         if (sheenWeight > kEps) {                                                     // :191
             float cr, cg, cb;
             ldrgb(c.sheen_color, ii, cr, cg, cb);
-            Ggx g = ggx_make(wo, N, T, false, cr, cg, cb, ldp(c.sheen_ior, ii), ldp(c.sheen_roughness, ii), 0.0f);
+            Ggx g = ggx_make<true>(wo, N, T, false, cr, cg, cb, ldp(c.sheen_ior, ii), ldp(c.sheen_roughness, ii), 0.0f);
             VndfView w = vndf_view_from(local, g.ax, g.ay);
             float aF;
             ggx_glossy_loop<G>(g, w, tab, a.spp, sub, scr[0], scr[1], shR, shG, shB, aF);
@@ -405,7 +405,7 @@ __global__ RLS_INT_ATTR void skin_integrate_kernel(SkinIntIO a)
         if (specWeight > kEps) {                                                      // :214
             float cr, cg, cb;
             ldrgb(c.specular_color, ii, cr, cg, cb);
-            Ggx g = ggx_make(wo, N, T, false, cr, cg, cb, ldp(c.specular_ior, ii), ldp(c.specular_roughness, ii), 0.0f);
+            Ggx g = ggx_make<true>(wo, N, T, false, cr, cg, cb, ldp(c.specular_ior, ii), ldp(c.specular_roughness, ii), 0.0f);
             VndfView w = vndf_view_from(local, g.ax, g.ay);
             float aF;
             ggx_glossy_loop<G>(g, w, tab, a.spp, sub, scr[2], scr[3], spR, spG, spB, aF);

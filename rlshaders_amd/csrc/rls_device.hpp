@@ -464,6 +464,9 @@ struct Ggx {
     float g1v;            // G1(mViewDir, m, n) where it is not zero, src/rlGgx.h:353-356
 };
 
+// ISOTROPIC: the caller passes anisotropic = 0 (rlSkin's lobes, src/rlSkin.cpp:192,215): aspect = sqrtf(1 - 0 * 0.9) is
+// exactly 1, r^2 / 1 and r^2 * 1 are r^2 -- the square root, the division and the product are skipped, same bits
+template <bool ISOTROPIC = false>
 RLS_DEV Ggx ggx_make(V3 wo, V3 N, V3 T, bool exiting, float ksR, float ksG, float ksB,
                      float ior, float roughness, float anisotropic)
 {
@@ -476,9 +479,14 @@ RLS_DEV Ggx ggx_make(V3 wo, V3 N, V3 T, bool exiting, float ksR, float ksG, floa
     g.fr.N = N;
     g.fr.U = T;
     g.fr.V = cross(N, T);
-    float aspect = R_SQRT1M(anisotropic * 0.9f);
-    g.ax = maxf(1e-4f, R_DIV(sqr(roughness), aspect));
-    g.ay = maxf(1e-4f, sqr(roughness) * aspect);
+    if (ISOTROPIC) {
+        g.ax = maxf(1e-4f, sqr(roughness));
+        g.ay = g.ax;
+    } else {
+        float aspect = R_SQRT1M(anisotropic * 0.9f);
+        g.ax = maxf(1e-4f, R_DIV(sqr(roughness), aspect));
+        g.ay = maxf(1e-4f, sqr(roughness) * aspect);
+    }
     g.rough = maxf(1e-5f, sqr(roughness));
     // mIorOut / mIorIn (src/rlGgx.h:258) and mIorIn / mIorOut (refraction): one of the two iors is exactly 1, so one
     // ratio is the other ior itself (x / 1 = x exactly) and the other its reciprocal; out >= 1e-4 (or it is 1e-4)

@@ -18,12 +18,22 @@ using rlsh::SkinIO;
 
 struct LobeOut { V3 wi; float fr, fg, fb, pdf, F; };
 
+// the part of a lobe after the microfacet normal: reflect, Fresnel side effect, evalBrdf, evalPdf
+__device__ __forceinline__ LobeOut lobe_from_microfacet(const Ggx &g, V3 M)
+{
+    LobeOut o;
+    o.wi = reflect_direction(g.view, M);
+    o.F = ggx_fresnel(g, o.wi, M);
+    ggx_eval_pdf<true, true>(g, o.wi, o.fr, o.fg, o.fb, o.pdf);
+    return o;
+}
+
 // One isotropic GGX lobe of rlSkin (src/rlSkin.cpp:192,215: anisotropic defaulted to 0).
 __device__ __forceinline__ LobeOut ggx_lobe(V3 wo, V3 N, V3 T, V3 local, float cr, float cg, float cb,
                                             float ior, float rough, float rx, float ry)
 {
     LobeOut o;
-    Ggx g = ggx_make(wo, N, T, false, cr, cg, cb, ior, rough, 0.0f);
+    Ggx g = ggx_make<true>(wo, N, T, false, cr, cg, cb, ior, rough, 0.0f);
     // `local` = the view in the shared (T, N x T, N) frame: the same for both lobes, computed once
     VndfView w = vndf_view_from(local, g.ax, g.ay);
     V3 M = vndf_microfacet(w, g.fr, rx, ry);
@@ -56,19 +66,36 @@ __global__ __launch_bounds__(rlsh::kBlock) void skin_kernel(SkinIO a)
         ldrgb<STREAMED>(c.sheen_color, i, shr, shg, shb);
         float sheenIor = ldp<STREAMED>(c.sheen_ior, i), sheenRough = ldp<STREAMED>(c.sheen_roughness, i);
         float rx0 = ldg(a.xi[0], i), ry0 = ldg(a.xi[1], i);
-        if (sheenWeight > kEps) {                                           // src/rlSkin.cpp:191
-            sh = ggx_lobe(wo, N, T, local, shr, shg, shb, sheenIor, sheenRough, rx0, ry0);
-            sheenFresnel = sh.F * sheenWeight;                              // :204 (one sample)
-        }
-
         float specWeight = ldp<STREAMED>(c.specular_weight, i);
         float spr, spg, spb;
         ldrgb<STREAMED>(c.specular_color, i, spr, spg, spb);
         float specIor = ldp<STREAMED>(c.specular_ior, i), specRough = ldp<STREAMED>(c.specular_roughness, i);
         float rx1 = ldg(a.xi[2], i), ry1 = ldg(a.xi[3], i);
-        if (specWeight > kEps) {                                            // :214
-            sp = ggx_lobe(wo, N, T, local, spr, spg, spb, specIor, specRough, rx1, ry1);
+        const bool sheenOn = sheenWeight > kEps, specOn = specWeight > kEps;          // src/rlSkin.cpp:191, 214
+#ifndef RLS_NO_PAIR_COMPACTION
+        if (__builtin_amdgcn_ballot_w64(sheenOn && specOn) == ~0ull) {
+            // every lane of the wavefront evaluates both lobes: their two microfacet samples share one pass of the
+            // uniform-slope fallback (vndf_microfacet_pair)
+            Ggx g1 = ggx_make<true>(wo, N, T, false, shr, shg, shb, sheenIor, sheenRough, 0.0f);
+            Ggx g2 = ggx_make<true>(wo, N, T, false, spr, spg, spb, specIor, specRough, 0.0f);
+            VndfView w1 = vndf_view_from(local, g1.ax, g1.ay), w2 = vndf_view_from(local, g2.ax, g2.ay);
+            V3 M1, M2;
+            vndf_microfacet_pair(w1, g1.fr, rx0, ry0, w2, g2.fr, rx1, ry1, M1, M2);
+            sh = lobe_from_microfacet(g1, M1);
+            sp = lobe_from_microfacet(g2, M2);
+            sheenFresnel = sh.F * sheenWeight;                              // :204 (one sample)
             specularFresnel = sp.F * specWeight;                            // :228
+        } else
+#endif
+        {
+            if (sheenOn) {
+                sh = ggx_lobe(wo, N, T, local, shr, shg, shb, sheenIor, sheenRough, rx0, ry0);
+                sheenFresnel = sh.F * sheenWeight;
+            }
+            if (specOn) {
+                sp = ggx_lobe(wo, N, T, local, spr, spg, spb, specIor, specRough, rx1, ry1);
+                specularFresnel = sp.F * specWeight;
+            }
         }
 
         float mult = ldp<STREAMED>(c.sss_dist_multiplier, i);                         // :235-236

@@ -199,14 +199,12 @@ RLS_DEV V2 concentric_disk(float rx, float ry)
         out.x = 0.0f; out.y = 0.0f;
         return out;
     }
-    float r, phi;
-    if (absf(rx) > absf(ry)) {
-        r = rx;
-        phi = R_DIV(kHalfPi * 0.5f * ry, rx);
-    } else {
-        r = ry;
-        phi = kHalfPi * (1.0f - R_DIV(0.5f * rx, ry));
-    }
+    // the two cases divide different operands; the lanes of a wavefront take both, so the operands are selected and
+    // ONE division serves either case (each lane still divides exactly what its case divides)
+    const bool wide = absf(rx) > absf(ry);
+    const float q = R_DIV(wide ? kHalfPi * 0.5f * ry : 0.5f * rx, wide ? rx : ry);
+    const float r = wide ? rx : ry;
+    const float phi = wide ? q : kHalfPi * (1.0f - q);
     float s, c;
     t_sincos(phi, &s, &c);
     out.x = r * c;
@@ -875,11 +873,12 @@ RLS_DEV V3 disney_sample_specular(const Disney &d, const VndfView &w, float rx, 
 {
     V3 M;
     float gtr2Weight = d.gtr2Weight;                 // disney_prepare()
-    if (rx < gtr2Weight) {
-        rx = R_DIV(rx, gtr2Weight);
+    // rx / w for the GTR2 lobe, (rx - w) / (1 - w) for the clearcoat lobe: one division of selected operands
+    const bool gtr2 = rx < gtr2Weight;
+    rx = R_DIV(gtr2 ? rx : rx - gtr2Weight, gtr2 ? gtr2Weight : 1.0f - gtr2Weight);
+    if (gtr2) {
         M = vndf_microfacet(w, d.fr, rx, ry);
     } else {
-        rx = R_DIV(rx - gtr2Weight, 1.0f - gtr2Weight);
         M = disney_gtr1_microfacet(d, rx, ry);
     }
     if (dot(d.fr.N, M) < 0.0f) return mk(0.0f, 0.0f, 0.0f);

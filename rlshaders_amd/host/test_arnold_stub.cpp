@@ -52,7 +52,7 @@ int decl()
     std::printf("{\"nodes\": {");
     for (int i = 0; i < rlstub::kNodeCount; i++) {
         Recorder r;
-        rlstub::node_parameters(i, r);
+        rlstub::declare_node(i, r);
         r.flush();
         std::string en;
         for (int k = 0; k < rlstub::kNodes[i].count; k++)
@@ -66,7 +66,7 @@ int decl()
     std::printf("}, \"node_loader\": [");
     for (int i = 0;; i++) {
         NodeLibRec nl = {};
-        if (!rlstub::node_loader(i, &nl, ResolveRec(), "4.2.11.0")) {
+        if (!rlstub::load_node(i, &nl, ResolveRec(), "4.2.11.0")) {
             if (i != rlstub::kNodeCount) { std::fprintf(stderr, "node_loader stopped at %d\n", i); return 1; }
             break;
         }

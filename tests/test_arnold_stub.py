@@ -46,3 +46,14 @@ def test_stub_declares_the_reference_nodes():
         for k in ("id", "methods", "output_type", "name", "node_type"):
             assert a[k] == b[k], (k, a, b)
         assert a["version"] == "4.2.11.0"
+
+
+def test_arnold_glue_is_well_formed():
+    """the RLS_STUB_WITH_ARNOLD block (ArnoldHost / ArnoldEval / the node_parameters and node_loader bodies) compiled
+    with -fsyntax-only against mock declarations of the SDK symbols it touches (tests/native/mock_arnold/ai.h; Arnold's
+    node_parameters / node_loader are MACROS, so nothing of the stub may carry those names)"""
+    cmd = ["g++", "-std=c++14", "-fsyntax-only", "-Wall", "-Werror", "-I", str(ROOT / "tests" / "native" / "mock_arnold"),
+           "-I", str(ROOT / "include"), "-I", str(ROOT / "rlshaders_amd" / "host"),
+           str(ROOT / "tests" / "native" / "arnold_glue_check.cpp")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]

@@ -37,32 +37,6 @@ __global__ RLS_KERNEL_ATTR void ggx_kernel(GgxIO a)
     for (int64_t base = tiles.first; base < tiles.end; base += tiles.step) {
         const Idx i = make_idx(base);
         if (i.full() >= a.n) continue;
-#ifdef RLS_LATE_ARGS
-        if (OP == OP_REFLECT_REFRACT) {
-            RLS_ARGS_REFRESH(GgxIO, a);
-            Ggx g = load_closure<STREAMED>(a.c, i);
-            float rx = ldg(a.rx, i), ry = ldg(a.ry, i);
-            float rx2 = ldg(a.rx2, i), ry2 = ldg(a.ry2, i);
-            VndfView w = vndf_view(g.view, g.fr, g.ax, g.ay);
-            V3 M, M2;
-            vndf_microfacet_pair(w, g.fr, rx, ry, w, g.fr, rx2, ry2, M, M2);
-            V3 L = reflect_direction(g.view, M);
-            float F = ggx_fresnel(g, L, M);
-            float fr, fg, fb, pdf;
-            ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pdf);
-            V3 dir;
-            ggx_refract(g, M2, dir);
-            float wgt = ggx_sample_weight(g, g.view, dir, M2);
-            RLS_ARGS_REFRESH(GgxIO, a);
-            st3(a.wi, i, L);
-            if (a.fresnel) stg(a.fresnel, i, F);
-            strgb(a.f, i, fr, fg, fb);
-            stg(a.pdf, i, pdf);
-            st3(a.wt, i, dir);
-            stg(a.weight, i, wgt);
-            continue;
-        }
-#endif
         Ggx g = load_closure<STREAMED>(a.c, i);
 
         if (OP == OP_SAMPLE || OP == OP_FUSED || OP == OP_REFLECT_REFRACT) {

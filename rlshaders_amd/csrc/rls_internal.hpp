@@ -241,20 +241,6 @@ inline bool ok_rgb(const rls_param_rgb &p) { return (p.r && p.g && p.b) || (!p.r
 
 } // namespace rlsh
 
-// Re-read a kernel's by-value argument struct from the kernarg segment through a pointer the optimizer cannot see
-// through: the (scalar, cached) loads then sit where the fields are used instead of at the top of the kernel, and the
-// ~30 plane pointers of a pointwise kernel stop occupying 60 SGPRs across its whole body.
-#define RLS_ARGS_REFRESH(T, local)                                                                              \
-    do {                                                                                                        \
-        const __attribute__((address_space(4))) T *p_ =                                                         \
-            (const __attribute__((address_space(4))) T *)__builtin_amdgcn_kernarg_segment_ptr();                \
-        asm volatile("" : "+s"(p_));                                                                            \
-        static_assert(sizeof(T) % 8 == 0, "argument struct is copied in 8-byte words");                         \
-        const __attribute__((address_space(4))) uint64_t *q_ = (const __attribute__((address_space(4))) uint64_t *)p_; \
-        uint64_t *d_ = (uint64_t *)&(local);                                                                    \
-        _Pragma("unroll") for (unsigned k_ = 0; k_ < sizeof(T) / 8; k_++) d_[k_] = q_[k_];                      \
-    } while (0)
-
 // device-side views of the ABI structs ---------------------------------------------------------
 namespace rlsd {
 

@@ -52,7 +52,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--log2-points", type=int, default=26, help="points per GPU = 2^this (config: 26)")
     ap.add_argument("--workload", default="ggx_reflect_refract",
-                    choices=["ggx_reflect_refract", "ggx_reflect", "ggx_direct", "disney_integrate", "disney_stream", "sss_probe",
+                    choices=["ggx_reflect_refract", "ggx_reflect", "ggx_direct", "disney_direct", "disney_integrate", "disney_stream", "sss_probe",
                              "sss_scatter", "skin", "skin_integrate"])
     ap.add_argument("--chunk-log2", type=int, default=20, help="disney_stream: points per chunk = 2^this")
     ap.add_argument("--math", default="exact", choices=["exact", "fast"],
@@ -84,7 +84,8 @@ class Workload:
 # planes (n floats each) a workload reads and writes: sizes its arena
 PLANES = {"ggx_reflect_refract": 19 + 12, "ggx_reflect": 17 + 8, "disney_integrate": 22 + 8, "disney_stream": 22 + 8,
           "sss_probe": 17 + 12,
-          "sss_scatter": 15 + 3, "skin": 35 + 24, "skin_integrate": 29 + 3 + 15, "ggx_direct": 15 + 3 + 6 + 6}     # (the generator's wo planes included where the closure ignores them)
+          "sss_scatter": 15 + 3, "skin": 35 + 24, "skin_integrate": 29 + 3 + 15, "ggx_direct": 15 + 3 + 6 + 6,
+          "disney_direct": 22 + 3 + 6}     # (the generator's wo planes included where the closure ignores them)
 
 
 def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, chunk_log2: int = 20):
@@ -128,6 +129,21 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
                       "ggx_direct_kernel<1, {m}>",
                       "rlGgx light loop: Oren-Nayar + GGX under a spherical light, 16 light + 2 x 16 BSDF samples per "
                       "point, power-heuristic MIS (SURVEY 8f rank 2; VALU-bound)", bound="valu")
+    elif name == "disney_direct":
+        # the light loop of rlDisney (direct diffuse + direct specular) under two spherical lights: per light 16 light
+        # samples (evaluated by both lobes) + 16 BSDF samples per lobe
+        base = u3(S_KS)
+        sc = {k: u(S_PARAM0 + j) for j, k in enumerate(R._capi.DISNEY_SCALARS)}
+        d = R.DisneySampler(ctx, wo, N, T, base_color=base, **sc)
+        P = u3(S_PARAM0 + 16, 0.0, 4.0)
+        lights = [R.make_light(center=(2.0, 2.0, 6.0), radius=1.25, radiance=(3.0, 2.0, 1.0)),
+                  R.make_light(center=(-1.0, 5.0, 7.0), radius=0.6, radiance=(0.5, 0.5, 4.0))]
+        out = (A.planes(3), A.planes(3))
+        wl = Workload(name, 96, (22 + 3 + 6) * 4,
+                      lambda: d.directLighting(P, lights, 4, SEED, out=out, first_index=first),
+                      "disney_direct_kernel<1, {m}>",
+                      "rlDisney light loop: both lobes under two spherical lights, per light 16 light + 2 x 16 BSDF samples "
+                      "per point, power-heuristic MIS (src/rlDisney.cpp:695-705; VALU-bound)", bound="valu")
     elif name in ("disney_integrate", "disney_stream"):
         base = u3(S_KS)
         sc = {k: u(S_PARAM0 + j) for j, k in enumerate(R._capi.DISNEY_SCALARS)}
@@ -223,10 +239,15 @@ def _cpu_leg(workload: str, n: int, threads: int):
         kdc, kd, kdr, ks = u3(S_PARAM0), u(S_PARAM0 + 3), u(S_PARAM0 + 4), u(S_PARAM0 + 5)
         return (lambda: g.direct_lighting(P, lt, 4, SEED, Kd_color=kdc, Kd=kd, Kd_roughness=kdr, Ks=ks)), 48, \
             "orc_batch_ggx_direct_lighting"
-    if workload in ("disney_integrate", "disney_stream"):
+    if workload in ("disney_integrate", "disney_stream", "disney_direct"):
         c = cases.disney_mixed(SEED, n)
         sc = {k: c[k] for k in O.DISNEY_SCALARS}
         d = O.Disney(c["wo"], c["N"], c["T"], base_color=c["base_color"], nthreads=threads, **sc)
+        if workload == "disney_direct":
+            P = u3(S_PARAM0 + 16, 0.0, 4.0)
+            lts = [O.make_light(center=(2.0, 2.0, 6.0), radius=1.25, radiance=(3.0, 2.0, 1.0)),
+                   O.make_light(center=(-1.0, 5.0, 7.0), radius=0.6, radiance=(0.5, 0.5, 4.0))]
+            return (lambda: d.direct_lighting(P, lts, 4, SEED)), 96, "orc_batch_disney_direct_lighting"
         streamed = workload == "disney_stream"
         return (lambda: d.integrate(8, SEED, streamed=streamed)), 128, "orc_batch_disney_integrate"
     if workload in ("sss_probe", "sss_scatter"):

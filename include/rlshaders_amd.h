@@ -237,7 +237,11 @@ rls_status rls_ggx_integrate_refract(rls_context *ctx, int64_t n, const rls_ggx_
  * over spp_n^2 light samples (shared by both lobes) and spp_n^2 BSDF samples per lobe; directions below
  * the shading normal contribute nothing.  The per-point partial sums of the G lanes that share a
  * shading point are reduced with wave shuffles.  mis_mode selects the estimator: both strategies, light
- * samples only, BSDF samples only -- equal in expectation when sample / eval / pdf are consistent. */
+ * samples only, BSDF samples only -- equal in expectation when sample / eval / pdf are consistent.
+ * `lights` is an array of n_lights (1 .. RLS_MAX_LIGHTS) lights: the loop `while (AiLightsGetSample(sg))` visits
+ * every sample of every light, so light l runs the estimator above with its own sample streams (3 l .. 3 l + 2) and
+ * the AOVs are the sums over the lights, added in array order. */
+#define RLS_MAX_LIGHTS     8
 #define RLS_MIS_BOTH       0
 #define RLS_MIS_LIGHT_ONLY 1
 #define RLS_MIS_BSDF_ONLY  2
@@ -252,7 +256,7 @@ typedef struct rls_ggx_shader {
     rls_param     Kd, diffuseRoughness, Ks;
 } rls_ggx_shader;
 rls_status rls_ggx_direct_lighting(rls_context *ctx, int64_t n, const rls_ggx_closure *c, const rls_ggx_shader *sh,
-                                   rls_cvec3 P, const rls_sphere_light *light, int spp_n, uint32_t seed,
+                                   rls_cvec3 P, const rls_sphere_light *lights, int n_lights, int spp_n, uint32_t seed,
                                    uint64_t first_index, rls_rgb direct_diffuse, rls_rgb direct_specular);
 
 /* ------------------------------------------------------------------------------------------
@@ -303,6 +307,19 @@ rls_status rls_disney_integrate_chunked(rls_context *ctx, int64_t n, const rls_d
                                         rls_rgb specular_sum, float *specular_count,
                                         int64_t chunk_points, const rls_disney_stream_out *chunk,
                                         rls_disney_chunk_fn consume /* optional */, void *user);
+
+/* Direct lighting of the rlDisney node: the light loop of shader_evaluate (src/rlDisney.cpp:695-705) --
+ *     diffuse  += sampler.evalDiffuseLightSample(sg)     (setSampleType(AI_RAY_DIFFUSE), AiEvaluateLightSample over
+ *     specular += sampler.evalSpecularLightSample(sg)     the triple; setSampleType(AI_RAY_GLOSSY), the same: 265-277)
+ * = the two direct AOVs (src/rlDisney.cpp:714-715; the indirect_diffuse / indirect_specular factors that secondary
+ * rays apply at 707-710 are the caller's).  AiEvaluateLightSample and the light loop are closed: the stand-ins are
+ * those of rls_ggx_direct_lighting (spherical lights sampled over the cone they subtend, no occluders, the
+ * two-sample power-heuristic estimator with spp_n^2 light samples shared by the two lobes and spp_n^2 BSDF samples
+ * per lobe, per light; directions below the shading normal contribute nothing; parity unpinned).  A BSDF sample
+ * counts when its pdf exceeds AI_EPSILON, like the valid-sample test of src/rlDisney.cpp:309. */
+rls_status rls_disney_direct_lighting(rls_context *ctx, int64_t n, const rls_disney_closure *c, rls_cvec3 P,
+                                      const rls_sphere_light *lights, int n_lights, int spp_n, uint32_t seed,
+                                      uint64_t first_index, rls_rgb direct_diffuse, rls_rgb direct_specular);
 
 /* Alternates the reference compiles but never selects (mSampleFromVisibleNormal is hard-wired to
  * true, src/rlDisney.cpp:191): the plain-NDF microfacet samplers, the matching pdf branch and D_GTR2. */
@@ -420,16 +437,24 @@ rls_status rls_skin_sample_eval_pdf(rls_context *ctx, int64_t n, const rls_skin_
  *     sss = sssWeight < AI_EPSILON ? black : integrateScatter(scatterDist = sss_scatter_dist * sss_dist_multiplier) * sssWeight   (244-246)
  * The mean is a wave-shuffle reduction over the lanes that share a shading point (a17).  What the reference gets
  * from the closed renderer is supplied as for the single-closure integrators (parity unpinned): AiBRDFIntegrate ->
- * the mean of evalBrdf / evalPdf over the samples times the radiance env[3] of a uniform environment; the light
- * loops of 195-200 / 218-223 draw no samples; integrateScatter -> rls_sss_integrate_scatter's analytic scene. */
+ * the mean of evalBrdf / evalPdf over the samples times the radiance env[3] of a uniform environment;
+ * integrateScatter -> rls_sss_integrate_scatter's analytic scene; the light loops of 193-198 / 217-222
+ * (evalLightSample per light, BEFORE integrateGlossy) -> the estimator of rls_ggx_direct_lighting's specular lobe
+ * over `lights` (n_lights = 0: no lights, the loops draw no samples).  The BSDF-sampling half of that estimator calls
+ * evalSample, so its Fresnel terms enter the mean too: getAvgReflectWeight = (sum over the light loops' BSDF samples
+ * and integrateGlossy's samples) / (their count).  integrateGlossy draws no samples for a small colour (174-176),
+ * the light loop does (167-170).  Scramble streams: sheen glossy 0, specular glossy 1, scatter 2 (as without
+ * lights), then light l of the sheen lobe 3 + 4 l (light samples), 4 + 4 l (BSDF samples), of the specular lobe
+ * 5 + 4 l, 6 + 4 l. */
 typedef struct rls_skin_integrate_out {
     rls_rgb sheen, specular, sss;                          /* the three AOVs (src/rlSkin.cpp:249-251)            */
     rls_rgb out;                                           /* optional: sg->out.RGB = their sum (254)            */
     float  *sheenFresnel, *specularFresnel, *sssWeight;    /* optional: the hand-down scalars (204, 228, 238)    */
 } rls_skin_integrate_out;
 rls_status rls_skin_integrate(rls_context *ctx, int64_t n, const rls_skin_closure *c, rls_cvec3 P,
-                              const rls_sss_scene *scene, const float env[3], int spp_n, uint32_t seed,
-                              uint64_t first_index, const rls_skin_integrate_out *out);
+                              const rls_sss_scene *scene, const float env[3],
+                              const rls_sphere_light *lights /* NULL when n_lights == 0 */, int n_lights,
+                              int spp_n, uint32_t seed, uint64_t first_index, const rls_skin_integrate_out *out);
 
 /* ------------------------------------------------------------------------------------------
  * rlUtil closures (src/rlUtil.h:21-29, src/rlUtil.cpp:3-27), batch form for parity checks:

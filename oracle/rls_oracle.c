@@ -1640,6 +1640,88 @@ void orc_batch_sss_integrate_scatter(int64_t n, const orc_sss_soa *in, int has_d
     parallel_for(n, nthreads, scatter_range, &j);
 }
 
+/* ============================ light loops: shared stand-ins ============================== */
+/* What stands in for the closed light loop (AiLightsPrepare / AiLightsGetSample / AiEvaluateLightSample): spherical
+ * lights sampled over the cone they subtend, no occluders, and per light the two-sample estimator with the power
+ * heuristic over spp light samples and spp BSDF samples (rls_oracle.h, orc_light).  PARITY UNPINNED. */
+
+typedef struct { int valid; orc_v3 d, u, v, w; float c2, cosMax, pdf; } light_cone;
+
+/* the cone the sphere subtends from P: axis w, basis (u, v) (Duff et al. 2017), uniform pdf */
+static light_cone cone_make(const orc_light *lt, orc_v3 P)
+{
+    light_cone c;
+    memset(&c, 0, sizeof(c));
+    c.d = v3sub(arr3(lt->center), P);
+    float dist2 = v3dot(c.d, c.d), r2 = lt->radius * lt->radius;
+    c.c2 = dist2 - r2;
+    if (!(c.c2 > 0.0f)) return c;                 /* inside the light */
+    c.valid = 1;
+    float sin2 = r2 / dist2;
+    c.cosMax = sqrtf(MAXf(0.0f, 1.0f - sin2));
+    c.pdf = 1.0f / (AI_PITIMES2 * (sin2 / (1.0f + c.cosMax)));   /* 1 - cosMax = sin^2 / (1 + cosMax) */
+    float inv = 1.0f / sqrtf(dist2);
+    c.w = v3scale(c.d, inv);
+    float sg = copysignf(1.0f, c.w.z);
+    float a = -1.0f / (sg + c.w.z);
+    float b = c.w.x * c.w.y * a;
+    c.u = v3(1.0f + sg * c.w.x * c.w.x * a, sg * b, -sg * c.w.x);
+    c.v = v3(b, sg + c.w.y * c.w.y * a, -c.w.y);
+    return c;
+}
+
+static orc_v3 cone_sample(const light_cone *c, float rx, float ry)
+{
+    float ct = 1.0f - rx * (1.0f - c->cosMax);
+    float st = sqrtf(MAXf(0.0f, 1.0f - ct * ct));
+    float phi = AI_PITIMES2 * ry;
+    float x = st * cosf(phi), y = st * sinf(phi);
+    return v3add(v3add(v3scale(c->u, x), v3scale(c->v, y)), v3scale(c->w, ct));
+}
+
+static int cone_hit(const light_cone *c, orc_v3 dir)
+{
+    float b = v3dot(c->d, dir);
+    return b > 0.0f && !(b * b - c->c2 * v3dot(dir, dir) < 0.0f);
+}
+
+static inline float power_heuristic(float pa, float pb) { return (pa * pa) / (pa * pa + pb * pb); }
+
+/* evalLightSample of a GGX closure for one light (src/rlGgx.h:167-170): sample streams `stream` (light samples) and
+ * `stream` + 1 (BSDF samples; orc_ggx_eval_sample adds its Fresnel term and bumps the sample count, src/rlGgx.h:103) */
+static orc_rgb ggx_eval_light_sample(orc_ggx *g, orc_v3 N, orc_v3 P, const orc_light *lt, int spp, uint32_t seed,
+                                     uint64_t index, uint32_t stream)
+{
+    const light_cone c = cone_make(lt, P);
+    const int mode = lt->mis_mode;
+    float sR = 0.0f, sG = 0.0f, sB = 0.0f;
+    for (int s = 0; s < spp && c.valid; s++) {
+        float rx, ry;
+        if (mode != 2) {
+            orc_sample_02(seed, index, stream, (uint32_t)s, &rx, &ry);
+            orc_v3 L = cone_sample(&c, rx, ry);
+            if (v3dot(L, N) > 0.0f) {
+                orc_rgb f = orc_ggx_eval_brdf(g, L);
+                float pb = orc_ggx_eval_pdf(g, L);
+                float w = mode == 1 ? 1.0f : power_heuristic(c.pdf, pb);
+                sR += f.r * w / c.pdf; sG += f.g * w / c.pdf; sB += f.b * w / c.pdf;
+            }
+        }
+        if (mode != 1) {
+            orc_sample_02(seed, index, stream + 1, (uint32_t)s, &rx, &ry);
+            orc_v3 L = orc_ggx_eval_sample(g, rx, ry);
+            if (!v3iszero(L) && v3dot(L, N) > 0.0f && cone_hit(&c, L)) {
+                orc_rgb f = orc_ggx_eval_brdf(g, L);
+                float pb = orc_ggx_eval_pdf(g, L);
+                float w = mode == 2 ? 1.0f : power_heuristic(pb, c.pdf);
+                sR += f.r * w / pb; sG += f.g * w / pb; sB += f.b * w / pb;
+            }
+        }
+    }
+    const float inv = 1.0f / (float)spp;
+    return rgb(lt->radiance[0] * sR * inv, lt->radiance[1] * sG * inv, lt->radiance[2] * sB * inv);
+}
+
 /* ============================ rlSkin over n^2 samples per layer ========================== */
 
 /* integrateGlossy (src/rlGgx.h:172-179) with the stand-in for the closed AiBRDFIntegrate: the mean of
@@ -1665,7 +1747,8 @@ static orc_rgb ggx_integrate_glossy(orc_ggx *g, const float env[3], int spp, uin
 
 /* shader_evaluate, src/rlSkin.cpp:174-254 */
 void orc_skin_integrate(const orc_skin_params *p, orc_v3 wo, orc_v3 Nf, orc_v3 T, orc_v3 P, const orc_scene *sc,
-                        const float env[3], int spp, uint32_t seed, uint64_t index, orc_skin_int_out *o)
+                        const float env[3], const orc_light *lights, int n_lights, int spp, uint32_t seed, uint64_t index,
+                        orc_skin_int_out *o)
 {
     float sheenFresnel = 0.0f;
     orc_rgb sheen = RGB_BLACK;
@@ -1675,6 +1758,10 @@ void orc_skin_integrate(const orc_skin_params *p, orc_v3 wo, orc_v3 Nf, orc_v3 T
     if (p->sheen_weight > AI_EPSILON) {                                      /* :191 */
         orc_ggx g;
         orc_ggx_init(&g, wo, Nf, T, 0, p->sheen_color, p->sheen_ior, p->sheen_roughness, 0.0f);
+        for (int l = 0; l < n_lights; l++) {                                 /* :193-198 */
+            orc_rgb c = ggx_eval_light_sample(&g, Nf, P, &lights[l], spp, seed, index, 3u + 4u * (uint32_t)l);
+            sheen = rgb(sheen.r + c.r, sheen.g + c.g, sheen.b + c.b);
+        }
         orc_rgb c = ggx_integrate_glossy(&g, env, spp, seed, index, 0);      /* :201-202 */
         sheen = rgb(sheen.r + c.r, sheen.g + c.g, sheen.b + c.b);
         sheenFresnel = orc_ggx_avg_reflect_weight(&g) * p->sheen_weight;     /* :204 */
@@ -1684,6 +1771,10 @@ void orc_skin_integrate(const orc_skin_params *p, orc_v3 wo, orc_v3 Nf, orc_v3 T
     if (p->specular_weight > AI_EPSILON) {                                   /* :214 */
         orc_ggx g;
         orc_ggx_init(&g, wo, Nf, T, 0, p->specular_color, p->specular_ior, p->specular_roughness, 0.0f);
+        for (int l = 0; l < n_lights; l++) {                                 /* :217-222 */
+            orc_rgb c = ggx_eval_light_sample(&g, Nf, P, &lights[l], spp, seed, index, 5u + 4u * (uint32_t)l);
+            specular = rgb(specular.r + c.r, specular.g + c.g, specular.b + c.b);
+        }
         orc_rgb c = ggx_integrate_glossy(&g, env, spp, seed, index, 1);      /* :224-226 */
         specular = rgb(specular.r + c.r, specular.g + c.g, specular.b + c.b);
         specularFresnel = orc_ggx_avg_reflect_weight(&g) * p->specular_weight;   /* :228 */
@@ -1713,7 +1804,8 @@ void orc_skin_integrate(const orc_skin_params *p, orc_v3 wo, orc_v3 Nf, orc_v3 T
 }
 
 typedef struct {
-    const orc_skin_soa *in; orc_cv3p P; const orc_scene *sc; const float *env; int spp; uint32_t seed; uint64_t first;
+    const orc_skin_soa *in; orc_cv3p P; const orc_scene *sc; const float *env; const orc_light *lights; int n_lights;
+    int spp; uint32_t seed; uint64_t first;
     const orc_skin_int_out_soa *out;
 } skin_int_job;
 
@@ -1724,8 +1816,8 @@ static void skin_int_range(int64_t lo, int64_t hi, void *ctx)
         orc_skin_params p;
         skin_load(j->in, i, &p);
         orc_skin_int_out o;
-        orc_skin_integrate(&p, ld3(j->in->wo, i), ld3(j->in->N, i), ld3(j->in->T, i), ld3(j->P, i), j->sc, j->env, j->spp,
-                           j->seed, j->first + (uint64_t)i, &o);
+        orc_skin_integrate(&p, ld3(j->in->wo, i), ld3(j->in->N, i), ld3(j->in->T, i), ld3(j->P, i), j->sc, j->env, j->lights,
+                           j->n_lights, j->spp, j->seed, j->first + (uint64_t)i, &o);
         stc(j->out->sheen, i, o.sheen); stc(j->out->specular, i, o.specular); stc(j->out->sss, i, o.sss);
         stc(j->out->out, i, o.out);
         j->out->sheenFresnel[i] = o.sheenFresnel; j->out->specularFresnel[i] = o.specularFresnel;
@@ -1734,9 +1826,10 @@ static void skin_int_range(int64_t lo, int64_t hi, void *ctx)
 }
 
 void orc_batch_skin_integrate(int64_t n, const orc_skin_soa *in, orc_cv3p P, const orc_scene *sc, const float env[3],
-                              int spp_n, uint32_t seed, uint64_t first_index, const orc_skin_int_out_soa *out, int nthreads)
+                              const orc_light *lights, int n_lights, int spp_n, uint32_t seed, uint64_t first_index,
+                              const orc_skin_int_out_soa *out, int nthreads)
 {
-    skin_int_job j = { in, P, sc, env, spp_n * spp_n, seed, first_index, out };
+    skin_int_job j = { in, P, sc, env, lights, n_lights, spp_n * spp_n, seed, first_index, out };
     parallel_for(n, nthreads, skin_int_range, &j);
 }
 
@@ -1828,116 +1921,158 @@ float orc_oren_nayar_pdf(const orc_oren_nayar *o, orc_v3 wi)
     return ci > 0.0f ? ci * AI_ONEOVERPI : 0.0f;
 }
 
-typedef struct { int valid; orc_v3 d, u, v, w; float c2, cosMax, pdf; } light_cone;
-
-/* the cone the sphere subtends from P: axis w, basis (u, v) (Duff et al. 2017), uniform pdf */
-static light_cone cone_make(const orc_light *lt, orc_v3 P)
-{
-    light_cone c;
-    memset(&c, 0, sizeof(c));
-    c.d = v3sub(arr3(lt->center), P);
-    float dist2 = v3dot(c.d, c.d), r2 = lt->radius * lt->radius;
-    c.c2 = dist2 - r2;
-    if (!(c.c2 > 0.0f)) return c;                 /* inside the light */
-    c.valid = 1;
-    float sin2 = r2 / dist2;
-    c.cosMax = sqrtf(MAXf(0.0f, 1.0f - sin2));
-    c.pdf = 1.0f / (AI_PITIMES2 * (sin2 / (1.0f + c.cosMax)));   /* 1 - cosMax = sin^2 / (1 + cosMax) */
-    float inv = 1.0f / sqrtf(dist2);
-    c.w = v3scale(c.d, inv);
-    float sg = copysignf(1.0f, c.w.z);
-    float a = -1.0f / (sg + c.w.z);
-    float b = c.w.x * c.w.y * a;
-    c.u = v3(1.0f + sg * c.w.x * c.w.x * a, sg * b, -sg * c.w.x);
-    c.v = v3(b, sg + c.w.y * c.w.y * a, -c.w.y);
-    return c;
-}
-
-static orc_v3 cone_sample(const light_cone *c, float rx, float ry)
-{
-    float ct = 1.0f - rx * (1.0f - c->cosMax);
-    float st = sqrtf(MAXf(0.0f, 1.0f - ct * ct));
-    float phi = AI_PITIMES2 * ry;
-    float x = st * cosf(phi), y = st * sinf(phi);
-    return v3add(v3add(v3scale(c->u, x), v3scale(c->v, y)), v3scale(c->w, ct));
-}
-
-static int cone_hit(const light_cone *c, orc_v3 dir)
-{
-    float b = v3dot(c->d, dir);
-    return b > 0.0f && !(b * b - c->c2 * v3dot(dir, dir) < 0.0f);
-}
-
-static inline float power_heuristic(float pa, float pb) { return (pa * pa) / (pa * pa + pb * pb); }
-
 typedef struct {
-    const orc_ggx_soa *in; const orc_ggx_shader_soa *sh; orc_cv3p P; const orc_light *lt; int spp; uint32_t seed;
-    uint64_t first;
+    const orc_ggx_soa *in; const orc_ggx_shader_soa *sh; orc_cv3p P; const orc_light *lights; int n_lights; int spp;
+    uint32_t seed; uint64_t first;
     orc_v3p dd, ds;
 } light_job;
 
 static void light_range(int64_t lo, int64_t hi, void *ctx)
 {
     light_job *j = (light_job *)ctx;
-    const int mode = j->lt->mis_mode;
     for (int64_t i = lo; i < hi; i++) {
         orc_ggx g;
         ggx_load(j->in, i, &g);
         const orc_v3 N = ld3(j->in->N, i), T = ld3(j->in->T, i), wo = ld3(j->in->wo, i);
         orc_oren_nayar on;
         orc_oren_nayar_init(&on, N, T, j->sh->Kd_roughness[i]);
-        light_cone c = cone_make(j->lt, ld3(j->P, i));
-        float sR = 0.0f, sG = 0.0f, sB = 0.0f, dA = 0.0f;
-        for (int s = 0; s < j->spp && c.valid; s++) {
-            float rx, ry;
-            if (mode != 2) {                                   /* one light sample, both lobes */
-                orc_sample_02(j->seed, j->first + (uint64_t)i, 0, (uint32_t)s, &rx, &ry);
-                orc_v3 L = cone_sample(&c, rx, ry);
-                if (v3dot(L, N) > 0.0f) {
-                    orc_rgb f = orc_ggx_eval_brdf(&g, L);
-                    float pb = orc_ggx_eval_pdf(&g, L);
-                    float w = mode == 1 ? 1.0f : power_heuristic(c.pdf, pb);
-                    sR += f.r * w / c.pdf; sG += f.g * w / c.pdf; sB += f.b * w / c.pdf;
-                    float fd = orc_oren_nayar_brdf(&on, wo, L);
-                    float wd = mode == 1 ? 1.0f : power_heuristic(c.pdf, orc_oren_nayar_pdf(&on, L));
-                    dA += fd * wd / c.pdf;
-                }
-            }
-            if (mode != 1) {                                   /* one BSDF sample per lobe */
-                orc_sample_02(j->seed, j->first + (uint64_t)i, 1, (uint32_t)s, &rx, &ry);
-                orc_v3 L = orc_ggx_eval_sample(&g, rx, ry);
-                if (!v3iszero(L) && v3dot(L, N) > 0.0f && cone_hit(&c, L)) {
-                    orc_rgb f = orc_ggx_eval_brdf(&g, L);
-                    float pb = orc_ggx_eval_pdf(&g, L);
-                    float w = mode == 2 ? 1.0f : power_heuristic(pb, c.pdf);
-                    sR += f.r * w / pb; sG += f.g * w / pb; sB += f.b * w / pb;
-                }
-                orc_sample_02(j->seed, j->first + (uint64_t)i, 2, (uint32_t)s, &rx, &ry);
-                orc_v3 Ld = orc_sss_sample_diffuse_direction(rx, ry, N, T);
-                float pd = orc_oren_nayar_pdf(&on, Ld);
-                if (pd > 0.0f && cone_hit(&c, Ld)) {
-                    float fd = orc_oren_nayar_brdf(&on, wo, Ld);
-                    float wd = mode == 2 ? 1.0f : power_heuristic(pd, c.pdf);
-                    dA += fd * wd / pd;
-                }
-            }
-        }
         const float inv = 1.0f / (float)j->spp;
         const float ks = j->sh->Ks[i], kd = j->sh->Kd[i];
         const orc_rgb kdc = ldc(j->sh->Kd_color, i);
-        const float *rad = j->lt->radiance;
-        stc(j->ds, i, rgb(rad[0] * ks * sR * inv, rad[1] * ks * sG * inv, rad[2] * ks * sB * inv));
-        stc(j->dd, i, rgb(rad[0] * (kdc.r * kd) * dA * inv, rad[1] * (kdc.g * kd) * dA * inv,
-                          rad[2] * (kdc.b * kd) * dA * inv));
+        orc_rgb oS = RGB_BLACK, oD = RGB_BLACK;
+        for (int l = 0; l < j->n_lights; l++) {                    /* while (AiLightsGetSample(sg)), src/rlGgx.cpp:286 */
+            const orc_light *lt = &j->lights[l];
+            const int mode = lt->mis_mode;
+            const uint32_t st = 3u * (uint32_t)l;
+            light_cone c = cone_make(lt, ld3(j->P, i));
+            float sR = 0.0f, sG = 0.0f, sB = 0.0f, dA = 0.0f;
+            for (int s = 0; s < j->spp && c.valid; s++) {
+                float rx, ry;
+                if (mode != 2) {                                   /* one light sample, both lobes */
+                    orc_sample_02(j->seed, j->first + (uint64_t)i, st, (uint32_t)s, &rx, &ry);
+                    orc_v3 L = cone_sample(&c, rx, ry);
+                    if (v3dot(L, N) > 0.0f) {
+                        orc_rgb f = orc_ggx_eval_brdf(&g, L);
+                        float pb = orc_ggx_eval_pdf(&g, L);
+                        float w = mode == 1 ? 1.0f : power_heuristic(c.pdf, pb);
+                        sR += f.r * w / c.pdf; sG += f.g * w / c.pdf; sB += f.b * w / c.pdf;
+                        float fd = orc_oren_nayar_brdf(&on, wo, L);
+                        float wd = mode == 1 ? 1.0f : power_heuristic(c.pdf, orc_oren_nayar_pdf(&on, L));
+                        dA += fd * wd / c.pdf;
+                    }
+                }
+                if (mode != 1) {                                   /* one BSDF sample per lobe */
+                    orc_sample_02(j->seed, j->first + (uint64_t)i, st + 1, (uint32_t)s, &rx, &ry);
+                    orc_v3 L = orc_ggx_eval_sample(&g, rx, ry);
+                    if (!v3iszero(L) && v3dot(L, N) > 0.0f && cone_hit(&c, L)) {
+                        orc_rgb f = orc_ggx_eval_brdf(&g, L);
+                        float pb = orc_ggx_eval_pdf(&g, L);
+                        float w = mode == 2 ? 1.0f : power_heuristic(pb, c.pdf);
+                        sR += f.r * w / pb; sG += f.g * w / pb; sB += f.b * w / pb;
+                    }
+                    orc_sample_02(j->seed, j->first + (uint64_t)i, st + 2, (uint32_t)s, &rx, &ry);
+                    orc_v3 Ld = orc_sss_sample_diffuse_direction(rx, ry, N, T);
+                    float pd = orc_oren_nayar_pdf(&on, Ld);
+                    if (pd > 0.0f && cone_hit(&c, Ld)) {
+                        float fd = orc_oren_nayar_brdf(&on, wo, Ld);
+                        float wd = mode == 2 ? 1.0f : power_heuristic(pd, c.pdf);
+                        dA += fd * wd / pd;
+                    }
+                }
+            }
+            const float *rad = lt->radiance;
+            const orc_rgb tS = rgb(rad[0] * ks * sR * inv, rad[1] * ks * sG * inv, rad[2] * ks * sB * inv);
+            const orc_rgb tD = rgb(rad[0] * (kdc.r * kd) * dA * inv, rad[1] * (kdc.g * kd) * dA * inv,
+                                   rad[2] * (kdc.b * kd) * dA * inv);
+            /* specular += ..., diffuse += ...; the first light assigns */
+            oS = l == 0 ? tS : rgb(oS.r + tS.r, oS.g + tS.g, oS.b + tS.b);
+            oD = l == 0 ? tD : rgb(oD.r + tD.r, oD.g + tD.g, oD.b + tD.b);
+        }
+        stc(j->ds, i, oS);
+        stc(j->dd, i, oD);
     }
 }
 
 void orc_batch_ggx_direct_lighting(int64_t n, const orc_ggx_soa *in, const orc_ggx_shader_soa *sh, orc_cv3p P,
-                                   const orc_light *light, int spp_n, uint32_t seed, uint64_t first_index,
+                                   const orc_light *lights, int n_lights, int spp_n, uint32_t seed, uint64_t first_index,
                                    orc_v3p direct_diffuse, orc_v3p direct_specular, int nthreads)
 {
-    light_job j = { in, sh, P, light, spp_n * spp_n, seed, first_index, direct_diffuse, direct_specular };
+    light_job j = { in, sh, P, lights, n_lights, spp_n * spp_n, seed, first_index, direct_diffuse, direct_specular };
     parallel_for(n, nthreads, light_range, &j);
+}
+
+/* ============================== rlDisney direct lighting =============================== */
+/* src/rlDisney.cpp:695-705: per light evalDiffuseLightSample + evalSpecularLightSample (265-277), each
+ * AiEvaluateLightSample over the triple with the sample type set; the same stand-ins as above */
+
+typedef struct {
+    const orc_disney_soa *in; orc_cv3p P; const orc_light *lights; int n_lights; int spp; uint32_t seed; uint64_t first;
+    orc_v3p dd, ds;
+} dlight_job;
+
+static void dlight_range(int64_t lo, int64_t hi, void *ctx)
+{
+    dlight_job *j = (dlight_job *)ctx;
+    for (int64_t i = lo; i < hi; i++) {
+        orc_disney d;
+        float sc[10];
+        for (int k = 0; k < 10; k++) sc[k] = j->in->scalars[k][i];
+        const orc_v3 N = ld3(j->in->N, i);
+        orc_disney_init(&d, ld3(j->in->wo, i), N, ld3(j->in->T, i), ldc(j->in->base_color, i), sc);
+        const float inv = 1.0f / (float)j->spp;
+        orc_rgb oS = RGB_BLACK, oD = RGB_BLACK;
+        for (int l = 0; l < j->n_lights; l++) {                    /* while (AiLightsGetSample(sg)), :696 */
+            const orc_light *lt = &j->lights[l];
+            const int mode = lt->mis_mode;
+            const uint32_t st = 3u * (uint32_t)l;
+            light_cone c = cone_make(lt, ld3(j->P, i));
+            float acc[2][3] = { { 0 } };                           /* [diffuse, specular][r, g, b] */
+            for (int s = 0; s < j->spp && c.valid; s++) {
+                float rx, ry;
+                if (mode != 2) {                                   /* one light sample, both lobes */
+                    orc_sample_02(j->seed, j->first + (uint64_t)i, st, (uint32_t)s, &rx, &ry);
+                    orc_v3 L = cone_sample(&c, rx, ry);
+                    if (v3dot(L, N) > 0.0f) {
+                        for (int lobe = 0; lobe < 2; lobe++) {
+                            d.sampleType = lobe == 0 ? ORC_RAY_DIFFUSE : ORC_RAY_GLOSSY;   /* :267, :274 */
+                            orc_rgb f = orc_disney_eval_brdf(&d, L);
+                            float p = orc_disney_eval_pdf(&d, L);
+                            float w = mode == 1 ? 1.0f : power_heuristic(c.pdf, p);
+                            acc[lobe][0] += f.r * w / c.pdf; acc[lobe][1] += f.g * w / c.pdf; acc[lobe][2] += f.b * w / c.pdf;
+                        }
+                    }
+                }
+                if (mode != 1) {                                   /* one BSDF sample per lobe */
+                    for (int lobe = 0; lobe < 2; lobe++) {
+                        d.sampleType = lobe == 0 ? ORC_RAY_DIFFUSE : ORC_RAY_GLOSSY;
+                        orc_sample_02(j->seed, j->first + (uint64_t)i, st + 1 + (uint32_t)lobe, (uint32_t)s, &rx, &ry);
+                        orc_v3 L = orc_disney_eval_sample(&d, rx, ry);
+                        orc_rgb f = orc_disney_eval_brdf(&d, L);
+                        float p = orc_disney_eval_pdf(&d, L);
+                        if (p > AI_EPSILON && cone_hit(&c, L)) {   /* valid sample: src/rlDisney.cpp:309 */
+                            float w = mode == 2 ? 1.0f : power_heuristic(p, c.pdf);
+                            acc[lobe][0] += f.r * w / p; acc[lobe][1] += f.g * w / p; acc[lobe][2] += f.b * w / p;
+                        }
+                    }
+                }
+            }
+            const float *rad = lt->radiance;
+            const orc_rgb tD = rgb(rad[0] * acc[0][0] * inv, rad[1] * acc[0][1] * inv, rad[2] * acc[0][2] * inv);
+            const orc_rgb tS = rgb(rad[0] * acc[1][0] * inv, rad[1] * acc[1][1] * inv, rad[2] * acc[1][2] * inv);
+            oD = l == 0 ? tD : rgb(oD.r + tD.r, oD.g + tD.g, oD.b + tD.b);
+            oS = l == 0 ? tS : rgb(oS.r + tS.r, oS.g + tS.g, oS.b + tS.b);
+        }
+        stc(j->dd, i, oD);
+        stc(j->ds, i, oS);
+    }
+}
+
+void orc_batch_disney_direct_lighting(int64_t n, const orc_disney_soa *in, orc_cv3p P, const orc_light *lights,
+                                      int n_lights, int spp_n, uint32_t seed, uint64_t first_index,
+                                      orc_v3p direct_diffuse, orc_v3p direct_specular, int nthreads)
+{
+    dlight_job j = { in, P, lights, n_lights, spp_n * spp_n, seed, first_index, direct_diffuse, direct_specular };
+    parallel_for(n, nthreads, dlight_range, &j);
 }
 
 /* ================================ synthetic generator ================================== */

@@ -323,20 +323,30 @@ void orc_sss_scatter_point(const orc_sss *S, orc_v3 Po, const orc_scene *sc, int
 
 /* shader_evaluate of rlSkin over spp samples per layer (src/rlSkin.cpp:174-254): integrateGlossy per GGX lobe with
  * the Fresnel mean of getAvgReflectWeight (src/rlGgx.h:181-184) handed down, integrateScatter x sssWeight.
- * AiBRDFIntegrate -> mean of evalBrdf / evalPdf x env (uniform environment); no light-loop samples; scene as above.
+ * AiBRDFIntegrate -> mean of evalBrdf / evalPdf x env (uniform environment); scene as above.
  * Dimension pairs of the sampler: 0 sheen, 1 specular, 2 probe rays. */
+/* a spherical light of the light loops' stand-in (see orc_batch_ggx_direct_lighting); layout of rls_sphere_light */
+typedef struct {
+    float center[3], radius;
+    float radiance[3];
+    int   mis_mode;
+} orc_light;
 typedef struct {
     orc_rgb sheen, specular, sss, out;
     float sheenFresnel, specularFresnel, sssWeight;
 } orc_skin_int_out;
+/* lights / n_lights: the light loops of src/rlSkin.cpp:193-198, 217-222 (n_lights 0: none); streams 3 + 4 l, 4 + 4 l
+ * (sheen lobe: light samples, BSDF samples), 5 + 4 l, 6 + 4 l (specular lobe) */
 void orc_skin_integrate(const orc_skin_params *p, orc_v3 wo, orc_v3 Nf, orc_v3 T, orc_v3 P, const orc_scene *sc,
-                        const float env[3], int spp, uint32_t seed, uint64_t index, orc_skin_int_out *out);
+                        const float env[3], const orc_light *lights, int n_lights, int spp, uint32_t seed, uint64_t index,
+                        orc_skin_int_out *out);
 typedef struct {
     orc_v3p sheen, specular, sss, out;
     float *sheenFresnel, *specularFresnel, *sssWeight;
 } orc_skin_int_out_soa;
 void orc_batch_skin_integrate(int64_t n, const orc_skin_soa *in, orc_cv3p P, const orc_scene *sc, const float env[3],
-                              int spp_n, uint32_t seed, uint64_t first_index, const orc_skin_int_out_soa *out, int nthreads);
+                              const orc_light *lights, int n_lights, int spp_n, uint32_t seed, uint64_t first_index,
+                              const orc_skin_int_out_soa *out, int nthreads);
 
 /* integrateRefract (src/rlGgx.h:205-245): traced -> the sample loop (228-244), else the single refraction about
  * the shading normal (213-222); radiance of a uniform environment env */
@@ -354,12 +364,7 @@ void orc_batch_ggx_integrate_refract(int64_t n, const orc_ggx_soa *in, int trace
  * cosine-weighted sampling, and the two-sample estimator with the power heuristic
  * w_a = p_a^2 / (p_a^2 + p_b^2) over spp_n^2 light samples and spp_n^2 BSDF samples per lobe.
  * mis_mode 1 / 2 keep only the light / only the BSDF samples (weight 1): the three modes have the same
- * expectation, which is what the tests check.  Same layout as rls_sphere_light. */
-typedef struct {
-    float center[3], radius;
-    float radiance[3];
-    int   mis_mode;
-} orc_light;
+ * expectation, which is what the tests check. */
 typedef struct {
     orc_cv3p Kd_color;
     const float *Kd, *Kd_roughness, *Ks;
@@ -368,9 +373,16 @@ typedef struct { orc_v3 N, T; float A, B; } orc_oren_nayar;
 void  orc_oren_nayar_init(orc_oren_nayar *o, orc_v3 N, orc_v3 T, float sigma);
 float orc_oren_nayar_brdf(const orc_oren_nayar *o, orc_v3 wo, orc_v3 wi);   /* BRDF x cos(theta_i) */
 float orc_oren_nayar_pdf(const orc_oren_nayar *o, orc_v3 wi);
+/* lights: n_lights of them; light l uses the sample streams 3 l (light samples, shared by both lobes), 3 l + 1 and
+ * 3 l + 2 (BSDF samples of the specular / diffuse lobe); the AOVs are the sums over the lights in array order */
 void  orc_batch_ggx_direct_lighting(int64_t n, const orc_ggx_soa *in, const orc_ggx_shader_soa *sh, orc_cv3p P,
-                                    const orc_light *light, int spp_n, uint32_t seed, uint64_t first_index,
+                                    const orc_light *lights, int n_lights, int spp_n, uint32_t seed, uint64_t first_index,
                                     orc_v3p direct_diffuse, orc_v3p direct_specular, int nthreads);
+/* Direct lighting of the rlDisney node (src/rlDisney.cpp:695-705: evalDiffuseLightSample + evalSpecularLightSample per
+ * light, 265-277), same stand-ins; streams 3 l (light samples), 3 l + 1 (diffuse BSDF samples), 3 l + 2 (specular) */
+void  orc_batch_disney_direct_lighting(int64_t n, const orc_disney_soa *in, orc_cv3p P, const orc_light *lights,
+                                       int n_lights, int spp_n, uint32_t seed, uint64_t first_index,
+                                       orc_v3p direct_diffuse, orc_v3p direct_specular, int nthreads);
 
 /* utility closures, batch form (a2-a5) */
 void orc_batch_util(int64_t n, const float *a, const float *b, orc_v3p spherical, orc_v3p disk, int nthreads);

@@ -186,11 +186,14 @@ PROTOTYPES = {
     "rls_ggx_microfacet": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), C.c_int, _vp, _vp, Vec3]),
     "rls_ggx_ndf_pdf": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), CVec3, _vp]),
     "rls_ggx_direct_lighting": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), C.POINTER(GgxShader), CVec3,
-                                          C.POINTER(SphereLight), C.c_int, C.c_uint32, C.c_uint64, Rgb, Rgb]),
+                                          C.POINTER(SphereLight), C.c_int, C.c_int, C.c_uint32, C.c_uint64, Rgb, Rgb]),
+    "rls_disney_direct_lighting": (C.c_int, [_ctx, _i64, C.POINTER(DisneyClosure), CVec3, C.POINTER(SphereLight), C.c_int,
+                                             C.c_int, C.c_uint32, C.c_uint64, Rgb, Rgb]),
     "rls_ggx_integrate_refract": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), C.c_int, C.POINTER(C.c_float), C.c_int,
                                             C.c_uint32, C.c_uint64, Rgb, _vp]),
     "rls_skin_integrate": (C.c_int, [_ctx, _i64, C.POINTER(SkinClosure), CVec3, C.POINTER(SssScene), C.POINTER(C.c_float),
-                                     C.c_int, C.c_uint32, C.c_uint64, C.POINTER(SkinIntegrateOut)]),
+                                     C.POINTER(SphereLight), C.c_int, C.c_int, C.c_uint32, C.c_uint64,
+                                     C.POINTER(SkinIntegrateOut)]),
     "rls_ggx_integrate": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), C.c_int, C.c_uint32, C.c_uint64, Rgb, _vp]),
     # rlDisney
     "rls_disney_sample": (C.c_int, [_ctx, _i64, C.POINTER(DisneyClosure), C.c_int, _vp, _vp, Vec3]),

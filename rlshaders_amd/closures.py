@@ -332,16 +332,17 @@ class GgxSampler:
             vec3(wt, n, "wt"), plane(w, n, "weight")))
         return out
 
-    def directLighting(self, P, light: "capi.SphereLight", spp_n: int, seed: int, KdColor: Color = (1.0, 1.0, 1.0),
+    def directLighting(self, P, light, spp_n: int, seed: int, KdColor: Color = (1.0, 1.0, 1.0),
                        Kd: Scalar = 0.5, diffuseRoughness: Scalar = 0.0, Ks: Scalar = 0.5, out=None, first_index: int = 0):
-        """The light loop of rlGgx's shader_evaluate (src/rlGgx.cpp:274-299) under one spherical light ->
-        (direct_diffuse [3,n], direct_specular [3,n]); parameter names and defaults of src/rlGgx.cpp:170-175."""
+        """The light loop of rlGgx's shader_evaluate (src/rlGgx.cpp:274-299) under one spherical light or a sequence
+        of them -> (direct_diffuse [3,n], direct_specular [3,n]); parameter names and defaults of src/rlGgx.cpp:170-175."""
         n, ctx = self.n, self.ctx
         dd, ds = out if out is not None else (ctx.empty(3, n), ctx.empty(3, n))
         sh = capi.GgxShader(param_rgb(KdColor, n, "KdColor"), param(Kd, n, "Kd"),
                             param(diffuseRoughness, n, "diffuseRoughness"), param(Ks, n, "Ks"))
+        lights, nl = light_array(light)
         check(ctx.lib.rls_ggx_direct_lighting(ctx.handle, n, C.byref(self.c), C.byref(sh), cvec3(P, n, "P"),
-                                              C.byref(light), int(spp_n), int(seed) & 0xFFFFFFFF, int(first_index),
+                                              lights, nl, int(spp_n), int(seed) & 0xFFFFFFFF, int(first_index),
                                               rgb(dd, n, "direct_diffuse"), rgb(ds, n, "direct_specular")))
         return dd, ds
 
@@ -482,6 +483,18 @@ class DisneySampler:
             rgb(out["specular_sum"], n, "specular_sum"), plane(out["specular_count"], n, "specular_count"),
             C.byref(so) if so is not None else None))
         return out
+
+    def directLighting(self, P, light, spp_n: int, seed: int, out=None, first_index: int = 0):
+        """The light loop of rlDisney's shader_evaluate (src/rlDisney.cpp:695-705: evalDiffuseLightSample +
+        evalSpecularLightSample per light) under one spherical light or a sequence of them ->
+        (direct_diffuse [3,n], direct_specular [3,n]), the two direct AOVs (714-715)."""
+        n, ctx = self.n, self.ctx
+        dd, ds = out if out is not None else (ctx.empty(3, n), ctx.empty(3, n))
+        lights, nl = light_array(light)
+        check(ctx.lib.rls_disney_direct_lighting(ctx.handle, n, C.byref(self.c), cvec3(P, n, "P"), lights, nl, int(spp_n),
+                                                 int(seed) & 0xFFFFFFFF, int(first_index),
+                                                 rgb(dd, n, "direct_diffuse"), rgb(ds, n, "direct_specular")))
+        return dd, ds
 
     def integrateChunked(self, spp_n: int, seed: int, chunk_points: int, consume=None, out=None, chunk=None,
                          first_index: int = 0):
@@ -653,6 +666,18 @@ class SssSampler:
         return wi
 
 
+def light_array(lights):
+    """one SphereLight, a sequence of them or None -> (ctypes array or None, count)"""
+    if lights is None:
+        return None, 0
+    if isinstance(lights, capi.SphereLight):
+        lights = [lights]
+    lights = list(lights)
+    if not lights:
+        return None, 0
+    return (capi.SphereLight * len(lights))(*lights), len(lights)
+
+
 def make_light(center=(0.0, 0.0, 5.0), radius=1.0, radiance=(1.0, 1.0, 1.0), mis_mode=capi.RLS_MIS_BOTH) -> "capi.SphereLight":
     """The spherical area light of ``GgxSampler.directLighting`` (rls_sphere_light)."""
     lt = capi.SphereLight()
@@ -751,9 +776,10 @@ class SkinShader:
 
 
     def integrate(self, P, scene: "capi.SssScene", spp_n: int, seed: int, env=(1.0, 1.0, 1.0), out=None,
-                  first_index: int = 0) -> dict:
+                  first_index: int = 0, lights=None) -> dict:
         """shader_evaluate over spp_n^2 samples per layer (src/rlSkin.cpp:174-254; rls_skin_integrate) -> dict(sheen,
-        specular, sss, out [3,n]; sheenFresnel, specularFresnel, sssWeight [n])."""
+        specular, sss, out [3,n]; sheenFresnel, specularFresnel, sssWeight [n]).  ``lights``: the spherical lights of
+        the two light loops (193-198, 217-222); None = no lights."""
         n, ctx = self.n, self.ctx
         if out is None:
             out = {k: ctx.empty(3, n) for k in ("sheen", "specular", "sss", "out")}
@@ -766,8 +792,9 @@ class SkinShader:
             if k in out:
                 setattr(o, k, plane(out[k], n, k))
         e = (C.c_float * 3)(*[float(v) for v in env])
-        check(ctx.lib.rls_skin_integrate(ctx.handle, n, C.byref(self.c), cvec3(P, n, "P"), C.byref(scene), e, int(spp_n),
-                                         int(seed) & 0xFFFFFFFF, int(first_index), C.byref(o)))
+        la, nl = light_array(lights)
+        check(ctx.lib.rls_skin_integrate(ctx.handle, n, C.byref(self.c), cvec3(P, n, "P"), C.byref(scene), e, la, nl,
+                                         int(spp_n), int(seed) & 0xFFFFFFFF, int(first_index), C.byref(o)))
         return out
 
 

@@ -76,9 +76,10 @@ __device__ __forceinline__ float group_sum(float v)
 template <int G>
 __device__ __forceinline__ void ggx_glossy_loop(const Ggx &g, const VndfView &w, const uint32_t (*tab)[kMaxSpp], int spp,
                                                 int sub, uint32_t sx, uint32_t sy,
-                                                float &accR, float &accG, float &accB, float &accF)
+                                                float &accR, float &accG, float &accB, float &accF, float f0 = 0.0f)
 {
-    accR = 0.0f; accG = 0.0f; accB = 0.0f; accF = 0.0f;
+    // f0: this lane's Fresnel sum of the samples drawn on the closure before (rlSkin's light loops)
+    accR = 0.0f; accG = 0.0f; accB = 0.0f; accF = f0;
     for (int s = sub; s < spp; s += G) {
         float rx = bits_u01(tab[0][s] ^ sx);
         float ry = bits_u01(tab[1][s] ^ sy);
@@ -92,6 +93,68 @@ __device__ __forceinline__ void ggx_glossy_loop(const Ggx &g, const VndfView &w,
     if (G > 1) {
         accR = group_sum<G>(accR); accG = group_sum<G>(accG);
         accB = group_sum<G>(accB); accF = group_sum<G>(accF);
+    }
+}
+
+// One light of a light loop, as the kernels below read it from the argument struct (l is wave-uniform)
+struct LightRegs { int mode; float rad[3]; LightCone cone; };
+__device__ __forceinline__ LightRegs light_regs(const rls_sphere_light &lt, V3 P)
+{
+    LightRegs r;
+    r.mode = lt.mis_mode;
+    r.rad[0] = lt.radiance[0]; r.rad[1] = lt.radiance[1]; r.rad[2] = lt.radiance[2];
+    r.cone = cone_make(arr3(lt.center), lt.radius, P);
+    return r;
+}
+
+// The light loop of one GGX lobe of rlSkin (src/rlSkin.cpp:193-198 / 217-222): per light evalLightSample
+// (src/rlGgx.h:167-170) = the two-sample estimator of rls_ggx_direct_lighting's specular lobe.  out: the sum over the
+// lights (group-reduced); f / cnt: THIS LANE's running Fresnel sum and count of the evalSample calls (src/rlGgx.h:103)
+// -- the caller carries them into integrateGlossy's loop and reduces once, so that one lane per point adds in the
+// reference's order.  Sample streams: `stream` + 4 l (light samples), `stream` + 1 + 4 l (BSDF samples).
+template <int G>
+__device__ __forceinline__ void ggx_light_loops(const Ggx &g, const VndfView &w, V3 N, V3 P,
+                                                const rls_sphere_light *lights, int nl,
+                                                const uint32_t (*tab)[kMaxSpp], int spp, int sub, float inv,
+                                                uint32_t seed, uint64_t index, uint32_t stream,
+                                                float out[3], float &f, float &cnt)
+{
+    out[0] = 0.0f; out[1] = 0.0f; out[2] = 0.0f; f = 0.0f; cnt = 0.0f;
+    for (int l = 0; l < nl; l++) {
+        const LightRegs lt = light_regs(lights[l], P);
+        const LightCone &cone = lt.cone;
+        const int mode = lt.mode;
+        uint32_t scr[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) scr[k] = hash_u32(seed, index, kScrambleStream + 2 * (stream + 4 * l) + k);
+        float sR = 0.0f, sG = 0.0f, sB = 0.0f;
+        for (int s = sub; s < spp && cone.valid; s += G) {
+            if (mode != RLS_MIS_BSDF_ONLY) {
+                float rx = bits_u01(tab[0][s] ^ scr[0]), ry = bits_u01(tab[1][s] ^ scr[1]);
+                V3 L = cone_sample(cone, rx, ry);
+                if (dot(L, N) > 0.0f) {
+                    float fr, fg, fb, pb;
+                    ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pb);
+                    float wgt = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, pb);
+                    sR += R_DIV(fr * wgt, cone.pdf); sG += R_DIV(fg * wgt, cone.pdf); sB += R_DIV(fb * wgt, cone.pdf);
+                }
+            }
+            if (mode != RLS_MIS_LIGHT_ONLY) {
+                float rx = bits_u01(tab[0][s] ^ scr[2]), ry = bits_u01(tab[1][s] ^ scr[3]);
+                V3 M = vndf_microfacet(w, g.fr, rx, ry);
+                V3 L = reflect_direction(g.view, M);
+                f += ggx_fresnel(g, L, M);                      // mReflectWeight += ..., mMisSampleCount += 1
+                cnt += 1.0f;
+                if (!is_zero(L) && dot(L, N) > 0.0f && cone_hit(cone, L)) {
+                    float fr, fg, fb, pb;
+                    ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pb);
+                    float wgt = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(pb, cone.pdf);
+                    sR += R_DIV(fr * wgt, pb); sG += R_DIV(fg * wgt, pb); sB += R_DIV(fb * wgt, pb);
+                }
+            }
+        }
+        if (G > 1) { sR = group_sum<G>(sR); sG = group_sum<G>(sG); sB = group_sum<G>(sB); }
+        out[0] += lt.rad[0] * sR * inv; out[1] += lt.rad[1] * sG * inv; out[2] += lt.rad[2] * sB * inv;
     }
 }
 
@@ -353,7 +416,7 @@ __global__ RLS_INT_ATTR void sss_scatter_kernel(ScatterIO a)
 // the next layer -- sheenFresnel = avg * sheen_weight (:204), specular *= specular_weight * (1 - sheenFresnel) (:231),
 // specularFresnel (:228), sssWeight *= 1 - specularFresnel * (1 - sheenFresnel) (:238) -- then integrateScatter *
 // sssWeight (:244-246).  AiBRDFIntegrate is closed: its stand-in is the mean of eval/pdf over the samples under a
-// uniform environment of radiance `env` (parity unpinned); the light loops of :195-200,218-223 contribute no samples.
+// uniform environment of radiance `env` (parity unpinned); the light loops of :193-198,217-222 -> ggx_light_loops.
 using rlsh::SkinIntIO;
 
 template <int G, int FAST_MATH = RLS_FAST>
@@ -380,6 +443,7 @@ __global__ RLS_INT_ATTR void skin_integrate_kernel(SkinIntIO a)
         Frame gfr;
         gfr.N = N; gfr.U = T; gfr.V = cross(N, T);
         const V3 local = vndf_local(wo, gfr);       // shared by the two lobes (same frame, same view)
+        const V3 P = ld3(a.P, ii);
 
         float sheenFresnel = 0.0f, specularFresnel = 0.0f;
         float shR = 0.0f, shG = 0.0f, shB = 0.0f, spR = 0.0f, spG = 0.0f, spB = 0.0f;
@@ -390,15 +454,19 @@ __global__ RLS_INT_ATTR void skin_integrate_kernel(SkinIntIO a)
             ldrgb(c.sheen_color, ii, cr, cg, cb);
             Ggx g = ggx_make<true>(wo, N, T, false, cr, cg, cb, ldp(c.sheen_ior, ii), ldp(c.sheen_roughness, ii), 0.0f);
             VndfView w = vndf_view_from(local, g.ax, g.ay);
-            float aF;
-            ggx_glossy_loop<G>(g, w, tab, a.spp, sub, scr[0], scr[1], shR, shG, shB, aF);
-            // integrateGlossy returns black for a small colour without sampling (src/rlGgx.h:174-176): no samples,
-            // getAvgReflectWeight = 1
+            float lit[3], lf, lc, aF;
+            ggx_light_loops<G>(g, w, N, P, a.lights, a.nl, tab, a.spp, sub, inv, a.seed, a.first + (uint64_t)ii, 3,
+                               lit, lf, lc);                                          // :193-198
+            ggx_glossy_loop<G>(g, w, tab, a.spp, sub, scr[0], scr[1], shR, shG, shB, aF, lf);
+            // integrateGlossy returns black for a small colour without sampling (src/rlGgx.h:174-176); the light
+            // loop samples regardless; getAvgReflectWeight (181-184) = sum / count over both, 1 when none were drawn
             const bool small = absf(cr) < kEps && absf(cg) < kEps && absf(cb) < kEps;
-            const float avg = small ? 1.0f : aF * inv;
+            if (G > 1) { lf = group_sum<G>(lf); lc = group_sum<G>(lc); }
+            const float fsum = small ? lf : aF, fcnt = small ? lc : lc + (float)a.spp;
+            const float avg = fcnt > 0.0f ? R_DIV(fsum, fcnt) : 1.0f;
             if (small) { shR = 0.0f; shG = 0.0f; shB = 0.0f; }
             sheenFresnel = avg * sheenWeight;                                         // :204
-            shR = shR * inv * a.env[0]; shG = shG * inv * a.env[1]; shB = shB * inv * a.env[2];
+            shR = lit[0] + shR * inv * a.env[0]; shG = lit[1] + shG * inv * a.env[1]; shB = lit[2] + shB * inv * a.env[2];
         }
         shR *= sheenWeight; shG *= sheenWeight; shB *= sheenWeight;                   // :207
         const float specWeight = ldp(c.specular_weight, ii);
@@ -407,13 +475,17 @@ __global__ RLS_INT_ATTR void skin_integrate_kernel(SkinIntIO a)
             ldrgb(c.specular_color, ii, cr, cg, cb);
             Ggx g = ggx_make<true>(wo, N, T, false, cr, cg, cb, ldp(c.specular_ior, ii), ldp(c.specular_roughness, ii), 0.0f);
             VndfView w = vndf_view_from(local, g.ax, g.ay);
-            float aF;
-            ggx_glossy_loop<G>(g, w, tab, a.spp, sub, scr[2], scr[3], spR, spG, spB, aF);
+            float lit[3], lf, lc, aF;
+            ggx_light_loops<G>(g, w, N, P, a.lights, a.nl, tab, a.spp, sub, inv, a.seed, a.first + (uint64_t)ii, 5,
+                               lit, lf, lc);                                          // :217-222
+            ggx_glossy_loop<G>(g, w, tab, a.spp, sub, scr[2], scr[3], spR, spG, spB, aF, lf);
             const bool small = absf(cr) < kEps && absf(cg) < kEps && absf(cb) < kEps;
-            const float avg = small ? 1.0f : aF * inv;
+            if (G > 1) { lf = group_sum<G>(lf); lc = group_sum<G>(lc); }
+            const float fsum = small ? lf : aF, fcnt = small ? lc : lc + (float)a.spp;
+            const float avg = fcnt > 0.0f ? R_DIV(fsum, fcnt) : 1.0f;
             if (small) { spR = 0.0f; spG = 0.0f; spB = 0.0f; }
             specularFresnel = avg * specWeight;                                       // :228
-            spR = spR * inv * a.env[0]; spG = spG * inv * a.env[1]; spB = spB * inv * a.env[2];
+            spR = lit[0] + spR * inv * a.env[0]; spG = lit[1] + spG * inv * a.env[1]; spB = lit[2] + spB * inv * a.env[2];
         }
         const float sw = specWeight * (1.0f - sheenFresnel);                          // :231
         spR *= sw; spG *= sw; spB *= sw;
@@ -428,7 +500,7 @@ __global__ RLS_INT_ATTR void skin_integrate_kernel(SkinIntIO a)
             Frame fr = sss_frame(N, T, true);
             float br, bg, bb, accD;
             ldrgb(c.sss_color, ii, br, bg, bb);
-            scatter_loop<G>(p, fr, ld3(a.P, ii), sc, tab, a.spp, sub, scr[4], scr[5], ssR, ssG, ssB, accD);
+            scatter_loop<G>(p, fr, P, sc, tab, a.spp, sub, scr[4], scr[5], ssR, ssG, ssB, accD);
             ssR = br * ssR * inv * sssWeight; ssG = bg * ssG * inv * sssWeight; ssB = bb * ssB * inv * sssWeight;
         }
         if (live && sub == 0) {
@@ -511,12 +583,11 @@ __global__ RLS_INT_ATTR void ggx_direct_kernel(LightIO a)
     __shared__ uint32_t tab[2][kMaxSpp];
     stage_libm_tables();   // atanf range table (+ expf / logf / powf tables) -> LDS
     stage_table(tab, a.spp);
-    const int mode = a.light.mis_mode;
-    const V3 center = arr3(a.light.center);
     const int sub = threadIdx.x % G;
     const int64_t groups_per_block = rlsh::kBlock / G;
     const int64_t stride = (int64_t)gridDim.x * groups_per_block;
     const int64_t rounds = (a.n + stride - 1) / stride;
+    const float inv = 1.0f / (float)a.spp;
     int64_t i = (int64_t)blockIdx.x * groups_per_block + threadIdx.x / G;
     for (int64_t it = 0; it < rounds; it++, i += stride) {
         const bool live = i < a.n;
@@ -530,57 +601,168 @@ __global__ RLS_INT_ATTR void ggx_direct_kernel(LightIO a)
                          ldp(c.anisotropic, ii));
         VndfView w = vndf_view(g.view, g.fr, g.ax, g.ay);
         OrenNayar on = oren_nayar_make(N, ldp(a.sh.diffuseRoughness, ii));
-        LightCone cone = cone_make(center, a.light.radius, ld3(a.P, ii));
-        uint32_t scr[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) scr[k] = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream + k);
+        const V3 P = ld3(a.P, ii);
+        const float ks = ldp(a.sh.Ks, ii), kd = ldp(a.sh.Kd, ii);
+        float dr, dg, db;
+        ldrgb(a.sh.KdColor, ii, dr, dg, db);
 
-        float sR = 0.0f, sG = 0.0f, sB = 0.0f, dA = 0.0f;
-        for (int s = sub; s < a.spp && cone.valid; s += G) {
-            if (mode != RLS_MIS_BSDF_ONLY) {                     // one light sample, both lobes
-                float rx = bits_u01(tab[0][s] ^ scr[0]), ry = bits_u01(tab[1][s] ^ scr[1]);
-                V3 L = cone_sample(cone, rx, ry);
-                if (dot(L, N) > 0.0f) {
-                    float fr, fg, fb, pb;
-                    ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pb);
-                    float wgt = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, pb);
-                    sR += R_DIV(fr * wgt, cone.pdf); sG += R_DIV(fg * wgt, cone.pdf); sB += R_DIV(fb * wgt, cone.pdf);
-                    float fd = oren_nayar_brdf(on, wo, L);
-                    float wd = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, oren_nayar_pdf(on, L));
-                    dA += R_DIV(fd * wd, cone.pdf);
+        float oS[3] = { 0.0f, 0.0f, 0.0f }, oD[3] = { 0.0f, 0.0f, 0.0f };
+        for (int l = 0; l < a.nl; l++) {                             // while (AiLightsGetSample(sg)), src/rlGgx.cpp:286
+            const LightRegs lt = light_regs(a.lights[l], P);
+            const LightCone &cone = lt.cone;
+            const int mode = lt.mode;
+            uint32_t scr[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) scr[k] = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream + 6 * l + k);
+
+            float sR = 0.0f, sG = 0.0f, sB = 0.0f, dA = 0.0f;
+            for (int s = sub; s < a.spp && cone.valid; s += G) {
+                if (mode != RLS_MIS_BSDF_ONLY) {                     // one light sample, both lobes
+                    float rx = bits_u01(tab[0][s] ^ scr[0]), ry = bits_u01(tab[1][s] ^ scr[1]);
+                    V3 L = cone_sample(cone, rx, ry);
+                    if (dot(L, N) > 0.0f) {
+                        float fr, fg, fb, pb;
+                        ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pb);
+                        float wgt = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, pb);
+                        sR += R_DIV(fr * wgt, cone.pdf); sG += R_DIV(fg * wgt, cone.pdf); sB += R_DIV(fb * wgt, cone.pdf);
+                        float fd = oren_nayar_brdf(on, wo, L);
+                        float wd = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, oren_nayar_pdf(on, L));
+                        dA += R_DIV(fd * wd, cone.pdf);
+                    }
+                }
+                if (mode != RLS_MIS_LIGHT_ONLY) {                    // one BSDF sample per lobe
+                    float rx = bits_u01(tab[0][s] ^ scr[2]), ry = bits_u01(tab[1][s] ^ scr[3]);
+                    V3 M = vndf_microfacet(w, g.fr, rx, ry);
+                    V3 L = reflect_direction(g.view, M);
+                    if (!is_zero(L) && dot(L, N) > 0.0f && cone_hit(cone, L)) {
+                        float fr, fg, fb, pb;
+                        ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pb);
+                        float wgt = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(pb, cone.pdf);
+                        sR += R_DIV(fr * wgt, pb); sG += R_DIV(fg * wgt, pb); sB += R_DIV(fb * wgt, pb);
+                    }
+                    rx = bits_u01(tab[0][s] ^ scr[4]); ry = bits_u01(tab[1][s] ^ scr[5]);
+                    V3 Ld = cosine_hemisphere(g.fr, rx, ry);
+                    float pd = oren_nayar_pdf(on, Ld);
+                    if (pd > 0.0f && cone_hit(cone, Ld)) {
+                        float fd = oren_nayar_brdf(on, wo, Ld);
+                        float wd = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(pd, cone.pdf);
+                        dA += R_DIV(fd * wd, pd);
+                    }
                 }
             }
-            if (mode != RLS_MIS_LIGHT_ONLY) {                    // one BSDF sample per lobe
-                float rx = bits_u01(tab[0][s] ^ scr[2]), ry = bits_u01(tab[1][s] ^ scr[3]);
-                V3 M = vndf_microfacet(w, g.fr, rx, ry);
-                V3 L = reflect_direction(g.view, M);
-                if (!is_zero(L) && dot(L, N) > 0.0f && cone_hit(cone, L)) {
-                    float fr, fg, fb, pb;
-                    ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pb);
-                    float wgt = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(pb, cone.pdf);
-                    sR += R_DIV(fr * wgt, pb); sG += R_DIV(fg * wgt, pb); sB += R_DIV(fb * wgt, pb);
-                }
-                rx = bits_u01(tab[0][s] ^ scr[4]); ry = bits_u01(tab[1][s] ^ scr[5]);
-                V3 Ld = cosine_hemisphere(g.fr, rx, ry);
-                float pd = oren_nayar_pdf(on, Ld);
-                if (pd > 0.0f && cone_hit(cone, Ld)) {
-                    float fd = oren_nayar_brdf(on, wo, Ld);
-                    float wd = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(pd, cone.pdf);
-                    dA += R_DIV(fd * wd, pd);
-                }
+            if (G > 1) {
+                sR = group_sum<G>(sR); sG = group_sum<G>(sG); sB = group_sum<G>(sB); dA = group_sum<G>(dA);
             }
-        }
-        if (G > 1) {
-            sR = group_sum<G>(sR); sG = group_sum<G>(sG); sB = group_sum<G>(sB); dA = group_sum<G>(dA);
+            // diffuse *= KdColor * Kd, specular *= Ks (src/rlGgx.cpp:307-308), light by light; the first light
+            // assigns (0 + x keeps x but loses the sign of a zero)
+            const float tS[3] = { lt.rad[0] * ks * sR * inv, lt.rad[1] * ks * sG * inv, lt.rad[2] * ks * sB * inv };
+            const float tD[3] = { lt.rad[0] * (dr * kd) * dA * inv, lt.rad[1] * (dg * kd) * dA * inv,
+                                  lt.rad[2] * (db * kd) * dA * inv };
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                oS[k] = l == 0 ? tS[k] : oS[k] + tS[k];
+                oD[k] = l == 0 ? tD[k] : oD[k] + tD[k];
+            }
         }
         if (live && sub == 0) {
-            const float inv = 1.0f / (float)a.spp;
-            const float ks = ldp(a.sh.Ks, ii), kd = ldp(a.sh.Kd, ii);
-            float dr, dg, db;
-            ldrgb(a.sh.KdColor, ii, dr, dg, db);
-            const float *rad = a.light.radiance;
-            strgb(a.ds, i, rad[0] * ks * sR * inv, rad[1] * ks * sG * inv, rad[2] * ks * sB * inv);
-            strgb(a.dd, i, rad[0] * (dr * kd) * dA * inv, rad[1] * (dg * kd) * dA * inv, rad[2] * (db * kd) * dA * inv);
+            strgb(a.ds, i, oS[0], oS[1], oS[2]);
+            strgb(a.dd, i, oD[0], oD[1], oD[2]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Direct lighting of the rlDisney node (src/rlDisney.cpp:695-705): per light the diffuse lobe's and the specular
+// lobe's AiEvaluateLightSample over the callback triple (265-277); include/rlshaders_amd.h,
+// rls_disney_direct_lighting, says what stands in for the closed light loop.
+using rlsh::DisneyLightIO;
+
+template <int G, int FAST_MATH = RLS_FAST>
+__global__ RLS_INT_ATTR void disney_direct_kernel(DisneyLightIO a)
+{
+    __shared__ uint32_t tab[2][kMaxSpp];
+    stage_libm_tables();
+    stage_table(tab, a.spp);
+    const int sub = threadIdx.x % G;
+    const int64_t groups_per_block = rlsh::kBlock / G;
+    const int64_t stride = (int64_t)gridDim.x * groups_per_block;
+    const int64_t rounds = (a.n + stride - 1) / stride;
+    const float inv = 1.0f / (float)a.spp;
+    int64_t i = (int64_t)blockIdx.x * groups_per_block + threadIdx.x / G;
+    for (int64_t it = 0; it < rounds; it++, i += stride) {
+        const bool live = i < a.n;
+        const int64_t ii = live ? i : a.n - 1;
+        const rls_disney_closure &c = a.c;
+        V3 wo = ld3(c.wo, ii), N = ld3(c.N, ii), T = ld3(c.T, ii);
+        float br, bg, bb;
+        ldrgb(c.base_color, ii, br, bg, bb);
+        float sc[10];
+        sc[0] = ldp(c.subsurface, ii); sc[1] = ldp(c.metallic, ii); sc[2] = ldp(c.specular, ii);
+        sc[3] = ldp(c.specular_tint, ii); sc[4] = ldp(c.roughness, ii); sc[5] = ldp(c.anisotropic, ii);
+        sc[6] = ldp(c.sheen, ii); sc[7] = ldp(c.sheen_tint, ii); sc[8] = ldp(c.clearcoat, ii);
+        sc[9] = ldp(c.clearcoat_gloss, ii);
+        Disney d = disney_make(wo, N, T, br, bg, bb, sc);
+        disney_prepare(d);
+        VndfView w = vndf_view(d.view, d.fr, d.ax, d.ay);
+        const V3 P = ld3(a.P, ii);
+
+        float oS[3] = { 0.0f, 0.0f, 0.0f }, oD[3] = { 0.0f, 0.0f, 0.0f };
+        for (int l = 0; l < a.nl; l++) {                             // while (AiLightsGetSample(sg)), :696
+            const LightRegs lt = light_regs(a.lights[l], P);
+            const LightCone &cone = lt.cone;
+            const int mode = lt.mode;
+            uint32_t scr[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) scr[k] = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream + 6 * l + k);
+
+            float sR = 0.0f, sG = 0.0f, sB = 0.0f, dR = 0.0f, dG = 0.0f, dB = 0.0f;
+            for (int s = sub; s < a.spp && cone.valid; s += G) {
+                if (mode != RLS_MIS_BSDF_ONLY) {                     // one light sample, both lobes
+                    float rx = bits_u01(tab[0][s] ^ scr[0]), ry = bits_u01(tab[1][s] ^ scr[1]);
+                    V3 L = cone_sample(cone, rx, ry);
+                    if (dot(L, N) > 0.0f) {
+                        float r, g, b, p;
+                        disney_eval_pdf<true, true, true>(d, L, r, g, b, p);       // evalDiffuseLightSample, :265-269
+                        float wgt = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, p);
+                        dR += R_DIV(r * wgt, cone.pdf); dG += R_DIV(g * wgt, cone.pdf); dB += R_DIV(b * wgt, cone.pdf);
+                        disney_eval_pdf<false, true, true>(d, L, r, g, b, p);      // evalSpecularLightSample, :272-276
+                        wgt = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, p);
+                        sR += R_DIV(r * wgt, cone.pdf); sG += R_DIV(g * wgt, cone.pdf); sB += R_DIV(b * wgt, cone.pdf);
+                    }
+                }
+                if (mode != RLS_MIS_LIGHT_ONLY) {                    // one BSDF sample per lobe
+                    float rx = bits_u01(tab[0][s] ^ scr[2]), ry = bits_u01(tab[1][s] ^ scr[3]);
+                    V3 L = cosine_hemisphere(d.fr, rx, ry);
+                    float r, g, b, p;
+                    disney_eval_pdf<true, true, true>(d, L, r, g, b, p);
+                    if (p > kEps && cone_hit(cone, L)) {
+                        float wgt = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(p, cone.pdf);
+                        dR += R_DIV(r * wgt, p); dG += R_DIV(g * wgt, p); dB += R_DIV(b * wgt, p);
+                    }
+                    rx = bits_u01(tab[0][s] ^ scr[4]); ry = bits_u01(tab[1][s] ^ scr[5]);
+                    L = disney_sample_specular(d, w, rx, ry);
+                    disney_eval_pdf<false, true, true>(d, L, r, g, b, p);
+                    if (p > kEps && cone_hit(cone, L)) {
+                        float wgt = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(p, cone.pdf);
+                        sR += R_DIV(r * wgt, p); sG += R_DIV(g * wgt, p); sB += R_DIV(b * wgt, p);
+                    }
+                }
+            }
+            if (G > 1) {
+                dR = group_sum<G>(dR); dG = group_sum<G>(dG); dB = group_sum<G>(dB);
+                sR = group_sum<G>(sR); sG = group_sum<G>(sG); sB = group_sum<G>(sB);
+            }
+            const float tD[3] = { lt.rad[0] * dR * inv, lt.rad[1] * dG * inv, lt.rad[2] * dB * inv };
+            const float tS[3] = { lt.rad[0] * sR * inv, lt.rad[1] * sG * inv, lt.rad[2] * sB * inv };
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                oD[k] = l == 0 ? tD[k] : oD[k] + tD[k];
+                oS[k] = l == 0 ? tS[k] : oS[k] + tS[k];
+            }
+        }
+        if (live && sub == 0) {
+            strgb(a.dd, i, oD[0], oD[1], oD[2]);
+            strgb(a.ds, i, oS[0], oS[1], oS[2]);
         }
     }
 }
@@ -607,6 +789,20 @@ rls_status launch_g(rls_context *ctx, K k1, K k4, K k16, K k64, int g, const IO 
     return rlsh::check_launch(name);
 }
 
+// the lights of a light loop, validated and copied into a kernel's argument struct
+inline rls_status copy_lights(const rls_sphere_light *lights, int n_lights, int at_least, rls_sphere_light *dst, int *count)
+{
+    RLS_REQUIRE(n_lights >= at_least && n_lights <= RLS_MAX_LIGHTS, "n_lights out of range (RLS_MAX_LIGHTS)");
+    RLS_REQUIRE(n_lights == 0 || lights != nullptr, "lights is NULL");
+    for (int l = 0; l < n_lights; l++) {
+        RLS_REQUIRE(lights[l].mis_mode >= RLS_MIS_BOTH && lights[l].mis_mode <= RLS_MIS_BSDF_ONLY, "unknown mis_mode");
+        RLS_REQUIRE(lights[l].radius > 0.0f, "light radius must be positive");
+        dst[l] = lights[l];
+    }
+    *count = n_lights;
+    return RLS_OK;
+}
+
 // plane pointers advanced by k points (chunked / sharded calls)
 inline rls_param adv(rls_param p, int64_t k) { if (p.v) p.v += k; return p; }
 inline rls_param_rgb adv(rls_param_rgb p, int64_t k) { if (p.r) { p.r += k; p.g += k; p.b += k; } return p; }
@@ -631,6 +827,11 @@ RLS_HIDDEN rls_status rls_fast_ggx_direct(rls_context *ctx, int g, const rlsh::L
     return launch_g(ctx, ggx_direct_kernel<1>, ggx_direct_kernel<4>, ggx_direct_kernel<16>,
                     ggx_direct_kernel<64>, g, *io, "rls_ggx_direct_lighting[fast]");
 }
+RLS_HIDDEN rls_status rls_fast_disney_direct(rls_context *ctx, int g, const rlsh::DisneyLightIO *io)
+{
+    return launch_g(ctx, disney_direct_kernel<1>, disney_direct_kernel<4>, disney_direct_kernel<16>,
+                    disney_direct_kernel<64>, g, *io, "rls_disney_direct_lighting[fast]");
+}
 RLS_HIDDEN rls_status rls_fast_skin_integrate(rls_context *ctx, int g, const rlsh::SkinIntIO *io)
 {
     return launch_g(ctx, skin_integrate_kernel<1>, skin_integrate_kernel<4>, skin_integrate_kernel<16>,
@@ -652,13 +853,15 @@ RLS_HIDDEN rls_status rls_fast_disney_integrate(rls_context *ctx, int g, const r
 RLS_HIDDEN rls_status rls_fast_sss_scatter(rls_context *ctx, int g, const rlsh::ScatterIO *io);
 RLS_HIDDEN rls_status rls_fast_ggx_direct(rls_context *ctx, int g, const rlsh::LightIO *io);
 RLS_HIDDEN rls_status rls_fast_skin_integrate(rls_context *ctx, int g, const rlsh::SkinIntIO *io);
+RLS_HIDDEN rls_status rls_fast_disney_direct(rls_context *ctx, int g, const rlsh::DisneyLightIO *io);
 RLS_HIDDEN rls_status rls_fast_ggx_refract_integrate(rls_context *ctx, int g, const rlsh::RefractIntIO *io);
 
 extern "C" {
 
 rls_status rls_skin_integrate(rls_context *ctx, int64_t n, const rls_skin_closure *c, rls_cvec3 P,
-                              const rls_sss_scene *scene, const float env[3], int spp_n, uint32_t seed,
-                              uint64_t first_index, const rls_skin_integrate_out *out)
+                              const rls_sss_scene *scene, const float env[3],
+                              const rls_sphere_light *lights, int n_lights,
+                              int spp_n, uint32_t seed, uint64_t first_index, const rls_skin_integrate_out *out)
 {
     RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
     RLS_REQUIRE(n >= 0, "n < 0");
@@ -672,6 +875,7 @@ rls_status rls_skin_integrate(rls_context *ctx, int64_t n, const rls_skin_closur
     RLS_REQUIRE(rlsh::has3(out->sheen) && rlsh::has3(out->specular) && rlsh::has3(out->sss), "NULL AOV plane");
     RLS_REQUIRE(rlsh::has3(out->out) || (!out->out.r && !out->out.g && !out->out.b), "out planes must be all set or all NULL");
     rlsh::SkinIntIO io = {};
+    if (rls_status st = copy_lights(lights, n_lights, 0, io.lights, &io.nl)) return st;
     io.c = *c; io.P = P; io.scene = *scene; io.env[0] = env[0]; io.env[1] = env[1]; io.env[2] = env[2];
     io.sheen = out->sheen; io.specular = out->specular; io.sss = out->sss; io.out = out->out;
     io.sheenFresnel = out->sheenFresnel; io.specularFresnel = out->specularFresnel; io.sssWeight = out->sssWeight;
@@ -817,26 +1021,47 @@ rls_status rls_sss_integrate_scatter(rls_context *ctx, int64_t n, const rls_sss_
 }
 
 rls_status rls_ggx_direct_lighting(rls_context *ctx, int64_t n, const rls_ggx_closure *c, const rls_ggx_shader *sh,
-                                   rls_cvec3 P, const rls_sphere_light *light, int spp_n, uint32_t seed,
+                                   rls_cvec3 P, const rls_sphere_light *lights, int n_lights, int spp_n, uint32_t seed,
                                    uint64_t first_index, rls_rgb direct_diffuse, rls_rgb direct_specular)
 {
     RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
     RLS_REQUIRE(n >= 0, "n < 0");
     RLS_REQUIRE(spp_n >= 1 && spp_n * spp_n <= kMaxSpp, "spp_n must be in [1, 16]");
     if (n == 0) return RLS_OK;
-    RLS_REQUIRE(c != nullptr && sh != nullptr && light != nullptr, "closure, shader or light is NULL");
+    RLS_REQUIRE(c != nullptr && sh != nullptr, "closure or shader is NULL");
     RLS_REQUIRE(rlsh::has3(c->wo) && rlsh::has3(c->N) && rlsh::has3(c->T) && rlsh::has3(P), "wo/N/T/P plane is NULL");
     RLS_REQUIRE(rlsh::ok_rgb(c->KsColor) && rlsh::ok_rgb(sh->KdColor), "colour planes must be all set or all NULL");
-    RLS_REQUIRE(light->mis_mode >= RLS_MIS_BOTH && light->mis_mode <= RLS_MIS_BSDF_ONLY, "unknown mis_mode");
-    RLS_REQUIRE(light->radius > 0.0f, "light radius must be positive");
     RLS_REQUIRE(rlsh::has3(direct_diffuse) && rlsh::has3(direct_specular), "NULL output plane");
     LightIO io = {};
-    io.c = *c; io.sh = *sh; io.P = P; io.light = *light; io.dd = direct_diffuse; io.ds = direct_specular;
+    if (rls_status st = copy_lights(lights, n_lights, 1, io.lights, &io.nl)) return st;
+    io.c = *c; io.sh = *sh; io.P = P; io.dd = direct_diffuse; io.ds = direct_specular;
     io.n = n; io.spp = spp_n * spp_n; io.seed = seed; io.first = first_index;
     int g = pick_group(ctx, n, io.spp);
     if (ctx->fast) return rls_fast_ggx_direct(ctx, g, &io);
     return launch_g(ctx, ggx_direct_kernel<1>, ggx_direct_kernel<4>, ggx_direct_kernel<16>,
                     ggx_direct_kernel<64>, g, io, "rls_ggx_direct_lighting");
+}
+
+rls_status rls_disney_direct_lighting(rls_context *ctx, int64_t n, const rls_disney_closure *c, rls_cvec3 P,
+                                      const rls_sphere_light *lights, int n_lights, int spp_n, uint32_t seed,
+                                      uint64_t first_index, rls_rgb direct_diffuse, rls_rgb direct_specular)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_REQUIRE(n >= 0, "n < 0");
+    RLS_REQUIRE(spp_n >= 1 && spp_n * spp_n <= kMaxSpp, "spp_n must be in [1, 16]");
+    if (n == 0) return RLS_OK;
+    RLS_REQUIRE(c != nullptr, "closure is NULL");
+    RLS_REQUIRE(rlsh::has3(c->wo) && rlsh::has3(c->N) && rlsh::has3(c->T) && rlsh::has3(P), "wo/N/T/P plane is NULL");
+    RLS_REQUIRE(rlsh::ok_rgb(c->base_color), "base_color planes must be all set or all NULL");
+    RLS_REQUIRE(rlsh::has3(direct_diffuse) && rlsh::has3(direct_specular), "NULL output plane");
+    DisneyLightIO io = {};
+    if (rls_status st = copy_lights(lights, n_lights, 1, io.lights, &io.nl)) return st;
+    io.c = *c; io.P = P; io.dd = direct_diffuse; io.ds = direct_specular;
+    io.n = n; io.spp = spp_n * spp_n; io.seed = seed; io.first = first_index;
+    int g = pick_group(ctx, n, io.spp);
+    if (ctx->fast) return rls_fast_disney_direct(ctx, g, &io);
+    return launch_g(ctx, disney_direct_kernel<1>, disney_direct_kernel<4>, disney_direct_kernel<16>,
+                    disney_direct_kernel<64>, g, io, "rls_disney_direct_lighting");
 }
 
 } // extern "C"

@@ -120,12 +120,24 @@ struct LightIO {
     rls_ggx_closure c;
     rls_ggx_shader sh;
     rls_cvec3 P;
-    rls_sphere_light light;
+    rls_sphere_light lights[RLS_MAX_LIGHTS];
+    int nl;
     rls_rgb dd, ds;
     int64_t n;
     int spp;
     uint32_t seed;
     uint64_t first;         // global index of point 0 (the sampler scrambles hash first + i)
+};
+struct DisneyLightIO {
+    rls_disney_closure c;
+    rls_cvec3 P;
+    rls_sphere_light lights[RLS_MAX_LIGHTS];
+    int nl;
+    rls_rgb dd, ds;
+    int64_t n;
+    int spp;
+    uint32_t seed;
+    uint64_t first;
 };
 
 struct ScatterIO {
@@ -145,6 +157,8 @@ struct SkinIntIO {
     rls_cvec3 P;
     rls_sss_scene scene;
     float env[3];
+    rls_sphere_light lights[RLS_MAX_LIGHTS];
+    int nl;
     rls_rgb sheen, specular, sss, out;
     float *sheenFresnel, *specularFresnel, *sssWeight;
     int64_t n;

@@ -287,15 +287,22 @@ public:
         check(rls_ggx_integrate(dev_.ctx(), n_, &c_, spp_n, seed, first_index, sum_f_over_pdf.rgb(),
                                 avgReflectWeight.plane(0)));
     }
-    // the light loop of shader_evaluate (src/rlGgx.cpp:274-299) under one spherical area light:
+    // the light loop of shader_evaluate (src/rlGgx.cpp:274-299) under n_lights spherical area lights:
     // direct_diffuse (Oren-Nayar, KdColor * Kd) and direct_specular (this closure, Ks)
+    void directLighting(const Planes &P, const rls_sphere_light *lights, int n_lights, int spp_n, uint32_t seed,
+                        ParamRGB KdColor, Param Kd, Param diffuseRoughness, Param Ks, Planes &direct_diffuse,
+                        Planes &direct_specular, uint64_t first_index = 0) const
+    {
+        rls_ggx_shader sh{KdColor.c(), Kd.c(), diffuseRoughness.c(), Ks.c()};
+        check(rls_ggx_direct_lighting(dev_.ctx(), n_, &c_, &sh, P.cvec3(), lights, n_lights, spp_n, seed, first_index,
+                                      direct_diffuse.rgb(), direct_specular.rgb()));
+    }
     void directLighting(const Planes &P, const rls_sphere_light &light, int spp_n, uint32_t seed, ParamRGB KdColor,
                         Param Kd, Param diffuseRoughness, Param Ks, Planes &direct_diffuse,
                         Planes &direct_specular, uint64_t first_index = 0) const
     {
-        rls_ggx_shader sh{KdColor.c(), Kd.c(), diffuseRoughness.c(), Ks.c()};
-        check(rls_ggx_direct_lighting(dev_.ctx(), n_, &c_, &sh, P.cvec3(), &light, spp_n, seed, first_index,
-                                      direct_diffuse.rgb(), direct_specular.rgb()));
+        directLighting(P, &light, 1, spp_n, seed, KdColor, Kd, diffuseRoughness, Ks, direct_diffuse, direct_specular,
+                       first_index);
     }
 
 private:
@@ -351,6 +358,14 @@ public:
     {
         check(rls_disney_integrate(dev_.ctx(), n_, &c_, spp_n, seed, first_index, diffuse_sum.rgb(), diffuse_count.plane(0),
                                    specular_sum.rgb(), specular_count.plane(0), nullptr));
+    }
+    // the light loop of shader_evaluate (src/rlDisney.cpp:695-705): evalDiffuseLightSample + evalSpecularLightSample
+    // per light -> the two direct AOVs
+    void directLighting(const Planes &P, const rls_sphere_light *lights, int n_lights, int spp_n, uint32_t seed,
+                        Planes &direct_diffuse, Planes &direct_specular, uint64_t first_index = 0) const
+    {
+        check(rls_disney_direct_lighting(dev_.ctx(), n_, &c_, P.cvec3(), lights, n_lights, spp_n, seed, first_index,
+                                         direct_diffuse.rgb(), direct_specular.rgb()));
     }
     // the same with every sample handed to `consume` chunk by chunk (the loop body of src/rlDisney.cpp:299-312);
     // chunk_wi / chunk_f: 3 x (2 * spp * chunk_points) planes, chunk_pdf: 1 x the same
@@ -490,13 +505,15 @@ public:
     // shader_evaluate over spp_n^2 samples per layer  (src/rlSkin.cpp:174-254): the mean Fresnel of each GGX lobe
     // (getAvgReflectWeight, src/rlGgx.h:181-184) handed down to the next, integrateScatter x sssWeight.
     // aov: 12 planes {sheen3, specular3, sss3, out3}; layers (optional): 3 planes {sheenFresnel, specularFresnel, sssWeight}
+    // lights / n_lights: the spherical lights of the two light loops (193-198, 217-222); none by default
     void integrate(const Planes &P, const rls_sss_scene &scene, const float env[3], int spp_n, uint32_t seed, Planes &aov,
-                   Planes *layers = nullptr, uint64_t first_index = 0) const
+                   Planes *layers = nullptr, uint64_t first_index = 0, const rls_sphere_light *lights = nullptr,
+                   int n_lights = 0) const
     {
         rls_skin_integrate_out o{};
         o.sheen = aov.rgb(0); o.specular = aov.rgb(3); o.sss = aov.rgb(6); o.out = aov.rgb(9);
         if (layers) { o.sheenFresnel = layers->plane(0); o.specularFresnel = layers->plane(1); o.sssWeight = layers->plane(2); }
-        check(rls_skin_integrate(dev_.ctx(), n_, &c_, P.cvec3(), &scene, env, spp_n, seed, first_index, &o));
+        check(rls_skin_integrate(dev_.ctx(), n_, &c_, P.cvec3(), &scene, env, lights, n_lights, spp_n, seed, first_index, &o));
     }
 
 private:

@@ -60,6 +60,18 @@ def make_light(center=(0, 0, 5), radius=1.0, radiance=(1, 1, 1), mis_mode=0) -> 
     return lt
 
 
+def light_array(lights):
+    """one Light, a sequence of them or None -> (ctypes array or None, count)"""
+    if lights is None:
+        return None, 0
+    if isinstance(lights, Light):
+        lights = [lights]
+    lights = list(lights)
+    if not lights:
+        return None, 0
+    return (Light * len(lights))(*lights), len(lights)
+
+
 class GgxShaderSoa(C.Structure):
     _fields_ = [("Kd_color", CV3P), ("Kd", fp), ("Kd_roughness", fp), ("Ks", fp)]
 
@@ -231,15 +243,16 @@ class Ggx:
         lib().orc_batch_ggx_ndf_pdf(C.c_int64(n), C.byref(self.soa), _v(wi), _p(pdf), self.nthreads)
         return pdf
 
-    def direct_lighting(self, P, light: "Light", spp_n, seed, Kd_color=(1, 1, 1), Kd=1.0, Kd_roughness=0.0, Ks=1.0,
+    def direct_lighting(self, P, light, spp_n, seed, Kd_color=(1, 1, 1), Kd=1.0, Kd_roughness=0.0, Ks=1.0,
                         first_index=0):
-        """orc_batch_ggx_direct_lighting -> (direct_diffuse [3,n], direct_specular [3,n])"""
+        """orc_batch_ggx_direct_lighting (one Light or a sequence) -> (direct_diffuse [3,n], direct_specular [3,n])"""
         n = self.n
         P = f32(P)
         kdc, kd, kdr, ks = _full3(Kd_color, n), _full(Kd, n), _full(Kd_roughness, n), _full(Ks, n)
         sh = GgxShaderSoa(_v(kdc), _p(kd), _p(kdr), _p(ks))
         dd, ds = np.empty((3, n), np.float32), np.empty((3, n), np.float32)
-        lib().orc_batch_ggx_direct_lighting(C.c_int64(n), C.byref(self.soa), C.byref(sh), _v(P), C.byref(light),
+        la, nl = light_array(light)
+        lib().orc_batch_ggx_direct_lighting(C.c_int64(n), C.byref(self.soa), C.byref(sh), _v(P), la, nl,
                                             int(spp_n), C.c_uint32(seed), C.c_uint64(first_index), _v(dd), _v(ds),
                                             self.nthreads)
         return dd, ds
@@ -309,6 +322,16 @@ class Disney:
         lib().orc_batch_disney_alt(C.c_int64(n), C.byref(self.soa), int(kind), _p(rx), _p(ry), _v(v), _v(out3),
                                    _p(out1), self.nthreads)
         return out3 if kind < 2 else out1
+
+    def direct_lighting(self, P, light, spp_n, seed, first_index=0):
+        """orc_batch_disney_direct_lighting (one Light or a sequence) -> (direct_diffuse [3,n], direct_specular [3,n])"""
+        n = self.n
+        P = f32(P)
+        dd, ds = np.empty((3, n), np.float32), np.empty((3, n), np.float32)
+        la, nl = light_array(light)
+        lib().orc_batch_disney_direct_lighting(C.c_int64(n), C.byref(self.soa), _v(P), la, nl, int(spp_n), C.c_uint32(seed),
+                                               C.c_uint64(first_index), _v(dd), _v(ds), self.nthreads)
+        return dd, ds
 
     def integrate(self, spp_n, seed, streamed=False, first_index=0):
         n = self.n
@@ -495,7 +518,7 @@ def _skin_soa(wo, N, T, params: dict, xi):
 
 
 def skin_integrate(wo, N, T, params: dict, P, scene: "Scene", spp_n, seed, env=(1.0, 1.0, 1.0), first_index=0,
-                   nthreads=1) -> dict:
+                   nthreads=1, lights=None) -> dict:
     """orc_batch_skin_integrate -> dict(sheen, specular, sss, out [3,n]; sheenFresnel, specularFresnel, sssWeight [n])"""
     n = wo.shape[1]
     soa, keep = _skin_soa(wo, N, T, params, None)
@@ -505,8 +528,9 @@ def skin_integrate(wo, N, T, params: dict, P, scene: "Scene", spp_n, seed, env=(
     o = SkinIntOutSoa(_v(out["sheen"]), _v(out["specular"]), _v(out["sss"]), _v(out["out"]),
                       _p(out["sheenFresnel"]), _p(out["specularFresnel"]), _p(out["sssWeight"]))
     e = (C.c_float * 3)(*[float(v) for v in env])
-    lib().orc_batch_skin_integrate(C.c_int64(n), C.byref(soa), _v(P), C.byref(scene), e, int(spp_n), C.c_uint32(seed),
-                                   C.c_uint64(first_index), C.byref(o), nthreads)
+    la, nl = light_array(lights)
+    lib().orc_batch_skin_integrate(C.c_int64(n), C.byref(soa), _v(P), C.byref(scene), e, la, nl, int(spp_n),
+                                   C.c_uint32(seed), C.c_uint64(first_index), C.byref(o), nthreads)
     return out
 
 

@@ -117,3 +117,98 @@ def test_fast_mode_and_argument_checks(oracle):
             s.directLighting(dev(P), lg, 4, 1)
     finally:
         ctx.close()
+
+
+# ---- several lights; the light loops of rlDisney and rlSkin --------------------------------------------------------
+LIGHTS = (dict(center=(2.0, 2.0, 3.0), radius=1.25, radiance=(3.0, 2.0, 1.0), mis_mode=0),
+          dict(center=(-3.0, 1.0, 2.5), radius=0.5, radiance=(0.5, 4.0, 2.0), mis_mode=1),
+          dict(center=(0.5, -2.5, 6.0), radius=2.0, radiance=(1.0, 1.0, 6.0), mis_mode=2))
+
+
+def _lights(oracle, specs=LIGHTS):
+    pairs = [_pair(oracle, **kw) for kw in specs]
+    return [p[0] for p in pairs], [p[1] for p in pairs]
+
+
+def _slab(n):
+    return (cases.xi(cases.SEED_PARITY, n, 3) * np.array([[4.0], [4.0], [1.0]], np.float32)).astype(np.float32)
+
+
+def test_ggx_several_lights(gpu, oracle):
+    """`while (AiLightsGetSample(sg))` over three lights in three estimator modes: bit-equal to the oracle with one lane
+    per point; the AOVs are the per-light AOVs added in array order (linearity in the light set)"""
+    n = 1 << 13
+    c = cases.ggx_mixed(cases.SEED_PARITY, n)
+    P = _slab(n)
+    lo, lg = _lights(oracle)
+    og, s = ggx_oracle(oracle, c, nthreads=oracle.hardware_threads()), ggx_sampler(gpu, c)
+    kw = dict(Kd=0.7, Ks=0.4)
+    dd_ref, ds_ref = og.direct_lighting(P, lo, 3, 99, Kd_color=(0.9, 0.5, 0.3), Kd_roughness=0.4, first_index=1 << 33, **kw)
+    run = lambda: [host(t) for t in s.directLighting(dev(P), lg, 3, 99, KdColor=(0.9, 0.5, 0.3), diffuseRoughness=0.4,
+                                                      first_index=1 << 33, **kw)]
+    dd, ds = _with_group(1, run)
+    cases.assert_tight(cases.summarize(cases.rel_err(dd, dd_ref)), "3 lights diffuse")
+    cases.assert_tight(cases.summarize(cases.rel_err(ds, ds_ref)), "3 lights specular")
+    assert (ds_ref > 0).mean() > 0.1
+    for g in (4, 64):
+        dd2, ds2 = _with_group(g, run)
+        assert np.quantile(cases.rel_err(dd2, dd), 0.999) <= 2e-5, g
+        assert np.quantile(cases.rel_err(ds2, ds), 0.999) <= 1e-4, g
+    # light 0 alone draws the numbers it draws in the set: the set's AOV starts with it
+    d0, s0 = _with_group(1, lambda: [host(t) for t in s.directLighting(dev(P), lg[0], 3, 99, KdColor=(0.9, 0.5, 0.3),
+                                                                      diffuseRoughness=0.4, first_index=1 << 33, **kw)])
+    d01, s01 = _with_group(1, lambda: [host(t) for t in s.directLighting(dev(P), lg[:2], 3, 99, KdColor=(0.9, 0.5, 0.3),
+                                                                        diffuseRoughness=0.4, first_index=1 << 33, **kw)])
+    assert np.all(d01 >= d0) and np.all(s01 >= s0) and np.all(dd >= d01) and np.all(ds >= s01)
+    with pytest.raises(R.RlsError):
+        s.directLighting(dev(P), lg * 3, 3, 99)                       # nine lights > RLS_MAX_LIGHTS
+    with pytest.raises(R.RlsError):
+        s.directLighting(dev(P), [], 3, 99)
+
+
+@pytest.mark.parametrize("nl", [1, 3])
+def test_disney_direct_lighting(gpu, oracle, nl):
+    """rls_disney_direct_lighting (src/rlDisney.cpp:695-705) against the oracle: bit-equal with one lane per point,
+    within reduction-order noise with 4 / 16 / 64 lanes"""
+    from gpu_util import disney_oracle, disney_sampler
+    n = 1 << 13
+    c = cases.disney_mixed(cases.SEED_PARITY, n)
+    P = _slab(n)
+    lo, lg = _lights(oracle, LIGHTS[:nl])
+    dd_ref, ds_ref = disney_oracle(oracle, c).direct_lighting(P, lo, 4, 17, first_index=12345)
+    d = disney_sampler(gpu, c)
+    run = lambda: [host(t) for t in d.directLighting(dev(P), lg, 4, 17, first_index=12345)]
+    dd, ds = _with_group(1, run)
+    sd, ss = cases.summarize(cases.rel_err(dd, dd_ref)), cases.summarize(cases.rel_err(ds, ds_ref))
+    print("disney direct", nl, "diffuse", sd)
+    print("disney direct", nl, "specular", ss)
+    cases.assert_tight(sd, "disney direct diffuse")
+    cases.assert_tight(ss, "disney direct specular")
+    assert (dd_ref > 0).mean() > 0.2 and (ds_ref > 0).mean() > 0.1
+    for g in (4, 16, 64):
+        dd2, ds2 = _with_group(g, run)
+        assert np.quantile(cases.rel_err(dd2, dd), 0.999) <= 2e-5, g
+        assert np.quantile(cases.rel_err(ds2, ds), 0.999) <= 1e-4, g
+
+
+def test_disney_mis_consistency_at_scale(gpu):
+    """2^18 identical Disney closures x 64 samples per strategy: light-only, BSDF-only and MIS estimates of both direct
+    AOVs agree (sample / eval / pdf of each lobe are consistent)"""
+    import torch
+    n = 1 << 18
+    wo = torch.tensor([0.4, 0.1, 0.9], device="cuda"); wo = (wo / wo.norm()).reshape(3, 1).repeat(1, n).contiguous()
+    Ns = torch.zeros(3, n, device="cuda"); Ns[2] = 1
+    ang = torch.rand(n, device="cuda") * 6.2831853
+    T = torch.stack([torch.cos(ang), torch.sin(ang), torch.zeros_like(ang)])
+    P = torch.zeros(3, n, device="cuda")
+    # clearcoat = 0: the reference's clearcoat sampler and pdf disagree (tests/test_oracle_light_loops.py)
+    d = R.DisneySampler(gpu, wo, Ns, T, base_color=(0.8, 0.6, 0.4), roughness=0.35, metallic=0.3, specular=0.5,
+                        clearcoat=0.0, clearcoat_gloss=0.6, sheen=0.3, anisotropic=0.3)
+    means = {}
+    for mode in (0, 1, 2):
+        lt = R.make_light(center=(-1.5, 0.3, 3.0), radius=1.2, mis_mode=mode)
+        dd, ds = d.directLighting(P, lt, 8, 11)
+        means[mode] = (dd.double().mean(dim=1).cpu().numpy(), ds.double().mean(dim=1).cpu().numpy())
+    for mode in (1, 2):
+        np.testing.assert_allclose(means[mode][0], means[0][0], rtol=5e-3)
+        np.testing.assert_allclose(means[mode][1], means[0][1], rtol=1e-2)

@@ -161,3 +161,35 @@ def test_integrators_in_fast_mode(fast, oracle):
     gr, gt = [host(t) for t in ggx_sampler(fast, g).integrateRefract(spp_n, seed, want_tir=True)]
     assert np.array_equal(gt, tir)
     assert abs(gr.astype(np.float64).mean() / res.astype(np.float64).mean() - 1) < 2e-3
+
+
+def test_light_loops_in_fast_mode(fast, oracle):
+    """rls_disney_direct_lighting and rls_skin_integrate's light loops in FAST mode: Monte-Carlo sums in which a BSDF
+    sample grazing a light's rim may flip in or out, so the AOVs are held at the batch's scale and per point in bulk"""
+    n, spp_n, seed = 1 << 12, 4, 23
+    P = (cases.xi(cases.SEED_PARITY, n, 3) * np.array([[4.0], [4.0], [1.0]], np.float32)).astype(np.float32)
+    specs = (dict(center=(2.0, 2.0, 3.0), radius=1.25, radiance=(3.0, 2.0, 1.0)),
+             dict(center=(-3.0, 1.0, 2.5), radius=0.5, radiance=(0.5, 4.0, 2.0), mis_mode=1))
+    lo = [oracle.make_light(**s) for s in specs]
+    lg = [R._capi.SphereLight.from_buffer_copy(bytes(l)) for l in lo]
+    d = cases.disney_mixed(cases.SEED_PARITY, n)
+    ref = disney_oracle(oracle, d).direct_lighting(P, lo, spp_n, seed)
+    got = [host(t) for t in disney_sampler(fast, d).directLighting(dev(P), lg, spp_n, seed)]
+    for nm, a, b in zip(("diffuse", "specular"), got, ref):
+        assert np.isfinite(a).all(), nm
+        assert abs(a.astype(np.float64).mean() / b.astype(np.float64).mean() - 1) < 5e-3, nm
+        assert np.quantile(cases.rel_err(a, b), 0.9) <= 1e-3, nm
+    sk = cases.skin_mixed(cases.SEED_PARITY, n)
+    kw = dict(geometry="sphere", sphere_radius=1.0, light_dir=(0.0, 0.6, 0.8), use_cavity_fade=True)
+    skl = [oracle.make_light(center=(0.5, 0.5, 4.0), radius=1.0, radiance=(2.0, 1.5, 1.0))]
+    skg = [R._capi.SphereLight.from_buffer_copy(bytes(l)) for l in skl]
+    refk = oracle.skin_integrate(sk["wo"], sk["N"], sk["T"], sk["params"], sk["N"], oracle.make_scene(**kw), spp_n, seed,
+                                 nthreads=4, lights=skl)
+    shader = R.SkinShader(fast, dev(sk["wo"]), dev(sk["N"]), dev(sk["T"]), **{k: dev(v) for k, v in sk["params"].items()})
+    gotk = {k: host(v) for k, v in shader.integrate(dev(sk["N"]), R.make_scene(**kw), spp_n, seed, lights=skg).items()}
+    for k in ("sheenFresnel", "specularFresnel", "sssWeight"):
+        st = cases.summarize(cases.rel_err(gotk[k], refk[k]))
+        assert st["nonfinite"] == 0 and st["median"] <= 1e-5 and st["p99"] <= 1e-3, (k, st)
+    for k in ("sheen", "specular", "sss", "out"):
+        a, b = gotk[k].astype(np.float64), refk[k].astype(np.float64)
+        assert np.isfinite(a).all() and abs(a.mean() / b.mean() - 1) < 5e-3, (k, a.mean(), b.mean())

@@ -136,5 +136,22 @@ def test_integrators_hostile_inputs(gpu, oracle):
         got = {k: host(v) for k, v in shader.integrate(dev(P), R.make_scene(**kw), spp_n, seed).items()}
         for k in ref:
             _same(got[k], ref[k], f"skin integrate {k}")
+        # the light loops: poisoned shading positions put points inside lights, at infinity, at NaN
+        lo = [oracle.make_light(center=(0.5, 0.5, 4.0), radius=1.0, radiance=(2.0, 1.5, 1.0)),
+              oracle.make_light(center=(-2.0, 0.0, 1.0), radius=0.7, radiance=(0.2, 0.4, 3.0), mis_mode=2)]
+        lg = [R._capi.SphereLight.from_buffer_copy(bytes(l)) for l in lo]
+        ref = oracle.skin_integrate(sk["wo"], sk["N"], sk["T"], p, P, oracle.make_scene(**kw), spp_n, seed, nthreads=4, lights=lo)
+        got = {k: host(v) for k, v in shader.integrate(dev(P), R.make_scene(**kw), spp_n, seed, lights=lg).items()}
+        for k in ref:
+            _same(got[k], ref[k], f"skin integrate lit {k}")
+        ref = disney_oracle(oracle, d).direct_lighting(P, lo, spp_n, seed)
+        got = [host(t) for t in disney_sampler(gpu, d).directLighting(dev(P), lg, spp_n, seed)]
+        for nm, a, b in zip(("diffuse", "specular"), got, ref):
+            _same(a, b, f"disney direct {nm}")
+        ref = og.direct_lighting(P, lo, spp_n, seed, Kd_color=(0.8, 0.7, 0.6), Kd=0.5, Kd_roughness=0.3, Ks=0.5)
+        got = [host(t) for t in s.directLighting(dev(P), lg, spp_n, seed, KdColor=(0.8, 0.7, 0.6), Kd=0.5,
+                                                  diffuseRoughness=0.3, Ks=0.5)]
+        for nm, a, b in zip(("diffuse", "specular"), got, ref):
+            _same(a, b, f"ggx direct {nm}")
     finally:
         del os.environ["RLS_INTEGRATE_GROUP"]

@@ -113,3 +113,54 @@ def test_integrate_refract_matches_oracle(gpu, oracle, traced):
                                                                                    want_tir=True, first_index=first)])
             assert np.array_equal(atir, tir)
             assert np.quantile(cases.rel_err(alt, got), 0.999) <= 1e-4, g
+
+
+@pytest.mark.parametrize("spp_n", [3, 4])
+def test_skin_integrate_with_light_loops(gpu, oracle, spp_n):
+    """the light loops of src/rlSkin.cpp:193-198 / 217-222 (evalLightSample per light, before integrateGlossy): their
+    BSDF samples enter getAvgReflectWeight's mean, so the hand-down scalars change with the lights; spp_n = 3 makes the
+    sample count 9 (the mean is a division by the count, not a multiplication by its reciprocal)"""
+    n, seed, first = 1 << 11, 5, 1 << 34
+    c = cases.skin_mixed(cases.SEED_PARITY, n)
+    p = dict(c["params"])
+    # a tenth of the points with a black sheen colour: integrateGlossy samples nothing there, the light loop does
+    black = (np.arange(n) % 10) == 0
+    p["sheen_color"] = np.where(black[None, :], np.float32(0.0), p["sheen_color"]).astype(np.float32)
+    kw = dict(geometry="sphere", sphere_radius=1.0, light_dir=(0.0, 0.6, 0.8), use_cavity_fade=True)
+    P = c["N"]
+    specs = (dict(center=(0.5, 0.5, 4.0), radius=1.0, radiance=(2.0, 1.5, 1.0), mis_mode=0),
+             dict(center=(-3.0, 0.0, 1.0), radius=0.7, radiance=(0.2, 0.4, 3.0), mis_mode=2),
+             dict(center=(0.0, 3.0, -1.0), radius=0.9, radiance=(1.0, 0.1, 0.1), mis_mode=1))
+    lo = [oracle.make_light(**s) for s in specs]
+    lg = [R._capi.SphereLight.from_buffer_copy(bytes(l)) for l in lo]
+    env = (0.3, 0.3, 0.4)
+    ref = oracle.skin_integrate(c["wo"], c["N"], c["T"], p, P, oracle.make_scene(**kw), spp_n, seed, env=env,
+                                first_index=first, nthreads=4, lights=lo)
+    dark = oracle.skin_integrate(c["wo"], c["N"], c["T"], p, P, oracle.make_scene(**kw), spp_n, seed, env=env,
+                                 first_index=first, nthreads=4)
+    sk = _skin(gpu, c, p)
+    scene = R.make_scene(**kw)
+    got = _with_group(1, lambda: {k: host(v) for k, v in sk.integrate(dev(P), scene, spp_n, seed, env=env,
+                                                                      first_index=first, lights=lg).items()})
+    for k in KEYS:
+        st = cases.summarize(cases.rel_err(got[k], ref[k]))
+        print("skin integrate lit", spp_n, k, st)
+        cases.assert_tight(st, ("lit", k))
+    # the lights add light and move the Fresnel means
+    assert (ref["sheen"].sum(0) > dark["sheen"].sum(0)).mean() > 0.3
+    assert (ref["sheenFresnel"] != dark["sheenFresnel"]).mean() > 0.5
+    # black sheen colour, no lights: no samples at all, getAvgReflectWeight() = 1 (src/rlGgx.h:181-184)
+    on = black & (p["sheen_weight"] > 1e-4)
+    assert np.array_equal(dark["sheenFresnel"][on], p["sheen_weight"][on])
+    assert (ref["sheenFresnel"][on] != p["sheen_weight"][on]).mean() > 0.5     # with lights: the light loops' mean
+    # without lights the call is the one it was
+    unlit = _with_group(1, lambda: {k: host(v) for k, v in sk.integrate(dev(P), scene, spp_n, seed, env=env,
+                                                                        first_index=first).items()})
+    for k in KEYS:
+        cases.assert_tight(cases.summarize(cases.rel_err(unlit[k], dark[k])), ("unlit", k))
+    for g in (4, 16):
+        alt = _with_group(g, lambda: {k: host(v) for k, v in sk.integrate(dev(P), scene, spp_n, seed, env=env,
+                                                                          first_index=first, lights=lg).items()})
+        for k in KEYS:
+            e = cases.rel_err(alt[k], got[k])
+            assert np.quantile(e, 0.999) <= 2e-4, (g, k, float(e.max()))

@@ -62,6 +62,8 @@ def sweep(ctx, n: int, seed: int, spp_n: int = 2, verbose: bool = True) -> dict:
               [hostf(t) for t in g.directLighting(P, lg, spp_n, seed, KdColor=Ks, Kd=kd, diffuseRoughness=kdr, Ks=ks)],
               og.direct_lighting(hostf(P), lt, spp_n, seed, Kd_color=c["KsColor"], Kd=hostf(kd), Kd_roughness=hostf(kdr),
                                  Ks=hostf(ks)))
+        tally("ggx integrateRefract", [hostf(t) for t in g.integrateRefract(spp_n, seed, want_tir=True)],
+              og.integrate_refract(spp_n, seed))
         # --- rlSss integrateScatter on the unit sphere
         dsmall = torch.stack([u(32 + j, 0.02, 0.3) for j in range(3)])
         ss = R.SssSampler(ctx, N, T, Ks, dsmall)
@@ -85,6 +87,12 @@ def sweep(ctx, n: int, seed: int, spp_n: int = 2, verbose: bool = True) -> dict:
         keys = ("diffuse_sum", "diffuse_count", "specular_sum", "specular_count")
         gi, ri = d.integrate(spp_n, seed), od.integrate(spp_n, seed)
         tally("disney integrate", [hostf(gi[k]) for k in keys], [ri[k] for k in keys])
+        # the light loop of rlDisney under two lights (MIS; light samples only)
+        lts = [O.make_light(center=(2.0, 2.0, 3.0), radius=1.25, radiance=(3.0, 2.0, 1.0)),
+               O.make_light(center=(-3.0, 1.0, 2.5), radius=0.5, radiance=(0.5, 4.0, 2.0), mis_mode=1)]
+        lgs = [R._capi.SphereLight.from_buffer_copy(bytes(l)) for l in lts]
+        tally("disney direct lighting", [hostf(t) for t in d.directLighting(P, lgs, spp_n, seed)],
+              od.direct_lighting(hostf(P), lts, spp_n, seed))
     finally:
         del os.environ["RLS_INTEGRATE_GROUP"]
     # --- rlSss probe
@@ -105,4 +113,17 @@ def sweep(ctx, n: int, seed: int, spp_n: int = 2, verbose: bool = True) -> dict:
     rout = O.skin(c["wo"], c["N"], c["T"], {k: hostf(v) for k, v in p.items()}, np.stack(hxi), nthreads=th)
     names = list(O.SKIN_VEC) + list(O.SKIN_SCALAR)
     tally("skin", [hostf(gout[k]) for k in names], [rout[k] for k in names])
+    # rlSkin's shader_evaluate over spp_n^2 samples per layer, one light in the two light loops
+    os.environ["RLS_INTEGRATE_GROUP"] = "1"
+    try:
+        pk = dict(p, sss_scatter_dist=dsmall)
+        ski = R.SkinShader(ctx, wo, N, T, **pk)
+        one = [O.make_light(center=(0.5, 0.5, 4.0), radius=1.0, radiance=(2.0, 1.5, 1.0))]
+        gi = ski.integrate(Psph, sg, spp_n, seed, env=(1.0, 0.9, 0.8), lights=[R._capi.SphereLight.from_buffer_copy(bytes(one[0]))])
+        ri = O.skin_integrate(c["wo"], c["N"], c["T"], {k: hostf(v) for k, v in pk.items()}, hostf(Psph), so, spp_n, seed,
+                              env=(1.0, 0.9, 0.8), nthreads=th, lights=one)
+        keys = ("sheen", "specular", "sss", "out", "sheenFresnel", "specularFresnel", "sssWeight")
+        tally("skin shader_evaluate", [hostf(gi[k]) for k in keys], [ri[k] for k in keys])
+    finally:
+        del os.environ["RLS_INTEGRATE_GROUP"]
     return report

@@ -52,7 +52,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--log2-points", type=int, default=26, help="points per GPU = 2^this (config: 26)")
     ap.add_argument("--workload", default="ggx_reflect_refract",
-                    choices=["ggx_reflect_refract", "ggx_reflect", "ggx_direct", "disney_direct", "disney_integrate", "disney_stream", "sss_probe",
+                    choices=["ggx_reflect_refract", "ggx_reflect", "ggx_direct", "ggx_shade", "disney_direct", "disney_shade", "disney_integrate", "disney_stream", "sss_probe",
                              "sss_scatter", "skin", "skin_integrate"])
     ap.add_argument("--chunk-log2", type=int, default=20, help="disney_stream: points per chunk = 2^this")
     ap.add_argument("--math", default="exact", choices=["exact", "fast"],
@@ -85,7 +85,7 @@ class Workload:
 PLANES = {"ggx_reflect_refract": 19 + 12, "ggx_reflect": 17 + 8, "disney_integrate": 22 + 8, "disney_stream": 22 + 8,
           "sss_probe": 17 + 12,
           "sss_scatter": 15 + 3, "skin": 35 + 24, "skin_integrate": 29 + 3 + 15, "ggx_direct": 15 + 3 + 6 + 6,
-          "disney_direct": 22 + 3 + 6}     # (the generator's wo planes included where the closure ignores them)
+          "disney_direct": 22 + 3 + 6, "ggx_shade": 15 + 3 + 6 + 4 + 18, "disney_shade": 22 + 3 + 15}     # (the generator's wo planes included where the closure ignores them)
 
 
 def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, chunk_log2: int = 20):
@@ -129,6 +129,37 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
                       "ggx_direct_kernel<1, {m}>",
                       "rlGgx light loop: Oren-Nayar + GGX under a spherical light, 16 light + 2 x 16 BSDF samples per "
                       "point, power-heuristic MIS (SURVEY 8f rank 2; VALU-bound)", bound="valu")
+    elif name == "ggx_shade":
+        # shader_evaluate of rlGgx, whole: the light loop under two lights + transmission + indirect diffuse + indirect
+        # glossy, 16 samples per loop
+        g = R.GgxSampler(ctx, wo, N, T, specColor=u3(S_KS), ior=u(S_IOR, 1.05, 2.55),
+                         roughness=u(S_ROUGH, 0.05, 1.0), anisotropic=R.gen_aniso(ctx, SEED, first, n, out=A.plane()))
+        P = u3(S_PARAM0 + 8, 0.0, 4.0)
+        kdc, kd, kdr, ks = u3(S_PARAM0), u(S_PARAM0 + 3), u(S_PARAM0 + 4), u(S_PARAM0 + 5)
+        ktc, kt = u3(S_PARAM0 + 11), u(S_PARAM0 + 14)
+        lights = [R.make_light(center=(2.0, 2.0, 6.0), radius=1.25, radiance=(3.0, 2.0, 1.0)),
+                  R.make_light(center=(-1.0, 5.0, 7.0), radius=0.6, radiance=(0.5, 0.5, 4.0))]
+        out = {k: A.planes(3) for k in R.GgxSampler.SHADE_AOVS + ("out",)}
+        wl = Workload(name, 144, (15 + 3 + 6 + 4 + 18) * 4,
+                      lambda: g.shade(P, lights, 4, SEED, KdColor=kdc, Kd=kd, diffuseRoughness=kdr, Ks=ks, KtColor=ktc, Kt=kt,
+                                      env=(1.0, 0.9, 0.8), out=out, first_index=first),
+                      "ggx_shade_kernel<1, {m}>",
+                      "rlGgx shader_evaluate, whole: light loop under two spherical lights (2 x 48 samples) + integrateRefract + "
+                      "indirect diffuse + integrateGlossy (3 x 16 samples) per point (src/rlGgx.cpp:248-327; VALU-bound)",
+                      bound="valu")
+    elif name == "disney_shade":
+        base = u3(S_KS)
+        sc = {k: u(S_PARAM0 + j) for j, k in enumerate(R._capi.DISNEY_SCALARS)}
+        d = R.DisneySampler(ctx, wo, N, T, base_color=base, **sc)
+        P = u3(S_PARAM0 + 16, 0.0, 4.0)
+        lights = [R.make_light(center=(2.0, 2.0, 6.0), radius=1.25, radiance=(3.0, 2.0, 1.0)),
+                  R.make_light(center=(-1.0, 5.0, 7.0), radius=0.6, radiance=(0.5, 0.5, 4.0))]
+        out = {k: A.planes(3) for k in R.DisneySampler.SHADE_AOVS + ("out",)}
+        wl = Workload(name, 128, (22 + 3 + 15) * 4,
+                      lambda: d.shade(P, lights, 4, SEED, env=(1.0, 0.9, 0.8), out=out, first_index=first),
+                      "disney_shade_kernel<1, {m}>",
+                      "rlDisney shader_evaluate, whole: light loop under two spherical lights (2 x 48 samples) + integrateDiffuse + "
+                      "integrateGlossy (2 x 16 samples) per point (src/rlDisney.cpp:685-727; VALU-bound)", bound="valu")
     elif name == "disney_direct":
         # the light loop of rlDisney (direct diffuse + direct specular) under two spherical lights: per light 16 light
         # samples (evaluated by both lobes) + 16 BSDF samples per lobe
@@ -224,7 +255,7 @@ def _cpu_leg(workload: str, n: int, threads: int):
     import cases
     u = lambda stream, lo=0.0, hi=1.0: O.gen_uniform(SEED, 0, n, stream, lo, hi)
     u3 = lambda stream, lo=0.0, hi=1.0: np.stack([u(stream + j, lo, hi) for j in range(3)])
-    if workload in ("ggx_reflect_refract", "ggx_reflect", "ggx_direct"):
+    if workload in ("ggx_reflect_refract", "ggx_reflect", "ggx_direct", "ggx_shade"):
         c = cases.ggx_mixed(SEED, n)
         g = O.Ggx(c["wo"], c["N"], c["T"], KsColor=c["KsColor"], ior=c["ior"], roughness=c["roughness"],
                   anisotropic=c["anisotropic"], nthreads=threads)
@@ -237,9 +268,14 @@ def _cpu_leg(workload: str, n: int, threads: int):
         P = u3(S_PARAM0 + 8, 0.0, 4.0)
         lt = O.make_light(center=(2.0, 2.0, 6.0), radius=1.25, radiance=(3.0, 2.0, 1.0))
         kdc, kd, kdr, ks = u3(S_PARAM0), u(S_PARAM0 + 3), u(S_PARAM0 + 4), u(S_PARAM0 + 5)
+        if workload == "ggx_shade":
+            ktc, kt = u3(S_PARAM0 + 11), u(S_PARAM0 + 14)
+            lts = [lt, O.make_light(center=(-1.0, 5.0, 7.0), radius=0.6, radiance=(0.5, 0.5, 4.0))]
+            return (lambda: g.shade(P, lts, 4, SEED, Kd_color=kdc, Kd=kd, Kd_roughness=kdr, Ks=ks, Kt_color=ktc, Kt=kt,
+                                    env=(1.0, 0.9, 0.8))), 144, "orc_batch_ggx_shade"
         return (lambda: g.direct_lighting(P, lt, 4, SEED, Kd_color=kdc, Kd=kd, Kd_roughness=kdr, Ks=ks)), 48, \
             "orc_batch_ggx_direct_lighting"
-    if workload in ("disney_integrate", "disney_stream", "disney_direct"):
+    if workload in ("disney_integrate", "disney_stream", "disney_direct", "disney_shade"):
         c = cases.disney_mixed(SEED, n)
         sc = {k: c[k] for k in O.DISNEY_SCALARS}
         d = O.Disney(c["wo"], c["N"], c["T"], base_color=c["base_color"], nthreads=threads, **sc)
@@ -248,6 +284,11 @@ def _cpu_leg(workload: str, n: int, threads: int):
             lts = [O.make_light(center=(2.0, 2.0, 6.0), radius=1.25, radiance=(3.0, 2.0, 1.0)),
                    O.make_light(center=(-1.0, 5.0, 7.0), radius=0.6, radiance=(0.5, 0.5, 4.0))]
             return (lambda: d.direct_lighting(P, lts, 4, SEED)), 96, "orc_batch_disney_direct_lighting"
+        if workload == "disney_shade":
+            P = u3(S_PARAM0 + 16, 0.0, 4.0)
+            lts = [O.make_light(center=(2.0, 2.0, 6.0), radius=1.25, radiance=(3.0, 2.0, 1.0)),
+                   O.make_light(center=(-1.0, 5.0, 7.0), radius=0.6, radiance=(0.5, 0.5, 4.0))]
+            return (lambda: d.shade(P, lts, 4, SEED, env=(1.0, 0.9, 0.8))), 128, "orc_batch_disney_shade"
         streamed = workload == "disney_stream"
         return (lambda: d.integrate(8, SEED, streamed=streamed)), 128, "orc_batch_disney_integrate"
     if workload in ("sss_probe", "sss_scatter"):

@@ -250,14 +250,41 @@ typedef struct rls_sphere_light {
     float radiance[3];
     int   mis_mode;
 } rls_sphere_light;
-/* the node parameters of the light loop that are not part of the specular closure (src/rlGgx.cpp:170-175) */
+/* the node parameters of shader_evaluate that are not part of the specular closure (src/rlGgx.cpp:170-179);
+ * the light loop reads the first four, rls_ggx_shade all of them */
 typedef struct rls_ggx_shader {
     rls_param_rgb KdColor;
     rls_param     Kd, diffuseRoughness, Ks;
+    rls_param_rgb KtColor;
+    rls_param     Kt;
 } rls_ggx_shader;
 rls_status rls_ggx_direct_lighting(rls_context *ctx, int64_t n, const rls_ggx_closure *c, const rls_ggx_shader *sh,
                                    rls_cvec3 P, const rls_sphere_light *lights, int n_lights, int spp_n, uint32_t seed,
                                    uint64_t first_index, rls_rgb direct_diffuse, rls_rgb direct_specular);
+
+/* shader_evaluate of the rlGgx node for a camera ray, whole (src/rlGgx.cpp:248-327), in one pass over one closure
+ * set-up:
+ *     the light loop (285-299) -> diffuse *= KdColor * Kd, specular *= Ks                       (304-305)
+ *     transmission = AiColorIsSmall(KtColor * Kt) ? black : integrateRefract * (KtColor * Kt)    (307-309)
+ *     indirectDiffuse = sampleDiffuse ? (KdColor * Kd) * AiBRDFIntegrate(Oren-Nayar) : black     (315-319)
+ *     indirectGlossy  = integrateGlossy * Ks                                                     (321)
+ *     sg->out.RGB = (diffuse + specular + transmission) + (indirectDiffuse + indirectGlossy)     (311, 323)
+ * with sampleDiffuse = !AiColorIsSmall(KdColor * Kd) (280; the ray-depth tests are the caller's: this is depth 0).
+ * Opacity (250-254, 326) and the shadow-ray branch (264-269) read no closure and stay with the caller.  The closed
+ * renderer services are supplied as in the single-purpose entry points, each loop with spp_n^2 samples (parity
+ * unpinned): the light loop as rls_ggx_direct_lighting (n_lights may be 0), integrateRefract as
+ * rls_ggx_integrate_refract (`traced`, `env`), AiBRDFIntegrate as the mean of brdf / pdf over the samples times the
+ * radiance `env` of a uniform environment (cosine-weighted samples for the Oren-Nayar closure, the GGX triple for
+ * integrateGlossy, which returns black for a small KsColor, src/rlGgx.h:174-176).  Sample streams: light l uses
+ * 3 l .. 3 l + 2, integrateGlossy 24, integrateRefract 25, the indirect diffuse loop 26. */
+typedef struct rls_ggx_shade_out {
+    rls_rgb direct_diffuse, direct_specular, refraction, indirect_diffuse, indirect_specular;   /* the AOVs, 314-316, 324-325 */
+    rls_rgb out;                                                                                /* optional: sg->out.RGB     */
+} rls_ggx_shade_out;
+rls_status rls_ggx_shade(rls_context *ctx, int64_t n, const rls_ggx_closure *c, const rls_ggx_shader *sh, rls_cvec3 P,
+                         const rls_sphere_light *lights /* NULL when n_lights == 0 */, int n_lights,
+                         const float env[3], int traced, int spp_n, uint32_t seed, uint64_t first_index,
+                         const rls_ggx_shade_out *out);
 
 /* ------------------------------------------------------------------------------------------
  * rlDisney closure: DisneySampler (src/rlDisney.cpp:105-602)
@@ -320,6 +347,22 @@ rls_status rls_disney_integrate_chunked(rls_context *ctx, int64_t n, const rls_d
 rls_status rls_disney_direct_lighting(rls_context *ctx, int64_t n, const rls_disney_closure *c, rls_cvec3 P,
                                       const rls_sphere_light *lights, int n_lights, int spp_n, uint32_t seed,
                                       uint64_t first_index, rls_rgb direct_diffuse, rls_rgb direct_specular);
+
+/* shader_evaluate of the rlDisney node for a camera ray, whole (src/rlDisney.cpp:685-727): the light loop (695-705)
+ * and integrateDiffuse + integrateGlossy (718-719 -> AiBRDFIntegrate over the triple with the sample type set,
+ * 240-243, 279-283) on one closure set-up;
+ *     sg->out.RGB = (diffuse + specular) + (indirectDiffuse + indirectGlossy)                    (712, 722)
+ * The closed services as in rls_disney_direct_lighting and rls_disney_integrate: AiBRDFIntegrate -> the sum of
+ * evalBrdf / evalPdf over the valid samples (pdf > AI_EPSILON, 309) x 1 / spp_n^2 x `env`.  Sample streams: light l
+ * 3 l .. 3 l + 2, indirect diffuse 24, indirect glossy 25. */
+typedef struct rls_disney_shade_out {
+    rls_rgb direct_diffuse, direct_specular, indirect_diffuse, indirect_specular;   /* the AOVs, 714-715, 723-724 */
+    rls_rgb out;                                                                    /* optional: sg->out.RGB     */
+} rls_disney_shade_out;
+rls_status rls_disney_shade(rls_context *ctx, int64_t n, const rls_disney_closure *c, rls_cvec3 P,
+                            const rls_sphere_light *lights /* NULL when n_lights == 0 */, int n_lights,
+                            const float env[3], int spp_n, uint32_t seed, uint64_t first_index,
+                            const rls_disney_shade_out *out);
 
 /* Alternates the reference compiles but never selects (mSampleFromVisibleNormal is hard-wired to
  * true, src/rlDisney.cpp:191): the plain-NDF microfacet samplers, the matching pdf branch and D_GTR2. */

@@ -1836,8 +1836,15 @@ void orc_batch_skin_integrate(int64_t n, const orc_skin_soa *in, orc_cv3p P, con
 /* ================================ rlGgx integrateRefract =============================== */
 
 /* src/rlGgx.h:205-245 with a uniform environment of radiance env standing in for AiTrace / AiTraceBackground */
+static orc_rgb ggx_integrate_refract_stream(const orc_ggx *g, int traced, const float env[3], int spp, uint32_t seed,
+                                            uint64_t index, uint32_t stream, float *tir_fraction);
 orc_rgb orc_ggx_integrate_refract(const orc_ggx *g, int traced, const float env[3], int spp, uint32_t seed,
                                   uint64_t index, float *tir_fraction)
+{
+    return ggx_integrate_refract_stream(g, traced, env, spp, seed, index, 0, tir_fraction);
+}
+static orc_rgb ggx_integrate_refract_stream(const orc_ggx *g, int traced, const float env[3], int spp, uint32_t seed,
+                                            uint64_t index, uint32_t stream, float *tir_fraction)
 {
     float acc = 0.0f, tir = 0.0f;
     if (!traced) {                                                           /* :213-222 */
@@ -1856,7 +1863,7 @@ orc_rgb orc_ggx_integrate_refract(const orc_ggx *g, int traced, const float env[
     } else {
         for (int s = 0; s < spp; s++) {                                      /* :228-242 */
             float rx, ry;
-            orc_sample_02(seed, index, 0, (uint32_t)s, &rx, &ry);
+            orc_sample_02(seed, index, stream, (uint32_t)s, &rx, &ry);
             orc_v3 dir; float w;
             if (!orc_ggx_refract_sample(g, rx, ry, &dir, &w)) tir += 1.0f;
             acc += w;
@@ -1921,11 +1928,77 @@ float orc_oren_nayar_pdf(const orc_oren_nayar *o, orc_v3 wi)
     return ci > 0.0f ? ci * AI_ONEOVERPI : 0.0f;
 }
 
+/* the light loop of rlGgx for one shading point (src/rlGgx.cpp:285-299): the sums over the lights of the Oren-Nayar
+ * closure's and of the GGX triple's AiEvaluateLightSample, BEFORE diffuse *= diffuseColor, specular *= specularWeight */
+static void ggx_light_loop(orc_ggx *g, const orc_oren_nayar *on, orc_v3 wo, orc_v3 N, orc_v3 T, orc_v3 P, int sampleDiffuse,
+                           const orc_light *lights, int n_lights, int spp, uint32_t seed, uint64_t index,
+                           orc_rgb *diffuse, orc_rgb *specular)
+{
+    const float inv = 1.0f / (float)spp;
+    orc_rgb oS = RGB_BLACK, oD = RGB_BLACK;
+    for (int l = 0; l < n_lights; l++) {                       /* while (AiLightsGetSample(sg)), :286 */
+        const orc_light *lt = &lights[l];
+        const int mode = lt->mis_mode;
+        const uint32_t st = 3u * (uint32_t)l;
+        light_cone c = cone_make(lt, P);
+        float sR = 0.0f, sG = 0.0f, sB = 0.0f, dA = 0.0f;
+        for (int s = 0; s < spp && c.valid; s++) {
+            float rx, ry;
+            if (mode != 2) {                                   /* one light sample, both lobes */
+                orc_sample_02(seed, index, st, (uint32_t)s, &rx, &ry);
+                orc_v3 L = cone_sample(&c, rx, ry);
+                if (v3dot(L, N) > 0.0f) {
+                    orc_rgb f = orc_ggx_eval_brdf(g, L);
+                    float pb = orc_ggx_eval_pdf(g, L);
+                    float w = mode == 1 ? 1.0f : power_heuristic(c.pdf, pb);
+                    sR += f.r * w / c.pdf; sG += f.g * w / c.pdf; sB += f.b * w / c.pdf;
+                    if (sampleDiffuse) {
+                        float fd = orc_oren_nayar_brdf(on, wo, L);
+                        float wd = mode == 1 ? 1.0f : power_heuristic(c.pdf, orc_oren_nayar_pdf(on, L));
+                        dA += fd * wd / c.pdf;
+                    }
+                }
+            }
+            if (mode != 1) {                                   /* one BSDF sample per lobe */
+                orc_sample_02(seed, index, st + 1, (uint32_t)s, &rx, &ry);
+                orc_v3 L = orc_ggx_eval_sample(g, rx, ry);
+                if (!v3iszero(L) && v3dot(L, N) > 0.0f && cone_hit(&c, L)) {
+                    orc_rgb f = orc_ggx_eval_brdf(g, L);
+                    float pb = orc_ggx_eval_pdf(g, L);
+                    float w = mode == 2 ? 1.0f : power_heuristic(pb, c.pdf);
+                    sR += f.r * w / pb; sG += f.g * w / pb; sB += f.b * w / pb;
+                }
+                if (sampleDiffuse) {
+                    orc_sample_02(seed, index, st + 2, (uint32_t)s, &rx, &ry);
+                    orc_v3 Ld = orc_sss_sample_diffuse_direction(rx, ry, N, T);
+                    float pd = orc_oren_nayar_pdf(on, Ld);
+                    if (pd > 0.0f && cone_hit(&c, Ld)) {
+                        float fd = orc_oren_nayar_brdf(on, wo, Ld);
+                        float wd = mode == 2 ? 1.0f : power_heuristic(pd, c.pdf);
+                        dA += fd * wd / pd;
+                    }
+                }
+            }
+        }
+        const float *rad = lt->radiance;
+        const orc_rgb tS = rgb(rad[0] * sR * inv, rad[1] * sG * inv, rad[2] * sB * inv);
+        const orc_rgb tD = rgb(rad[0] * dA * inv, rad[1] * dA * inv, rad[2] * dA * inv);
+        /* specular += ..., diffuse += ...; the first light assigns */
+        oS = l == 0 ? tS : rgb(oS.r + tS.r, oS.g + tS.g, oS.b + tS.b);
+        oD = l == 0 ? tD : rgb(oD.r + tD.r, oD.g + tD.g, oD.b + tD.b);
+    }
+    *diffuse = oD; *specular = oS;
+}
+
 typedef struct {
     const orc_ggx_soa *in; const orc_ggx_shader_soa *sh; orc_cv3p P; const orc_light *lights; int n_lights; int spp;
     uint32_t seed; uint64_t first;
     orc_v3p dd, ds;
+    /* the whole shader_evaluate (orc_batch_ggx_shade) */
+    int shade, traced; const float *env; orc_v3p refr, id, is, out;
 } light_job;
+
+#define SHADE_STREAM (3u * 8u)      /* first sample stream after the lights' (RLS_MAX_LIGHTS = 8) */
 
 static void light_range(int64_t lo, int64_t hi, void *ctx)
 {
@@ -1934,62 +2007,56 @@ static void light_range(int64_t lo, int64_t hi, void *ctx)
         orc_ggx g;
         ggx_load(j->in, i, &g);
         const orc_v3 N = ld3(j->in->N, i), T = ld3(j->in->T, i), wo = ld3(j->in->wo, i);
+        const uint64_t index = j->first + (uint64_t)i;
         orc_oren_nayar on;
         orc_oren_nayar_init(&on, N, T, j->sh->Kd_roughness[i]);
-        const float inv = 1.0f / (float)j->spp;
         const float ks = j->sh->Ks[i], kd = j->sh->Kd[i];
         const orc_rgb kdc = ldc(j->sh->Kd_color, i);
-        orc_rgb oS = RGB_BLACK, oD = RGB_BLACK;
-        for (int l = 0; l < j->n_lights; l++) {                    /* while (AiLightsGetSample(sg)), src/rlGgx.cpp:286 */
-            const orc_light *lt = &j->lights[l];
-            const int mode = lt->mis_mode;
-            const uint32_t st = 3u * (uint32_t)l;
-            light_cone c = cone_make(lt, ld3(j->P, i));
-            float sR = 0.0f, sG = 0.0f, sB = 0.0f, dA = 0.0f;
-            for (int s = 0; s < j->spp && c.valid; s++) {
-                float rx, ry;
-                if (mode != 2) {                                   /* one light sample, both lobes */
-                    orc_sample_02(j->seed, j->first + (uint64_t)i, st, (uint32_t)s, &rx, &ry);
-                    orc_v3 L = cone_sample(&c, rx, ry);
-                    if (v3dot(L, N) > 0.0f) {
-                        orc_rgb f = orc_ggx_eval_brdf(&g, L);
-                        float pb = orc_ggx_eval_pdf(&g, L);
-                        float w = mode == 1 ? 1.0f : power_heuristic(c.pdf, pb);
-                        sR += f.r * w / c.pdf; sG += f.g * w / c.pdf; sB += f.b * w / c.pdf;
-                        float fd = orc_oren_nayar_brdf(&on, wo, L);
-                        float wd = mode == 1 ? 1.0f : power_heuristic(c.pdf, orc_oren_nayar_pdf(&on, L));
-                        dA += fd * wd / c.pdf;
-                    }
-                }
-                if (mode != 1) {                                   /* one BSDF sample per lobe */
-                    orc_sample_02(j->seed, j->first + (uint64_t)i, st + 1, (uint32_t)s, &rx, &ry);
-                    orc_v3 L = orc_ggx_eval_sample(&g, rx, ry);
-                    if (!v3iszero(L) && v3dot(L, N) > 0.0f && cone_hit(&c, L)) {
-                        orc_rgb f = orc_ggx_eval_brdf(&g, L);
-                        float pb = orc_ggx_eval_pdf(&g, L);
-                        float w = mode == 2 ? 1.0f : power_heuristic(pb, c.pdf);
-                        sR += f.r * w / pb; sG += f.g * w / pb; sB += f.b * w / pb;
-                    }
-                    orc_sample_02(j->seed, j->first + (uint64_t)i, st + 2, (uint32_t)s, &rx, &ry);
-                    orc_v3 Ld = orc_sss_sample_diffuse_direction(rx, ry, N, T);
-                    float pd = orc_oren_nayar_pdf(&on, Ld);
-                    if (pd > 0.0f && cone_hit(&c, Ld)) {
-                        float fd = orc_oren_nayar_brdf(&on, wo, Ld);
-                        float wd = mode == 2 ? 1.0f : power_heuristic(pd, c.pdf);
-                        dA += fd * wd / pd;
-                    }
-                }
-            }
-            const float *rad = lt->radiance;
-            const orc_rgb tS = rgb(rad[0] * ks * sR * inv, rad[1] * ks * sG * inv, rad[2] * ks * sB * inv);
-            const orc_rgb tD = rgb(rad[0] * (kdc.r * kd) * dA * inv, rad[1] * (kdc.g * kd) * dA * inv,
-                                   rad[2] * (kdc.b * kd) * dA * inv);
-            /* specular += ..., diffuse += ...; the first light assigns */
-            oS = l == 0 ? tS : rgb(oS.r + tS.r, oS.g + tS.g, oS.b + tS.b);
-            oD = l == 0 ? tD : rgb(oD.r + tD.r, oD.g + tD.g, oD.b + tD.b);
+        const orc_rgb diffuseColor = rgb(kdc.r * kd, kdc.g * kd, kdc.b * kd);          /* :279 */
+        const int sampleDiffuse = !rgb_is_small(diffuseColor);                          /* :280 */
+        orc_rgb diffuse, specular;
+        ggx_light_loop(&g, &on, wo, N, T, ld3(j->P, i), sampleDiffuse, j->lights, j->n_lights, j->spp, j->seed, index,
+                       &diffuse, &specular);
+        diffuse = rgb(diffuse.r * diffuseColor.r, diffuse.g * diffuseColor.g, diffuse.b * diffuseColor.b);   /* :304 */
+        specular = rgb(specular.r * ks, specular.g * ks, specular.b * ks);                                  /* :305 */
+        stc(j->ds, i, specular);
+        stc(j->dd, i, diffuse);
+        if (!j->shade) continue;
+        const float inv = 1.0f / (float)j->spp;
+        /* transmission, :307-309 */
+        const float kt = j->sh->Kt[i];
+        const orc_rgb ktc = ldc(j->sh->Kt_color, i);
+        const orc_rgb ktColor = rgb(ktc.r * kt, ktc.g * kt, ktc.b * kt);
+        orc_rgb transmission = RGB_BLACK;
+        if (!rgb_is_small(ktColor)) {
+            float tir;
+            orc_rgb r = ggx_integrate_refract_stream(&g, j->traced, j->env, j->spp, j->seed, index, SHADE_STREAM + 1, &tir);
+            transmission = rgb(r.r * ktColor.r, r.g * ktColor.g, r.b * ktColor.b);
         }
-        stc(j->ds, i, oS);
-        stc(j->dd, i, oD);
+        /* indirect diffuse, :315-319 */
+        orc_rgb indirectDiffuse = RGB_BLACK;
+        if (sampleDiffuse) {
+            float acc = 0.0f;
+            for (int s = 0; s < j->spp; s++) {
+                float rx, ry;
+                orc_sample_02(j->seed, index, SHADE_STREAM + 2, (uint32_t)s, &rx, &ry);
+                orc_v3 Ld = orc_sss_sample_diffuse_direction(rx, ry, N, T);
+                float pd = orc_oren_nayar_pdf(&on, Ld);
+                if (pd > 0.0f) acc += orc_oren_nayar_brdf(&on, wo, Ld) / pd;
+            }
+            acc *= inv;
+            indirectDiffuse = rgb(diffuseColor.r * (acc * j->env[0]), diffuseColor.g * (acc * j->env[1]),
+                                  diffuseColor.b * (acc * j->env[2]));
+        }
+        /* indirect glossy, :321 */
+        orc_rgb gl = ggx_integrate_glossy(&g, j->env, j->spp, j->seed, index, SHADE_STREAM);
+        orc_rgb indirectGlossy = rgb(gl.r * ks, gl.g * ks, gl.b * ks);
+        stc(j->refr, i, transmission); stc(j->id, i, indirectDiffuse); stc(j->is, i, indirectGlossy);
+        if (j->out.x) {                                                                  /* :311, :323 */
+            stc(j->out, i, rgb(((diffuse.r + specular.r) + transmission.r) + (indirectDiffuse.r + indirectGlossy.r),
+                               ((diffuse.g + specular.g) + transmission.g) + (indirectDiffuse.g + indirectGlossy.g),
+                               ((diffuse.b + specular.b) + transmission.b) + (indirectDiffuse.b + indirectGlossy.b)));
+        }
     }
 }
 
@@ -1997,7 +2064,17 @@ void orc_batch_ggx_direct_lighting(int64_t n, const orc_ggx_soa *in, const orc_g
                                    const orc_light *lights, int n_lights, int spp_n, uint32_t seed, uint64_t first_index,
                                    orc_v3p direct_diffuse, orc_v3p direct_specular, int nthreads)
 {
-    light_job j = { in, sh, P, lights, n_lights, spp_n * spp_n, seed, first_index, direct_diffuse, direct_specular };
+    light_job j = { in, sh, P, lights, n_lights, spp_n * spp_n, seed, first_index, direct_diffuse, direct_specular,
+                    0, 0, NULL, {0}, {0}, {0}, {0} };
+    parallel_for(n, nthreads, light_range, &j);
+}
+
+void orc_batch_ggx_shade(int64_t n, const orc_ggx_soa *in, const orc_ggx_shader_soa *sh, orc_cv3p P,
+                         const orc_light *lights, int n_lights, const float env[3], int traced, int spp_n, uint32_t seed,
+                         uint64_t first_index, const orc_ggx_shade_out_soa *out, int nthreads)
+{
+    light_job j = { in, sh, P, lights, n_lights, spp_n * spp_n, seed, first_index, out->direct_diffuse, out->direct_specular,
+                    1, traced, env, out->refraction, out->indirect_diffuse, out->indirect_specular, out->out };
     parallel_for(n, nthreads, light_range, &j);
 }
 
@@ -2008,6 +2085,8 @@ void orc_batch_ggx_direct_lighting(int64_t n, const orc_ggx_soa *in, const orc_g
 typedef struct {
     const orc_disney_soa *in; orc_cv3p P; const orc_light *lights; int n_lights; int spp; uint32_t seed; uint64_t first;
     orc_v3p dd, ds;
+    /* the whole shader_evaluate (orc_batch_disney_shade) */
+    int shade; const float *env; orc_v3p id, is, out;
 } dlight_job;
 
 static void dlight_range(int64_t lo, int64_t hi, void *ctx)
@@ -2018,6 +2097,7 @@ static void dlight_range(int64_t lo, int64_t hi, void *ctx)
         float sc[10];
         for (int k = 0; k < 10; k++) sc[k] = j->in->scalars[k][i];
         const orc_v3 N = ld3(j->in->N, i);
+        const uint64_t index = j->first + (uint64_t)i;
         orc_disney_init(&d, ld3(j->in->wo, i), N, ld3(j->in->T, i), ldc(j->in->base_color, i), sc);
         const float inv = 1.0f / (float)j->spp;
         orc_rgb oS = RGB_BLACK, oD = RGB_BLACK;
@@ -2030,7 +2110,7 @@ static void dlight_range(int64_t lo, int64_t hi, void *ctx)
             for (int s = 0; s < j->spp && c.valid; s++) {
                 float rx, ry;
                 if (mode != 2) {                                   /* one light sample, both lobes */
-                    orc_sample_02(j->seed, j->first + (uint64_t)i, st, (uint32_t)s, &rx, &ry);
+                    orc_sample_02(j->seed, index, st, (uint32_t)s, &rx, &ry);
                     orc_v3 L = cone_sample(&c, rx, ry);
                     if (v3dot(L, N) > 0.0f) {
                         for (int lobe = 0; lobe < 2; lobe++) {
@@ -2045,7 +2125,7 @@ static void dlight_range(int64_t lo, int64_t hi, void *ctx)
                 if (mode != 1) {                                   /* one BSDF sample per lobe */
                     for (int lobe = 0; lobe < 2; lobe++) {
                         d.sampleType = lobe == 0 ? ORC_RAY_DIFFUSE : ORC_RAY_GLOSSY;
-                        orc_sample_02(j->seed, j->first + (uint64_t)i, st + 1 + (uint32_t)lobe, (uint32_t)s, &rx, &ry);
+                        orc_sample_02(j->seed, index, st + 1 + (uint32_t)lobe, (uint32_t)s, &rx, &ry);
                         orc_v3 L = orc_disney_eval_sample(&d, rx, ry);
                         orc_rgb f = orc_disney_eval_brdf(&d, L);
                         float p = orc_disney_eval_pdf(&d, L);
@@ -2064,6 +2144,28 @@ static void dlight_range(int64_t lo, int64_t hi, void *ctx)
         }
         stc(j->dd, i, oD);
         stc(j->ds, i, oS);
+        if (!j->shade) continue;
+        /* integrateDiffuse + integrateGlossy, :718-719 (240-243, 279-283): AiBRDFIntegrate over the triple */
+        float ind[2][3] = { { 0 } };
+        for (int s = 0; s < j->spp; s++) {
+            for (int lobe = 0; lobe < 2; lobe++) {
+                d.sampleType = lobe == 0 ? ORC_RAY_DIFFUSE : ORC_RAY_GLOSSY;
+                float rx, ry;
+                orc_sample_02(j->seed, index, SHADE_STREAM + (uint32_t)lobe, (uint32_t)s, &rx, &ry);
+                orc_v3 L = orc_disney_eval_sample(&d, rx, ry);
+                orc_rgb f = orc_disney_eval_brdf(&d, L);
+                float pdf = orc_disney_eval_pdf(&d, L);
+                if (pdf > AI_EPSILON) {                            /* :309 */
+                    ind[lobe][0] += f.r / pdf; ind[lobe][1] += f.g / pdf; ind[lobe][2] += f.b / pdf;
+                }
+            }
+        }
+        const orc_rgb iD = rgb(ind[0][0] * inv * j->env[0], ind[0][1] * inv * j->env[1], ind[0][2] * inv * j->env[2]);
+        const orc_rgb iS = rgb(ind[1][0] * inv * j->env[0], ind[1][1] * inv * j->env[1], ind[1][2] * inv * j->env[2]);
+        stc(j->id, i, iD); stc(j->is, i, iS);
+        if (j->out.x) {                                            /* :712, :722 */
+            stc(j->out, i, rgb((oD.r + oS.r) + (iD.r + iS.r), (oD.g + oS.g) + (iD.g + iS.g), (oD.b + oS.b) + (iD.b + iS.b)));
+        }
     }
 }
 
@@ -2071,7 +2173,17 @@ void orc_batch_disney_direct_lighting(int64_t n, const orc_disney_soa *in, orc_c
                                       int n_lights, int spp_n, uint32_t seed, uint64_t first_index,
                                       orc_v3p direct_diffuse, orc_v3p direct_specular, int nthreads)
 {
-    dlight_job j = { in, P, lights, n_lights, spp_n * spp_n, seed, first_index, direct_diffuse, direct_specular };
+    dlight_job j = { in, P, lights, n_lights, spp_n * spp_n, seed, first_index, direct_diffuse, direct_specular,
+                     0, NULL, {0}, {0}, {0} };
+    parallel_for(n, nthreads, dlight_range, &j);
+}
+
+void orc_batch_disney_shade(int64_t n, const orc_disney_soa *in, orc_cv3p P, const orc_light *lights, int n_lights,
+                            const float env[3], int spp_n, uint32_t seed, uint64_t first_index,
+                            const orc_disney_shade_out_soa *out, int nthreads)
+{
+    dlight_job j = { in, P, lights, n_lights, spp_n * spp_n, seed, first_index, out->direct_diffuse, out->direct_specular,
+                     1, env, out->indirect_diffuse, out->indirect_specular, out->out };
     parallel_for(n, nthreads, dlight_range, &j);
 }
 

@@ -368,6 +368,8 @@ void orc_batch_ggx_integrate_refract(int64_t n, const orc_ggx_soa *in, int trace
 typedef struct {
     orc_cv3p Kd_color;
     const float *Kd, *Kd_roughness, *Ks;
+    orc_cv3p Kt_color;          /* read by orc_batch_ggx_shade only */
+    const float *Kt;
 } orc_ggx_shader_soa;
 typedef struct { orc_v3 N, T; float A, B; } orc_oren_nayar;
 void  orc_oren_nayar_init(orc_oren_nayar *o, orc_v3 N, orc_v3 T, float sigma);
@@ -378,6 +380,21 @@ float orc_oren_nayar_pdf(const orc_oren_nayar *o, orc_v3 wi);
 void  orc_batch_ggx_direct_lighting(int64_t n, const orc_ggx_soa *in, const orc_ggx_shader_soa *sh, orc_cv3p P,
                                     const orc_light *lights, int n_lights, int spp_n, uint32_t seed, uint64_t first_index,
                                     orc_v3p direct_diffuse, orc_v3p direct_specular, int nthreads);
+/* shader_evaluate of rlGgx for a camera ray, whole (src/rlGgx.cpp:248-327): the light loop, transmission =
+ * integrateRefract x KtColor x Kt (black for a small product), indirect diffuse = diffuseColor x AiBRDFIntegrate over the
+ * Oren-Nayar closure (mean of brdf / pdf over cosine-weighted samples x env), indirect glossy = integrateGlossy x Ks,
+ * out = (diffuse + specular + transmission) + (indirectDiffuse + indirectGlossy).  Sample streams: light l 3 l .. 3 l + 2,
+ * integrateGlossy 24, integrateRefract 25, indirect diffuse 26.  n_lights may be 0; out->out.x may be NULL. */
+typedef struct { orc_v3p direct_diffuse, direct_specular, refraction, indirect_diffuse, indirect_specular, out; } orc_ggx_shade_out_soa;
+void  orc_batch_ggx_shade(int64_t n, const orc_ggx_soa *in, const orc_ggx_shader_soa *sh, orc_cv3p P,
+                          const orc_light *lights, int n_lights, const float env[3], int traced, int spp_n, uint32_t seed,
+                          uint64_t first_index, const orc_ggx_shade_out_soa *out, int nthreads);
+/* shader_evaluate of rlDisney for a camera ray, whole (src/rlDisney.cpp:685-727): the light loop + integrateDiffuse +
+ * integrateGlossy (sum of brdf / pdf over the valid samples x 1 / spp x env); streams: lights as above, 24, 25 */
+typedef struct { orc_v3p direct_diffuse, direct_specular, indirect_diffuse, indirect_specular, out; } orc_disney_shade_out_soa;
+void  orc_batch_disney_shade(int64_t n, const orc_disney_soa *in, orc_cv3p P, const orc_light *lights, int n_lights,
+                             const float env[3], int spp_n, uint32_t seed, uint64_t first_index,
+                             const orc_disney_shade_out_soa *out, int nthreads);
 /* Direct lighting of the rlDisney node (src/rlDisney.cpp:695-705: evalDiffuseLightSample + evalSpecularLightSample per
  * light, 265-277), same stand-ins; streams 3 l (light samples), 3 l + 1 (diffuse BSDF samples), 3 l + 2 (specular) */
 void  orc_batch_disney_direct_lighting(int64_t n, const orc_disney_soa *in, orc_cv3p P, const orc_light *lights,

@@ -89,8 +89,9 @@ class SphereLight(C.Structure):
 
 
 class GgxShader(C.Structure):
-    """rls_ggx_shader: KdColor, Kd, diffuseRoughness, Ks (src/rlGgx.cpp:170-175)"""
-    _fields_ = [("KdColor", ParamRgb), ("Kd", Param), ("diffuseRoughness", Param), ("Ks", Param)]
+    """rls_ggx_shader: KdColor, Kd, diffuseRoughness, Ks, KtColor, Kt (src/rlGgx.cpp:170-179)"""
+    _fields_ = [("KdColor", ParamRgb), ("Kd", Param), ("diffuseRoughness", Param), ("Ks", Param),
+                ("KtColor", ParamRgb), ("Kt", Param)]
 
 
 RLS_MIS_BOTH, RLS_MIS_LIGHT_ONLY, RLS_MIS_BSDF_ONLY = 0, 1, 2
@@ -126,6 +127,18 @@ class SkinOut(C.Structure):
                 ("spec_wi", Vec3), ("spec_f", Rgb), ("spec_pdf", C.c_void_p), ("spec_fresnel", C.c_void_p),
                 ("r", C.c_void_p), ("r_pdf", C.c_void_p), ("profile", Rgb),
                 ("sheenFresnel", C.c_void_p), ("specularFresnel", C.c_void_p), ("sssWeight", C.c_void_p)]
+
+
+class GgxShadeOut(C.Structure):
+    """rls_ggx_shade_out."""
+    _fields_ = [("direct_diffuse", Rgb), ("direct_specular", Rgb), ("refraction", Rgb), ("indirect_diffuse", Rgb),
+                ("indirect_specular", Rgb), ("out", Rgb)]
+
+
+class DisneyShadeOut(C.Structure):
+    """rls_disney_shade_out."""
+    _fields_ = [("direct_diffuse", Rgb), ("direct_specular", Rgb), ("indirect_diffuse", Rgb), ("indirect_specular", Rgb),
+                ("out", Rgb)]
 
 
 class SkinIntegrateOut(C.Structure):
@@ -187,6 +200,11 @@ PROTOTYPES = {
     "rls_ggx_ndf_pdf": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), CVec3, _vp]),
     "rls_ggx_direct_lighting": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), C.POINTER(GgxShader), CVec3,
                                           C.POINTER(SphereLight), C.c_int, C.c_int, C.c_uint32, C.c_uint64, Rgb, Rgb]),
+    "rls_ggx_shade": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), C.POINTER(GgxShader), CVec3, C.POINTER(SphereLight),
+                                C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_uint32, C.c_uint64,
+                                C.POINTER(GgxShadeOut)]),
+    "rls_disney_shade": (C.c_int, [_ctx, _i64, C.POINTER(DisneyClosure), CVec3, C.POINTER(SphereLight), C.c_int,
+                                   C.POINTER(C.c_float), C.c_int, C.c_uint32, C.c_uint64, C.POINTER(DisneyShadeOut)]),
     "rls_disney_direct_lighting": (C.c_int, [_ctx, _i64, C.POINTER(DisneyClosure), CVec3, C.POINTER(SphereLight), C.c_int,
                                              C.c_int, C.c_uint32, C.c_uint64, Rgb, Rgb]),
     "rls_ggx_integrate_refract": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), C.c_int, C.POINTER(C.c_float), C.c_int,

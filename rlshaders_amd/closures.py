@@ -339,12 +339,38 @@ class GgxSampler:
         n, ctx = self.n, self.ctx
         dd, ds = out if out is not None else (ctx.empty(3, n), ctx.empty(3, n))
         sh = capi.GgxShader(param_rgb(KdColor, n, "KdColor"), param(Kd, n, "Kd"),
-                            param(diffuseRoughness, n, "diffuseRoughness"), param(Ks, n, "Ks"))
+                            param(diffuseRoughness, n, "diffuseRoughness"), param(Ks, n, "Ks"),
+                            param_rgb((1.0, 1.0, 1.0), n, "KtColor"), param(0.0, n, "Kt"))
         lights, nl = light_array(light)
         check(ctx.lib.rls_ggx_direct_lighting(ctx.handle, n, C.byref(self.c), C.byref(sh), cvec3(P, n, "P"),
                                               lights, nl, int(spp_n), int(seed) & 0xFFFFFFFF, int(first_index),
                                               rgb(dd, n, "direct_diffuse"), rgb(ds, n, "direct_specular")))
         return dd, ds
+
+    SHADE_AOVS = ("direct_diffuse", "direct_specular", "refraction", "indirect_diffuse", "indirect_specular")
+
+    def shade(self, P, lights, spp_n: int, seed: int, KdColor: Color = (1.0, 1.0, 1.0), Kd: Scalar = 0.5,
+              diffuseRoughness: Scalar = 0.0, Ks: Scalar = 0.5, KtColor: Color = (1.0, 1.0, 1.0), Kt: Scalar = 0.0,
+              env=(1.0, 1.0, 1.0), traced: bool = True, out=None, first_index: int = 0) -> dict:
+        """shader_evaluate of the rlGgx node for a camera ray, whole (src/rlGgx.cpp:248-327; rls_ggx_shade) -> dict of the
+        five AOVs (direct_diffuse, direct_specular, refraction, indirect_diffuse, indirect_specular) and out = sg->out.RGB,
+        all [3,n]; parameter names and defaults of src/rlGgx.cpp:170-179; ``lights``: None, one light or a sequence."""
+        n, ctx = self.n, self.ctx
+        if out is None:
+            out = {k: ctx.empty(3, n) for k in self.SHADE_AOVS + ("out",)}
+        sh = capi.GgxShader(param_rgb(KdColor, n, "KdColor"), param(Kd, n, "Kd"),
+                            param(diffuseRoughness, n, "diffuseRoughness"), param(Ks, n, "Ks"),
+                            param_rgb(KtColor, n, "KtColor"), param(Kt, n, "Kt"))
+        o = capi.GgxShadeOut()
+        for k in self.SHADE_AOVS:
+            setattr(o, k, rgb(out[k], n, k))
+        if "out" in out:
+            o.out = rgb(out["out"], n, "out")
+        la, nl = light_array(lights)
+        e = (C.c_float * 3)(*[float(v) for v in env])
+        check(ctx.lib.rls_ggx_shade(ctx.handle, n, C.byref(self.c), C.byref(sh), cvec3(P, n, "P"), la, nl, e,
+                                    1 if traced else 0, int(spp_n), int(seed) & 0xFFFFFFFF, int(first_index), C.byref(o)))
+        return out
 
     def microfacet(self, rx, ry, kernel: int = RLS_KERNEL_VNDF):
         """VNDFKernel::evalSample (src/rlGgx.cpp:63-99) or NDFKernel::evalSample (src/rlGgx.h:33-41)."""
@@ -495,6 +521,25 @@ class DisneySampler:
                                                  int(seed) & 0xFFFFFFFF, int(first_index),
                                                  rgb(dd, n, "direct_diffuse"), rgb(ds, n, "direct_specular")))
         return dd, ds
+
+    SHADE_AOVS = ("direct_diffuse", "direct_specular", "indirect_diffuse", "indirect_specular")
+
+    def shade(self, P, lights, spp_n: int, seed: int, env=(1.0, 1.0, 1.0), out=None, first_index: int = 0) -> dict:
+        """shader_evaluate of the rlDisney node for a camera ray, whole (src/rlDisney.cpp:685-727; rls_disney_shade) ->
+        dict of the four AOVs and out = sg->out.RGB, all [3,n]; ``lights``: None, one light or a sequence."""
+        n, ctx = self.n, self.ctx
+        if out is None:
+            out = {k: ctx.empty(3, n) for k in self.SHADE_AOVS + ("out",)}
+        o = capi.DisneyShadeOut()
+        for k in self.SHADE_AOVS:
+            setattr(o, k, rgb(out[k], n, k))
+        if "out" in out:
+            o.out = rgb(out["out"], n, "out")
+        la, nl = light_array(lights)
+        e = (C.c_float * 3)(*[float(v) for v in env])
+        check(ctx.lib.rls_disney_shade(ctx.handle, n, C.byref(self.c), cvec3(P, n, "P"), la, nl, e, int(spp_n),
+                                       int(seed) & 0xFFFFFFFF, int(first_index), C.byref(o)))
+        return out
 
     def integrateChunked(self, spp_n: int, seed: int, chunk_points: int, consume=None, out=None, chunk=None,
                          first_index: int = 0):

@@ -112,16 +112,15 @@ __device__ __forceinline__ LightRegs light_regs(const rls_sphere_light &lt, V3 P
 // lights (group-reduced); f / cnt: THIS LANE's running Fresnel sum and count of the evalSample calls (src/rlGgx.h:103)
 // -- the caller carries them into integrateGlossy's loop and reduces once, so that one lane per point adds in the
 // reference's order.  Sample streams: `stream` + 4 l (light samples), `stream` + 1 + 4 l (BSDF samples).
-template <int G>
-__device__ __forceinline__ void ggx_light_loops(const Ggx &g, const VndfView &w, V3 N, V3 P,
-                                                const rls_sphere_light *lights, int nl,
+template <int G, class IO>
+__device__ __forceinline__ void ggx_light_loops(const Ggx &g, const VndfView &w, V3 N, V3 P, const IO &io,
                                                 const uint32_t (*tab)[kMaxSpp], int spp, int sub, float inv,
                                                 uint32_t seed, uint64_t index, uint32_t stream,
                                                 float out[3], float &f, float &cnt)
 {
     out[0] = 0.0f; out[1] = 0.0f; out[2] = 0.0f; f = 0.0f; cnt = 0.0f;
-    for (int l = 0; l < nl; l++) {
-        const LightRegs lt = light_regs(lights[l], P);
+    for (int l = 0; l < io.nl; l++) {
+        const LightRegs lt = light_regs(io.lights[l], P);   // io: the kernel's argument struct (scalar loads)
         const LightCone &cone = lt.cone;
         const int mode = lt.mode;
         uint32_t scr[4];
@@ -455,7 +454,7 @@ __global__ RLS_INT_ATTR void skin_integrate_kernel(SkinIntIO a)
             Ggx g = ggx_make<true>(wo, N, T, false, cr, cg, cb, ldp(c.sheen_ior, ii), ldp(c.sheen_roughness, ii), 0.0f);
             VndfView w = vndf_view_from(local, g.ax, g.ay);
             float lit[3], lf, lc, aF;
-            ggx_light_loops<G>(g, w, N, P, a.lights, a.nl, tab, a.spp, sub, inv, a.seed, a.first + (uint64_t)ii, 3,
+            ggx_light_loops<G>(g, w, N, P, a, tab, a.spp, sub, inv, a.seed, a.first + (uint64_t)ii, 3,
                                lit, lf, lc);                                          // :193-198
             ggx_glossy_loop<G>(g, w, tab, a.spp, sub, scr[0], scr[1], shR, shG, shB, aF, lf);
             // integrateGlossy returns black for a small colour without sampling (src/rlGgx.h:174-176); the light
@@ -476,7 +475,7 @@ __global__ RLS_INT_ATTR void skin_integrate_kernel(SkinIntIO a)
             Ggx g = ggx_make<true>(wo, N, T, false, cr, cg, cb, ldp(c.specular_ior, ii), ldp(c.specular_roughness, ii), 0.0f);
             VndfView w = vndf_view_from(local, g.ax, g.ay);
             float lit[3], lf, lc, aF;
-            ggx_light_loops<G>(g, w, N, P, a.lights, a.nl, tab, a.spp, sub, inv, a.seed, a.first + (uint64_t)ii, 5,
+            ggx_light_loops<G>(g, w, N, P, a, tab, a.spp, sub, inv, a.seed, a.first + (uint64_t)ii, 5,
                                lit, lf, lc);                                          // :217-222
             ggx_glossy_loop<G>(g, w, tab, a.spp, sub, scr[2], scr[3], spR, spG, spB, aF, lf);
             const bool small = absf(cr) < kEps && absf(cg) < kEps && absf(cb) < kEps;
@@ -523,6 +522,33 @@ __global__ RLS_INT_ATTR void skin_integrate_kernel(SkinIntIO a)
 // radiance is that of a uniform environment, `env` (parity unpinned).
 using rlsh::RefractIntIO;
 
+// the traced branch's sample loop (src/rlGgx.h:228-244): mean sample weight and fraction of total internal reflections
+template <int G>
+__device__ __forceinline__ void ggx_refract_loop(const Ggx &g, const VndfView &w, const uint32_t (*tab)[kMaxSpp], int spp,
+                                                 int sub, uint32_t sx, uint32_t sy, float &acc, float &tir)
+{
+    acc = 0.0f; tir = 0.0f;
+    for (int s = sub; s < spp; s += G) {
+        float rx = bits_u01(tab[0][s] ^ sx);
+        float ry = bits_u01(tab[1][s] ^ sy);
+        V3 M = vndf_microfacet(w, g.fr, rx, ry);
+        V3 dir;
+        if (!ggx_refract(g, M, dir)) tir += 1.0f;
+        acc += ggx_sample_weight(g, g.view, dir, M);                 // :241
+    }
+    if (G > 1) { acc = group_sum<G>(acc); tir = group_sum<G>(tir); }
+    const float inv = 1.0f / (float)spp;                             // AiSamplerGetSampleInvCount, :244
+    acc *= inv; tir *= inv;
+}
+// the untraced branch (213-222): one refraction about the shading normal
+__device__ __forceinline__ void ggx_refract_untraced(const Ggx &g, float &acc, float &tir)
+{
+    acc = 0.0f; tir = 0.0f;
+    V3 dir;
+    if (ggx_refract(g, g.fr.N, dir)) acc = g.eta2 * absf(dot(g.fr.N, dir));   // :216
+    else tir = 1.0f;
+}
+
 template <int G, int FAST_MATH = RLS_FAST>
 __global__ RLS_INT_ATTR void ggx_refract_integrate_kernel(RefractIntIO a)
 {
@@ -544,26 +570,14 @@ __global__ RLS_INT_ATTR void ggx_refract_integrate_kernel(RefractIntIO a)
         bool exiting = c.exiting ? (c.exiting[ii] != 0) : false;
         Ggx g = ggx_make(wo, N, T, exiting, kr, kg, kb, ldp(c.ior, ii), ldp(c.specularRoughness, ii),
                          ldp(c.anisotropic, ii));
-        float acc = 0.0f, tir = 0.0f;
+        float acc, tir;
         if (a.traced) {
             VndfView w = vndf_view(g.view, g.fr, g.ax, g.ay);
             const uint32_t sx = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream);
             const uint32_t sy = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream + 1);
-            for (int s = sub; s < a.spp; s += G) {
-                float rx = bits_u01(tab[0][s] ^ sx);
-                float ry = bits_u01(tab[1][s] ^ sy);
-                V3 M = vndf_microfacet(w, g.fr, rx, ry);
-                V3 dir;
-                if (!ggx_refract(g, M, dir)) tir += 1.0f;
-                acc += ggx_sample_weight(g, g.view, dir, M);                 // :241
-            }
-            if (G > 1) { acc = group_sum<G>(acc); tir = group_sum<G>(tir); }
-            const float inv = 1.0f / (float)a.spp;                           // AiSamplerGetSampleInvCount, :244
-            acc *= inv; tir *= inv;
+            ggx_refract_loop<G>(g, w, tab, a.spp, sub, sx, sy, acc, tir);
         } else {
-            V3 dir;
-            if (ggx_refract(g, g.fr.N, dir)) acc = g.eta2 * absf(dot(g.fr.N, dir));   // :216
-            else tir = 1.0f;
+            ggx_refract_untraced(g, acc, tir);
         }
         if (live && sub == 0) {
             strgb(a.result, i, a.env[0] * acc, a.env[1] * acc, a.env[2] * acc);
@@ -576,6 +590,82 @@ __global__ RLS_INT_ATTR void ggx_refract_integrate_kernel(RefractIntIO a)
 // Direct lighting of the rlGgx node (src/rlGgx.cpp:274-299); include/rlshaders_amd.h,
 // rls_ggx_direct_lighting, says what stands in for the closed light loop.
 using rlsh::LightIO;
+
+// The light loop of rlGgx (src/rlGgx.cpp:285-299) for one shading point: per light one AiEvaluateLightSample over the
+// Oren-Nayar closure (when sampleDiffuse) and one over the GGX triple; oD / oS = the sums over the lights, group-reduced,
+// BEFORE `diffuse *= diffuseColor; specular *= specularWeight` (304-305).  Light l: sample streams 3 l .. 3 l + 2.
+template <int G, class IO>
+__device__ __forceinline__ void ggx_direct_loops(const Ggx &g, const VndfView &w, const OrenNayar &on, V3 wo, V3 N, V3 P,
+                                                 bool sampleDiffuse, const IO &io,
+                                                 const uint32_t (*tab)[kMaxSpp], int spp, int sub, float inv,
+                                                 uint32_t seed, uint64_t index, float oD[3], float oS[3])
+{
+    oS[0] = 0.0f; oS[1] = 0.0f; oS[2] = 0.0f; oD[0] = 0.0f; oD[1] = 0.0f; oD[2] = 0.0f;
+    for (int l = 0; l < io.nl; l++) {                          // while (AiLightsGetSample(sg)), src/rlGgx.cpp:286
+        const LightRegs lt = light_regs(io.lights[l], P);      // io: the kernel's argument struct (scalar loads)
+        const LightCone &cone = lt.cone;
+        const int mode = lt.mode;
+        uint32_t scr[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) scr[k] = hash_u32(seed, index, kScrambleStream + 6 * l + k);
+
+        float sR = 0.0f, sG = 0.0f, sB = 0.0f, dA = 0.0f;
+        for (int s = sub; s < spp && cone.valid; s += G) {
+            if (mode != RLS_MIS_BSDF_ONLY) {                     // one light sample, both lobes
+                float rx = bits_u01(tab[0][s] ^ scr[0]), ry = bits_u01(tab[1][s] ^ scr[1]);
+                V3 L = cone_sample(cone, rx, ry);
+                if (dot(L, N) > 0.0f) {
+                    float fr, fg, fb, pb;
+                    ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pb);
+                    float wgt = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, pb);
+                    sR += R_DIV(fr * wgt, cone.pdf); sG += R_DIV(fg * wgt, cone.pdf); sB += R_DIV(fb * wgt, cone.pdf);
+                    if (sampleDiffuse) {
+                        float fd = oren_nayar_brdf(on, wo, L);
+                        float wd = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, oren_nayar_pdf(on, L));
+                        dA += R_DIV(fd * wd, cone.pdf);
+                    }
+                }
+            }
+            if (mode != RLS_MIS_LIGHT_ONLY) {                    // one BSDF sample per lobe
+                float rx = bits_u01(tab[0][s] ^ scr[2]), ry = bits_u01(tab[1][s] ^ scr[3]);
+                V3 M = vndf_microfacet(w, g.fr, rx, ry);
+                V3 L = reflect_direction(g.view, M);
+                if (!is_zero(L) && dot(L, N) > 0.0f && cone_hit(cone, L)) {
+                    float fr, fg, fb, pb;
+                    ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pb);
+                    float wgt = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(pb, cone.pdf);
+                    sR += R_DIV(fr * wgt, pb); sG += R_DIV(fg * wgt, pb); sB += R_DIV(fb * wgt, pb);
+                }
+                if (sampleDiffuse) {
+                    rx = bits_u01(tab[0][s] ^ scr[4]); ry = bits_u01(tab[1][s] ^ scr[5]);
+                    V3 Ld = cosine_hemisphere(g.fr, rx, ry);
+                    float pd = oren_nayar_pdf(on, Ld);
+                    if (pd > 0.0f && cone_hit(cone, Ld)) {
+                        float fd = oren_nayar_brdf(on, wo, Ld);
+                        float wd = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(pd, cone.pdf);
+                        dA += R_DIV(fd * wd, pd);
+                    }
+                }
+            }
+        }
+        if (G > 1) {
+            sR = group_sum<G>(sR); sG = group_sum<G>(sG); sB = group_sum<G>(sB); dA = group_sum<G>(dA);
+        }
+        // specular += ..., diffuse += ... (288-294); the first light assigns (0 + x loses the sign of a zero)
+        const float tS[3] = { lt.rad[0] * sR * inv, lt.rad[1] * sG * inv, lt.rad[2] * sB * inv };
+        const float tD[3] = { lt.rad[0] * dA * inv, lt.rad[1] * dA * inv, lt.rad[2] * dA * inv };
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            oS[k] = l == 0 ? tS[k] : oS[k] + tS[k];
+            oD[k] = l == 0 ? tD[k] : oD[k] + tD[k];
+        }
+    }
+}
+
+__device__ __forceinline__ bool color_is_small(float r, float g, float b)      // AiColorIsSmall
+{
+    return absf(r) < kEps && absf(g) < kEps && absf(b) < kEps;
+}
 
 template <int G, int FAST_MATH = RLS_FAST>
 __global__ RLS_INT_ATTR void ggx_direct_kernel(LightIO a)
@@ -601,72 +691,16 @@ __global__ RLS_INT_ATTR void ggx_direct_kernel(LightIO a)
                          ldp(c.anisotropic, ii));
         VndfView w = vndf_view(g.view, g.fr, g.ax, g.ay);
         OrenNayar on = oren_nayar_make(N, ldp(a.sh.diffuseRoughness, ii));
-        const V3 P = ld3(a.P, ii);
         const float ks = ldp(a.sh.Ks, ii), kd = ldp(a.sh.Kd, ii);
         float dr, dg, db;
         ldrgb(a.sh.KdColor, ii, dr, dg, db);
-
-        float oS[3] = { 0.0f, 0.0f, 0.0f }, oD[3] = { 0.0f, 0.0f, 0.0f };
-        for (int l = 0; l < a.nl; l++) {                             // while (AiLightsGetSample(sg)), src/rlGgx.cpp:286
-            const LightRegs lt = light_regs(a.lights[l], P);
-            const LightCone &cone = lt.cone;
-            const int mode = lt.mode;
-            uint32_t scr[6];
-#pragma unroll
-            for (int k = 0; k < 6; k++) scr[k] = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream + 6 * l + k);
-
-            float sR = 0.0f, sG = 0.0f, sB = 0.0f, dA = 0.0f;
-            for (int s = sub; s < a.spp && cone.valid; s += G) {
-                if (mode != RLS_MIS_BSDF_ONLY) {                     // one light sample, both lobes
-                    float rx = bits_u01(tab[0][s] ^ scr[0]), ry = bits_u01(tab[1][s] ^ scr[1]);
-                    V3 L = cone_sample(cone, rx, ry);
-                    if (dot(L, N) > 0.0f) {
-                        float fr, fg, fb, pb;
-                        ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pb);
-                        float wgt = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, pb);
-                        sR += R_DIV(fr * wgt, cone.pdf); sG += R_DIV(fg * wgt, cone.pdf); sB += R_DIV(fb * wgt, cone.pdf);
-                        float fd = oren_nayar_brdf(on, wo, L);
-                        float wd = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, oren_nayar_pdf(on, L));
-                        dA += R_DIV(fd * wd, cone.pdf);
-                    }
-                }
-                if (mode != RLS_MIS_LIGHT_ONLY) {                    // one BSDF sample per lobe
-                    float rx = bits_u01(tab[0][s] ^ scr[2]), ry = bits_u01(tab[1][s] ^ scr[3]);
-                    V3 M = vndf_microfacet(w, g.fr, rx, ry);
-                    V3 L = reflect_direction(g.view, M);
-                    if (!is_zero(L) && dot(L, N) > 0.0f && cone_hit(cone, L)) {
-                        float fr, fg, fb, pb;
-                        ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pb);
-                        float wgt = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(pb, cone.pdf);
-                        sR += R_DIV(fr * wgt, pb); sG += R_DIV(fg * wgt, pb); sB += R_DIV(fb * wgt, pb);
-                    }
-                    rx = bits_u01(tab[0][s] ^ scr[4]); ry = bits_u01(tab[1][s] ^ scr[5]);
-                    V3 Ld = cosine_hemisphere(g.fr, rx, ry);
-                    float pd = oren_nayar_pdf(on, Ld);
-                    if (pd > 0.0f && cone_hit(cone, Ld)) {
-                        float fd = oren_nayar_brdf(on, wo, Ld);
-                        float wd = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(pd, cone.pdf);
-                        dA += R_DIV(fd * wd, pd);
-                    }
-                }
-            }
-            if (G > 1) {
-                sR = group_sum<G>(sR); sG = group_sum<G>(sG); sB = group_sum<G>(sB); dA = group_sum<G>(dA);
-            }
-            // diffuse *= KdColor * Kd, specular *= Ks (src/rlGgx.cpp:307-308), light by light; the first light
-            // assigns (0 + x keeps x but loses the sign of a zero)
-            const float tS[3] = { lt.rad[0] * ks * sR * inv, lt.rad[1] * ks * sG * inv, lt.rad[2] * ks * sB * inv };
-            const float tD[3] = { lt.rad[0] * (dr * kd) * dA * inv, lt.rad[1] * (dg * kd) * dA * inv,
-                                  lt.rad[2] * (db * kd) * dA * inv };
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                oS[k] = l == 0 ? tS[k] : oS[k] + tS[k];
-                oD[k] = l == 0 ? tD[k] : oD[k] + tD[k];
-            }
-        }
+        dr *= kd; dg *= kd; db *= kd;                                       // diffuseColor, src/rlGgx.cpp:279
+        float oD[3], oS[3];
+        ggx_direct_loops<G>(g, w, on, wo, N, ld3(a.P, ii), !color_is_small(dr, dg, db), a, tab, a.spp, sub,
+                            inv, a.seed, a.first + (uint64_t)ii, oD, oS);
         if (live && sub == 0) {
-            strgb(a.ds, i, oS[0], oS[1], oS[2]);
-            strgb(a.dd, i, oD[0], oD[1], oD[2]);
+            strgb(a.ds, i, oS[0] * ks, oS[1] * ks, oS[2] * ks);            // specular *= specularWeight, :305
+            strgb(a.dd, i, oD[0] * dr, oD[1] * dg, oD[2] * db);            // diffuse *= diffuseColor, :304
         }
     }
 }
@@ -676,6 +710,83 @@ __global__ RLS_INT_ATTR void ggx_direct_kernel(LightIO a)
 // lobe's AiEvaluateLightSample over the callback triple (265-277); include/rlshaders_amd.h,
 // rls_disney_direct_lighting, says what stands in for the closed light loop.
 using rlsh::DisneyLightIO;
+
+// the closure of shading point ii, prepared (a macro: the same lines in a function cost 26 more spilled registers)
+#define RLS_DISNEY_LOAD(d, c, ii)                                                                          \
+    Disney d;                                                                                              \
+    {                                                                                                      \
+        float br_, bg_, bb_, sc_[10];                                                                      \
+        ldrgb((c).base_color, ii, br_, bg_, bb_);                                                          \
+        sc_[0] = ldp((c).subsurface, ii); sc_[1] = ldp((c).metallic, ii); sc_[2] = ldp((c).specular, ii);  \
+        sc_[3] = ldp((c).specular_tint, ii); sc_[4] = ldp((c).roughness, ii); sc_[5] = ldp((c).anisotropic, ii); \
+        sc_[6] = ldp((c).sheen, ii); sc_[7] = ldp((c).sheen_tint, ii); sc_[8] = ldp((c).clearcoat, ii);    \
+        sc_[9] = ldp((c).clearcoat_gloss, ii);                                                             \
+        d = disney_make(ld3((c).wo, ii), ld3((c).N, ii), ld3((c).T, ii), br_, bg_, bb_, sc_);              \
+        disney_prepare(d);                                                                                 \
+    }
+
+// The light loop of rlDisney (src/rlDisney.cpp:695-705) for one shading point: oD / oS = the sums over the lights of
+// evalDiffuseLightSample / evalSpecularLightSample, group-reduced.  Light l: sample streams 3 l .. 3 l + 2.
+template <int G, class IO>
+__device__ __forceinline__ void disney_direct_loops(const Disney &d, const VndfView &w, V3 N, V3 P, const IO &io,
+                                                    const uint32_t (*tab)[kMaxSpp], int spp, int sub, float inv,
+                                                    uint32_t seed, uint64_t index, float oD[3], float oS[3])
+{
+    oS[0] = 0.0f; oS[1] = 0.0f; oS[2] = 0.0f; oD[0] = 0.0f; oD[1] = 0.0f; oD[2] = 0.0f;
+    for (int l = 0; l < io.nl; l++) {                          // while (AiLightsGetSample(sg)), :696
+        const LightRegs lt = light_regs(io.lights[l], P);
+        const LightCone &cone = lt.cone;
+        const int mode = lt.mode;
+        uint32_t scr[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) scr[k] = hash_u32(seed, index, kScrambleStream + 6 * l + k);
+
+        float sR = 0.0f, sG = 0.0f, sB = 0.0f, dR = 0.0f, dG = 0.0f, dB = 0.0f;
+        for (int s = sub; s < spp && cone.valid; s += G) {
+            if (mode != RLS_MIS_BSDF_ONLY) {                     // one light sample, both lobes
+                float rx = bits_u01(tab[0][s] ^ scr[0]), ry = bits_u01(tab[1][s] ^ scr[1]);
+                V3 L = cone_sample(cone, rx, ry);
+                if (dot(L, N) > 0.0f) {
+                    float r, g, b, p;
+                    disney_eval_pdf<true, true, true>(d, L, r, g, b, p);       // evalDiffuseLightSample, :265-269
+                    float wgt = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, p);
+                    dR += R_DIV(r * wgt, cone.pdf); dG += R_DIV(g * wgt, cone.pdf); dB += R_DIV(b * wgt, cone.pdf);
+                    disney_eval_pdf<false, true, true>(d, L, r, g, b, p);      // evalSpecularLightSample, :272-276
+                    wgt = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, p);
+                    sR += R_DIV(r * wgt, cone.pdf); sG += R_DIV(g * wgt, cone.pdf); sB += R_DIV(b * wgt, cone.pdf);
+                }
+            }
+            if (mode != RLS_MIS_LIGHT_ONLY) {                    // one BSDF sample per lobe
+                float rx = bits_u01(tab[0][s] ^ scr[2]), ry = bits_u01(tab[1][s] ^ scr[3]);
+                V3 L = cosine_hemisphere(d.fr, rx, ry);
+                float r, g, b, p;
+                disney_eval_pdf<true, true, true>(d, L, r, g, b, p);
+                if (p > kEps && cone_hit(cone, L)) {
+                    float wgt = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(p, cone.pdf);
+                    dR += R_DIV(r * wgt, p); dG += R_DIV(g * wgt, p); dB += R_DIV(b * wgt, p);
+                }
+                rx = bits_u01(tab[0][s] ^ scr[4]); ry = bits_u01(tab[1][s] ^ scr[5]);
+                L = disney_sample_specular(d, w, rx, ry);
+                disney_eval_pdf<false, true, true>(d, L, r, g, b, p);
+                if (p > kEps && cone_hit(cone, L)) {
+                    float wgt = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(p, cone.pdf);
+                    sR += R_DIV(r * wgt, p); sG += R_DIV(g * wgt, p); sB += R_DIV(b * wgt, p);
+                }
+            }
+        }
+        if (G > 1) {
+            dR = group_sum<G>(dR); dG = group_sum<G>(dG); dB = group_sum<G>(dB);
+            sR = group_sum<G>(sR); sG = group_sum<G>(sG); sB = group_sum<G>(sB);
+        }
+        const float tD[3] = { lt.rad[0] * dR * inv, lt.rad[1] * dG * inv, lt.rad[2] * dB * inv };
+        const float tS[3] = { lt.rad[0] * sR * inv, lt.rad[1] * sG * inv, lt.rad[2] * sB * inv };
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            oD[k] = l == 0 ? tD[k] : oD[k] + tD[k];
+            oS[k] = l == 0 ? tS[k] : oS[k] + tS[k];
+        }
+    }
+}
 
 template <int G, int FAST_MATH = RLS_FAST>
 __global__ RLS_INT_ATTR void disney_direct_kernel(DisneyLightIO a)
@@ -692,77 +803,167 @@ __global__ RLS_INT_ATTR void disney_direct_kernel(DisneyLightIO a)
     for (int64_t it = 0; it < rounds; it++, i += stride) {
         const bool live = i < a.n;
         const int64_t ii = live ? i : a.n - 1;
-        const rls_disney_closure &c = a.c;
-        V3 wo = ld3(c.wo, ii), N = ld3(c.N, ii), T = ld3(c.T, ii);
-        float br, bg, bb;
-        ldrgb(c.base_color, ii, br, bg, bb);
-        float sc[10];
-        sc[0] = ldp(c.subsurface, ii); sc[1] = ldp(c.metallic, ii); sc[2] = ldp(c.specular, ii);
-        sc[3] = ldp(c.specular_tint, ii); sc[4] = ldp(c.roughness, ii); sc[5] = ldp(c.anisotropic, ii);
-        sc[6] = ldp(c.sheen, ii); sc[7] = ldp(c.sheen_tint, ii); sc[8] = ldp(c.clearcoat, ii);
-        sc[9] = ldp(c.clearcoat_gloss, ii);
-        Disney d = disney_make(wo, N, T, br, bg, bb, sc);
-        disney_prepare(d);
+        RLS_DISNEY_LOAD(d, a.c, ii)
         VndfView w = vndf_view(d.view, d.fr, d.ax, d.ay);
-        const V3 P = ld3(a.P, ii);
-
-        float oS[3] = { 0.0f, 0.0f, 0.0f }, oD[3] = { 0.0f, 0.0f, 0.0f };
-        for (int l = 0; l < a.nl; l++) {                             // while (AiLightsGetSample(sg)), :696
-            const LightRegs lt = light_regs(a.lights[l], P);
-            const LightCone &cone = lt.cone;
-            const int mode = lt.mode;
-            uint32_t scr[6];
-#pragma unroll
-            for (int k = 0; k < 6; k++) scr[k] = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream + 6 * l + k);
-
-            float sR = 0.0f, sG = 0.0f, sB = 0.0f, dR = 0.0f, dG = 0.0f, dB = 0.0f;
-            for (int s = sub; s < a.spp && cone.valid; s += G) {
-                if (mode != RLS_MIS_BSDF_ONLY) {                     // one light sample, both lobes
-                    float rx = bits_u01(tab[0][s] ^ scr[0]), ry = bits_u01(tab[1][s] ^ scr[1]);
-                    V3 L = cone_sample(cone, rx, ry);
-                    if (dot(L, N) > 0.0f) {
-                        float r, g, b, p;
-                        disney_eval_pdf<true, true, true>(d, L, r, g, b, p);       // evalDiffuseLightSample, :265-269
-                        float wgt = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, p);
-                        dR += R_DIV(r * wgt, cone.pdf); dG += R_DIV(g * wgt, cone.pdf); dB += R_DIV(b * wgt, cone.pdf);
-                        disney_eval_pdf<false, true, true>(d, L, r, g, b, p);      // evalSpecularLightSample, :272-276
-                        wgt = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, p);
-                        sR += R_DIV(r * wgt, cone.pdf); sG += R_DIV(g * wgt, cone.pdf); sB += R_DIV(b * wgt, cone.pdf);
-                    }
-                }
-                if (mode != RLS_MIS_LIGHT_ONLY) {                    // one BSDF sample per lobe
-                    float rx = bits_u01(tab[0][s] ^ scr[2]), ry = bits_u01(tab[1][s] ^ scr[3]);
-                    V3 L = cosine_hemisphere(d.fr, rx, ry);
-                    float r, g, b, p;
-                    disney_eval_pdf<true, true, true>(d, L, r, g, b, p);
-                    if (p > kEps && cone_hit(cone, L)) {
-                        float wgt = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(p, cone.pdf);
-                        dR += R_DIV(r * wgt, p); dG += R_DIV(g * wgt, p); dB += R_DIV(b * wgt, p);
-                    }
-                    rx = bits_u01(tab[0][s] ^ scr[4]); ry = bits_u01(tab[1][s] ^ scr[5]);
-                    L = disney_sample_specular(d, w, rx, ry);
-                    disney_eval_pdf<false, true, true>(d, L, r, g, b, p);
-                    if (p > kEps && cone_hit(cone, L)) {
-                        float wgt = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(p, cone.pdf);
-                        sR += R_DIV(r * wgt, p); sG += R_DIV(g * wgt, p); sB += R_DIV(b * wgt, p);
-                    }
-                }
-            }
-            if (G > 1) {
-                dR = group_sum<G>(dR); dG = group_sum<G>(dG); dB = group_sum<G>(dB);
-                sR = group_sum<G>(sR); sG = group_sum<G>(sG); sB = group_sum<G>(sB);
-            }
-            const float tD[3] = { lt.rad[0] * dR * inv, lt.rad[1] * dG * inv, lt.rad[2] * dB * inv };
-            const float tS[3] = { lt.rad[0] * sR * inv, lt.rad[1] * sG * inv, lt.rad[2] * sB * inv };
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                oD[k] = l == 0 ? tD[k] : oD[k] + tD[k];
-                oS[k] = l == 0 ? tS[k] : oS[k] + tS[k];
-            }
-        }
+        float oD[3], oS[3];
+        disney_direct_loops<G>(d, w, d.fr.N, ld3(a.P, ii), a, tab, a.spp, sub, inv, a.seed,
+                               a.first + (uint64_t)ii, oD, oS);
         if (live && sub == 0) {
             strgb(a.dd, i, oD[0], oD[1], oD[2]);
             strgb(a.ds, i, oS[0], oS[1], oS[2]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// shader_evaluate of rlGgx and of rlDisney for a camera ray, whole: the loops above run back to back on one closure
+// set-up (include/rlshaders_amd.h, rls_ggx_shade / rls_disney_shade).  Sample streams: light l 3 l .. 3 l + 2 (as in
+// the light-loop entry points), then 24, 25, 26 for the indirect loops.
+using rlsh::GgxShadeIO;
+using rlsh::DisneyShadeIO;
+constexpr uint32_t kShadeStream = 3 * RLS_MAX_LIGHTS;       // first sample stream after the lights'
+
+template <int G, int FAST_MATH = RLS_FAST>
+__global__ RLS_INT_ATTR void ggx_shade_kernel(GgxShadeIO a)
+{
+    __shared__ uint32_t tab[2][kMaxSpp];
+    stage_libm_tables();
+    stage_table(tab, a.spp);
+    const int sub = threadIdx.x % G;
+    const int64_t groups_per_block = rlsh::kBlock / G;
+    const int64_t stride = (int64_t)gridDim.x * groups_per_block;
+    const int64_t rounds = (a.n + stride - 1) / stride;
+    const float inv = 1.0f / (float)a.spp;
+    int64_t i = (int64_t)blockIdx.x * groups_per_block + threadIdx.x / G;
+    for (int64_t it = 0; it < rounds; it++, i += stride) {
+        const bool live = i < a.n;
+        const int64_t ii = live ? i : a.n - 1;
+        const uint64_t idx = a.first + (uint64_t)ii;
+        const rls_ggx_closure &c = a.c;
+        V3 wo = ld3(c.wo, ii), N = ld3(c.N, ii), T = ld3(c.T, ii);
+        float kr, kg, kb;
+        ldrgb(c.KsColor, ii, kr, kg, kb);
+        bool exiting = c.exiting ? (c.exiting[ii] != 0) : false;
+        Ggx g = ggx_make(wo, N, T, exiting, kr, kg, kb, ldp(c.ior, ii), ldp(c.specularRoughness, ii),
+                         ldp(c.anisotropic, ii));
+        VndfView w = vndf_view(g.view, g.fr, g.ax, g.ay);
+        OrenNayar on = oren_nayar_make(N, ldp(a.sh.diffuseRoughness, ii));
+        const float ks = ldp(a.sh.Ks, ii), kd = ldp(a.sh.Kd, ii), kt = ldp(a.sh.Kt, ii);
+        float dr, dg, db, tr, tg, tb;
+        ldrgb(a.sh.KdColor, ii, dr, dg, db);
+        ldrgb(a.sh.KtColor, ii, tr, tg, tb);
+        dr *= kd; dg *= kd; db *= kd;                                        // diffuseColor, src/rlGgx.cpp:279
+        tr *= kt; tg *= kt; tb *= kt;                                        // ktColor, :308
+        const bool sampleDiffuse = !color_is_small(dr, dg, db);              // :280 (Rr_diff = 0)
+        // the light loop, :285-305
+        float dD[3], dS[3];
+        ggx_direct_loops<G>(g, w, on, wo, N, ld3(a.P, ii), sampleDiffuse, a, tab, a.spp, sub, inv, a.seed,
+                            idx, dD, dS);
+        dD[0] *= dr; dD[1] *= dg; dD[2] *= db;
+        dS[0] *= ks; dS[1] *= ks; dS[2] *= ks;
+        // transmission, :307-309
+        float tx[3] = { 0.0f, 0.0f, 0.0f };
+        if (!color_is_small(tr, tg, tb)) {
+            float acc, tir;
+            if (a.traced) {
+                ggx_refract_loop<G>(g, w, tab, a.spp, sub, hash_u32(a.seed, idx, kScrambleStream + 2 * (kShadeStream + 1)),
+                                    hash_u32(a.seed, idx, kScrambleStream + 2 * (kShadeStream + 1) + 1), acc, tir);
+            } else {
+                ggx_refract_untraced(g, acc, tir);
+            }
+            tx[0] = a.env[0] * acc * tr; tx[1] = a.env[1] * acc * tg; tx[2] = a.env[2] * acc * tb;
+        }
+        // indirect diffuse, :315-319: AiBRDFIntegrate over the Oren-Nayar closure -> mean of brdf / pdf x env
+        float iD[3] = { 0.0f, 0.0f, 0.0f };
+        if (sampleDiffuse) {
+            const uint32_t sx = hash_u32(a.seed, idx, kScrambleStream + 2 * (kShadeStream + 2));
+            const uint32_t sy = hash_u32(a.seed, idx, kScrambleStream + 2 * (kShadeStream + 2) + 1);
+            float acc = 0.0f;
+            for (int s = sub; s < a.spp; s += G) {
+                V3 Ld = cosine_hemisphere(g.fr, bits_u01(tab[0][s] ^ sx), bits_u01(tab[1][s] ^ sy));
+                float pd = oren_nayar_pdf(on, Ld);
+                if (pd > 0.0f) acc += R_DIV(oren_nayar_brdf(on, wo, Ld), pd);
+            }
+            if (G > 1) acc = group_sum<G>(acc);
+            acc *= inv;
+            iD[0] = dr * (acc * a.env[0]); iD[1] = dg * (acc * a.env[1]); iD[2] = db * (acc * a.env[2]);
+        }
+        // indirect glossy, :321: integrateGlossy (black for a small colour, src/rlGgx.h:174-176) x specularWeight
+        float iS[3] = { 0.0f, 0.0f, 0.0f };
+        if (!color_is_small(kr, kg, kb)) {
+            float aR, aG, aB, aF;
+            ggx_glossy_loop<G>(g, w, tab, a.spp, sub, hash_u32(a.seed, idx, kScrambleStream + 2 * kShadeStream),
+                               hash_u32(a.seed, idx, kScrambleStream + 2 * kShadeStream + 1), aR, aG, aB, aF);
+            iS[0] = aR * inv * a.env[0] * ks; iS[1] = aG * inv * a.env[1] * ks; iS[2] = aB * inv * a.env[2] * ks;
+        }
+        if (live && sub == 0) {
+            strgb(a.dd, i, dD[0], dD[1], dD[2]);
+            strgb(a.ds, i, dS[0], dS[1], dS[2]);
+            strgb(a.refr, i, tx[0], tx[1], tx[2]);
+            strgb(a.id, i, iD[0], iD[1], iD[2]);
+            strgb(a.is, i, iS[0], iS[1], iS[2]);
+            // result = diffuse + specular + transmission (:311); result += indirectDiffuse + indirectGlossy (:323)
+            if (a.out.r) strgb(a.out, i, ((dD[0] + dS[0]) + tx[0]) + (iD[0] + iS[0]), ((dD[1] + dS[1]) + tx[1]) + (iD[1] + iS[1]),
+                               ((dD[2] + dS[2]) + tx[2]) + (iD[2] + iS[2]));
+        }
+    }
+}
+
+template <int G, int FAST_MATH = RLS_FAST>
+__global__ RLS_INT_ATTR void disney_shade_kernel(DisneyShadeIO a)
+{
+    __shared__ uint32_t tab[2][kMaxSpp];
+    stage_libm_tables();
+    stage_table(tab, a.spp);
+    const int sub = threadIdx.x % G;
+    const int64_t groups_per_block = rlsh::kBlock / G;
+    const int64_t stride = (int64_t)gridDim.x * groups_per_block;
+    const int64_t rounds = (a.n + stride - 1) / stride;
+    const float inv = 1.0f / (float)a.spp;
+    int64_t i = (int64_t)blockIdx.x * groups_per_block + threadIdx.x / G;
+    for (int64_t it = 0; it < rounds; it++, i += stride) {
+        const bool live = i < a.n;
+        const int64_t ii = live ? i : a.n - 1;
+        const uint64_t idx = a.first + (uint64_t)ii;
+        RLS_DISNEY_LOAD(d, a.c, ii)
+        VndfView w = vndf_view(d.view, d.fr, d.ax, d.ay);
+        // the light loop, src/rlDisney.cpp:695-705
+        float dD[3], dS[3];
+        disney_direct_loops<G>(d, w, d.fr.N, ld3(a.P, ii), a, tab, a.spp, sub, inv, a.seed, idx, dD, dS);
+        // integrateDiffuse / integrateGlossy (:718-719, 240-243, 279-283): AiBRDFIntegrate over the triple -> the sum of
+        // brdf / pdf over the valid samples (:309) x AiSamplerGetSampleInvCount x env
+        uint32_t scr[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) scr[k] = hash_u32(a.seed, idx, kScrambleStream + 2 * kShadeStream + k);
+        float iR = 0.0f, iG = 0.0f, iB = 0.0f, gR = 0.0f, gG = 0.0f, gB = 0.0f;
+        for (int s = sub; s < a.spp; s += G) {
+            {
+                V3 L = cosine_hemisphere(d.fr, bits_u01(tab[0][s] ^ scr[0]), bits_u01(tab[1][s] ^ scr[1]));
+                float r, g, b, pdf;
+                disney_eval_pdf<true, true, true>(d, L, r, g, b, pdf);
+                if (pdf > kEps) { iR += r / pdf; iG += g / pdf; iB += b / pdf; }
+            }
+            {
+                V3 L = disney_sample_specular(d, w, bits_u01(tab[0][s] ^ scr[2]), bits_u01(tab[1][s] ^ scr[3]));
+                float r, g, b, pdf;
+                disney_eval_pdf<false, true, true>(d, L, r, g, b, pdf);
+                if (pdf > kEps) { gR += r / pdf; gG += g / pdf; gB += b / pdf; }
+            }
+        }
+        if (G > 1) {
+            iR = group_sum<G>(iR); iG = group_sum<G>(iG); iB = group_sum<G>(iB);
+            gR = group_sum<G>(gR); gG = group_sum<G>(gG); gB = group_sum<G>(gB);
+        }
+        const float iD[3] = { iR * inv * a.env[0], iG * inv * a.env[1], iB * inv * a.env[2] };
+        const float iS[3] = { gR * inv * a.env[0], gG * inv * a.env[1], gB * inv * a.env[2] };
+        if (live && sub == 0) {
+            strgb(a.dd, i, dD[0], dD[1], dD[2]);
+            strgb(a.ds, i, dS[0], dS[1], dS[2]);
+            strgb(a.id, i, iD[0], iD[1], iD[2]);
+            strgb(a.is, i, iS[0], iS[1], iS[2]);
+            // result = diffuse + specular (:712); result += indirectDiffuse + indirectGlossy (:722)
+            if (a.out.r) strgb(a.out, i, (dD[0] + dS[0]) + (iD[0] + iS[0]), (dD[1] + dS[1]) + (iD[1] + iS[1]),
+                               (dD[2] + dS[2]) + (iD[2] + iS[2]));
         }
     }
 }
@@ -827,6 +1028,16 @@ RLS_HIDDEN rls_status rls_fast_ggx_direct(rls_context *ctx, int g, const rlsh::L
     return launch_g(ctx, ggx_direct_kernel<1>, ggx_direct_kernel<4>, ggx_direct_kernel<16>,
                     ggx_direct_kernel<64>, g, *io, "rls_ggx_direct_lighting[fast]");
 }
+RLS_HIDDEN rls_status rls_fast_ggx_shade(rls_context *ctx, int g, const rlsh::GgxShadeIO *io)
+{
+    return launch_g(ctx, ggx_shade_kernel<1>, ggx_shade_kernel<4>, ggx_shade_kernel<16>, ggx_shade_kernel<64>, g, *io,
+                    "rls_ggx_shade[fast]");
+}
+RLS_HIDDEN rls_status rls_fast_disney_shade(rls_context *ctx, int g, const rlsh::DisneyShadeIO *io)
+{
+    return launch_g(ctx, disney_shade_kernel<1>, disney_shade_kernel<4>, disney_shade_kernel<16>, disney_shade_kernel<64>, g,
+                    *io, "rls_disney_shade[fast]");
+}
 RLS_HIDDEN rls_status rls_fast_disney_direct(rls_context *ctx, int g, const rlsh::DisneyLightIO *io)
 {
     return launch_g(ctx, disney_direct_kernel<1>, disney_direct_kernel<4>, disney_direct_kernel<16>,
@@ -854,6 +1065,8 @@ RLS_HIDDEN rls_status rls_fast_sss_scatter(rls_context *ctx, int g, const rlsh::
 RLS_HIDDEN rls_status rls_fast_ggx_direct(rls_context *ctx, int g, const rlsh::LightIO *io);
 RLS_HIDDEN rls_status rls_fast_skin_integrate(rls_context *ctx, int g, const rlsh::SkinIntIO *io);
 RLS_HIDDEN rls_status rls_fast_disney_direct(rls_context *ctx, int g, const rlsh::DisneyLightIO *io);
+RLS_HIDDEN rls_status rls_fast_ggx_shade(rls_context *ctx, int g, const rlsh::GgxShadeIO *io);
+RLS_HIDDEN rls_status rls_fast_disney_shade(rls_context *ctx, int g, const rlsh::DisneyShadeIO *io);
 RLS_HIDDEN rls_status rls_fast_ggx_refract_integrate(rls_context *ctx, int g, const rlsh::RefractIntIO *io);
 
 extern "C" {
@@ -1040,6 +1253,59 @@ rls_status rls_ggx_direct_lighting(rls_context *ctx, int64_t n, const rls_ggx_cl
     if (ctx->fast) return rls_fast_ggx_direct(ctx, g, &io);
     return launch_g(ctx, ggx_direct_kernel<1>, ggx_direct_kernel<4>, ggx_direct_kernel<16>,
                     ggx_direct_kernel<64>, g, io, "rls_ggx_direct_lighting");
+}
+
+rls_status rls_ggx_shade(rls_context *ctx, int64_t n, const rls_ggx_closure *c, const rls_ggx_shader *sh, rls_cvec3 P,
+                         const rls_sphere_light *lights, int n_lights, const float env[3], int traced, int spp_n,
+                         uint32_t seed, uint64_t first_index, const rls_ggx_shade_out *out)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_REQUIRE(n >= 0, "n < 0");
+    RLS_REQUIRE(spp_n >= 1 && spp_n * spp_n <= kMaxSpp, "spp_n must be in [1, 16]");
+    if (n == 0) return RLS_OK;
+    RLS_REQUIRE(c != nullptr && sh != nullptr && env != nullptr && out != nullptr, "closure, shader, env or out is NULL");
+    RLS_REQUIRE(rlsh::has3(c->wo) && rlsh::has3(c->N) && rlsh::has3(c->T) && rlsh::has3(P), "wo/N/T/P plane is NULL");
+    RLS_REQUIRE(rlsh::ok_rgb(c->KsColor) && rlsh::ok_rgb(sh->KdColor) && rlsh::ok_rgb(sh->KtColor),
+                "colour planes must be all set or all NULL");
+    RLS_REQUIRE(rlsh::has3(out->direct_diffuse) && rlsh::has3(out->direct_specular) && rlsh::has3(out->refraction) &&
+                rlsh::has3(out->indirect_diffuse) && rlsh::has3(out->indirect_specular), "NULL AOV plane");
+    RLS_REQUIRE(rlsh::has3(out->out) || (!out->out.r && !out->out.g && !out->out.b), "out planes must be all set or all NULL");
+    rlsh::GgxShadeIO io = {};
+    if (rls_status st = copy_lights(lights, n_lights, 0, io.lights, &io.nl)) return st;
+    io.c = *c; io.sh = *sh; io.P = P; io.env[0] = env[0]; io.env[1] = env[1]; io.env[2] = env[2]; io.traced = traced ? 1 : 0;
+    io.dd = out->direct_diffuse; io.ds = out->direct_specular; io.refr = out->refraction; io.id = out->indirect_diffuse;
+    io.is = out->indirect_specular; io.out = out->out;
+    io.n = n; io.spp = spp_n * spp_n; io.seed = seed; io.first = first_index;
+    int g = pick_group(ctx, n, io.spp);
+    if (ctx->fast) return rls_fast_ggx_shade(ctx, g, &io);
+    return launch_g(ctx, ggx_shade_kernel<1>, ggx_shade_kernel<4>, ggx_shade_kernel<16>, ggx_shade_kernel<64>, g, io,
+                    "rls_ggx_shade");
+}
+
+rls_status rls_disney_shade(rls_context *ctx, int64_t n, const rls_disney_closure *c, rls_cvec3 P,
+                            const rls_sphere_light *lights, int n_lights, const float env[3], int spp_n, uint32_t seed,
+                            uint64_t first_index, const rls_disney_shade_out *out)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_REQUIRE(n >= 0, "n < 0");
+    RLS_REQUIRE(spp_n >= 1 && spp_n * spp_n <= kMaxSpp, "spp_n must be in [1, 16]");
+    if (n == 0) return RLS_OK;
+    RLS_REQUIRE(c != nullptr && env != nullptr && out != nullptr, "closure, env or out is NULL");
+    RLS_REQUIRE(rlsh::has3(c->wo) && rlsh::has3(c->N) && rlsh::has3(c->T) && rlsh::has3(P), "wo/N/T/P plane is NULL");
+    RLS_REQUIRE(rlsh::ok_rgb(c->base_color), "base_color planes must be all set or all NULL");
+    RLS_REQUIRE(rlsh::has3(out->direct_diffuse) && rlsh::has3(out->direct_specular) && rlsh::has3(out->indirect_diffuse) &&
+                rlsh::has3(out->indirect_specular), "NULL AOV plane");
+    RLS_REQUIRE(rlsh::has3(out->out) || (!out->out.r && !out->out.g && !out->out.b), "out planes must be all set or all NULL");
+    rlsh::DisneyShadeIO io = {};
+    if (rls_status st = copy_lights(lights, n_lights, 0, io.lights, &io.nl)) return st;
+    io.c = *c; io.P = P; io.env[0] = env[0]; io.env[1] = env[1]; io.env[2] = env[2];
+    io.dd = out->direct_diffuse; io.ds = out->direct_specular; io.id = out->indirect_diffuse; io.is = out->indirect_specular;
+    io.out = out->out;
+    io.n = n; io.spp = spp_n * spp_n; io.seed = seed; io.first = first_index;
+    int g = pick_group(ctx, n, io.spp);
+    if (ctx->fast) return rls_fast_disney_shade(ctx, g, &io);
+    return launch_g(ctx, disney_shade_kernel<1>, disney_shade_kernel<4>, disney_shade_kernel<16>, disney_shade_kernel<64>, g,
+                    io, "rls_disney_shade");
 }
 
 rls_status rls_disney_direct_lighting(rls_context *ctx, int64_t n, const rls_disney_closure *c, rls_cvec3 P,

@@ -128,6 +128,32 @@ struct LightIO {
     uint32_t seed;
     uint64_t first;         // global index of point 0 (the sampler scrambles hash first + i)
 };
+struct GgxShadeIO {
+    rls_ggx_closure c;
+    rls_ggx_shader sh;
+    rls_cvec3 P;
+    rls_sphere_light lights[RLS_MAX_LIGHTS];
+    int nl;
+    float env[3];
+    int traced;
+    rls_rgb dd, ds, refr, id, is, out;
+    int64_t n;
+    int spp;
+    uint32_t seed;
+    uint64_t first;
+};
+struct DisneyShadeIO {
+    rls_disney_closure c;
+    rls_cvec3 P;
+    rls_sphere_light lights[RLS_MAX_LIGHTS];
+    int nl;
+    float env[3];
+    rls_rgb dd, ds, id, is, out;
+    int64_t n;
+    int spp;
+    uint32_t seed;
+    uint64_t first;
+};
 struct DisneyLightIO {
     rls_disney_closure c;
     rls_cvec3 P;

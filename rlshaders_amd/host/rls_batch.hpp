@@ -293,9 +293,23 @@ public:
                         ParamRGB KdColor, Param Kd, Param diffuseRoughness, Param Ks, Planes &direct_diffuse,
                         Planes &direct_specular, uint64_t first_index = 0) const
     {
-        rls_ggx_shader sh{KdColor.c(), Kd.c(), diffuseRoughness.c(), Ks.c()};
+        rls_ggx_shader sh{KdColor.c(), Kd.c(), diffuseRoughness.c(), Ks.c(), ParamRGB(1.0f, 1.0f, 1.0f).c(), Param(0.0f).c()};
         check(rls_ggx_direct_lighting(dev_.ctx(), n_, &c_, &sh, P.cvec3(), lights, n_lights, spp_n, seed, first_index,
                                       direct_diffuse.rgb(), direct_specular.rgb()));
+    }
+    // shader_evaluate of the rlGgx node for a camera ray, whole (src/rlGgx.cpp:248-327): aov = 15 planes {direct_diffuse3,
+    // direct_specular3, refraction3, indirect_diffuse3, indirect_specular3}, rgb (optional) = sg->out.RGB
+    void shade(const Planes &P, const rls_sphere_light *lights, int n_lights, const float env[3], bool traced, int spp_n,
+               uint32_t seed, ParamRGB KdColor, Param Kd, Param diffuseRoughness, Param Ks, ParamRGB KtColor, Param Kt,
+               Planes &aov, Planes *rgb = nullptr, uint64_t first_index = 0) const
+    {
+        rls_ggx_shader sh{KdColor.c(), Kd.c(), diffuseRoughness.c(), Ks.c(), KtColor.c(), Kt.c()};
+        rls_ggx_shade_out o{};
+        o.direct_diffuse = aov.rgb(0); o.direct_specular = aov.rgb(3); o.refraction = aov.rgb(6);
+        o.indirect_diffuse = aov.rgb(9); o.indirect_specular = aov.rgb(12);
+        if (rgb) o.out = rgb->rgb(0);
+        check(rls_ggx_shade(dev_.ctx(), n_, &c_, &sh, P.cvec3(), lights, n_lights, env, traced ? 1 : 0, spp_n, seed,
+                            first_index, &o));
     }
     void directLighting(const Planes &P, const rls_sphere_light &light, int spp_n, uint32_t seed, ParamRGB KdColor,
                         Param Kd, Param diffuseRoughness, Param Ks, Planes &direct_diffuse,
@@ -366,6 +380,17 @@ public:
     {
         check(rls_disney_direct_lighting(dev_.ctx(), n_, &c_, P.cvec3(), lights, n_lights, spp_n, seed, first_index,
                                          direct_diffuse.rgb(), direct_specular.rgb()));
+    }
+    // shader_evaluate of the rlDisney node for a camera ray, whole (src/rlDisney.cpp:685-727): aov = 12 planes
+    // {direct_diffuse3, direct_specular3, indirect_diffuse3, indirect_specular3}, rgb (optional) = sg->out.RGB
+    void shade(const Planes &P, const rls_sphere_light *lights, int n_lights, const float env[3], int spp_n, uint32_t seed,
+               Planes &aov, Planes *rgb = nullptr, uint64_t first_index = 0) const
+    {
+        rls_disney_shade_out o{};
+        o.direct_diffuse = aov.rgb(0); o.direct_specular = aov.rgb(3); o.indirect_diffuse = aov.rgb(6);
+        o.indirect_specular = aov.rgb(9);
+        if (rgb) o.out = rgb->rgb(0);
+        check(rls_disney_shade(dev_.ctx(), n_, &c_, P.cvec3(), lights, n_lights, env, spp_n, seed, first_index, &o));
     }
     // the same with every sample handed to `consume` chunk by chunk (the loop body of src/rlDisney.cpp:299-312);
     // chunk_wi / chunk_f: 3 x (2 * spp * chunk_points) planes, chunk_pdf: 1 x the same

@@ -73,7 +73,15 @@ def light_array(lights):
 
 
 class GgxShaderSoa(C.Structure):
-    _fields_ = [("Kd_color", CV3P), ("Kd", fp), ("Kd_roughness", fp), ("Ks", fp)]
+    _fields_ = [("Kd_color", CV3P), ("Kd", fp), ("Kd_roughness", fp), ("Ks", fp), ("Kt_color", CV3P), ("Kt", fp)]
+
+
+class GgxShadeOutSoa(C.Structure):
+    _fields_ = [(k, CV3P) for k in ("direct_diffuse", "direct_specular", "refraction", "indirect_diffuse", "indirect_specular", "out")]
+
+
+class DisneyShadeOutSoa(C.Structure):
+    _fields_ = [(k, CV3P) for k in ("direct_diffuse", "direct_specular", "indirect_diffuse", "indirect_specular", "out")]
 
 
 class DisneySoa(C.Structure):
@@ -249,13 +257,30 @@ class Ggx:
         n = self.n
         P = f32(P)
         kdc, kd, kdr, ks = _full3(Kd_color, n), _full(Kd, n), _full(Kd_roughness, n), _full(Ks, n)
-        sh = GgxShaderSoa(_v(kdc), _p(kd), _p(kdr), _p(ks))
+        sh = GgxShaderSoa(_v(kdc), _p(kd), _p(kdr), _p(ks), CV3P(), None)
         dd, ds = np.empty((3, n), np.float32), np.empty((3, n), np.float32)
         la, nl = light_array(light)
         lib().orc_batch_ggx_direct_lighting(C.c_int64(n), C.byref(self.soa), C.byref(sh), _v(P), la, nl,
                                             int(spp_n), C.c_uint32(seed), C.c_uint64(first_index), _v(dd), _v(ds),
                                             self.nthreads)
         return dd, ds
+
+    def shade(self, P, lights, spp_n, seed, Kd_color=(1, 1, 1), Kd=0.5, Kd_roughness=0.0, Ks=0.5, Kt_color=(1, 1, 1), Kt=0.0,
+              env=(1.0, 1.0, 1.0), traced=True, first_index=0) -> dict:
+        """orc_batch_ggx_shade -> dict of the five AOVs and out, [3,n] each"""
+        n = self.n
+        P = f32(P)
+        kdc, kd, kdr, ks = _full3(Kd_color, n), _full(Kd, n), _full(Kd_roughness, n), _full(Ks, n)
+        ktc, kt = _full3(Kt_color, n), _full(Kt, n)
+        sh = GgxShaderSoa(_v(kdc), _p(kd), _p(kdr), _p(ks), _v(ktc), _p(kt))
+        keys = ("direct_diffuse", "direct_specular", "refraction", "indirect_diffuse", "indirect_specular", "out")
+        out = {k: np.empty((3, n), np.float32) for k in keys}
+        o = GgxShadeOutSoa(*[_v(out[k]) for k in keys])
+        la, nl = light_array(lights)
+        e = (C.c_float * 3)(*[float(v) for v in env])
+        lib().orc_batch_ggx_shade(C.c_int64(n), C.byref(self.soa), C.byref(sh), _v(P), la, nl, e, 1 if traced else 0,
+                                  int(spp_n), C.c_uint32(seed), C.c_uint64(first_index), C.byref(o), self.nthreads)
+        return out
 
     def integrate_refract(self, spp_n, seed, traced=True, env=(1.0, 1.0, 1.0), first_index=0):
         """orc_batch_ggx_integrate_refract -> (result [3,n], tir_fraction [n])"""
@@ -332,6 +357,19 @@ class Disney:
         lib().orc_batch_disney_direct_lighting(C.c_int64(n), C.byref(self.soa), _v(P), la, nl, int(spp_n), C.c_uint32(seed),
                                                C.c_uint64(first_index), _v(dd), _v(ds), self.nthreads)
         return dd, ds
+
+    def shade(self, P, lights, spp_n, seed, env=(1.0, 1.0, 1.0), first_index=0) -> dict:
+        """orc_batch_disney_shade -> dict of the four AOVs and out, [3,n] each"""
+        n = self.n
+        P = f32(P)
+        keys = ("direct_diffuse", "direct_specular", "indirect_diffuse", "indirect_specular", "out")
+        out = {k: np.empty((3, n), np.float32) for k in keys}
+        o = DisneyShadeOutSoa(*[_v(out[k]) for k in keys])
+        la, nl = light_array(lights)
+        e = (C.c_float * 3)(*[float(v) for v in env])
+        lib().orc_batch_disney_shade(C.c_int64(n), C.byref(self.soa), _v(P), la, nl, e, int(spp_n), C.c_uint32(seed),
+                                     C.c_uint64(first_index), C.byref(o), self.nthreads)
+        return out
 
     def integrate(self, spp_n, seed, streamed=False, first_index=0):
         n = self.n

@@ -193,3 +193,26 @@ def test_light_loops_in_fast_mode(fast, oracle):
     for k in ("sheen", "specular", "sss", "out"):
         a, b = gotk[k].astype(np.float64), refk[k].astype(np.float64)
         assert np.isfinite(a).all() and abs(a.mean() / b.mean() - 1) < 5e-3, (k, a.mean(), b.mean())
+
+
+def test_whole_node_shading_in_fast_mode(fast, oracle):
+    """rls_ggx_shade / rls_disney_shade in FAST mode: every AOV at the batch's scale and per point in bulk"""
+    n, spp_n, seed = 1 << 12, 4, 29
+    P = (cases.xi(cases.SEED_PARITY, n, 3) * np.array([[4.0], [4.0], [1.0]], np.float32)).astype(np.float32)
+    lo = [oracle.make_light(center=(2.0, 2.0, 3.0), radius=1.25, radiance=(3.0, 2.0, 1.0)),
+          oracle.make_light(center=(-3.0, 1.0, 2.5), radius=0.5, radiance=(0.5, 4.0, 2.0), mis_mode=1)]
+    lg = [R._capi.SphereLight.from_buffer_copy(bytes(l)) for l in lo]
+    g = cases.ggx_mixed(cases.SEED_PARITY, n)
+    kw = dict(Kd=0.6, Ks=0.4, Kt=0.5)
+    ref = ggx_oracle(oracle, g).shade(P, lo, spp_n, seed, Kd_color=(0.9, 0.5, 0.3), Kd_roughness=0.4, Kt_color=(0.2, 0.9, 0.9), **kw)
+    got = {k: host(v) for k, v in ggx_sampler(fast, g).shade(dev(P), lg, spp_n, seed, KdColor=(0.9, 0.5, 0.3), diffuseRoughness=0.4,
+                                                            KtColor=(0.2, 0.9, 0.9), **kw).items()}
+    d = cases.disney_mixed(cases.SEED_PARITY, n)
+    refd = disney_oracle(oracle, d).shade(P, lo, spp_n, seed)
+    gotd = {k: host(v) for k, v in disney_sampler(fast, d).shade(dev(P), lg, spp_n, seed).items()}
+    for name, r, q in (("ggx", ref, got), ("disney", refd, gotd)):
+        for k in r:
+            a, b = q[k].astype(np.float64), r[k].astype(np.float64)
+            assert np.isfinite(a).all(), (name, k)
+            assert abs(a.mean() / b.mean() - 1) < 5e-3, (name, k, a.mean(), b.mean())
+            assert np.quantile(cases.rel_err(q[k], r[k]), 0.9) <= 2e-3, (name, k)

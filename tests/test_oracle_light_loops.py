@@ -136,3 +136,58 @@ def test_skin_light_loops_feed_the_fresnel_mean():
     for r in (dark, light_only, both):
         for k in r:
             assert np.isfinite(r[k]).all(), k
+
+
+def test_whole_node_shading_closed_forms():
+    """orc_batch_ggx_shade / orc_batch_disney_shade (shader_evaluate of the two nodes, src/rlGgx.cpp:248-327,
+    src/rlDisney.cpp:685-727): a Lambertian diffuse closure under a uniform environment reflects diffuseColor x env
+    (brdf x cos / pdf = 1 for every cosine-weighted sample); the untraced transmission is SQR(iorOut / iorIn) |N . dir|
+    x env x KtColor x Kt; the output is the AOVs added in the reference's order; radiance scales linearly."""
+    n, spp_n, seed = 512, 3, 8
+    wo, N, T, P = _points(n, (0.3, 0.1, 0.9))
+    g = O.Ggx(wo, N, T, KsColor=(0.9, 0.8, 0.7), roughness=0.4, ior=1.5, nthreads=4)
+    A = O.make_light(center=(2.0, 2.0, 6.0), radius=1.25, radiance=(3.0, 2.0, 1.0))
+    env = (0.5, 0.25, 2.0)
+    r = g.shade(P, [A], spp_n, seed, Kd_color=(0.8, 0.6, 0.4), Kd=0.5, Kd_roughness=0.0, Ks=0.5, Kt_color=(0.2, 0.4, 0.8), Kt=0.5,
+                env=env, traced=False)
+    for k in range(3):
+        np.testing.assert_allclose(r["indirect_diffuse"][k], (0.8, 0.6, 0.4)[k] * 0.5 * env[k], rtol=2e-6)
+    # untraced refraction about N: Snell, eta = 1 / 1.5 for an entering ray
+    ci = float(wo[2, 0]); eta = 1.0 / 1.5
+    ct = math.sqrt(1.0 - eta * eta * (1.0 - ci * ci))
+    for k in range(3):
+        np.testing.assert_allclose(r["refraction"][k], 1.5 ** 2 * ct * env[k] * (0.2, 0.4, 0.8)[k] * 0.5, rtol=1e-5)
+    want = ((r["direct_diffuse"] + r["direct_specular"]) + r["refraction"]) + (r["indirect_diffuse"] + r["indirect_specular"])
+    assert np.array_equal(want.view(np.uint32), r["out"].view(np.uint32))
+    dd, ds = g.direct_lighting(P, [A], spp_n, seed, Kd_color=(0.8, 0.6, 0.4), Kd=0.5, Kd_roughness=0.0, Ks=0.5)
+    assert np.array_equal(dd.view(np.uint32), r["direct_diffuse"].view(np.uint32))
+    assert np.array_equal(ds.view(np.uint32), r["direct_specular"].view(np.uint32))
+    r2 = g.shade(P, [A], spp_n, seed, Kd_color=(0.8, 0.6, 0.4), Kd=0.5, Kd_roughness=0.0, Ks=0.5, Kt_color=(0.2, 0.4, 0.8), Kt=0.5,
+                 env=tuple(2 * e for e in env), traced=False)
+    for q in ("refraction", "indirect_diffuse", "indirect_specular"):
+        assert np.array_equal((2 * r[q]).view(np.uint32), r2[q].view(np.uint32)), q
+    # Kd = 0: AiColorIsSmall(diffuseColor) switches both diffuse estimators off (280, 315)
+    r0 = g.shade(P, [A], spp_n, seed, Kd=0.0, Kt=0.0, env=env)
+    assert not r0["direct_diffuse"].any() and not r0["indirect_diffuse"].any() and not r0["refraction"].any()
+    assert np.array_equal(r0["direct_specular"].view(np.uint32), r["direct_specular"].view(np.uint32))
+
+    c = cases.disney_mixed(cases.SEED_PARITY, n)
+    d = disney_oracle(O, c)
+    Pd = np.stack([O.gen_uniform(seed, 0, n, 40 + j, 0.0, 4.0) for j in range(3)])
+    s1 = d.shade(Pd, [A], spp_n, seed, env=(1.0, 1.0, 1.0))
+    s2 = d.shade(Pd, [A], spp_n, seed, env=(2.0, 4.0, 0.5))
+    for q in ("indirect_diffuse", "indirect_specular"):
+        assert np.array_equal((s1[q] * np.array([[2.0], [4.0], [0.5]], np.float32)).view(np.uint32), s2[q].view(np.uint32)), q
+        assert np.isfinite(s1[q]).all() and (s1[q] >= 0).all() and (s1[q] > 0).mean() > 0.5
+    dd, ds = d.direct_lighting(Pd, [A], spp_n, seed)
+    assert np.array_equal(dd.view(np.uint32), s1["direct_diffuse"].view(np.uint32))
+    assert np.array_equal(ds.view(np.uint32), s1["direct_specular"].view(np.uint32))
+    want = (s1["direct_diffuse"] + s1["direct_specular"]) + (s1["indirect_diffuse"] + s1["indirect_specular"])
+    assert np.array_equal(want.view(np.uint32), s1["out"].view(np.uint32))
+    # the indirect loops are the n^2-spp integrator's (other sample streams): the same integrals
+    whole = d.integrate(8, seed)
+    big = d.shade(Pd, None, 8, seed)
+    np.testing.assert_allclose(big["indirect_diffuse"].astype(np.float64).mean(axis=1),
+                               (whole["diffuse_sum"].astype(np.float64) / 64).mean(axis=1), rtol=0.02)
+    np.testing.assert_allclose(big["indirect_specular"].astype(np.float64).mean(axis=1),
+                               (whole["specular_sum"].astype(np.float64) / 64).mean(axis=1), rtol=0.1)

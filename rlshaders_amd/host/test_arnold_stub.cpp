@@ -1,4 +1,5 @@
 // test_arnold_stub.cpp -- drives rl_arnold_stub.hpp without Arnold (tests/test_arnold_stub.py, tests/test_gpu_arnold_stub.py).
+//   test_arnold_stub shade <in> <out>     the whole shader_evaluate of the three nodes (addShade per point, shade per batch)
 //   test_arnold_stub decl                 replay node_parameters / node_loader of the three nodes through a recording
 //                                         host and print what was declared, as JSON
 //   test_arnold_stub run <in> <out>       read shading points + parameter values, push them through GgxNode, DisneyNode and
@@ -147,12 +148,70 @@ int run(const char *in, const char *out)
     }
 }
 
+// the whole shader_evaluate of the three nodes: file layout as `run` with 15 geometry rows (Rd3 N3 Nf3 U3 P3) and no xi
+int shade(const char *in, const char *out)
+{
+    std::vector<float> d = read_file(in);
+    const int64_t n = (int64_t)d[0];
+    const float *p = d.data() + 1;
+    auto take = [&](int rows) { const float *q = p; p += (size_t)rows * (size_t)n; return q; };
+    const float *geo = take(15);
+    const float *tg = take(3 * rlstub::ggx::p_count), *td = take(3 * rlstub::disney::p_count), *ts = take(3 * rlstub::skin::p_count);
+    auto rows_of = [&](const float *base, int count) {
+        std::vector<const float *> r((size_t)count * 3);
+        for (int k = 0; k < count * 3; k++) r[(size_t)k] = base + (size_t)k * (size_t)n;
+        return r;
+    };
+    std::vector<const float *> rg = rows_of(tg, rlstub::ggx::p_count), rd = rows_of(td, rlstub::disney::p_count),
+                               rs = rows_of(ts, rlstub::skin::p_count);
+    // the scene the test's oracle call uses: two spherical lights, a uniform environment, the unit sphere for the probes
+    rls_sphere_light lights[2] = {{{2.0f, 2.0f, 3.0f}, 1.25f, {3.0f, 2.0f, 1.0f}, RLS_MIS_BOTH},
+                                  {{-3.0f, 1.0f, 2.5f}, 0.5f, {0.5f, 4.0f, 2.0f}, RLS_MIS_BSDF_ONLY}};
+    const float env[3] = {0.7f, 0.8f, 0.9f};
+    rls_sss_scene scene = {};
+    scene.geometry = RLS_SCENE_SPHERE; scene.sphere_radius = 1.0f;
+    scene.light_dir[1] = 0.6f; scene.light_dir[2] = 0.8f;
+    scene.light_color[0] = scene.light_color[1] = scene.light_color[2] = 1.0f;
+    scene.use_cavity_fade = 1;
+    try {
+        rlsb::Device dev(0);
+        rlstub::GgxNode ggx;
+        rlstub::DisneyNode disney;
+        rlstub::SkinNode skin;
+        for (int64_t i = 0; i < n; i++) {
+            rlstub::Globals sg = {};
+            for (int c = 0; c < 3; c++) {
+                sg.Rd[c] = geo[(size_t)c * n + i]; sg.N[c] = geo[(size_t)(3 + c) * n + i];
+                sg.Nf[c] = geo[(size_t)(6 + c) * n + i]; sg.U[c] = geo[(size_t)(9 + c) * n + i];
+                sg.P[c] = geo[(size_t)(12 + c) * n + i];
+            }
+            ggx.addShade(sg, TableEval{rg.data(), n, i});
+            disney.addShade(sg, TableEval{rd.data(), n, i});
+            skin.addShade(sg, TableEval{rs.data(), n, i});
+        }
+        std::vector<float> a = ggx.shade(dev, lights, 2, env, true, 3, 77u), b = disney.shade(dev, lights, 2, env, 3, 77u),
+                           c = skin.shade(dev, scene, lights, 1, env, 3, 77u);
+        if (ggx.size() != 0 || disney.size() != 0 || skin.size() != 0) { std::fprintf(stderr, "shade left points behind\n"); return 1; }
+        std::FILE *f = std::fopen(out, "wb");
+        if (!f) { std::perror(out); return 1; }
+        std::fwrite(a.data(), 4, a.size(), f); std::fwrite(b.data(), 4, b.size(), f); std::fwrite(c.data(), 4, c.size(), f);
+        std::fclose(f);
+        std::printf("{\"n\": %lld, \"ggx_planes\": %zu, \"disney_planes\": %zu, \"skin_planes\": %zu}\n", (long long)n,
+                    a.size() / (size_t)n, b.size() / (size_t)n, c.size() / (size_t)n);
+        return 0;
+    } catch (const rlsb::Error &e) {
+        std::fprintf(stderr, "rlshaders_amd: %s\n", e.what());
+        return e.status == RLS_ERR_NO_DEVICE ? 2 : 1;
+    }
+}
+
 } // namespace
 
 int main(int argc, char **argv)
 {
     if (argc >= 2 && !std::strcmp(argv[1], "decl")) return decl();
     if (argc >= 4 && !std::strcmp(argv[1], "run")) return run(argv[2], argv[3]);
-    std::fprintf(stderr, "usage: test_arnold_stub decl | run <in> <out>\n");
+    if (argc >= 4 && !std::strcmp(argv[1], "shade")) return shade(argv[2], argv[3]);
+    std::fprintf(stderr, "usage: test_arnold_stub decl | run <in> <out> | shade <in> <out>\n");
     return 64;
 }

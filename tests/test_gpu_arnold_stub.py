@@ -85,3 +85,61 @@ def test_three_nodes_through_the_stub(oracle, tmp_path):
         cases.assert_tight(cases.summarize(cases.rel_err(a, ref[k])), ("rlSkin", k))
         row += rows
     assert row == 24
+
+
+@pytest.mark.gpu
+def test_whole_shader_evaluate_through_the_stub(oracle, tmp_path):
+    """`addShade(globals, evaluator)` per shading point and one `shade()` per node: the whole shader_evaluate of rlGgx,
+    rlDisney and rlSkin (rls_ggx_shade, rls_disney_shade, rls_skin_integrate) through the generated stub, against the
+    oracle's shader_evaluate on the same points, lights, environment and sample seeds"""
+    import os
+    from rlshaders_amd import build
+    build.build_library()
+    build.build_host_examples()
+    exe = build.OBJDIR / "test_arnold_stub"
+    n = 2000
+    g = cases.ggx_mixed(cases.SEED_PARITY, n)
+    d = cases.disney_mixed(cases.SEED_PARITY, n)
+    s = cases.skin_mixed(cases.SEED_PARITY, n)
+    wo, N, T = g["wo"], g["N"], g["T"]
+    P = N.copy()                                            # shading points on the unit sphere (the skin scene's surface)
+    geo = np.concatenate([-wo, N, N, T, P])
+    u = lambda j: oracle.gen_uniform(cases.SEED_PARITY, 0, n, oracle.S_PARAM0 + j)
+    shader = dict(KdColor=np.stack([u(0), u(1), u(2)]), Kd=u(3), diffuseRoughness=u(4), Ks=u(5),
+                  KtColor=np.stack([u(6), u(7), u(8)]), Kt=u(9))
+    tg = _table("rlGgx", n, dict(KsColor=g["KsColor"], ior=g["ior"], specularRoughness=g["roughness"],
+                                 anisotropic=g["anisotropic"], **shader))
+    td = _table("rlDisney", n, {k: d[k] for k in ("base_color",) + tuple(oracle.DISNEY_SCALARS)})
+    sp = dict(s["params"], sss_scatter_dist=(s["params"]["sss_scatter_dist"] * np.float32(0.1)).astype(np.float32))
+    ts = _table("rlSkin", n, sp)
+    inp = tmp_path / "in.bin"
+    with open(inp, "wb") as f:
+        np.array([n], np.float32).tofile(f)
+        for a in (geo, tg, td, ts):
+            np.ascontiguousarray(a, np.float32).tofile(f)
+    outp = tmp_path / "out.bin"
+    env = dict(os.environ, RLS_INTEGRATE_GROUP="1")         # one lane per point: the reference's summation order
+    p = subprocess.run([str(exe), "shade", str(inp), str(outp)], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr
+    info = json.loads(p.stdout.strip().splitlines()[-1])
+    assert info == {"n": n, "ggx_planes": 18, "disney_planes": 15, "skin_planes": 15}
+    out = np.fromfile(outp, np.float32).reshape(-1, n)
+    og, od, osk = out[:18], out[18:33], out[33:]
+    lights = [oracle.make_light(center=(2.0, 2.0, 3.0), radius=1.25, radiance=(3.0, 2.0, 1.0), mis_mode=0),
+              oracle.make_light(center=(-3.0, 1.0, 2.5), radius=0.5, radiance=(0.5, 4.0, 2.0), mis_mode=2)]
+    envc = (0.7, 0.8, 0.9)
+    ref = ggx_oracle(oracle, g).shade(P, lights, 3, 77, Kd_color=shader["KdColor"], Kd=shader["Kd"],
+                                      Kd_roughness=shader["diffuseRoughness"], Ks=shader["Ks"], Kt_color=shader["KtColor"],
+                                      Kt=shader["Kt"], env=envc, traced=True)
+    for j, k in enumerate(("direct_diffuse", "direct_specular", "refraction", "indirect_diffuse", "indirect_specular", "out")):
+        cases.assert_tight(cases.summarize(cases.rel_err(og[3 * j:3 * j + 3], ref[k])), ("rlGgx", k))
+    ref = disney_oracle(oracle, d).shade(P, lights, 3, 77, env=envc)
+    for j, k in enumerate(("direct_diffuse", "direct_specular", "indirect_diffuse", "indirect_specular", "out")):
+        cases.assert_tight(cases.summarize(cases.rel_err(od[3 * j:3 * j + 3], ref[k])), ("rlDisney", k))
+    scene = oracle.make_scene(geometry="sphere", sphere_radius=1.0, light_dir=(0.0, 0.6, 0.8), use_cavity_fade=True)
+    ref = oracle.skin_integrate(wo, N, T, sp, P, scene, 3, 77, env=envc, nthreads=4, lights=lights[:1])
+    for j, k in enumerate(("sheen", "specular", "sss", "out")):
+        cases.assert_tight(cases.summarize(cases.rel_err(osk[3 * j:3 * j + 3], ref[k])), ("rlSkin", k))
+    for j, k in enumerate(("sheenFresnel", "specularFresnel", "sssWeight")):
+        cases.assert_tight(cases.summarize(cases.rel_err(osk[12 + j], ref[k])), ("rlSkin", k))
+    assert (ref["sss"] > 0).mean() > 0.2

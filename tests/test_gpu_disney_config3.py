@@ -142,7 +142,7 @@ def test_full_size_config3(gpu, oracle):
 def test_sharded_integrators_draw_the_batch_numbers(gpu, oracle):
     """first_index: two shards of a batch reproduce the unsplit call bit for bit, for every in-kernel-sampling
     entry point (rls_ggx_integrate, rls_ggx_direct_lighting, rls_disney_integrate, rls_disney_direct_lighting,
-    rls_sss_integrate_scatter)."""
+    rls_ggx_shade, rls_disney_shade, rls_sss_integrate_scatter)."""
     n, h, spp_n, seed = 4096, 1500, 4, 31
     cut = lambda a, sl: a[..., sl] if isinstance(a, np.ndarray) else a
     parts = (slice(0, h), slice(h, n))
@@ -175,6 +175,15 @@ def test_sharded_integrators_draw_the_batch_numbers(gpu, oracle):
     run(lambda: [host(t) for t in mkd(slice(0, n)).directLighting(dev(P), lts, spp_n, seed)],
         lambda sl: [host(t) for t in mkd(sl).directLighting(dev(np.ascontiguousarray(P[:, sl])), lts, spp_n, seed,
                                                             first_index=sl.start)])
+    # the whole-node entry points
+    keysd = ("direct_diffuse", "direct_specular", "indirect_diffuse", "indirect_specular", "out")
+    run(lambda: [host(mkd(slice(0, n)).shade(dev(P), lts, spp_n, seed)[k]) for k in keysd],
+        lambda sl: [host(mkd(sl).shade(dev(np.ascontiguousarray(P[:, sl])), lts, spp_n, seed, first_index=sl.start)[k])
+                    for k in keysd])
+    keysg = ("direct_diffuse", "direct_specular", "refraction", "indirect_diffuse", "indirect_specular", "out")
+    run(lambda: [host(mk(slice(0, n)).shade(dev(P), lts, spp_n, seed, Kt=0.5)[k]) for k in keysg],
+        lambda sl: [host(mk(sl).shade(dev(np.ascontiguousarray(P[:, sl])), lts, spp_n, seed, Kt=0.5, first_index=sl.start)[k])
+                    for k in keysg])
     # rlSss integrateScatter on the unit sphere
     dist = np.stack([oracle.gen_uniform(seed, 0, n, 32 + j, 0.02, 0.3) for j in range(3)])
     scene = R.make_scene("sphere", sphere_radius=1.0, light_dir=(0.0, 0.6, 0.8), use_cavity_fade=True)

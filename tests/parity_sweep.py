@@ -62,6 +62,15 @@ def sweep(ctx, n: int, seed: int, spp_n: int = 2, verbose: bool = True) -> dict:
               [hostf(t) for t in g.directLighting(P, lg, spp_n, seed, KdColor=Ks, Kd=kd, diffuseRoughness=kdr, Ks=ks)],
               og.direct_lighting(hostf(P), lt, spp_n, seed, Kd_color=c["KsColor"], Kd=hostf(kd), Kd_roughness=hostf(kdr),
                                  Ks=hostf(ks)))
+        # the whole shader_evaluate of rlGgx under two lights
+        lt2 = [lt, O.make_light(center=(-3.0, 1.0, 2.5), radius=0.5, radiance=(0.5, 4.0, 2.0), mis_mode=2)]
+        lg2 = [R._capi.SphereLight.from_buffer_copy(bytes(l)) for l in lt2]
+        ktc, kt = torch.stack([u(58), u(59), u(60)]), u(61)
+        keys = ("direct_diffuse", "direct_specular", "refraction", "indirect_diffuse", "indirect_specular", "out")
+        gs = g.shade(P, lg2, spp_n, seed, KdColor=Ks, Kd=kd, diffuseRoughness=kdr, Ks=ks, KtColor=ktc, Kt=kt, env=(1.0, 0.9, 0.8))
+        rs = og.shade(hostf(P), lt2, spp_n, seed, Kd_color=c["KsColor"], Kd=hostf(kd), Kd_roughness=hostf(kdr), Ks=hostf(ks),
+                      Kt_color=hostf(ktc), Kt=hostf(kt), env=(1.0, 0.9, 0.8))
+        tally("ggx shader_evaluate", [hostf(gs[k]) for k in keys], [rs[k] for k in keys])
         tally("ggx integrateRefract", [hostf(t) for t in g.integrateRefract(spp_n, seed, want_tir=True)],
               og.integrate_refract(spp_n, seed))
         # --- rlSss integrateScatter on the unit sphere
@@ -93,6 +102,9 @@ def sweep(ctx, n: int, seed: int, spp_n: int = 2, verbose: bool = True) -> dict:
         lgs = [R._capi.SphereLight.from_buffer_copy(bytes(l)) for l in lts]
         tally("disney direct lighting", [hostf(t) for t in d.directLighting(P, lgs, spp_n, seed)],
               od.direct_lighting(hostf(P), lts, spp_n, seed))
+        keys = ("direct_diffuse", "direct_specular", "indirect_diffuse", "indirect_specular", "out")
+        gs, rs = d.shade(P, lgs, spp_n, seed, env=(1.0, 0.9, 0.8)), od.shade(hostf(P), lts, spp_n, seed, env=(1.0, 0.9, 0.8))
+        tally("disney shader_evaluate", [hostf(gs[k]) for k in keys], [rs[k] for k in keys])
     finally:
         del os.environ["RLS_INTEGRATE_GROUP"]
     # --- rlSss probe

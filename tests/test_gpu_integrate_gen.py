@@ -121,6 +121,6 @@ def test_large_parity_sweep(gpu, oracle):
     many seeds: profiles/r02_parity_soak*.json.)"""
     import parity_sweep
     report = parity_sweep.sweep(gpu, 1 << 22, 4242)
-    assert len(report) == 12
+    assert len(report) == 14
     for name, r in report.items():
         assert r["words_differing"] <= 4 and r["beyond_1e5"] == 0, (name, r)

@@ -148,10 +148,16 @@ RLS_DEV void t_sincos(float x, float *s, float *c) { rlm::sincos32_v<false>(x, s
 RLS_DEV void t_sincos_any(float x, float *s, float *c) { rlm::sincos32_v<true>(x, s, c); }
 #ifdef RLS_ATAN_SELECTS   // experiment switch: range constants by selects instead of the LDS table
 RLS_DEV float t_atan2(float y, float x) { return rlm::atan2_32_v(y, x); }
-#else
+#elif defined(RLS_ANGLE_SELECTS)   // experiment switch: the exceptional arguments by selects instead of a branch
 RLS_DEV float t_atan2(float y, float x) { return rlm::atan2_32_t(y, x, s_libm_tables); }
+#else
+RLS_DEV float t_atan2(float y, float x) { return rlm::atan2_32_q(y, x, s_libm_tables); }
 #endif
+#ifdef RLS_ANGLE_SELECTS
 RLS_DEV float t_acos(float x) { return rlm::acos32_v(x); }
+#else
+RLS_DEV float t_acos(float x) { return rlm::acos32_q(x); }
+#endif
 RLS_DEV float t_tan(float x) { return rlm::tan32_v<false>(x); }
 #endif
 

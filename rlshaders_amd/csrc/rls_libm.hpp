@@ -785,6 +785,73 @@ RLM_FN float atan2_32_t(float y, float x, const Tables &tab)
     return res;
 }
 
+// atan2f with the exceptional arguments on a branch of their own.  Of the selects of atan2_32_t / atan32_t seven exist
+// for zeros, infinities, NaNs, subnormals and quotients that are tiny or huge (|y / x| < 2^-29: atanf returns its
+// argument; >= 2^25: pi/2; exponents more than 60 apart: the atan2f shortcuts) -- compares and selects cost 1.5 x an fma
+// each on gfx950 (profiles/r02_valu_rates.txt) and a closure's two atan2f calls never need them.  Both operands normal and
+// their exponent fields no more than 27 below / 23 above each other  =>  2^-28 < |y / x| < 2^24, none of the seven fires,
+// and what remains is the same expressions in the same order.  Anything else takes atan2_32_t (the wave pays for it).
+RLM_FN float atan2_32_q(float y, float x, const Tables &tab)
+{
+    const float pi = u2f(0x40490fdbu), pi_lo = u2f(0xb3bbbd2eu);
+    const float aT0 = u2f(0x3eaaaaabu), aT1 = u2f(0xbe4ccccdu), aT2 = u2f(0x3e124925u), aT3 = u2f(0xbde38e38u),
+                aT4 = u2f(0x3dba2e6eu), aT5 = u2f(0xbd9d8795u), aT6 = u2f(0x3d886b35u), aT7 = u2f(0xbd6ef16bu),
+                aT8 = u2f(0x3d4bda59u), aT9 = u2f(0xbd15a221u), aT10 = u2f(0x3c8569d7u);
+    const int32_t hx = (int32_t)f2u(x), hy = (int32_t)f2u(y);
+    const uint32_t ix = (uint32_t)hx & 0x7fffffffu, iy = (uint32_t)hy & 0x7fffffffu;
+    const int32_t k = ((int32_t)iy - (int32_t)ix) >> 23;
+    if (__builtin_expect(ix - 0x00800000u >= 0x7f000000u || iy - 0x00800000u >= 0x7f000000u || (uint32_t)(k + 27) > 50u, 0))
+        return atan2_32_t(y, x, tab);
+    const float q = fabs32(div32(y, x));                          // 2^-28 < q < 2^24
+    // atan32_t(q) for such q: positive, neither tiny nor huge
+    const uint32_t iq = f2u(q);
+    const bool r0 = iq < 0x3ee00000u;                             // q < 7/16: no reduction
+    const int id = (iq >= 0x3f300000u) + (iq >= 0x3f980000u) + (iq >= 0x401c0000u);
+    const float *c = tab.atan_k[id];
+    const float A = c[0], B = c[1], C = c[2], D = c[3], hi = c[4], lo = c[5];
+    const float num = r0 ? q : A * q + B;
+    const float den = r0 ? 1.0f : C * q + D;
+    const float t = div32_m(num, den);
+    const float zz = t * t;
+    const float w = zz * zz;
+    const float s1 = zz * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    const float ts = t * (s1 + s2);
+    const float z = r0 ? t - ts : hi - ((ts - lo) - t);
+    // the quadrant, as atan2_32_t
+    const float zl = z - pi_lo;
+    return hx < 0 ? (hy < 0 ? zl - pi : pi - zl) : (hy < 0 ? -z : z);
+}
+
+// acosf with |x| < 2^-57, |x| >= 1 and NaN on a branch of their own (acos32): the three trailing selects of acos32_v
+// and the division that makes its NaN go away; the rest is acos32_v
+RLM_FN float acos32_q(float x)
+{
+    const float pi = u2f(0x40490fdau), pio2_hi = u2f(0x3fc90fdau), pio2_lo = u2f(0x33a22168u);
+    const float pS0 = u2f(0x3e2aaaabu), pS1 = u2f(0xbea6b090u), pS2 = u2f(0x3e4e0aa8u), pS3 = u2f(0xbd241146u),
+                pS4 = u2f(0x3a4f7f04u), pS5 = u2f(0x3811ef08u);
+    const float qS1 = u2f(0xc019d139u), qS2 = u2f(0x4001572du), qS3 = u2f(0xbf303361u), qS4 = u2f(0x3d9dc62eu);
+    const int32_t hx = (int32_t)f2u(x);
+    const uint32_t ix = (uint32_t)hx & 0x7fffffffu;
+    if (__builtin_expect(ix - 0x23000001u >= 0x3f800000u - 0x23000001u, 0)) return acos32(x);
+    const bool mid = ix < 0x3f000000u;                            // |x| < 0.5
+    const bool neg = hx < 0;
+    const float z = mid ? x * x : (neg ? (1.0f + x) * 0.5f : (1.0f - x) * 0.5f);
+    const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const float r = div32_m(p, q);              // q in [0.3, 1.1] for z in [0, 1/2]
+    float res = pio2_hi - (x - (pio2_lo - x * r));
+    if (!mid) {
+        const float s = sqrt32<false>(z);         // z = (1 -+ x) / 2 >= 2^-26 here
+        const float df = u2f(f2u(s) & 0xfffff000u);
+        const float c = div32_m(z - df * df, s + df);   // s + df >= 2^-12
+        const float r_pos = 2.0f * (df + (r * s + c));
+        const float r_neg = pi - 2.0f * (s + (r * s - pio2_lo));
+        res = neg ? r_neg : r_pos;
+    }
+    return res;
+}
+
 // acosf for |x| <= 1 (|x| > 1 gives NaN through the sqrt of a negative number)
 RLM_FN float acos32_v(float x)
 {

@@ -55,15 +55,15 @@ int main(int argc, char **argv)
         a_atan.add(rlm::atan32(t), atanf(t)); v_atan.add(rlm::atan32_v(t), atanf(t));
         // atan2f: components of unit-ish vectors, plus scaled pairs
         float y = 2.0f * u01() - 1.0f, x = 2.0f * u01() - 1.0f;
-        a_atan2.add(rlm::atan2_32(y, x), atan2f(y, x)); v_atan2.add(rlm::atan2_32_v(y, x), atan2f(y, x)); v_atan2.add(rlm::atan2_32_t(y, x, tab), atan2f(y, x));
+        a_atan2.add(rlm::atan2_32(y, x), atan2f(y, x)); v_atan2.add(rlm::atan2_32_v(y, x), atan2f(y, x)); v_atan2.add(rlm::atan2_32_t(y, x, tab), atan2f(y, x)); v_atan2.add(rlm::atan2_32_q(y, x, tab), atan2f(y, x));
         float sc = exp2f(20.0f * u01() - 18.0f);
-        a_atan2.add(rlm::atan2_32(y * sc, x), atan2f(y * sc, x)); v_atan2.add(rlm::atan2_32_v(y * sc, x), atan2f(y * sc, x));
-        a_atan2.add(rlm::atan2_32(y, x * sc), atan2f(y, x * sc)); v_atan2.add(rlm::atan2_32_v(y, x * sc), atan2f(y, x * sc));
+        a_atan2.add(rlm::atan2_32(y * sc, x), atan2f(y * sc, x)); v_atan2.add(rlm::atan2_32_v(y * sc, x), atan2f(y * sc, x)); v_atan2.add(rlm::atan2_32_q(y * sc, x, tab), atan2f(y * sc, x));
+        a_atan2.add(rlm::atan2_32(y, x * sc), atan2f(y, x * sc)); v_atan2.add(rlm::atan2_32_v(y, x * sc), atan2f(y, x * sc)); v_atan2.add(rlm::atan2_32_q(y, x * sc, tab), atan2f(y, x * sc));
         // acosf on [-1, 1], dense near 1
         float c = 2.0f * u01() - 1.0f;
-        a_acos.add(rlm::acos32(c), acosf(c)); v_acos.add(rlm::acos32_v(c), acosf(c));
+        a_acos.add(rlm::acos32(c), acosf(c)); v_acos.add(rlm::acos32_v(c), acosf(c)); v_acos.add(rlm::acos32_q(c), acosf(c));
         float c1 = 1.0f - exp2f(-24.0f * u01());
-        a_acos.add(rlm::acos32(c1), acosf(c1)); v_acos.add(rlm::acos32_v(c1), acosf(c1));
+        a_acos.add(rlm::acos32(c1), acosf(c1)); v_acos.add(rlm::acos32_v(c1), acosf(c1)); v_acos.add(rlm::acos32_q(c1), acosf(c1));
         // tanf on [0, 3pi/4), dense near pi/2 and 0
         float th = 2.3561f * u01();
         a_tan.add(rlm::tan32(th), tanf(th)); v_tan.add(rlm::tan32_v(th), tanf(th));
@@ -94,11 +94,11 @@ int main(int argc, char **argv)
                          1.5707964f, 3.1415927f, 0.75f, 0.7853981f, 1e-30f, -1e-30f, 0x1p-13f, 0x1p-12f };
     for (float v : sp) {
         a_atan.add(rlm::atan32(v), atanf(v)); v_atan.add(rlm::atan32_v(v), atanf(v));
-        if (v >= -1.0f && v <= 1.0f) { a_acos.add(rlm::acos32(v), acosf(v)); v_acos.add(rlm::acos32_v(v), acosf(v)); }
+        if (v >= -1.0f && v <= 1.0f) { a_acos.add(rlm::acos32(v), acosf(v)); v_acos.add(rlm::acos32_v(v), acosf(v)); v_acos.add(rlm::acos32_q(v), acosf(v)); }
         if (v >= 0.0f && v < 2.35f) { a_tan.add(rlm::tan32(v), tanf(v)); v_tan.add(rlm::tan32_v(v), tanf(v)); }
         float s, co; rlm::sincos32(v, &s, &co); a_sin.add(s, sinf(v)); a_cos.add(co, cosf(v));
         rlm::sincos32_v(v, &s, &co); v_sin.add(s, sinf(v)); v_cos.add(co, cosf(v));
-        for (float w : sp) { a_atan2.add(rlm::atan2_32(v, w), atan2f(v, w)); v_atan2.add(rlm::atan2_32_v(v, w), atan2f(v, w)); }
+        for (float w : sp) { a_atan2.add(rlm::atan2_32(v, w), atan2f(v, w)); v_atan2.add(rlm::atan2_32_v(v, w), atan2f(v, w)); v_atan2.add(rlm::atan2_32_q(v, w, tab), atan2f(v, w)); }
     }
     const float spv[] = { 0.0f, -0.0f, 1.0f, 0.5f, 2.0f, 1e-40f, 1e-38f, 88.0f, -103.0f, -104.5f, 89.0f, 3.4e38f };
     for (float v : spv) {

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(rlsh::kBlock) void alt_kernel(AltIO a)
 #else
             case RLS_FN_ATAN2: r = t_atan2(x, y); break;
             case RLS_FN_ACOS: r = t_acos(x); break;
-            case RLS_FN_TAN: r = rlm::tan32_v<true>(x); break;
+            case RLS_FN_TAN: r = rlm::tan32_q<true>(x); break;
             case RLS_FN_SIN: rlm::sincos32_v<true>(x, &r, &unused); break;
             case RLS_FN_COS: rlm::sincos32_v<true>(x, &unused, &r); break;
             case RLS_FN_TAN_BOUNDED: r = t_tan(x); break;

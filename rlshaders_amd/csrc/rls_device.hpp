@@ -158,7 +158,11 @@ RLS_DEV float t_acos(float x) { return rlm::acos32_v(x); }
 #else
 RLS_DEV float t_acos(float x) { return rlm::acos32_q(x); }
 #endif
+#ifdef RLS_ANGLE_SELECTS
 RLS_DEV float t_tan(float x) { return rlm::tan32_v<false>(x); }
+#else
+RLS_DEV float t_tan(float x) { return rlm::tan32_q<false>(x); }
+#endif
 #endif
 
 

@@ -1004,4 +1004,59 @@ RLM_FN float tan32_v(float xin)
     return res;
 }
 
+// tanf with its two tiny-argument exits on a branch of their own (tan32_v): a reduced argument below 2^-13 (x within
+// 2^-13 of a multiple of pi/2; +0 itself excepted: the arithmetic below returns +0 for it, and the closures do pass +0)
+// and a reflected argument below 2^-13 (x within 2^-13 of an odd multiple of pi/4).  The rest is tan32_v, same expressions in the same order.
+template <bool FULL = true>
+RLM_FN float tan32_q(float xin)
+{
+    const float pio4 = u2f(0x3f490fdau), pio4lo = u2f(0x33222168u);
+    const float T0 = u2f(0x3eaaaaabu), T1 = u2f(0x3e088889u), T2 = u2f(0x3d5d0dd1u), T3 = u2f(0x3cb327a4u),
+                T4 = u2f(0x3c11371fu), T5 = u2f(0x3b6b6916u), T6 = u2f(0x3abede48u), T7 = u2f(0x3a1a26c8u),
+                T8 = u2f(0x398137b9u), T9 = u2f(0x38a3f445u), T10 = u2f(0x3895c07au), T11 = u2f(0xb79bae5fu),
+                T12 = u2f(0x37d95384u);
+    int n;
+    bool lneg;
+    double dx = reduce_pio2<FULL, false>(xin, &n, &lneg);
+    if (lneg) { dx = -dx; n = -n; }
+    float x = (float)dx;
+    float y = (float)(dx - (double)x);
+    const uint32_t ixin = f2u(xin) & 0x7fffffffu;
+    const bool direct = ixin <= 0x3f490fdau;
+    x = direct ? xin : x;
+    y = direct ? 0.0f : y;
+    const int iy = direct ? 1 : 1 - ((n & 1) << 1);
+    const float fiy = (float)iy;
+
+    const int32_t hx = (int32_t)f2u(x);
+    const uint32_t ix = (uint32_t)hx & 0x7fffffffu;
+    const bool big = ix >= 0x3f2ca140u;                           // |x| >= 0.6744
+    const float sgn = (float)(1 - ((hx >> 30) & 2));
+    const float xa = hx < 0 ? -x : x;
+    const float ya = hx < 0 ? -y : y;
+    const float xr = (pio4 - xa) + (pio4lo - ya);                 // the reflected argument of the big case
+    // (the tiny test is on the REDUCED argument, as in tan32_v; xin = +0 is the one tiny argument the arithmetic below
+    // gets right: direct, iy = 1, w = +0)
+    if (__builtin_expect((ix < 0x39000000u && f2u(xin) != 0u) || (big && fabs32(xr) < 0x1p-13f), 0))
+        return tan32_v<FULL>(xin);
+    x = big ? xr : x;
+    y = big ? 0.0f : y;
+    const float z = x * x;
+    float w = z * z;
+    float r = T1 + w * (T3 + w * (T5 + w * (T7 + w * (T9 + w * T11))));
+    const float v = z * (T2 + w * (T4 + w * (T6 + w * (T8 + w * (T10 + w * T12)))));
+    const float s = z * x;
+    r = y + z * (s * (r + v) + y);
+    r += T0 * s;
+    w = x + r;
+    const float q = div32_m(big ? w * w : -1.0f, big ? w + fiy : w);
+    const float r_big = sgn * (fiy - 2.0f * (x - (q - r)));
+    const float zt = u2f(f2u(w) & 0xfffff000u);
+    const float vt = r - (zt - x);
+    const float t = u2f(f2u(q) & 0xfffff000u);
+    const float st = 1.0f + t * zt;
+    const float r_cot = t + q * (st + t * vt);
+    return big ? r_big : (iy == 1 ? w : r_cot);
+}
+
 } // namespace rlm

@@ -66,11 +66,11 @@ int main(int argc, char **argv)
         a_acos.add(rlm::acos32(c1), acosf(c1)); v_acos.add(rlm::acos32_v(c1), acosf(c1)); v_acos.add(rlm::acos32_q(c1), acosf(c1));
         // tanf on [0, 3pi/4), dense near pi/2 and 0
         float th = 2.3561f * u01();
-        a_tan.add(rlm::tan32(th), tanf(th)); v_tan.add(rlm::tan32_v(th), tanf(th));
+        a_tan.add(rlm::tan32(th), tanf(th)); v_tan.add(rlm::tan32_v(th), tanf(th)); v_tan.add(rlm::tan32_q(th), tanf(th));
         float th2 = 1.5707964f - exp2f(-22.0f * u01());
-        a_tan.add(rlm::tan32(th2), tanf(th2)); v_tan.add(rlm::tan32_v(th2), tanf(th2));
+        a_tan.add(rlm::tan32(th2), tanf(th2)); v_tan.add(rlm::tan32_v(th2), tanf(th2)); v_tan.add(rlm::tan32_q(th2), tanf(th2));
         float th3 = exp2f(-20.0f * u01());
-        a_tan.add(rlm::tan32(th3), tanf(th3)); v_tan.add(rlm::tan32_v(th3), tanf(th3));
+        a_tan.add(rlm::tan32(th3), tanf(th3)); v_tan.add(rlm::tan32_v(th3), tanf(th3)); v_tan.add(rlm::tan32_q(th3), tanf(th3));
         // sinf / cosf on [-2pi, 2pi] and up to +-100
         float p = 12.566371f * u01() - 6.2831855f;
         float s, co;
@@ -95,7 +95,7 @@ int main(int argc, char **argv)
     for (float v : sp) {
         a_atan.add(rlm::atan32(v), atanf(v)); v_atan.add(rlm::atan32_v(v), atanf(v));
         if (v >= -1.0f && v <= 1.0f) { a_acos.add(rlm::acos32(v), acosf(v)); v_acos.add(rlm::acos32_v(v), acosf(v)); v_acos.add(rlm::acos32_q(v), acosf(v)); }
-        if (v >= 0.0f && v < 2.35f) { a_tan.add(rlm::tan32(v), tanf(v)); v_tan.add(rlm::tan32_v(v), tanf(v)); }
+        if (v >= 0.0f && v < 2.35f) { a_tan.add(rlm::tan32(v), tanf(v)); v_tan.add(rlm::tan32_v(v), tanf(v)); v_tan.add(rlm::tan32_q(v), tanf(v)); }
         float s, co; rlm::sincos32(v, &s, &co); a_sin.add(s, sinf(v)); a_cos.add(co, cosf(v));
         rlm::sincos32_v(v, &s, &co); v_sin.add(s, sinf(v)); v_cos.add(co, cosf(v));
         for (float w : sp) { a_atan2.add(rlm::atan2_32(v, w), atan2f(v, w)); v_atan2.add(rlm::atan2_32_v(v, w), atan2f(v, w)); v_atan2.add(rlm::atan2_32_q(v, w, tab), atan2f(v, w)); }

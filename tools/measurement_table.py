@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Print the measurement table of DESIGN.md section 5 from profiles/<tag>_*: one row per workload, nothing typed by hand.
+usage: tools/measurement_table.py [tag]"""
+import json
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+ROWS = (("ggx_reflect_refract", "2"), ("sss_probe", "4 (kernel; 2²⁸ points over 8 GPUs)"), ("skin", "5 (kernel; 2³⁰ points over 8 GPUs)"),
+        ("disney_integrate", "3, mode R (reduced)"), ("disney_stream", "3, mode S (streamed, 64 chunks of 2²⁰ points)"),
+        ("skin_integrate", "— (rlSkin `shader_evaluate`, 16 samples per layer, no lights)"),
+        ("ggx_shade", "— (rlGgx `shader_evaluate`, whole: two lights × 48 + 3 × 16 samples per point)"),
+        ("disney_shade", "— (rlDisney `shader_evaluate`, whole: two lights × 48 + 2 × 16 samples per point)"),
+        ("disney_direct", "— (rlDisney light loop, two lights × 48 samples per point)"),
+        ("ggx_direct", "— (rlGgx light loop, one light, 48 samples per point)"),
+        ("sss_scatter", "— (`integrateScatter`, 16 probe rays per point)"))
+
+
+def load(w, kind):
+    p = ROOT / "profiles" / f"{TAG}_{w}_{kind}.json"
+    return json.loads(p.read_text()) if p.exists() else None
+
+
+def thousands(x):
+    return f"{x:,.0f}".replace(",", " ")
+
+
+print("| workload (`bench.py --workload`) | BASELINE config | time per pass (rocprofv3 average) | throughput | roofline | HBM traffic ÷ algorithmic | VALU instr. per point | CPU baseline (oracle, all host threads) |")
+print("|---|---|---|---|---|---|---|---|")
+for w, cfg in ROWS:
+    b, f, t, tr = load(w, "bench"), load(w, "flops"), load(w, "traffic"), load(w, "bench_trace")
+    if b is None:
+        continue
+    r = b["roofline"]
+    prof = tr["roofline"]["kernel_ms"] if tr else None
+    ms = b["ms_per_step"]
+    lp = r.get("launches_per_step", 1)
+    tm = f"{ms:.3f} ms" if ms < 20 else f"{ms:.1f} ms"
+    if lp > 1:
+        tm += f" = {lp} × {r['kernel_ms']:.3f} ms"
+    if r["bound"] == "hbm":
+        roof = f"{r['frac']:.3f} of 8 TB/s ({r['achieved'] / 1000:.2f} TB/s on {r['algorithmic_bytes_per_point']} B/point)"
+    else:
+        roof = f"VALU: {r['achieved']:.1f} of {r['peak']} TFLOP/s = {r['frac']:.2f} ({thousands(r['flops_per_point'])} executed flops per point)"
+    ratio = f"{t['ratio_to_algorithmic']:.3f}" if t else "—"
+    valu = thousands(f["instructions_per_point"]["SQ_INSTS_VALU"]) if f else "—"
+    unit = b["unit"]
+    print(f"| `{w}` | {cfg} | {tm}" + (f" ({prof:.3f})" if prof and lp == 1 else "") + f" | {b['value']:.1f} {unit} | {roof} | {ratio} | {valu} | "
+          f"{b['cpu_baseline']['value']:.3f} ({b['cpu_baseline']['cores']} threads) |")
+for name, label in (("ggx_reflect_bench_only", "`ggx_reflect` | — (reflect triple only)"), ("bench_fast", "`ggx_reflect_refract --math fast` | 2, FAST arithmetic")):
+    p = ROOT / "profiles" / f"{TAG}_{name}.json"
+    if p.exists():
+        b = json.loads(p.read_text()); r = b["roofline"]
+        print(f"| {label} | {b['ms_per_step']:.3f} ms | {b['value']:.1f} {b['unit']} | {r['frac']:.3f} of 8 TB/s | — | — | " +
+              (f"{b['cpu_baseline']['value']:.3f}" if b.get("cpu_baseline") else "—") + " |")

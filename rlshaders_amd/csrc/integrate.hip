@@ -37,13 +37,9 @@ namespace {
 
 constexpr int kMaxSpp = 256;   // spp_n <= 16
 
-// samples per pass of the loops that pack their samplers' rare branches (rls_device.hpp, slow_requests).  Measured on
-// rlDisney 64 spp: 1 (the plain loop) 90.2 ms, 2: 82.2 ms, 4: 104.1 ms, 8: 109.4 ms -- the unrolled block keeps every
-// sample's slopes and requests in registers, and beyond two samples that spills (13 / 42 / 94 registers).  The light
-// loop and the whole-node kernel hold more state per point and lose with blocks of two already (+20 %): they keep the
-// plain loop
+// samples per pass of the loops that pack their samplers' rare branches (SlowLds below)
 #ifndef RLS_SPEC_BLOCK
-#define RLS_SPEC_BLOCK 2
+#define RLS_SPEC_BLOCK 4
 #endif
 
 // hash stream ids of the per-point scrambles (DESIGN.md "Synthetic inputs": streams 64..67)
@@ -77,6 +73,103 @@ __device__ __forceinline__ float group_sum(float v)
 #pragma unroll
     for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Packed evaluation of the samplers' rare branches through LDS (rls_device.hpp, slow_eval, says which and why): the loop
+// takes K samples per pass; in a first sweep every lane runs the common part of each sample and queues what needs the
+// rare branch (per wavefront, in LDS), the queue is evaluated 64 requests at a time, and a second sweep picks the
+// results up and finishes the samples in order.  Both sweeps are rolled loops -- the K samples' state lives in LDS, not
+// in registers -- so the code and the register count stay those of the plain loop.
+template <int K>
+struct SlowLds {
+    float q[rlsh::kBlock / 64][3][K * 64];      // per wavefront: requests (p, q, t), overwritten by results (x, y, z)
+    float st[3][K][rlsh::kBlock];               // per lane and sample: two values of the caller's + flags | slot << 2
+};
+
+__device__ __forceinline__ void wave_lds_fence()   // LDS traffic between the lanes of ONE wavefront: order it, no s_barrier
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// first sweep, sample k: every lane of the wavefront calls this (ballot); flags: the caller's two low bits
+template <int K>
+__device__ __forceinline__ void slow_push(SlowLds<K> &L, int k, int &cnt, bool want, float p, float q, float t,
+                                          float u, float v, int flags)
+{
+    const int tid = (int)threadIdx.x, wave = tid >> 6;
+    const uint64_t m = __builtin_amdgcn_ballot_w64(want);
+    const int slot = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (want) { L.q[wave][0][slot] = p; L.q[wave][1][slot] = q; L.q[wave][2][slot] = t; }
+    L.st[0][k][tid] = u; L.st[1][k][tid] = v;
+    L.st[2][k][tid] = __int_as_float((flags & 1) | (want ? 2 : 0) | (slot << 2));
+    cnt += __builtin_popcountll(m);
+}
+template <int K>
+__device__ __forceinline__ void slow_run(SlowLds<K> &L, int cnt)
+{
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    wave_lds_fence();
+    for (int base = 0; base < cnt; base += 64) {
+        const int j = base + lane;
+        if (j < cnt) {
+            const SlowOut o = slow_eval(L.q[wave][0][j], L.q[wave][1][j], L.q[wave][2][j]);
+            L.q[wave][0][j] = o.x; L.q[wave][1][j] = o.y; L.q[wave][2][j] = o.z;
+        }
+    }
+    wave_lds_fence();
+}
+// second sweep, sample k: the caller's two values, its flag, whether a result was asked for, and the result
+template <int K>
+__device__ __forceinline__ bool slow_pop(const SlowLds<K> &L, int k, float &u, float &v, int &flag, SlowOut &o)
+{
+    const int tid = (int)threadIdx.x, wave = tid >> 6;
+    u = L.st[0][k][tid]; v = L.st[1][k][tid];
+    const int f = __float_as_int(L.st[2][k][tid]);
+    flag = f & 1;
+    const bool want = (f & 2) != 0;
+    o.x = 0.0f; o.y = 0.0f; o.z = 0.0f;
+    if (want) { const int slot = f >> 2; o.x = L.q[wave][0][slot]; o.y = L.q[wave][1][slot]; o.z = L.q[wave][2][slot]; }
+    return want;
+}
+
+// sampleSpecularDirection (src/rlDisney.cpp:367-390) in two halves around the packed evaluation.  First half: the lobe
+// pick, the closed-form slopes, the request.  Second half: the microfacet normal from whichever source, the reflection.
+// Together they return what disney_sample_specular(d, w, rx, ry) returns.
+template <int K>
+__device__ __forceinline__ void disney_spec_push(SlowLds<K> &L, int k, int &cnt, bool ok, const Disney &d, const VndfView &w,
+                                                 float rx, float ry)
+{
+    const bool gtr2 = rx < d.gtr2Weight;
+    const float rxp = R_DIV(gtr2 ? rx : rx - d.gtr2Weight, gtr2 ? d.gtr2Weight : 1.0f - d.gtr2Weight);
+    V2 slope;
+    const bool needU = vndf_slope_closed(w, rxp, ry, slope);                 // every lane; used where gtr2
+    slow_push<K>(L, k, cnt, ok && (!gtr2 || needU), gtr2 ? ry : rxp, gtr2 ? rxp : ry, gtr2 ? -1.0f : sqr(d.roughness),
+                 slope.x, slope.y, gtr2 ? 1 : 0);
+}
+template <int K>
+__device__ __forceinline__ V3 disney_spec_pop(const SlowLds<K> &L, int k, const Disney &d, const VndfView &w)
+{
+    V2 slope;
+    int gtr2;
+    SlowOut o;
+    const bool got = slow_pop<K>(L, k, slope.x, slope.y, gtr2, o);
+    if (gtr2 && got) { slope.x = o.x; slope.y = o.y; }
+    V3 M;
+#if RLS_FAST
+    if (gtr2) M = vndf_from_slope(w, d.fr, slope);
+    else M = normalize(to_frame(mk(o.x, o.y, o.z), d.fr.U, d.fr.V, d.fr.N));
+#else
+    // normalize_h is normalize in EXACT arithmetic: one rotation + normalisation for both sources of omega
+    V3 omega;
+    omega.x = gtr2 ? -(w.cosPhi * slope.x - w.sinPhi * slope.y) * w.ax : o.x;
+    omega.y = gtr2 ? -(w.sinPhi * slope.x + w.cosPhi * slope.y) * w.ay : o.y;
+    omega.z = gtr2 ? 1.0f : o.z;
+    M = normalize(to_frame(omega, d.fr.U, d.fr.V, d.fr.N));
+#endif
+    return dot(d.fr.N, M) < 0.0f ? mk(0.0f, 0.0f, 0.0f) : reflect_direction(d.view, M);
 }
 
 // integrateGlossy's sample loop over one closure (src/rlGgx.h:172-179 -> AiBRDFIntegrate over the triple): lane `sub`
@@ -211,7 +304,9 @@ __global__ RLS_INT_ATTR void ggx_integrate_kernel(GgxIntIO a)
 template <int G, int FAST_MATH = RLS_FAST>
 __global__ RLS_INT_ATTR void disney_integrate_kernel(DisneyIntIO a)
 {
+    constexpr int K = RLS_SPEC_BLOCK;
     __shared__ uint32_t tab[2][kMaxSpp];
+    __shared__ SlowLds<K> slow;
     stage_libm_tables();   // powf / logf tables -> LDS (EXACT mode)
     stage_table(tab, a.spp);
     const int sub = threadIdx.x % G;
@@ -242,42 +337,43 @@ __global__ RLS_INT_ATTR void disney_integrate_kernel(DisneyIntIO a)
         float dR = 0.0f, dG = 0.0f, dB = 0.0f, dC = 0.0f;
         float sR = 0.0f, sG = 0.0f, sB = 0.0f, sC = 0.0f;
         // K samples per pass: the specular lobe's rare branches (clearcoat half vector, uniform-slope fallback) of the K
-        // samples are evaluated packed (rls_device.hpp, slow_requests); each lobe's sums still grow in sample order
-        constexpr int K = RLS_SPEC_BLOCK;
+        // samples are evaluated packed (slow_push / slow_run / slow_pop above); each lobe's sums still grow in sample order
         for (int s0 = sub; s0 - sub < a.spp; s0 += K * G) {      // the same trip count in every lane
-            float srx[K], sry[K];
-            bool ok[K];
-#pragma unroll
+            int cnt = 0;
+#pragma unroll 1
             for (int k = 0; k < K; k++) {
                 const int s = s0 + k * G;
-                ok[k] = s < a.spp;
-                const int sc = ok[k] ? s : 0;
-                srx[k] = bits_u01(tab[0][sc] ^ sx); sry[k] = bits_u01(tab[1][sc] ^ sy);
-                if (!ok[k]) continue;
-                // diffuse lobe (setSampleType(AI_RAY_DIFFUSE), src/rlDisney.cpp:242)
-                float rx = bits_u01(tab[0][s] ^ dx), ry = bits_u01(tab[1][s] ^ dy);
-                V3 L = cosine_hemisphere(d.fr, rx, ry);
-                float r, g, b, pdf;
-                disney_eval_pdf<true, true, true>(d, L, r, g, b, pdf);
-                if (pdf > kEps) { dR += r / pdf; dG += g / pdf; dB += b / pdf; dC += 1.0f; }
-                if (a.streamed && live) {
-                    int64_t o = (int64_t)s * a.n + i;
-                    st3(a.st.wi, o, L); strgb(a.st.f, o, r, g, b); stg(a.st.pdf, o, pdf);
-                }
+                const bool ok = s < a.spp;
+                const int sc = ok ? s : 0;
+                disney_spec_push<K>(slow, k, cnt, ok, d, w, bits_u01(tab[0][sc] ^ sx), bits_u01(tab[1][sc] ^ sy));
             }
-            // specular lobe (setSampleType(AI_RAY_GLOSSY), src/rlDisney.cpp:281,289)
-            V3 Ls[K];
-            disney_sample_specular_block<K>(d, w, srx, sry, ok, Ls);
-#pragma unroll
+            slow_run<K>(slow, cnt);
+#pragma unroll 1
             for (int k = 0; k < K; k++) {
-                if (!ok[k]) continue;
                 const int s = s0 + k * G;
-                float r, g, b, pdf;
-                disney_eval_pdf<false, true, true>(d, Ls[k], r, g, b, pdf);
-                if (pdf > kEps) { sR += r / pdf; sG += g / pdf; sB += b / pdf; sC += 1.0f; }   // :309
-                if (a.streamed && live) {
-                    int64_t o = ((int64_t)a.spp + s) * a.n + i;
-                    st3(a.st.wi, o, Ls[k]); strgb(a.st.f, o, r, g, b); stg(a.st.pdf, o, pdf);
+                if (s >= a.spp) continue;
+                // diffuse lobe (setSampleType(AI_RAY_DIFFUSE), src/rlDisney.cpp:242)
+                {
+                    float rx = bits_u01(tab[0][s] ^ dx), ry = bits_u01(tab[1][s] ^ dy);
+                    V3 L = cosine_hemisphere(d.fr, rx, ry);
+                    float r, g, b, pdf;
+                    disney_eval_pdf<true, true, true>(d, L, r, g, b, pdf);
+                    if (pdf > kEps) { dR += r / pdf; dG += g / pdf; dB += b / pdf; dC += 1.0f; }
+                    if (a.streamed && live) {
+                        int64_t o = (int64_t)s * a.n + i;
+                        st3(a.st.wi, o, L); strgb(a.st.f, o, r, g, b); stg(a.st.pdf, o, pdf);
+                    }
+                }
+                // specular lobe (setSampleType(AI_RAY_GLOSSY), src/rlDisney.cpp:281,289)
+                {
+                    V3 L = disney_spec_pop<K>(slow, k, d, w);
+                    float r, g, b, pdf;
+                    disney_eval_pdf<false, true, true>(d, L, r, g, b, pdf);
+                    if (pdf > kEps) { sR += r / pdf; sG += g / pdf; sB += b / pdf; sC += 1.0f; }   // :309
+                    if (a.streamed && live) {
+                        int64_t o = ((int64_t)a.spp + s) * a.n + i;
+                        st3(a.st.wi, o, L); strgb(a.st.f, o, r, g, b); stg(a.st.pdf, o, pdf);
+                    }
                 }
             }
         }
@@ -750,8 +846,8 @@ using rlsh::DisneyLightIO;
 
 // The light loop of rlDisney (src/rlDisney.cpp:695-705) for one shading point: oD / oS = the sums over the lights of
 // evalDiffuseLightSample / evalSpecularLightSample, group-reduced.  Light l: sample streams 3 l .. 3 l + 2.
-template <int G, class IO>
-__device__ __forceinline__ void disney_direct_loops(const Disney &d, const VndfView &w, V3 N, V3 P, const IO &io,
+template <int G, int K, class IO>
+__device__ __forceinline__ void disney_direct_loops(SlowLds<K> &slow, const Disney &d, const VndfView &w, V3 N, V3 P, const IO &io,
                                                     const uint32_t (*tab)[kMaxSpp], int spp, int sub, float inv,
                                                     uint32_t seed, uint64_t index, float oD[3], float oS[3])
 {
@@ -765,35 +861,52 @@ __device__ __forceinline__ void disney_direct_loops(const Disney &d, const VndfV
         for (int k = 0; k < 6; k++) scr[k] = hash_u32(seed, index, kScrambleStream + 6 * l + k);
 
         float sR = 0.0f, sG = 0.0f, sB = 0.0f, dR = 0.0f, dG = 0.0f, dB = 0.0f;
-        for (int s = sub; s < spp && cone.valid; s += G) {
-            if (mode != RLS_MIS_BSDF_ONLY) {                     // one light sample, both lobes
-                float rx = bits_u01(tab[0][s] ^ scr[0]), ry = bits_u01(tab[1][s] ^ scr[1]);
-                V3 L = cone_sample(cone, rx, ry);
-                if (dot(L, N) > 0.0f) {
-                    float r, g, b, p;
-                    disney_eval_pdf<true, true, true>(d, L, r, g, b, p);       // evalDiffuseLightSample, :265-269
-                    float wgt = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, p);
-                    dR += R_DIV(r * wgt, cone.pdf); dG += R_DIV(g * wgt, cone.pdf); dB += R_DIV(b * wgt, cone.pdf);
-                    disney_eval_pdf<false, true, true>(d, L, r, g, b, p);      // evalSpecularLightSample, :272-276
-                    wgt = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, p);
-                    sR += R_DIV(r * wgt, cone.pdf); sG += R_DIV(g * wgt, cone.pdf); sB += R_DIV(b * wgt, cone.pdf);
+        for (int s0 = sub; s0 - sub < spp; s0 += K * G) {          // K samples per pass; the same trip count in every lane
+            // first sweep: the specular lobe's BSDF samples, their rare branches queued and evaluated packed
+            if (mode != RLS_MIS_LIGHT_ONLY) {
+                int cnt = 0;
+#pragma unroll 1
+                for (int k = 0; k < K; k++) {
+                    const int s = s0 + k * G;
+                    const int sc = s < spp ? s : 0;
+                    disney_spec_push<K>(slow, k, cnt, s < spp && cone.valid, d, w, bits_u01(tab[0][sc] ^ scr[4]),
+                                        bits_u01(tab[1][sc] ^ scr[5]));
                 }
+                slow_run<K>(slow, cnt);
             }
-            if (mode != RLS_MIS_LIGHT_ONLY) {                    // one BSDF sample per lobe
-                float rx = bits_u01(tab[0][s] ^ scr[2]), ry = bits_u01(tab[1][s] ^ scr[3]);
-                V3 L = cosine_hemisphere(d.fr, rx, ry);
-                float r, g, b, p;
-                disney_eval_pdf<true, true, true>(d, L, r, g, b, p);
-                if (p > kEps && cone_hit(cone, L)) {
-                    float wgt = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(p, cone.pdf);
-                    dR += R_DIV(r * wgt, p); dG += R_DIV(g * wgt, p); dB += R_DIV(b * wgt, p);
+            // second sweep: the samples in order
+#pragma unroll 1
+            for (int k = 0; k < K; k++) {
+                const int s = s0 + k * G;
+                if (!(s < spp && cone.valid)) continue;
+                if (mode != RLS_MIS_BSDF_ONLY) {                     // one light sample, both lobes
+                    float rx = bits_u01(tab[0][s] ^ scr[0]), ry = bits_u01(tab[1][s] ^ scr[1]);
+                    V3 L = cone_sample(cone, rx, ry);
+                    if (dot(L, N) > 0.0f) {
+                        float r, g, b, p;
+                        disney_eval_pdf<true, true, true>(d, L, r, g, b, p);       // evalDiffuseLightSample, :265-269
+                        float wgt = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, p);
+                        dR += R_DIV(r * wgt, cone.pdf); dG += R_DIV(g * wgt, cone.pdf); dB += R_DIV(b * wgt, cone.pdf);
+                        disney_eval_pdf<false, true, true>(d, L, r, g, b, p);      // evalSpecularLightSample, :272-276
+                        wgt = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, p);
+                        sR += R_DIV(r * wgt, cone.pdf); sG += R_DIV(g * wgt, cone.pdf); sB += R_DIV(b * wgt, cone.pdf);
+                    }
                 }
-                rx = bits_u01(tab[0][s] ^ scr[4]); ry = bits_u01(tab[1][s] ^ scr[5]);
-                L = disney_sample_specular(d, w, rx, ry);
-                disney_eval_pdf<false, true, true>(d, L, r, g, b, p);
-                if (p > kEps && cone_hit(cone, L)) {
-                    float wgt = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(p, cone.pdf);
-                    sR += R_DIV(r * wgt, p); sG += R_DIV(g * wgt, p); sB += R_DIV(b * wgt, p);
+                if (mode != RLS_MIS_LIGHT_ONLY) {                    // one BSDF sample per lobe
+                    float rx = bits_u01(tab[0][s] ^ scr[2]), ry = bits_u01(tab[1][s] ^ scr[3]);
+                    V3 L = cosine_hemisphere(d.fr, rx, ry);
+                    float r, g, b, p;
+                    disney_eval_pdf<true, true, true>(d, L, r, g, b, p);
+                    if (p > kEps && cone_hit(cone, L)) {
+                        float wgt = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(p, cone.pdf);
+                        dR += R_DIV(r * wgt, p); dG += R_DIV(g * wgt, p); dB += R_DIV(b * wgt, p);
+                    }
+                    L = disney_spec_pop<K>(slow, k, d, w);
+                    disney_eval_pdf<false, true, true>(d, L, r, g, b, p);
+                    if (p > kEps && cone_hit(cone, L)) {
+                        float wgt = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(p, cone.pdf);
+                        sR += R_DIV(r * wgt, p); sG += R_DIV(g * wgt, p); sB += R_DIV(b * wgt, p);
+                    }
                 }
             }
         }
@@ -815,6 +928,7 @@ template <int G, int FAST_MATH = RLS_FAST>
 __global__ RLS_INT_ATTR void disney_direct_kernel(DisneyLightIO a)
 {
     __shared__ uint32_t tab[2][kMaxSpp];
+    __shared__ SlowLds<RLS_SPEC_BLOCK> slow;
     stage_libm_tables();
     stage_table(tab, a.spp);
     const int sub = threadIdx.x % G;
@@ -829,7 +943,7 @@ __global__ RLS_INT_ATTR void disney_direct_kernel(DisneyLightIO a)
         RLS_DISNEY_LOAD(d, a.c, ii)
         VndfView w = vndf_view(d.view, d.fr, d.ax, d.ay);
         float oD[3], oS[3];
-        disney_direct_loops<G>(d, w, d.fr.N, ld3(a.P, ii), a, tab, a.spp, sub, inv, a.seed,
+        disney_direct_loops<G>(slow, d, w, d.fr.N, ld3(a.P, ii), a, tab, a.spp, sub, inv, a.seed,
                                a.first + (uint64_t)ii, oD, oS);
         if (live && sub == 0) {
             strgb(a.dd, i, oD[0], oD[1], oD[2]);
@@ -935,7 +1049,9 @@ __global__ RLS_INT_ATTR void ggx_shade_kernel(GgxShadeIO a)
 template <int G, int FAST_MATH = RLS_FAST>
 __global__ RLS_INT_ATTR void disney_shade_kernel(DisneyShadeIO a)
 {
+    constexpr int K = RLS_SPEC_BLOCK;
     __shared__ uint32_t tab[2][kMaxSpp];
+    __shared__ SlowLds<K> slow;
     stage_libm_tables();
     stage_table(tab, a.spp);
     const int sub = threadIdx.x % G;
@@ -952,25 +1068,38 @@ __global__ RLS_INT_ATTR void disney_shade_kernel(DisneyShadeIO a)
         VndfView w = vndf_view(d.view, d.fr, d.ax, d.ay);
         // the light loop, src/rlDisney.cpp:695-705
         float dD[3], dS[3];
-        disney_direct_loops<G>(d, w, d.fr.N, ld3(a.P, ii), a, tab, a.spp, sub, inv, a.seed, idx, dD, dS);
+        disney_direct_loops<G>(slow, d, w, d.fr.N, ld3(a.P, ii), a, tab, a.spp, sub, inv, a.seed, idx, dD, dS);
         // integrateDiffuse / integrateGlossy (:718-719, 240-243, 279-283): AiBRDFIntegrate over the triple -> the sum of
         // brdf / pdf over the valid samples (:309) x AiSamplerGetSampleInvCount x env
         uint32_t scr[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) scr[k] = hash_u32(a.seed, idx, kScrambleStream + 2 * kShadeStream + k);
         float iR = 0.0f, iG = 0.0f, iB = 0.0f, gR = 0.0f, gG = 0.0f, gB = 0.0f;
-        for (int s = sub; s < a.spp; s += G) {
-            {
-                V3 L = cosine_hemisphere(d.fr, bits_u01(tab[0][s] ^ scr[0]), bits_u01(tab[1][s] ^ scr[1]));
-                float r, g, b, pdf;
-                disney_eval_pdf<true, true, true>(d, L, r, g, b, pdf);
-                if (pdf > kEps) { iR += r / pdf; iG += g / pdf; iB += b / pdf; }
+        for (int s0 = sub; s0 - sub < a.spp; s0 += K * G) {      // K samples per pass, as disney_integrate_kernel
+            int cnt = 0;
+#pragma unroll 1
+            for (int k = 0; k < K; k++) {
+                const int s = s0 + k * G;
+                const int sc = s < a.spp ? s : 0;
+                disney_spec_push<K>(slow, k, cnt, s < a.spp, d, w, bits_u01(tab[0][sc] ^ scr[2]), bits_u01(tab[1][sc] ^ scr[3]));
             }
-            {
-                V3 L = disney_sample_specular(d, w, bits_u01(tab[0][s] ^ scr[2]), bits_u01(tab[1][s] ^ scr[3]));
-                float r, g, b, pdf;
-                disney_eval_pdf<false, true, true>(d, L, r, g, b, pdf);
-                if (pdf > kEps) { gR += r / pdf; gG += g / pdf; gB += b / pdf; }
+            slow_run<K>(slow, cnt);
+#pragma unroll 1
+            for (int k = 0; k < K; k++) {
+                const int s = s0 + k * G;
+                if (s >= a.spp) continue;
+                {
+                    V3 L = cosine_hemisphere(d.fr, bits_u01(tab[0][s] ^ scr[0]), bits_u01(tab[1][s] ^ scr[1]));
+                    float r, g, b, pdf;
+                    disney_eval_pdf<true, true, true>(d, L, r, g, b, pdf);
+                    if (pdf > kEps) { iR += r / pdf; iG += g / pdf; iB += b / pdf; }
+                }
+                {
+                    V3 L = disney_spec_pop<K>(slow, k, d, w);
+                    float r, g, b, pdf;
+                    disney_eval_pdf<false, true, true>(d, L, r, g, b, pdf);
+                    if (pdf > kEps) { gR += r / pdf; gG += g / pdf; gB += b / pdf; }
+                }
             }
         }
         if (G > 1) {

@@ -900,12 +900,12 @@ RLS_DEV V3 disney_sample_specular(const Disney &d, const VndfView &w, float rx, 
 // n^2-spp loop: the uniform-slope fallback of visible-normal sampling (~7 % of the lanes of a mixed workload) and
 // rlDisney's clearcoat half vector (sampleGTR1Direction: the lanes whose random number falls beyond gtr2Weight).  Both
 // are "a radius from one random number, an azimuth 2 pi x the other": an exact division, one or two exact square roots,
-// an fp64 sincosf -- and powf for the clearcoat lobe.  slow_requests<K> takes the requests of K samples per lane, packs
-// them into the low lanes with ds_permute, evaluates them in ONE pass per 63 requests and hands the results back with
-// ds_bpermute: the same functions on the same arguments, on another lane.  Measured bound (the branches replaced by
-// nothing, profiles/r02_valu_rates.txt): rlDisney 64 spp -15 % (clearcoat) and -6 % (fallback); rlGgx loops -5 %.
-struct SlowReq { bool want; float p, q, t; };      // azimuth number p, radius number q; t = a2 >= 0: clearcoat, t < 0: uniform slope
+// an fp64 sincosf -- and powf for the clearcoat lobe.  slow_eval is that common form; the n^2-spp loops queue the
+// requests of K samples per wavefront in LDS and evaluate them 64 at a time (integrate.hip, SlowLds): the same functions
+// on the same arguments, on another lane.  Measured bound (the branches replaced by nothing,
+// profiles/r02_valu_rates.txt): rlDisney 64 spp -15 % (clearcoat) and -6 % (fallback); rlGgx loops -5 %.
 struct SlowOut { float x, y, z; };
+// azimuth number p, radius number q; t = a2 >= 0: clearcoat half vector, t < 0: uniform slope
 
 RLS_DEV SlowOut slow_eval(float p, float q, float t)
 {
@@ -924,100 +924,6 @@ RLS_DEV SlowOut slow_eval(float p, float q, float t)
     o.x = r * c;
     o.y = r * s;
     return o;
-}
-
-#if !RLS_FAST
-// every lane of the wavefront must be active (the callers check)
-template <int K>
-RLS_DEV void slow_requests(const SlowReq (&r)[K], SlowOut (&out)[K])
-{
-    const int lane = (int)(threadIdx.x & 63u);
-    int off[K + 1], slot[K];
-    off[0] = 0;
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        const uint64_t m = __builtin_amdgcn_ballot_w64(r[k].want);
-        off[k + 1] = off[k] + __builtin_popcountll(m);
-        slot[k] = off[k] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    }
-    const int total = off[K];
-    for (int base = 0; base < total; base += 63) {  // one pass per 63 requests; lane 63 takes what no pass wants
-        float p = 0.0f, q = 0.0f, t = 0.0f;
-        const int j = lane + base;                  // the request this lane evaluates
-#pragma unroll
-        for (int k = 0; k < K; k++) {
-            const bool mine = r[k].want && slot[k] >= base && slot[k] < base + 63;
-            const int dst = (mine ? slot[k] - base : 63) * 4;
-            const int a = __builtin_amdgcn_ds_permute(dst, (int)__float_as_uint(r[k].p));
-            const int b = __builtin_amdgcn_ds_permute(dst, (int)__float_as_uint(r[k].q));
-            const int c = __builtin_amdgcn_ds_permute(dst, (int)__float_as_uint(r[k].t));
-            const bool here = lane < 63 && j >= off[k] && j < off[k + 1];
-            p = here ? __uint_as_float((uint32_t)a) : p;
-            q = here ? __uint_as_float((uint32_t)b) : q;
-            t = here ? __uint_as_float((uint32_t)c) : t;
-        }
-        SlowOut o = { 0.0f, 0.0f, 0.0f };
-        if (lane < 63 && j < total) o = slow_eval(p, q, t);
-#pragma unroll
-        for (int k = 0; k < K; k++) {
-            const bool mine = r[k].want && slot[k] >= base && slot[k] < base + 63;
-            const int src = (mine ? slot[k] - base : 0) * 4;
-            const float x = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)__float_as_uint(o.x)));
-            const float y = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)__float_as_uint(o.y)));
-            const float z = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)__float_as_uint(o.z)));
-            if (mine) { out[k].x = x; out[k].y = y; out[k].z = z; }
-        }
-    }
-}
-#endif
-
-// sampleSpecularDirection (src/rlDisney.cpp:367-390) for K samples of one closure: the closed-form slopes per sample,
-// the clearcoat half vectors and the uniform-slope fallbacks of all K packed (slow_requests).  L[k] for valid[k];
-// the values are those of disney_sample_specular(d, w, rx[k], ry[k]).
-template <int K>
-RLS_DEV void disney_sample_specular_block(const Disney &d, const VndfView &w, const float (&rx)[K], const float (&ry)[K],
-                                          const bool (&valid)[K], V3 (&L)[K])
-{
-#if RLS_FAST
-#pragma unroll
-    for (int k = 0; k < K; k++) L[k] = disney_sample_specular(d, w, rx[k], ry[k]);
-#else
-    if (__builtin_amdgcn_ballot_w64(true) != ~0ull) {
-#pragma unroll
-        for (int k = 0; k < K; k++) L[k] = disney_sample_specular(d, w, rx[k], ry[k]);
-        return;
-    }
-    const float gtr2Weight = d.gtr2Weight;
-    const float a2 = sqr(d.roughness);
-    SlowReq req[K];
-    SlowOut slow[K];
-    V2 slope[K];
-    bool gtr2[K];
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        gtr2[k] = rx[k] < gtr2Weight;
-        const float rxp = R_DIV(gtr2[k] ? rx[k] : rx[k] - gtr2Weight, gtr2[k] ? gtr2Weight : 1.0f - gtr2Weight);
-        const bool needU = vndf_slope_closed(w, rxp, ry[k], slope[k]);      // all lanes; used where gtr2[k]
-        req[k].want = valid[k] && (!gtr2[k] || needU);
-        req[k].p = gtr2[k] ? ry[k] : rxp;
-        req[k].q = gtr2[k] ? rxp : ry[k];
-        req[k].t = gtr2[k] ? -1.0f : a2;
-        slow[k].x = 0.0f; slow[k].y = 0.0f; slow[k].z = 0.0f;
-    }
-    slow_requests<K>(req, slow);
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        V3 M;
-        if (gtr2[k]) {
-            V2 sl = slope[k];
-            if (req[k].want) { sl.x = slow[k].x; sl.y = slow[k].y; }
-            M = vndf_from_slope(w, d.fr, sl);
-        } else {
-            M = normalize(to_frame(mk(slow[k].x, slow[k].y, slow[k].z), d.fr.U, d.fr.V, d.fr.N));
-        }
-        L[k] = dot(d.fr.N, M) < 0.0f ? mk(0.0f, 0.0f, 0.0f) : reflect_direction(d.view, M);
-    }
-#endif
 }
 
 // evalDiffusePdf, src/rlDisney.cpp:515-518

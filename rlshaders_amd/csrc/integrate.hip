@@ -107,13 +107,18 @@ __device__ __forceinline__ void slow_push(SlowLds<K> &L, int k, int &cnt, bool w
     L.st[2][k][tid] = __int_as_float((flags & 1) | (want ? 2 : 0) | (slot << 2));
     cnt += __builtin_popcountll(m);
 }
+// the queue is worked off by the lanes that are active here (rlSkin runs its lobes inside per-point branches): the
+// r-th active lane takes requests r, r + A, ... of the A active lanes
 template <int K>
 __device__ __forceinline__ void slow_run(SlowLds<K> &L, int cnt)
 {
-    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = (int)threadIdx.x, wave = tid >> 6;
+    const uint64_t ex = __builtin_amdgcn_ballot_w64(true);
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ex >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ex, 0u));
+    const int nact = __builtin_popcountll(ex);
     wave_lds_fence();
-    for (int base = 0; base < cnt; base += 64) {
-        const int j = base + lane;
+    for (int base = 0; base < cnt; base += nact) {
+        const int j = base + rank;
         if (j < cnt) {
             const SlowOut o = slow_eval(L.q[wave][0][j], L.q[wave][1][j], L.q[wave][2][j]);
             L.q[wave][0][j] = o.x; L.q[wave][1][j] = o.y; L.q[wave][2][j] = o.z;
@@ -172,25 +177,68 @@ __device__ __forceinline__ V3 disney_spec_pop(const SlowLds<K> &L, int k, const 
     return dot(d.fr.N, M) < 0.0f ? mk(0.0f, 0.0f, 0.0f) : reflect_direction(d.view, M);
 }
 
+// VNDFKernel::evalSample (src/rlGgx.cpp:63-99) in two halves around the packed evaluation: the closed-form slopes and the
+// request for the uniform-slope fallback; then the microfacet normal.  Together: vndf_microfacet(w, fr, rx, ry).
+template <int K>
+__device__ __forceinline__ void ggx_vndf_push(SlowLds<K> &L, int k, int &cnt, bool ok, const VndfView &w, float rx, float ry)
+{
+    V2 slope;
+    const bool needU = vndf_slope_closed(w, rx, ry, slope);
+    slow_push<K>(L, k, cnt, ok && needU, ry, rx, -1.0f, slope.x, slope.y, 1);
+}
+template <int K>
+__device__ __forceinline__ V3 ggx_vndf_pop(const SlowLds<K> &L, int k, const VndfView &w, const Frame &fr)
+{
+    V2 slope;
+    int flag;
+    SlowOut o;
+    if (slow_pop<K>(L, k, slope.x, slope.y, flag, o)) { slope.x = o.x; slope.y = o.y; }
+    return vndf_from_slope(w, fr, slope);
+}
+
 // integrateGlossy's sample loop over one closure (src/rlGgx.h:172-179 -> AiBRDFIntegrate over the triple): lane `sub`
 // of a G-lane group takes samples sub, sub + G, ...; sums of f/pdf and of the Fresnel side effect of evalSample
 // (src/rlGgx.h:103), reduced over the group
-template <int G>
-__device__ __forceinline__ void ggx_glossy_loop(const Ggx &g, const VndfView &w, const uint32_t (*tab)[kMaxSpp], int spp,
-                                                int sub, uint32_t sx, uint32_t sy,
+// PACK = false: the plain loop.  rlSkin runs its two lobes inside per-point branches (src/rlSkin.cpp:191,214): wavefronts
+// arrive here partly active, and the packed form costs more than it saves there (+17 % on the whole kernel, measured)
+template <int G, int K, bool PACK = true>
+__device__ __forceinline__ void ggx_glossy_loop(SlowLds<K> &slow, const Ggx &g, const VndfView &w,
+                                                const uint32_t (*tab)[kMaxSpp], int spp, int sub, uint32_t sx, uint32_t sy,
                                                 float &accR, float &accG, float &accB, float &accF, float f0 = 0.0f)
 {
     // f0: this lane's Fresnel sum of the samples drawn on the closure before (rlSkin's light loops)
     accR = 0.0f; accG = 0.0f; accB = 0.0f; accF = f0;
-    for (int s = sub; s < spp; s += G) {
-        float rx = bits_u01(tab[0][s] ^ sx);
-        float ry = bits_u01(tab[1][s] ^ sy);
-        V3 M = vndf_microfacet(w, g.fr, rx, ry);
-        V3 L = reflect_direction(g.view, M);
-        accF += ggx_fresnel(g, L, M);                   // mReflectWeight, src/rlGgx.h:103
-        float fr, fg, fb, pdf;
-        ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pdf);
-        accR += fr / pdf; accG += fg / pdf; accB += fb / pdf;
+    if (!PACK) {
+        for (int s = sub; s < spp; s += G) {
+            float rx = bits_u01(tab[0][s] ^ sx);
+            float ry = bits_u01(tab[1][s] ^ sy);
+            V3 M = vndf_microfacet(w, g.fr, rx, ry);
+            V3 L = reflect_direction(g.view, M);
+            accF += ggx_fresnel(g, L, M);                   // mReflectWeight, src/rlGgx.h:103
+            float fr, fg, fb, pdf;
+            ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pdf);
+            accR += fr / pdf; accG += fg / pdf; accB += fb / pdf;
+        }
+    }
+    for (int s0 = sub; PACK && s0 - sub < spp; s0 += K * G) {   // K samples per pass (SlowLds)
+        int cnt = 0;
+#pragma unroll 1
+        for (int k = 0; k < K; k++) {
+            const int s = s0 + k * G;
+            const int sc = s < spp ? s : 0;
+            ggx_vndf_push<K>(slow, k, cnt, s < spp, w, bits_u01(tab[0][sc] ^ sx), bits_u01(tab[1][sc] ^ sy));
+        }
+        slow_run<K>(slow, cnt);
+#pragma unroll 1
+        for (int k = 0; k < K; k++) {
+            if (s0 + k * G >= spp) continue;
+            V3 M = ggx_vndf_pop<K>(slow, k, w, g.fr);
+            V3 L = reflect_direction(g.view, M);
+            accF += ggx_fresnel(g, L, M);                   // mReflectWeight, src/rlGgx.h:103
+            float fr, fg, fb, pdf;
+            ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pdf);
+            accR += fr / pdf; accG += fg / pdf; accB += fb / pdf;
+        }
     }
     if (G > 1) {
         accR = group_sum<G>(accR); accG = group_sum<G>(accG);
@@ -229,7 +277,7 @@ __device__ __forceinline__ void ggx_light_loops(const Ggx &g, const VndfView &w,
 #pragma unroll
         for (int k = 0; k < 4; k++) scr[k] = hash_u32(seed, index, kScrambleStream + 2 * (stream + 4 * l) + k);
         float sR = 0.0f, sG = 0.0f, sB = 0.0f;
-        for (int s = sub; s < spp && cone.valid; s += G) {
+        for (int s = sub; s < spp && cone.valid; s += G) {       // the plain loop: see ggx_glossy_loop, PACK = false
             if (mode != RLS_MIS_BSDF_ONLY) {
                 float rx = bits_u01(tab[0][s] ^ scr[0]), ry = bits_u01(tab[1][s] ^ scr[1]);
                 V3 L = cone_sample(cone, rx, ry);
@@ -267,6 +315,7 @@ template <int G, int FAST_MATH = RLS_FAST>
 __global__ RLS_INT_ATTR void ggx_integrate_kernel(GgxIntIO a)
 {
     __shared__ uint32_t tab[2][kMaxSpp];
+    __shared__ SlowLds<RLS_SPEC_BLOCK> slow;
     stage_libm_tables();   // atanf range table (+ expf / logf / powf tables) -> LDS
     stage_table(tab, a.spp);
     const int sub = threadIdx.x % G;
@@ -290,7 +339,7 @@ __global__ RLS_INT_ATTR void ggx_integrate_kernel(GgxIntIO a)
         const uint32_t sy = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream + 1);
 
         float accR, accG, accB, accF;
-        ggx_glossy_loop<G>(g, w, tab, a.spp, sub, sx, sy, accR, accG, accB, accF);
+        ggx_glossy_loop<G>(slow, g, w, tab, a.spp, sub, sx, sy, accR, accG, accB, accF);
         if (live && sub == 0) {
             strgb(a.sum, i, accR, accG, accB);
             // getAvgReflectWeight, src/rlGgx.h:181-184
@@ -541,6 +590,7 @@ template <int G, int FAST_MATH = RLS_FAST>
 __global__ RLS_INT_ATTR void skin_integrate_kernel(SkinIntIO a)
 {
     __shared__ uint32_t tab[2][kMaxSpp];
+    __shared__ SlowLds<1> slow;                   // the lobes run the plain loops here (ggx_glossy_loop, PACK = false)
     stage_libm_tables();
     stage_table(tab, a.spp);
     const SceneRegs sc = scene_regs(a.scene);
@@ -575,7 +625,7 @@ __global__ RLS_INT_ATTR void skin_integrate_kernel(SkinIntIO a)
             float lit[3], lf, lc, aF;
             ggx_light_loops<G>(g, w, N, P, a, tab, a.spp, sub, inv, a.seed, a.first + (uint64_t)ii, 3,
                                lit, lf, lc);                                          // :193-198
-            ggx_glossy_loop<G>(g, w, tab, a.spp, sub, scr[0], scr[1], shR, shG, shB, aF, lf);
+            ggx_glossy_loop<G, 1, false>(slow, g, w, tab, a.spp, sub, scr[0], scr[1], shR, shG, shB, aF, lf);
             // integrateGlossy returns black for a small colour without sampling (src/rlGgx.h:174-176); the light
             // loop samples regardless; getAvgReflectWeight (181-184) = sum / count over both, 1 when none were drawn
             const bool small = absf(cr) < kEps && absf(cg) < kEps && absf(cb) < kEps;
@@ -596,7 +646,7 @@ __global__ RLS_INT_ATTR void skin_integrate_kernel(SkinIntIO a)
             float lit[3], lf, lc, aF;
             ggx_light_loops<G>(g, w, N, P, a, tab, a.spp, sub, inv, a.seed, a.first + (uint64_t)ii, 5,
                                lit, lf, lc);                                          // :217-222
-            ggx_glossy_loop<G>(g, w, tab, a.spp, sub, scr[2], scr[3], spR, spG, spB, aF, lf);
+            ggx_glossy_loop<G, 1, false>(slow, g, w, tab, a.spp, sub, scr[2], scr[3], spR, spG, spB, aF, lf);
             const bool small = absf(cr) < kEps && absf(cg) < kEps && absf(cb) < kEps;
             if (G > 1) { lf = group_sum<G>(lf); lc = group_sum<G>(lc); }
             const float fsum = small ? lf : aF, fcnt = small ? lc : lc + (float)a.spp;
@@ -642,18 +692,29 @@ __global__ RLS_INT_ATTR void skin_integrate_kernel(SkinIntIO a)
 using rlsh::RefractIntIO;
 
 // the traced branch's sample loop (src/rlGgx.h:228-244): mean sample weight and fraction of total internal reflections
-template <int G>
-__device__ __forceinline__ void ggx_refract_loop(const Ggx &g, const VndfView &w, const uint32_t (*tab)[kMaxSpp], int spp,
-                                                 int sub, uint32_t sx, uint32_t sy, float &acc, float &tir)
+template <int G, int K>
+__device__ __forceinline__ void ggx_refract_loop(SlowLds<K> &slow, const Ggx &g, const VndfView &w,
+                                                 const uint32_t (*tab)[kMaxSpp], int spp, int sub, uint32_t sx, uint32_t sy,
+                                                 float &acc, float &tir)
 {
     acc = 0.0f; tir = 0.0f;
-    for (int s = sub; s < spp; s += G) {
-        float rx = bits_u01(tab[0][s] ^ sx);
-        float ry = bits_u01(tab[1][s] ^ sy);
-        V3 M = vndf_microfacet(w, g.fr, rx, ry);
-        V3 dir;
-        if (!ggx_refract(g, M, dir)) tir += 1.0f;
-        acc += ggx_sample_weight(g, g.view, dir, M);                 // :241
+    for (int s0 = sub; s0 - sub < spp; s0 += K * G) {           // K samples per pass (SlowLds)
+        int cnt = 0;
+#pragma unroll 1
+        for (int k = 0; k < K; k++) {
+            const int s = s0 + k * G;
+            const int sc = s < spp ? s : 0;
+            ggx_vndf_push<K>(slow, k, cnt, s < spp, w, bits_u01(tab[0][sc] ^ sx), bits_u01(tab[1][sc] ^ sy));
+        }
+        slow_run<K>(slow, cnt);
+#pragma unroll 1
+        for (int k = 0; k < K; k++) {
+            if (s0 + k * G >= spp) continue;
+            V3 M = ggx_vndf_pop<K>(slow, k, w, g.fr);
+            V3 dir;
+            if (!ggx_refract(g, M, dir)) tir += 1.0f;
+            acc += ggx_sample_weight(g, g.view, dir, M);                 // :241
+        }
     }
     if (G > 1) { acc = group_sum<G>(acc); tir = group_sum<G>(tir); }
     const float inv = 1.0f / (float)spp;                             // AiSamplerGetSampleInvCount, :244
@@ -672,6 +733,7 @@ template <int G, int FAST_MATH = RLS_FAST>
 __global__ RLS_INT_ATTR void ggx_refract_integrate_kernel(RefractIntIO a)
 {
     __shared__ uint32_t tab[2][kMaxSpp];
+    __shared__ SlowLds<RLS_SPEC_BLOCK> slow;
     stage_libm_tables();   // atanf range table (+ expf / logf / powf tables) -> LDS
     stage_table(tab, a.spp);
     const int sub = threadIdx.x % G;
@@ -694,7 +756,7 @@ __global__ RLS_INT_ATTR void ggx_refract_integrate_kernel(RefractIntIO a)
             VndfView w = vndf_view(g.view, g.fr, g.ax, g.ay);
             const uint32_t sx = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream);
             const uint32_t sy = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream + 1);
-            ggx_refract_loop<G>(g, w, tab, a.spp, sub, sx, sy, acc, tir);
+            ggx_refract_loop<G>(slow, g, w, tab, a.spp, sub, sx, sy, acc, tir);
         } else {
             ggx_refract_untraced(g, acc, tir);
         }
@@ -713,8 +775,8 @@ using rlsh::LightIO;
 // The light loop of rlGgx (src/rlGgx.cpp:285-299) for one shading point: per light one AiEvaluateLightSample over the
 // Oren-Nayar closure (when sampleDiffuse) and one over the GGX triple; oD / oS = the sums over the lights, group-reduced,
 // BEFORE `diffuse *= diffuseColor; specular *= specularWeight` (304-305).  Light l: sample streams 3 l .. 3 l + 2.
-template <int G, class IO>
-__device__ __forceinline__ void ggx_direct_loops(const Ggx &g, const VndfView &w, const OrenNayar &on, V3 wo, V3 N, V3 P,
+template <int G, int K, class IO>
+__device__ __forceinline__ void ggx_direct_loops(SlowLds<K> &slow, const Ggx &g, const VndfView &w, const OrenNayar &on, V3 wo, V3 N, V3 P,
                                                  bool sampleDiffuse, const IO &io,
                                                  const uint32_t (*tab)[kMaxSpp], int spp, int sub, float inv,
                                                  uint32_t seed, uint64_t index, float oD[3], float oS[3])
@@ -729,40 +791,55 @@ __device__ __forceinline__ void ggx_direct_loops(const Ggx &g, const VndfView &w
         for (int k = 0; k < 6; k++) scr[k] = hash_u32(seed, index, kScrambleStream + 6 * l + k);
 
         float sR = 0.0f, sG = 0.0f, sB = 0.0f, dA = 0.0f;
-        for (int s = sub; s < spp && cone.valid; s += G) {
-            if (mode != RLS_MIS_BSDF_ONLY) {                     // one light sample, both lobes
-                float rx = bits_u01(tab[0][s] ^ scr[0]), ry = bits_u01(tab[1][s] ^ scr[1]);
-                V3 L = cone_sample(cone, rx, ry);
-                if (dot(L, N) > 0.0f) {
-                    float fr, fg, fb, pb;
-                    ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pb);
-                    float wgt = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, pb);
-                    sR += R_DIV(fr * wgt, cone.pdf); sG += R_DIV(fg * wgt, cone.pdf); sB += R_DIV(fb * wgt, cone.pdf);
-                    if (sampleDiffuse) {
-                        float fd = oren_nayar_brdf(on, wo, L);
-                        float wd = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, oren_nayar_pdf(on, L));
-                        dA += R_DIV(fd * wd, cone.pdf);
+        for (int s0 = sub; s0 - sub < spp; s0 += K * G) {          // K samples per pass (SlowLds)
+            if (mode != RLS_MIS_LIGHT_ONLY) {
+                int qn = 0;
+#pragma unroll 1
+                for (int k = 0; k < K; k++) {
+                    const int s = s0 + k * G;
+                    const int sc = s < spp ? s : 0;
+                    ggx_vndf_push<K>(slow, k, qn, s < spp && cone.valid, w, bits_u01(tab[0][sc] ^ scr[2]),
+                                     bits_u01(tab[1][sc] ^ scr[3]));
+                }
+                slow_run<K>(slow, qn);
+            }
+#pragma unroll 1
+            for (int k = 0; k < K; k++) {
+                const int s = s0 + k * G;
+                if (!(s < spp && cone.valid)) continue;
+                if (mode != RLS_MIS_BSDF_ONLY) {                     // one light sample, both lobes
+                    float rx = bits_u01(tab[0][s] ^ scr[0]), ry = bits_u01(tab[1][s] ^ scr[1]);
+                    V3 L = cone_sample(cone, rx, ry);
+                    if (dot(L, N) > 0.0f) {
+                        float fr, fg, fb, pb;
+                        ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pb);
+                        float wgt = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, pb);
+                        sR += R_DIV(fr * wgt, cone.pdf); sG += R_DIV(fg * wgt, cone.pdf); sB += R_DIV(fb * wgt, cone.pdf);
+                        if (sampleDiffuse) {
+                            float fd = oren_nayar_brdf(on, wo, L);
+                            float wd = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, oren_nayar_pdf(on, L));
+                            dA += R_DIV(fd * wd, cone.pdf);
+                        }
                     }
                 }
-            }
-            if (mode != RLS_MIS_LIGHT_ONLY) {                    // one BSDF sample per lobe
-                float rx = bits_u01(tab[0][s] ^ scr[2]), ry = bits_u01(tab[1][s] ^ scr[3]);
-                V3 M = vndf_microfacet(w, g.fr, rx, ry);
-                V3 L = reflect_direction(g.view, M);
-                if (!is_zero(L) && dot(L, N) > 0.0f && cone_hit(cone, L)) {
-                    float fr, fg, fb, pb;
-                    ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pb);
-                    float wgt = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(pb, cone.pdf);
-                    sR += R_DIV(fr * wgt, pb); sG += R_DIV(fg * wgt, pb); sB += R_DIV(fb * wgt, pb);
-                }
-                if (sampleDiffuse) {
-                    rx = bits_u01(tab[0][s] ^ scr[4]); ry = bits_u01(tab[1][s] ^ scr[5]);
-                    V3 Ld = cosine_hemisphere(g.fr, rx, ry);
-                    float pd = oren_nayar_pdf(on, Ld);
-                    if (pd > 0.0f && cone_hit(cone, Ld)) {
-                        float fd = oren_nayar_brdf(on, wo, Ld);
-                        float wd = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(pd, cone.pdf);
-                        dA += R_DIV(fd * wd, pd);
+                if (mode != RLS_MIS_LIGHT_ONLY) {                    // one BSDF sample per lobe
+                    V3 M = ggx_vndf_pop<K>(slow, k, w, g.fr);
+                    V3 L = reflect_direction(g.view, M);
+                    if (!is_zero(L) && dot(L, N) > 0.0f && cone_hit(cone, L)) {
+                        float fr, fg, fb, pb;
+                        ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pb);
+                        float wgt = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(pb, cone.pdf);
+                        sR += R_DIV(fr * wgt, pb); sG += R_DIV(fg * wgt, pb); sB += R_DIV(fb * wgt, pb);
+                    }
+                    if (sampleDiffuse) {
+                        float rx = bits_u01(tab[0][s] ^ scr[4]), ry = bits_u01(tab[1][s] ^ scr[5]);
+                        V3 Ld = cosine_hemisphere(g.fr, rx, ry);
+                        float pd = oren_nayar_pdf(on, Ld);
+                        if (pd > 0.0f && cone_hit(cone, Ld)) {
+                            float fd = oren_nayar_brdf(on, wo, Ld);
+                            float wd = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(pd, cone.pdf);
+                            dA += R_DIV(fd * wd, pd);
+                        }
                     }
                 }
             }
@@ -790,6 +867,7 @@ template <int G, int FAST_MATH = RLS_FAST>
 __global__ RLS_INT_ATTR void ggx_direct_kernel(LightIO a)
 {
     __shared__ uint32_t tab[2][kMaxSpp];
+    __shared__ SlowLds<RLS_SPEC_BLOCK> slow;
     stage_libm_tables();   // atanf range table (+ expf / logf / powf tables) -> LDS
     stage_table(tab, a.spp);
     const int sub = threadIdx.x % G;
@@ -815,7 +893,7 @@ __global__ RLS_INT_ATTR void ggx_direct_kernel(LightIO a)
         ldrgb(a.sh.KdColor, ii, dr, dg, db);
         dr *= kd; dg *= kd; db *= kd;                                       // diffuseColor, src/rlGgx.cpp:279
         float oD[3], oS[3];
-        ggx_direct_loops<G>(g, w, on, wo, N, ld3(a.P, ii), !color_is_small(dr, dg, db), a, tab, a.spp, sub,
+        ggx_direct_loops<G>(slow, g, w, on, wo, N, ld3(a.P, ii), !color_is_small(dr, dg, db), a, tab, a.spp, sub,
                             inv, a.seed, a.first + (uint64_t)ii, oD, oS);
         if (live && sub == 0) {
             strgb(a.ds, i, oS[0] * ks, oS[1] * ks, oS[2] * ks);            // specular *= specularWeight, :305
@@ -964,6 +1042,7 @@ template <int G, int FAST_MATH = RLS_FAST>
 __global__ RLS_INT_ATTR void ggx_shade_kernel(GgxShadeIO a)
 {
     __shared__ uint32_t tab[2][kMaxSpp];
+    __shared__ SlowLds<RLS_SPEC_BLOCK> slow;
     stage_libm_tables();
     stage_table(tab, a.spp);
     const int sub = threadIdx.x % G;
@@ -994,7 +1073,7 @@ __global__ RLS_INT_ATTR void ggx_shade_kernel(GgxShadeIO a)
         const bool sampleDiffuse = !color_is_small(dr, dg, db);              // :280 (Rr_diff = 0)
         // the light loop, :285-305
         float dD[3], dS[3];
-        ggx_direct_loops<G>(g, w, on, wo, N, ld3(a.P, ii), sampleDiffuse, a, tab, a.spp, sub, inv, a.seed,
+        ggx_direct_loops<G>(slow, g, w, on, wo, N, ld3(a.P, ii), sampleDiffuse, a, tab, a.spp, sub, inv, a.seed,
                             idx, dD, dS);
         dD[0] *= dr; dD[1] *= dg; dD[2] *= db;
         dS[0] *= ks; dS[1] *= ks; dS[2] *= ks;
@@ -1003,7 +1082,7 @@ __global__ RLS_INT_ATTR void ggx_shade_kernel(GgxShadeIO a)
         if (!color_is_small(tr, tg, tb)) {
             float acc, tir;
             if (a.traced) {
-                ggx_refract_loop<G>(g, w, tab, a.spp, sub, hash_u32(a.seed, idx, kScrambleStream + 2 * (kShadeStream + 1)),
+                ggx_refract_loop<G>(slow, g, w, tab, a.spp, sub, hash_u32(a.seed, idx, kScrambleStream + 2 * (kShadeStream + 1)),
                                     hash_u32(a.seed, idx, kScrambleStream + 2 * (kShadeStream + 1) + 1), acc, tir);
             } else {
                 ggx_refract_untraced(g, acc, tir);
@@ -1029,7 +1108,7 @@ __global__ RLS_INT_ATTR void ggx_shade_kernel(GgxShadeIO a)
         float iS[3] = { 0.0f, 0.0f, 0.0f };
         if (!color_is_small(kr, kg, kb)) {
             float aR, aG, aB, aF;
-            ggx_glossy_loop<G>(g, w, tab, a.spp, sub, hash_u32(a.seed, idx, kScrambleStream + 2 * kShadeStream),
+            ggx_glossy_loop<G>(slow, g, w, tab, a.spp, sub, hash_u32(a.seed, idx, kScrambleStream + 2 * kShadeStream),
                                hash_u32(a.seed, idx, kScrambleStream + 2 * kShadeStream + 1), aR, aG, aB, aF);
             iS[0] = aR * inv * a.env[0] * ks; iS[1] = aG * inv * a.env[1] * ks; iS[2] = aB * inv * a.env[2] * ks;
         }

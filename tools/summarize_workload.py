@@ -82,6 +82,23 @@ def main():
              "source": "rocprofv3 --pmc SQ_INSTS_VALU_* in four passes (tools/profile_workload.sh)"}
         json.dump(f, open(os.path.join(dst, f"{tag}_{workload}_flops.json"), "w"), indent=1)
         print("flops/point", f["flops_per_point"], "VALU/point", per.get("SQ_INSTS_VALU"))
+        # the bench lines of this session priced their VALU roofline with the flops file the snapshot carried (the previous
+        # profile pass); re-price them with the mix measured in THIS session, and with the traffic measured in it
+        for name in ("bench.json", "bench_trace.json"):
+            q = os.path.join(dst, f"{tag}_{workload}_{name}")
+            if not os.path.exists(q):
+                continue
+            b = json.load(open(q))
+            r = b["roofline"]
+            if r.get("bound") == "valu":
+                tf = f["flops_per_point"] * points_per_launch / (r["kernel_ms"] * 1e-3) / 1e12
+                r.update(achieved=round(tf, 3), frac=round(tf / r["peak"], 4), flops_per_point=f["flops_per_point"],
+                         flops_source=f"profiles/{tag}_{workload}_flops.json (rocprofv3 --pmc passes of the same session)")
+            t = os.path.join(dst, f"{tag}_{workload}_traffic.json")
+            if os.path.exists(t):
+                r.update(traffic=round(json.load(open(t))["hbm_bytes_per_launch"]),
+                         traffic_source=f"profiles/{tag}_{workload}_traffic.json (rocprofv3 --pmc passes of the same session)")
+            json.dump(b, open(q, "w"), indent=1)
 
 
 if __name__ == "__main__":

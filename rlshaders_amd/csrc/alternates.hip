@@ -59,7 +59,7 @@ __global__ __launch_bounds__(rlsh::kBlock) void alt_kernel(AltIO a)
             case RLS_FN_COS_BOUNDED: t_sincos(x, &unused, &r); break;
             case RLS_FN_EXP: r = R_EXP(x); break;
             case RLS_FN_LOG: r = R_LOG(x); break;
-            case RLS_FN_POW: r = R_POW(x, y); break;
+            case RLS_FN_POW: r = y == 5.0f ? R_POW5(x) : R_POW(x, y); break;   // the Schlick exponent takes the closures' own path
             default: r = 0.0f; break;
             }
             stg(a.out1, i, r);

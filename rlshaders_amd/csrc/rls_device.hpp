@@ -83,6 +83,7 @@ struct Frame { V3 U, V, N; };
 #define R_EXP(x) __expf(x)
 #define R_LOG(x) __logf(x)
 #define R_POW(x, y) __powf(x, y)
+#define R_POW5(x) __powf(x, 5.0f)
 // the visible-normal slope equations amplify every rounding error: there,
 // and only there, FAST spends a Newton step on the reciprocal (~0.5 ulp) and the exact sqrt
 RLS_DEV float refined_div(float a, float b)
@@ -141,6 +142,11 @@ RLS_DEV void stage_libm_tables()
 #define R_EXP(x) rlm::exp32(x, s_libm_tables)
 #define R_LOG(x) rlm::log32(x, s_libm_tables)
 #define R_POW(x, y) rlm::pow32(x, y, s_libm_tables)
+#ifdef RLS_POW5_GENERAL   // experiment switch
+#define R_POW5(x) rlm::pow32(x, 5.0f, s_libm_tables)
+#else
+#define R_POW5(x) rlm::pow5_32(x, s_libm_tables)   // powf(x, 5.0f)
+#endif
 // t_sincos / t_tan: angles bounded by construction (results of atan2f / acosf, the concentric-disk mapping, the
 // in-kernel sampler) -- the forms without the |x| >= 120 branch (rls_libm.hpp).  t_sincos_any: angles computed from
 // caller-supplied random numbers (2 pi xi); full domain, so that even numbers outside [0, 1) give what the CPU gives.
@@ -737,7 +743,7 @@ RLS_DEV float D_GTR1_prepared(const Disney &d, float mn2)
 RLS_DEV void disney_prepare(Disney &d)
 {
     d.vn = dot(d.view, d.fr.N);
-    d.FV = R_POW(clampf(1.0f - d.vn, 0.0f, 1.0f), 5.0f);
+    d.FV = R_POW5(clampf(1.0f - d.vn, 0.0f, 1.0f));
     d.gsV = smithG_GGX(d.vn, d.specRough);
     d.grV = smithG_GGX(d.vn, 0.25f);
     float alpha = lerpf(d.clearcoatGloss, 0.1f, 0.001f);
@@ -762,8 +768,8 @@ RLS_DEV void disney_eval_diffuse(const Disney &d, V3 L, float &r, float &g, floa
     float vh = dot(d.view, H);     // the reference's "NdotH" (line 210)
     if (vh < kEps || lh < kEps) return;
     float lh2 = sqr(lh);
-    float FL = R_POW(clampf(1.0f - ln, 0.0f, 1.0f), 5.0f);
-    float FV = R_POW(clampf(1.0f - vn, 0.0f, 1.0f), 5.0f);
+    float FL = R_POW5(clampf(1.0f - ln, 0.0f, 1.0f));
+    float FV = R_POW5(clampf(1.0f - vn, 0.0f, 1.0f));
     float F90 = 0.5f + 2.0f * d.roughness * lh2;
     float diffuseFactor = lerpf(FL, 1.0f, F90) * lerpf(FV, 1.0f, F90);
     float Fss90 = d.roughness * lh2;
@@ -789,7 +795,7 @@ RLS_DEV void disney_eval_specular(const Disney &d, V3 L, float &r, float &g, flo
     if (nm < kEps || lm < kEps) return;
     float nm2 = sqr(nm);
     float Ds = D_GTR2Aniso(d, M, nm2);
-    float FH = R_POW(clampf(1.0f - lm, 0.0f, 1.0f), 5.0f);
+    float FH = R_POW5(clampf(1.0f - lm, 0.0f, 1.0f));
     float FsR = lerpf(FH, d.f0R, 1.0f);
     float FsG = lerpf(FH, d.f0G, 1.0f);
     float FsB = lerpf(FH, d.f0B, 1.0f);
@@ -982,7 +988,7 @@ RLS_DEV void disney_eval_pdf(const Disney &d, V3 L, float &r, float &g, float &b
         float vh = dot(d.view, H);
         if (vh < kEps || lh < kEps) return;
         float lh2 = sqr(lh);
-        float FL = R_POW(clampf(1.0f - ln, 0.0f, 1.0f), 5.0f);
+        float FL = R_POW5(clampf(1.0f - ln, 0.0f, 1.0f));
         float FV = d.FV;
         float F90 = 0.5f + 2.0f * d.roughness * lh2;
         float diffuseFactor = lerpf(FL, 1.0f, F90) * lerpf(FV, 1.0f, F90);
@@ -1010,7 +1016,7 @@ RLS_DEV void disney_eval_pdf(const Disney &d, V3 L, float &r, float &g, float &b
     if (WANT_F) {                                                    // evalSpecular, 318-356
         if (ln < kEps || vn < kEps) return;
         if (nm < kEps || lm < kEps) return;
-        float FH = R_POW(clampf(1.0f - lm, 0.0f, 1.0f), 5.0f);
+        float FH = R_POW5(clampf(1.0f - lm, 0.0f, 1.0f));
         float FsR = lerpf(FH, d.f0R, 1.0f);
         float FsG = lerpf(FH, d.f0G, 1.0f);
         float FsB = lerpf(FH, d.f0B, 1.0f);

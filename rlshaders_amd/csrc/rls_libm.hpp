@@ -668,6 +668,23 @@ RLM_FN float pow32(float x, float y, const Tables &t)
     return exp2_tail(rr, ki, 0x1.c6af84b912394p-5, 0x1.ebfce50fac4f3p-3, 0x1.62e42ff0c52d6p-1, t, sign_bias);
 }
 
+// powf(x, 5) for the Schlick weights (x = a clamped 1 - cos).  The host libm's powf(x, 5) is NOT the correctly rounded
+// x^5: its fp64 log2 / exp2 approximations put 145 179 of the 1 065 353 217 arguments in [0, 1] on the other side of an
+// fp32 rounding boundary -- but only where the exact x^5 lies within 2^-9.22 ulp of one (tools/micro/pow5.hip, every
+// argument).  So: x^5 by three fp64 products; when that lands within 2^-8 ulp of a boundary (0.16 % of the arguments),
+// or x is outside [2^-25, 1] (subnormal or zero result, negative, above 1, NaN), the full routine; otherwise the fp32
+// rounding of the product IS the libm's result.
+RLM_FN float pow5_32(float x, const Tables &t)
+{
+    const double d = (double)x;
+    const double d2 = d * d;
+    const double d5 = (d2 * d2) * d;
+    const uint32_t low = (uint32_t)d2u(d5) & 0x1fffffffu;      // the 29 bits fp32 drops; the boundary is 2^28
+    if (__builtin_expect(!(x >= 0x1p-25f && x <= 1.0f) || low - (0x10000000u - 0x00200000u) <= 0x00400000u, 0))
+        return pow32(x, 5.0f, t);
+    return (float)d5;
+}
+
 // =================================================================================================
 // Wave-friendly forms.  Same arithmetic, same results, but the range cases are expressed as
 // selects around ONE shared division / polynomial instead of separate branches, because the 64

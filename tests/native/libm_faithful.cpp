@@ -44,7 +44,7 @@ int main(int argc, char **argv)
         float lg3 = u01();
         a_log.add(rlm::log32(lg3, tab), logf(lg3));
         float pb = u01(), pe = u01();
-        a_pow.add(rlm::pow32(pb, 5.0f, tab), powf(pb, 5.0f));
+        a_pow.add(rlm::pow32(pb, 5.0f, tab), powf(pb, 5.0f)); a_pow.add(rlm::pow5_32(pb, tab), powf(pb, 5.0f));
         a_pow.add(rlm::pow32(pb, pe, tab), powf(pb, pe));
         float pb2 = 100.0f * u01(), pe2 = 20.0f * u01() - 10.0f;
         a_pow.add(rlm::pow32(pb2, pe2, tab), powf(pb2, pe2));

@@ -10,11 +10,20 @@ import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def newest(files):
+    """gpurun MERGES a call's files into gpurun_out/: earlier profile passes of the same workload are still there.  Keep
+    the files of the latest pass (written within a minute of the newest one)."""
+    if not files:
+        return []
+    t = max(os.path.getmtime(f) for f in files)
+    return [f for f in files if t - os.path.getmtime(f) < 60.0]
+
+
 def pmc(dirname, sub):
     """mean counter value per dispatch of kernels whose name contains `sub` (sum over the XCD/SE dimensions rocprofv3
     has already aggregated)"""
     acc = {}
-    for f in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
+    for f in newest(glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True)):
         per_dispatch = {}
         for r in csv.DictReader(open(f)):
             if sub in r["Kernel_Name"]:
@@ -44,7 +53,7 @@ def main():
     math = line["config"]["math"]
     launches = line["roofline"].get("launches_per_step", 1)
     points_per_launch = n / launches
-    for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    for f in newest(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)):
         shutil.copy(f, os.path.join(dst, f"{tag}_{workload}_kernel_stats.csv"))
         for r in csv.DictReader(open(f)):
             if ksub in r["Name"]:

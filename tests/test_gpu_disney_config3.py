@@ -193,3 +193,34 @@ def test_sharded_integrators_draw_the_batch_numbers(gpu, oracle):
     run(lambda: [host(mks(slice(0, n)).integrateScatter(dev(Nn), scene, spp_n, seed))],
         lambda sl: [host(mks(sl).integrateScatter(dev(np.ascontiguousarray(Nn[:, sl])), scene, spp_n, seed,
                                                   first_index=sl.start))])
+
+
+def test_packed_rare_branches_with_every_lane_asking(gpu, oracle):
+    """the n^2-spp loops queue the rare sampler branches of four samples per wavefront in LDS and evaluate them 64 at a
+    time (integrate.hip, SlowLds).  Here every lane asks at every sample -- views along the normal make every visible-
+    normal sample take the uniform-slope fallback, and clearcoat = 1 sends a fifth of the samples to the clearcoat lobe
+    -- so the queue holds 256 requests per pass of four samples and is worked off in four rounds; also a sample count (9)
+    that is not a multiple of four, and G > 1 (the lanes of a group hold different samples)."""
+    n, seed = 1 << 11, 77
+    wo, N, T = cases.frame(cases.SEED_PARITY, n)
+    wo = N.copy()                                                      # theta = 0: nearNormal in every lane
+    c = cases.disney_mixed(cases.SEED_PARITY, n)
+    c = dict(c, wo=wo, N=N, T=T, clearcoat=np.ones(n, np.float32))
+    od, d = disney_oracle(oracle, c), disney_sampler(gpu, c)
+    for spp_n in (3, 4):
+        ref = od.integrate(spp_n, seed, streamed=True)
+        got = _with_group(1, lambda: {k: host(v) for k, v in d.integrate(spp_n, seed, streamed=True).items()})
+        for k in ref:
+            cases.assert_tight(cases.summarize(cases.rel_err(got[k], ref[k])), ("every lane asks", spp_n, k))
+        for g in (4, 16):
+            alt = _with_group(g, lambda: {k: host(v) for k, v in d.integrate(spp_n, seed, streamed=True).items()})
+            for k in ("wi", "f", "pdf"):                               # the samples themselves do not depend on G
+                assert np.array_equal(alt[k].view(np.uint32), got[k].view(np.uint32)), (g, k)
+    # the rlGgx loops: the same view, low roughness
+    from gpu_util import ggx_oracle, ggx_sampler
+    g = cases.ggx_mixed(cases.SEED_PARITY, n)
+    g = dict(g, wo=wo, N=N, T=T)
+    ref = ggx_oracle(oracle, g).integrate(3, seed)
+    got = _with_group(1, lambda: [host(t) for t in ggx_sampler(gpu, g).integrate(3, seed)])
+    for nm, a, b in zip(("sum", "avg"), got, ref):
+        cases.assert_tight(cases.summarize(cases.rel_err(a, b)), ("ggx every lane asks", nm))

@@ -449,7 +449,7 @@ using rlsh::ScatterIO;
 __device__ __forceinline__ NdProfile scatter_profile(const rls_sss_closure &c, int64_t i)
 {
     float m = ldp(c.sss_dist_multiplier, i);   // src/rlSkin.cpp:235-236
-    return nd_make(ldp(c.sss_scatter_dist[0], i) * m, ldp(c.sss_scatter_dist[1], i) * m,
+    return nd_make<true>(ldp(c.sss_scatter_dist[0], i) * m, ldp(c.sss_scatter_dist[1], i) * m,
                    ldp(c.sss_scatter_dist[2], i) * m);
 }
 
@@ -663,7 +663,7 @@ __global__ RLS_INT_ATTR void skin_integrate_kernel(SkinIntIO a)
         sssWeight *= 1.0f - specularFresnel * (1.0f - sheenFresnel);                  // :238
         float ssR = 0.0f, ssG = 0.0f, ssB = 0.0f;
         if (!(sssWeight < kEps)) {                                                    // :244
-            NdProfile p = nd_make(ldp(c.sss_scatter_dist[0], ii) * mult, ldp(c.sss_scatter_dist[1], ii) * mult,
+            NdProfile p = nd_make<true>(ldp(c.sss_scatter_dist[0], ii) * mult, ldp(c.sss_scatter_dist[1], ii) * mult,
                                   ldp(c.sss_scatter_dist[2], ii) * mult);
             Frame fr = sss_frame(N, T, true);
             float br, bg, bb, accD;

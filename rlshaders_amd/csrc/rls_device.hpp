@@ -1034,8 +1034,17 @@ RLS_DEV void disney_eval_pdf(const Disney &d, V3 L, float &r, float &g, float &b
 struct NdProfile {
     float d[3], c1[3], c2[3];
     float maxR;
+#if !RLS_FAST
+    // getPdf divides by max(d_i, AI_EPSILON) twice and by c1_i + 3 c2_i once per channel, at every call: their correctly
+    // rounded reciprocals, and whether all six sit in the window of rlm::div32_y (2^-14 .. 2^14)
+    float dm[3], ydm[3], cw[3], ycw[3];
+    bool window;
+#endif
 };
 
+// RECIPROCALS: the profile is evaluated many times (the probe-ray loop of integrateScatter): keep the reciprocals of
+// getPdf's per-point denominators.  One-sample kernels do not (six reciprocals cost what they would save there).
+template <bool RECIPROCALS = false>
 RLS_DEV NdProfile nd_make(float dx, float dy, float dz)
 {
     NdProfile p;
@@ -1046,6 +1055,17 @@ RLS_DEV NdProfile nd_make(float dx, float dy, float dz)
         p.c1[i] = 1.0f - R_EXP(R_DIV(-p.maxR, p.d[i]));
         p.c2[i] = 1.0f - R_EXP(R_DIVC(R_DIV(-p.maxR, p.d[i]), 3.0f));
     }
+#if !RLS_FAST
+    p.window = RECIPROCALS;
+#pragma unroll
+    for (int i = 0; RECIPROCALS && i < 3; i++) {
+        p.dm[i] = maxf(p.d[i], kEps);
+        p.cw[i] = p.c1[i] + p.c2[i] * 3.0f;
+        p.ydm[i] = R_RCPW(p.dm[i]);                  // windowed below; outside it the reciprocals are not used
+        p.ycw[i] = R_RCPW(p.cw[i]);
+        p.window = p.window && p.dm[i] >= 0x1p-14f && p.dm[i] <= 0x1p14f && p.cw[i] >= 0x1p-14f && p.cw[i] <= 0x1p14f;
+    }
+#endif
     return p;
 }
 
@@ -1079,9 +1099,8 @@ RLS_DEV float nd_radius(const NdProfile &p, float rx)
 }
 
 // getPdf, src/rlSss.cpp:68-84
-RLS_DEV float nd_pdf(const NdProfile &p, float r)
+RLS_DEV float nd_pdf_ieee(const NdProfile &p, float r)
 {
-    if (p.maxR < kEps) return 1.0f;
     float pdf = 0.0f;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
@@ -1091,6 +1110,29 @@ RLS_DEV float nd_pdf(const NdProfile &p, float r)
         pdf += R_DIV(R_DIV(p1 + p2, d), p.c1[i] + p.c2[i] * 3.0f);
     }
     return R_DIV(pdf, kTwoPi * r * 3.0f);
+}
+RLS_DEV float nd_pdf(const NdProfile &p, float r)
+{
+    if (p.maxR < kEps) return 1.0f;
+#if RLS_FAST
+    return nd_pdf_ieee(p, r);
+#else
+    // Nine of the ten divisions have a per-point denominator: through its reciprocal (rlm::div32_y, five instructions
+    // each) when every operand is inside that routine's window -- the point's denominators (p.window), r, and the sums
+    // e^(-r/d) + e^(-r/3d), which fall below 2^-60 only for r > 41 d; the quotients (p1 + p2) / d are then >= 2^-74
+    if (__builtin_expect(!(p.window && r >= 0x1p-40f && r <= 0x1p40f), 0)) return nd_pdf_ieee(p, r);
+    float s[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float q = rlm::div32_y(-r, p.dm[i], p.ydm[i]);
+        s[i] = R_EXP(q) + R_EXP(R_DIVC(q, 3.0f));
+    }
+    if (__builtin_expect(!(minf(s[0], minf(s[1], s[2])) >= 0x1p-60f), 0)) return nd_pdf_ieee(p, r);
+    float pdf = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; i++) pdf += rlm::div32_y(rlm::div32_y(s[i], p.dm[i], p.ydm[i]), p.cw[i], p.ycw[i]);
+    return R_DIV(pdf, kTwoPi * r * 3.0f);
+#endif
 }
 
 // evalProfile, src/rlSss.cpp:86-106
@@ -1111,24 +1153,45 @@ RLS_DEV void nd_profile(const NdProfile &p, float r, float &R, float &G, float &
 // getPdf and evalProfile at the same radius (the probe-ray sample of rlSss / rlSkin asks for both): e^(-r / d_i) is one
 // value in both -- getPdf divides by max(d_i, AI_EPSILON), evalProfile by d_i and only when d_i >= AI_EPSILON -- so
 // the three divisions and exponentials are done once.  Same results as nd_pdf() and nd_profile().
-RLS_DEV void nd_pdf_profile(const NdProfile &p, float r, float &pdf, float &R, float &G, float &B)
+template <bool WINDOWED>
+RLS_DEV void nd_pdf_profile_t(const NdProfile &p, float r, float &pdf, float &R, float &G, float &B)
 {
-    if (p.maxR < kEps) { pdf = 1.0f; R = 0.0f; G = 0.0f; B = 0.0f; return; }
     const float denom = 8.0f * kPi * r;
     float acc = 0.0f;
     float out[3];
+    bool tiny = false;                                // WINDOWED: a sum e^(-r/d) + e^(-r/3d) below div32_y's window
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         const float d = maxf(p.d[i], kEps);
+#if !RLS_FAST
+        const float q = WINDOWED ? rlm::div32_y(-r, p.dm[i], p.ydm[i]) : R_DIV(-r, d);
+#else
         const float q = R_DIV(-r, d);
+#endif
         const float p1 = R_EXP(q);
         const float p2 = R_EXP(R_DIVC(q, 3.0f));
+#if !RLS_FAST
+        if (WINDOWED) {
+            tiny = tiny || !(p1 + p2 >= 0x1p-60f);
+            acc += rlm::div32_y(rlm::div32_y(p1 + p2, p.dm[i], p.ydm[i]), p.cw[i], p.ycw[i]);
+        } else
+#endif
         acc += R_DIV(R_DIV(p1 + p2, d), p.c1[i] + p.c2[i] * 3.0f);
         out[i] = p.d[i] < kEps ? 1.0f : R_DIV(p1 + R_EXP(R_DIV(-r, 3.0f * p.d[i])), denom * p.d[i]);
     }
+    if (WINDOWED && __builtin_expect(tiny, 0)) { nd_pdf_profile_t<false>(p, r, pdf, R, G, B); return; }
     pdf = R_DIV(acc, kTwoPi * r * 3.0f);
     const bool white = r < kEps;
     R = white ? 1.0f : out[0]; G = white ? 1.0f : out[1]; B = white ? 1.0f : out[2];
+}
+RLS_DEV void nd_pdf_profile(const NdProfile &p, float r, float &pdf, float &R, float &G, float &B)
+{
+    if (p.maxR < kEps) { pdf = 1.0f; R = 0.0f; G = 0.0f; B = 0.0f; return; }
+#if !RLS_FAST
+    // the divisions of getPdf by per-point denominators through their reciprocals, as nd_pdf()
+    if (__builtin_expect(p.window && r >= 0x1p-40f && r <= 0x1p40f, 1)) { nd_pdf_profile_t<true>(p, r, pdf, R, G, B); return; }
+#endif
+    nd_pdf_profile_t<false>(p, r, pdf, R, G, B);
 }
 
 // SssSampler frame, src/rlSss.h:149-158

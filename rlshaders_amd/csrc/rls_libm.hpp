@@ -668,6 +668,30 @@ RLM_FN float pow32(float x, float y, const Tables &t)
     return exp2_tail(rr, ki, 0x1.c6af84b912394p-5, 0x1.ebfce50fac4f3p-3, 0x1.62e42ff0c52d6p-1, t, sign_bias);
 }
 
+// a / b when y = RN(1 / b) is at hand (rcp32_w(b), kept per shading point for a denominator that many divisions share):
+// q0 = RN(a y) is within 1.5 ulp of a / b; one correction q1 = RN(q0 + RN(a - b q0) y) makes it faithful (within 0.5 ulp +
+// 2^-22 ulp), and with a faithful q1 the residual a - b q1 is exact and q2 = RN(q1 + (a - b q1) y) is the correctly
+// rounded quotient (Markstein, IBM J. R&D 34 (1990); Muller et al., Handbook of Floating-Point Arithmetic, 2nd ed.,
+// theorem 4.9).  Needs every intermediate representable: here for 2^-14 <= |b| <= 2^14 and 2^-75 <= |a| <= 2^40 (the
+// residuals are multiples of 2^(eb + eq - 46) >= 2^-149; fp32 subnormals are on).  Five full-rate instructions against
+// the fifteen fma-equivalents of the IEEE sequence; the CALLER guarantees the window (b once per point, a by a compare
+// where it is not known) -- zero, infinite and NaN operands do NOT come out as IEEE division makes them.
+// tools/micro/divy.hip: 64 x 2^30 random pairs inside the window, mantissas near their ends and the window's corners
+// included, 0 differences from the compiler's division.
+RLM_FN float div32_y(float a, float b, float y)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float q0 = a * y;
+    const float r0 = __builtin_fmaf(-b, q0, a);
+    const float q1 = __builtin_fmaf(r0, y, q0);
+    const float r1 = __builtin_fmaf(-b, q1, a);
+    return __builtin_fmaf(r1, y, q1);
+#else
+    (void)y;
+    return a / b;
+#endif
+}
+
 // powf(x, 5) for the Schlick weights (x = a clamped 1 - cos).  The host libm's powf(x, 5) is NOT the correctly rounded
 // x^5: its fp64 log2 / exp2 approximations put 145 179 of the 1 065 353 217 arguments in [0, 1] on the other side of an
 // fp32 rounding boundary -- but only where the exact x^5 lies within 2^-9.22 ulp of one (tools/micro/pow5.hip, every

@@ -17,7 +17,13 @@
 //
 // Roofline: fp32 VALU (not HBM) in reduced mode -- 88 B of parameters in and 32 B out per point
 // against 2*n^2 triples of arithmetic (SURVEY.md section 8(d), config 3 mode R).  Streamed mode
-// writes 28 B per triple and is HBM-bound.
+// writes 28 B per triple; it too runs at the speed of its arithmetic.
+//
+// The same file holds the loops built on those: integrateRefract, the light loops of rlGgx / rlDisney
+// (two-sample MIS over up to eight spherical lights), SssSampler::integrateScatter over an analytic
+// scene, and the three nodes' whole shader_evaluate (rls_ggx_shade, rls_disney_shade,
+// rls_skin_integrate).  The loops take K = 4 samples per pass and evaluate their samplers' rare
+// branches packed through LDS (SlowLds below).
 #include <stdlib.h>
 
 #include "rls_internal.hpp"

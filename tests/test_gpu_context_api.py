@@ -90,6 +90,18 @@ def test_error_paths():
     v = capi.Vec3(None, None, None)
     assert lib.rls_disney_sample(h, 8, C.byref(c), 3, None, None, v) == 1 and b"lobe" in lib.rls_last_error()
     assert lib.rls_ggx_integrate(h, 8, None, 0, 1, 0, capi.Rgb(None, None, None), None) == 1
+    # the light loops and whole-node entry points: n = 0 is a no-op before any pointer is looked at; then NULL
+    # arguments, light counts and sample counts are rejected with a message, never dereferenced
+    z3, zrgb = capi.CVec3(None, None, None), capi.Rgb(None, None, None)
+    env = (C.c_float * 3)(1.0, 1.0, 1.0)
+    assert lib.rls_ggx_shade(h, 0, None, None, z3, None, 0, None, 1, 4, 1, 0, None) == 0
+    assert lib.rls_disney_shade(h, 0, None, z3, None, 0, None, 4, 1, 0, None) == 0
+    assert lib.rls_disney_direct_lighting(h, 0, None, z3, None, 0, 4, 1, 0, zrgb, zrgb) == 0
+    assert lib.rls_ggx_shade(h, 8, None, None, z3, None, 0, env, 1, 4, 1, 0, None) == 1 and b"NULL" in lib.rls_last_error()
+    assert lib.rls_disney_shade(h, 8, None, z3, None, 0, env, 4, 1, 0, None) == 1 and b"NULL" in lib.rls_last_error()
+    d = capi.DisneyClosure()
+    assert lib.rls_disney_direct_lighting(h, 8, C.byref(d), z3, None, 1, 4, 1, 0, zrgb, zrgb) == 1      # planes are NULL
+    assert lib.rls_disney_direct_lighting(h, 8, C.byref(d), z3, None, 1, 17, 1, 0, zrgb, zrgb) == 1 and b"spp_n" in lib.rls_last_error()
     assert lib.rls_status_string(4) == b"out of device memory"
     assert lib.rls_version() == 1
     lib.rls_context_destroy(h)

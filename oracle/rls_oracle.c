@@ -1941,7 +1941,9 @@ static void ggx_light_loop(orc_ggx *g, const orc_oren_nayar *on, orc_v3 wo, orc_
         const int mode = lt->mis_mode;
         const uint32_t st = 3u * (uint32_t)l;
         light_cone c = cone_make(lt, P);
-        float sR = 0.0f, sG = 0.0f, sB = 0.0f, dA = 0.0f;
+        /* the two strategies of the estimator keep their own sums (light samples; BSDF samples), each grown in sample
+         * order and added at the end: the device runs the strategies as separate passes over the samples */
+        float lR = 0.0f, lG = 0.0f, lB = 0.0f, lA = 0.0f, bR = 0.0f, bG = 0.0f, bB = 0.0f, bA = 0.0f;
         for (int s = 0; s < spp && c.valid; s++) {
             float rx, ry;
             if (mode != 2) {                                   /* one light sample, both lobes */
@@ -1951,11 +1953,11 @@ static void ggx_light_loop(orc_ggx *g, const orc_oren_nayar *on, orc_v3 wo, orc_
                     orc_rgb f = orc_ggx_eval_brdf(g, L);
                     float pb = orc_ggx_eval_pdf(g, L);
                     float w = mode == 1 ? 1.0f : power_heuristic(c.pdf, pb);
-                    sR += f.r * w / c.pdf; sG += f.g * w / c.pdf; sB += f.b * w / c.pdf;
+                    lR += f.r * w / c.pdf; lG += f.g * w / c.pdf; lB += f.b * w / c.pdf;
                     if (sampleDiffuse) {
                         float fd = orc_oren_nayar_brdf(on, wo, L);
                         float wd = mode == 1 ? 1.0f : power_heuristic(c.pdf, orc_oren_nayar_pdf(on, L));
-                        dA += fd * wd / c.pdf;
+                        lA += fd * wd / c.pdf;
                     }
                 }
             }
@@ -1966,7 +1968,7 @@ static void ggx_light_loop(orc_ggx *g, const orc_oren_nayar *on, orc_v3 wo, orc_
                     orc_rgb f = orc_ggx_eval_brdf(g, L);
                     float pb = orc_ggx_eval_pdf(g, L);
                     float w = mode == 2 ? 1.0f : power_heuristic(pb, c.pdf);
-                    sR += f.r * w / pb; sG += f.g * w / pb; sB += f.b * w / pb;
+                    bR += f.r * w / pb; bG += f.g * w / pb; bB += f.b * w / pb;
                 }
                 if (sampleDiffuse) {
                     orc_sample_02(seed, index, st + 2, (uint32_t)s, &rx, &ry);
@@ -1975,11 +1977,12 @@ static void ggx_light_loop(orc_ggx *g, const orc_oren_nayar *on, orc_v3 wo, orc_
                     if (pd > 0.0f && cone_hit(&c, Ld)) {
                         float fd = orc_oren_nayar_brdf(on, wo, Ld);
                         float wd = mode == 2 ? 1.0f : power_heuristic(pd, c.pdf);
-                        dA += fd * wd / pd;
+                        bA += fd * wd / pd;
                     }
                 }
             }
         }
+        const float sR = lR + bR, sG = lG + bG, sB = lB + bB, dA = lA + bA;
         const float *rad = lt->radiance;
         const orc_rgb tS = rgb(rad[0] * sR * inv, rad[1] * sG * inv, rad[2] * sB * inv);
         const orc_rgb tD = rgb(rad[0] * dA * inv, rad[1] * dA * inv, rad[2] * dA * inv);

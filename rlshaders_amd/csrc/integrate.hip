@@ -796,60 +796,61 @@ __device__ __forceinline__ void ggx_direct_loops(SlowLds<K> &slow, const Ggx &g,
 #pragma unroll
         for (int k = 0; k < 6; k++) scr[k] = hash_u32(seed, index, kScrambleStream + 6 * l + k);
 
-        float sR = 0.0f, sG = 0.0f, sB = 0.0f, dA = 0.0f;
-        for (int s0 = sub; s0 - sub < spp; s0 += K * G) {          // K samples per pass (SlowLds)
-            if (mode != RLS_MIS_LIGHT_ONLY) {
-                int qn = 0;
-#pragma unroll 1
-                for (int k = 0; k < K; k++) {
-                    const int s = s0 + k * G;
-                    const int sc = s < spp ? s : 0;
-                    ggx_vndf_push<K>(slow, k, qn, s < spp && cone.valid, w, bits_u01(tab[0][sc] ^ scr[2]),
-                                     bits_u01(tab[1][sc] ^ scr[3]));
-                }
-                slow_run<K>(slow, qn);
-            }
-#pragma unroll 1
-            for (int k = 0; k < K; k++) {
-                const int s = s0 + k * G;
-                if (!(s < spp && cone.valid)) continue;
-                if (mode != RLS_MIS_BSDF_ONLY) {                     // one light sample, both lobes
-                    float rx = bits_u01(tab[0][s] ^ scr[0]), ry = bits_u01(tab[1][s] ^ scr[1]);
-                    V3 L = cone_sample(cone, rx, ry);
-                    if (dot(L, N) > 0.0f) {
-                        float fr, fg, fb, pb;
-                        ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pb);
-                        float wgt = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, pb);
-                        sR += R_DIV(fr * wgt, cone.pdf); sG += R_DIV(fg * wgt, cone.pdf); sB += R_DIV(fb * wgt, cone.pdf);
-                        if (sampleDiffuse) {
-                            float fd = oren_nayar_brdf(on, wo, L);
-                            float wd = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, oren_nayar_pdf(on, L));
-                            dA += R_DIV(fd * wd, cone.pdf);
-                        }
-                    }
-                }
-                if (mode != RLS_MIS_LIGHT_ONLY) {                    // one BSDF sample per lobe
-                    V3 M = ggx_vndf_pop<K>(slow, k, w, g.fr);
-                    V3 L = reflect_direction(g.view, M);
-                    if (!is_zero(L) && dot(L, N) > 0.0f && cone_hit(cone, L)) {
-                        float fr, fg, fb, pb;
-                        ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pb);
-                        float wgt = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(pb, cone.pdf);
-                        sR += R_DIV(fr * wgt, pb); sG += R_DIV(fg * wgt, pb); sB += R_DIV(fb * wgt, pb);
-                    }
+        // The estimator's two strategies as separate passes over the samples, each with its own sums (grown in sample order,
+        // added at the end): light samples first, then BSDF samples.
+        float lR = 0.0f, lG = 0.0f, lB = 0.0f, lA = 0.0f, bR = 0.0f, bG = 0.0f, bB = 0.0f, bA = 0.0f;
+        if (mode != RLS_MIS_BSDF_ONLY) {                             // one light sample, both lobes
+            for (int s = sub; s < spp && cone.valid; s += G) {
+                float rx = bits_u01(tab[0][s] ^ scr[0]), ry = bits_u01(tab[1][s] ^ scr[1]);
+                V3 L = cone_sample(cone, rx, ry);
+                if (dot(L, N) > 0.0f) {
+                    float fr, fg, fb, pb;
+                    ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pb);
+                    float wgt = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, pb);
+                    lR += R_DIV(fr * wgt, cone.pdf); lG += R_DIV(fg * wgt, cone.pdf); lB += R_DIV(fb * wgt, cone.pdf);
                     if (sampleDiffuse) {
-                        float rx = bits_u01(tab[0][s] ^ scr[4]), ry = bits_u01(tab[1][s] ^ scr[5]);
-                        V3 Ld = cosine_hemisphere(g.fr, rx, ry);
-                        float pd = oren_nayar_pdf(on, Ld);
-                        if (pd > 0.0f && cone_hit(cone, Ld)) {
-                            float fd = oren_nayar_brdf(on, wo, Ld);
-                            float wd = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(pd, cone.pdf);
-                            dA += R_DIV(fd * wd, pd);
-                        }
+                        float fd = oren_nayar_brdf(on, wo, L);
+                        float wd = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, oren_nayar_pdf(on, L));
+                        lA += R_DIV(fd * wd, cone.pdf);
                     }
                 }
             }
         }
+        for (int s0 = sub; mode != RLS_MIS_LIGHT_ONLY && s0 - sub < spp; s0 += K * G) {   // one BSDF sample per lobe; K per pass (SlowLds)
+            int qn = 0;
+#pragma unroll 1
+            for (int k = 0; k < K; k++) {
+                const int s = s0 + k * G;
+                const int sc = s < spp ? s : 0;
+                ggx_vndf_push<K>(slow, k, qn, s < spp && cone.valid, w, bits_u01(tab[0][sc] ^ scr[2]),
+                                 bits_u01(tab[1][sc] ^ scr[3]));
+            }
+            slow_run<K>(slow, qn);
+#pragma unroll 1
+            for (int k = 0; k < K; k++) {
+                const int s = s0 + k * G;
+                if (!(s < spp && cone.valid)) continue;
+                V3 M = ggx_vndf_pop<K>(slow, k, w, g.fr);
+                V3 L = reflect_direction(g.view, M);
+                if (!is_zero(L) && dot(L, N) > 0.0f && cone_hit(cone, L)) {
+                    float fr, fg, fb, pb;
+                    ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pb);
+                    float wgt = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(pb, cone.pdf);
+                    bR += R_DIV(fr * wgt, pb); bG += R_DIV(fg * wgt, pb); bB += R_DIV(fb * wgt, pb);
+                }
+                if (sampleDiffuse) {
+                    float rx = bits_u01(tab[0][s] ^ scr[4]), ry = bits_u01(tab[1][s] ^ scr[5]);
+                    V3 Ld = cosine_hemisphere(g.fr, rx, ry);
+                    float pd = oren_nayar_pdf(on, Ld);
+                    if (pd > 0.0f && cone_hit(cone, Ld)) {
+                        float fd = oren_nayar_brdf(on, wo, Ld);
+                        float wd = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(pd, cone.pdf);
+                        bA += R_DIV(fd * wd, pd);
+                    }
+                }
+            }
+        }
+        float sR = lR + bR, sG = lG + bG, sB = lB + bB, dA = lA + bA;
         if (G > 1) {
             sR = group_sum<G>(sR); sG = group_sum<G>(sG); sB = group_sum<G>(sB); dA = group_sum<G>(dA);
         }

@@ -89,7 +89,7 @@ __device__ __forceinline__ float group_sum(float v)
 // in registers -- so the code and the register count stay those of the plain loop.
 template <int K>
 struct SlowLds {
-    float q[rlsh::kBlock / 64][3][K * 64];      // per wavefront: requests (p, q, t), overwritten by results (x, y, z)
+    float q[rlsh::kBlock / 64][4][K * 64];      // per wavefront: requests (p, q, t[, lane]), overwritten by the results
     float st[3][K][rlsh::kBlock];               // per lane and sample: two values of the caller's + flags | slot << 2
 };
 
@@ -200,6 +200,90 @@ __device__ __forceinline__ V3 ggx_vndf_pop(const SlowLds<K> &L, int k, const Vnd
     SlowOut o;
     if (slow_pop<K>(L, k, slope.x, slope.y, flag, o)) { slope.x = o.x; slope.y = o.y; }
     return vndf_from_slope(w, fr, slope);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Evaluation requests: "evalBrdf / evalPdf of MY closure in THIS direction".  The light-sampling strategy of a light
+// loop evaluates only the samples above the horizon (half of the lanes of the bench's batches), the BSDF-sampling one
+// only those that hit the light (a few per cent), but a wavefront runs the evaluation whenever one lane needs it.
+// Queued like the samplers' rare branches (direction + requesting lane), evaluated 64 at a time by lanes that fetch the
+// requester's closure across the wavefront (ds_bpermute), results handed back through the queue.
+template <int K>
+__device__ __forceinline__ void eval_push(SlowLds<K> &L, int k, int &cnt, bool want, V3 dir)
+{
+    const int tid = (int)threadIdx.x, wave = tid >> 6;
+    const uint64_t m = __builtin_amdgcn_ballot_w64(want);
+    const int slot = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (want) {
+        L.q[wave][0][slot] = dir.x; L.q[wave][1][slot] = dir.y; L.q[wave][2][slot] = dir.z;
+        L.q[wave][3][slot] = __int_as_float(tid & 63);
+    }
+    L.st[2][k][tid] = __int_as_float((want ? 2 : 0) | (slot << 2));
+    cnt += __builtin_popcountll(m);
+}
+template <int K>
+__device__ __forceinline__ bool eval_pop(const SlowLds<K> &L, int k, float (&c)[4])
+{
+    const int tid = (int)threadIdx.x, wave = tid >> 6;
+    const int f = __float_as_int(L.st[2][k][tid]);
+    const bool want = (f & 2) != 0;
+    if (want) {
+        const int slot = f >> 2;
+        c[0] = L.q[wave][0][slot]; c[1] = L.q[wave][1][slot]; c[2] = L.q[wave][2][slot]; c[3] = L.q[wave][3][slot];
+    }
+    return want;
+}
+__device__ __forceinline__ float lane_fetch(float v, int src)
+{
+    return __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)__float_as_uint(v)));
+}
+__device__ __forceinline__ V3 lane_fetch(V3 v, int src) { return mk(lane_fetch(v.x, src), lane_fetch(v.y, src), lane_fetch(v.z, src)); }
+// what ggx_eval_pdf / ggx_fresnel / ggx_G read of a closure (the iors only enter through eta2)
+__device__ __forceinline__ Ggx ggx_fetch(const Ggx &g, int src)
+{
+    Ggx h;
+    h.fr.N = lane_fetch(g.fr.N, src); h.fr.U = lane_fetch(g.fr.U, src); h.fr.V = lane_fetch(g.fr.V, src);
+    h.view = lane_fetch(g.view, src);
+    h.ksR = lane_fetch(g.ksR, src); h.ksG = lane_fetch(g.ksG, src); h.ksB = lane_fetch(g.ksB, src);
+    h.rough = lane_fetch(g.rough, src); h.ax = lane_fetch(g.ax, src); h.ay = lane_fetch(g.ay, src);
+    h.iorIn = 0.0f; h.iorOut = 0.0f; h.etaIO = 0.0f;
+    h.eta2 = lane_fetch(g.eta2, src); h.vn = lane_fetch(g.vn, src); h.g1v = lane_fetch(g.g1v, src);
+    return h;
+}
+// the light-sampling strategy's evaluation (one light sample, both lobes) for the queued requests: per request the four
+// terms f_r w / p, f_g w / p, f_b w / p (GGX) and f_d w_d / p (Oren-Nayar) of ggx_direct_loops.  Whole wavefront.
+template <int K>
+__device__ __forceinline__ void ggx_light_eval_run(SlowLds<K> &Q, int cnt, const Ggx &g, const OrenNayar &on, float conePdf,
+                                                   bool sampleDiffuse, int mode)
+{
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    wave_lds_fence();
+    for (int base = 0; base < cnt; base += 64) {
+        const int j = base + lane;
+        const bool have = j < cnt;
+        V3 L = mk(0.0f, 0.0f, 1.0f);
+        int src = lane;
+        if (have) { L = mk(Q.q[wave][0][j], Q.q[wave][1][j], Q.q[wave][2][j]); src = __float_as_int(Q.q[wave][3][j]); }
+        const Ggx h = ggx_fetch(g, src);                        // every lane executes the fetches
+        OrenNayar o;
+        o.N = h.fr.N; o.A = lane_fetch(on.A, src); o.B = lane_fetch(on.B, src);
+        const float cp = lane_fetch(conePdf, src);
+        const bool sd = lane_fetch(sampleDiffuse ? 1.0f : 0.0f, src) != 0.0f;
+        if (have) {
+            float fr, fg, fb, pb;
+            ggx_eval_pdf<true, true>(h, L, fr, fg, fb, pb);
+            const float wgt = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cp, pb);
+            float cA = 0.0f;
+            if (sd) {
+                const float fd = oren_nayar_brdf(o, h.view, L);
+                const float wd = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cp, oren_nayar_pdf(o, L));
+                cA = R_DIV(fd * wd, cp);
+            }
+            Q.q[wave][0][j] = R_DIV(fr * wgt, cp); Q.q[wave][1][j] = R_DIV(fg * wgt, cp); Q.q[wave][2][j] = R_DIV(fb * wgt, cp);
+            Q.q[wave][3][j] = cA;
+        }
+    }
+    wave_lds_fence();
 }
 
 // integrateGlossy's sample loop over one closure (src/rlGgx.h:172-179 -> AiBRDFIntegrate over the triple): lane `sub`
@@ -799,20 +883,23 @@ __device__ __forceinline__ void ggx_direct_loops(SlowLds<K> &slow, const Ggx &g,
         // The estimator's two strategies as separate passes over the samples, each with its own sums (grown in sample order,
         // added at the end): light samples first, then BSDF samples.
         float lR = 0.0f, lG = 0.0f, lB = 0.0f, lA = 0.0f, bR = 0.0f, bG = 0.0f, bB = 0.0f, bA = 0.0f;
-        if (mode != RLS_MIS_BSDF_ONLY) {                             // one light sample, both lobes
-            for (int s = sub; s < spp && cone.valid; s += G) {
-                float rx = bits_u01(tab[0][s] ^ scr[0]), ry = bits_u01(tab[1][s] ^ scr[1]);
-                V3 L = cone_sample(cone, rx, ry);
-                if (dot(L, N) > 0.0f) {
-                    float fr, fg, fb, pb;
-                    ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pb);
-                    float wgt = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, pb);
-                    lR += R_DIV(fr * wgt, cone.pdf); lG += R_DIV(fg * wgt, cone.pdf); lB += R_DIV(fb * wgt, cone.pdf);
-                    if (sampleDiffuse) {
-                        float fd = oren_nayar_brdf(on, wo, L);
-                        float wd = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, oren_nayar_pdf(on, L));
-                        lA += R_DIV(fd * wd, cone.pdf);
-                    }
+        for (int s0 = sub; mode != RLS_MIS_BSDF_ONLY && s0 - sub < spp; s0 += K * G) {   // one light sample, both lobes
+            // the samples above the horizon are queued and evaluated packed (eval_push / ggx_light_eval_run / eval_pop)
+            int qn = 0;
+#pragma unroll 1
+            for (int k = 0; k < K; k++) {
+                const int s = s0 + k * G;
+                const int sc = s < spp ? s : 0;
+                V3 L = cone_sample(cone, bits_u01(tab[0][sc] ^ scr[0]), bits_u01(tab[1][sc] ^ scr[1]));
+                eval_push<K>(slow, k, qn, s < spp && cone.valid && dot(L, N) > 0.0f, L);
+            }
+            ggx_light_eval_run<K>(slow, qn, g, on, cone.pdf, sampleDiffuse, mode);
+#pragma unroll 1
+            for (int k = 0; k < K; k++) {
+                float t[4];
+                if (eval_pop<K>(slow, k, t)) {
+                    lR += t[0]; lG += t[1]; lB += t[2];
+                    if (sampleDiffuse) lA += t[3];
                 }
             }
         }

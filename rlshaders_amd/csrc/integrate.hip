@@ -286,6 +286,30 @@ __device__ __forceinline__ void ggx_light_eval_run(SlowLds<K> &Q, int cnt, const
     wave_lds_fence();
 }
 
+// the BSDF-sampling strategy's evaluation of the GGX samples that hit the light: f w / p_b per channel
+template <int K>
+__device__ __forceinline__ void ggx_hit_eval_run(SlowLds<K> &Q, int cnt, const Ggx &g, float conePdf, int mode)
+{
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    wave_lds_fence();
+    for (int base = 0; base < cnt; base += 64) {
+        const int j = base + lane;
+        const bool have = j < cnt;
+        V3 L = mk(0.0f, 0.0f, 1.0f);
+        int src = lane;
+        if (have) { L = mk(Q.q[wave][0][j], Q.q[wave][1][j], Q.q[wave][2][j]); src = __float_as_int(Q.q[wave][3][j]); }
+        const Ggx h = ggx_fetch(g, src);
+        const float cp = lane_fetch(conePdf, src);
+        if (have) {
+            float fr, fg, fb, pb;
+            ggx_eval_pdf<true, true>(h, L, fr, fg, fb, pb);
+            const float wgt = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(pb, cp);
+            Q.q[wave][0][j] = R_DIV(fr * wgt, pb); Q.q[wave][1][j] = R_DIV(fg * wgt, pb); Q.q[wave][2][j] = R_DIV(fb * wgt, pb);
+        }
+    }
+    wave_lds_fence();
+}
+
 // integrateGlossy's sample loop over one closure (src/rlGgx.h:172-179 -> AiBRDFIntegrate over the triple): lane `sub`
 // of a G-lane group takes samples sub, sub + G, ...; sums of f/pdf and of the Fresnel side effect of evalSample
 // (src/rlGgx.h:103), reduced over the group
@@ -913,18 +937,32 @@ __device__ __forceinline__ void ggx_direct_loops(SlowLds<K> &slow, const Ggx &g,
                                  bits_u01(tab[1][sc] ^ scr[3]));
             }
             slow_run<K>(slow, qn);
+            // the reflected directions; the few that hit the light are queued for evaluation (the queue is free again
+            // once every sample's slopes have been picked up)
+            uint32_t hits = 0;
+#pragma unroll 1
+            for (int k = 0; k < K; k++) {
+                const int s = s0 + k * G;
+                V3 M = ggx_vndf_pop<K>(slow, k, w, g.fr);
+                V3 L = reflect_direction(g.view, M);
+                const bool hit = s < spp && cone.valid && !is_zero(L) && dot(L, N) > 0.0f && cone_hit(cone, L);
+                hits |= (hit ? 1u : 0u) << k;
+                slow.st[0][k][threadIdx.x] = L.x; slow.st[1][k][threadIdx.x] = L.y; slow.st[2][k][threadIdx.x] = L.z;
+            }
+            wave_lds_fence();
+            qn = 0;
+#pragma unroll 1
+            for (int k = 0; k < K; k++) {
+                const V3 L = mk(slow.st[0][k][threadIdx.x], slow.st[1][k][threadIdx.x], slow.st[2][k][threadIdx.x]);
+                eval_push<K>(slow, k, qn, ((hits >> k) & 1u) != 0, L);
+            }
+            ggx_hit_eval_run<K>(slow, qn, g, cone.pdf, mode);
 #pragma unroll 1
             for (int k = 0; k < K; k++) {
                 const int s = s0 + k * G;
                 if (!(s < spp && cone.valid)) continue;
-                V3 M = ggx_vndf_pop<K>(slow, k, w, g.fr);
-                V3 L = reflect_direction(g.view, M);
-                if (!is_zero(L) && dot(L, N) > 0.0f && cone_hit(cone, L)) {
-                    float fr, fg, fb, pb;
-                    ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pb);
-                    float wgt = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(pb, cone.pdf);
-                    bR += R_DIV(fr * wgt, pb); bG += R_DIV(fg * wgt, pb); bB += R_DIV(fb * wgt, pb);
-                }
+                float t[4];
+                if (eval_pop<K>(slow, k, t)) { bR += t[0]; bG += t[1]; bB += t[2]; }
                 if (sampleDiffuse) {
                     float rx = bits_u01(tab[0][s] ^ scr[4]), ry = bits_u01(tab[1][s] ^ scr[5]);
                     V3 Ld = cosine_hemisphere(g.fr, rx, ry);

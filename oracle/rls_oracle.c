@@ -2109,7 +2109,9 @@ static void dlight_range(int64_t lo, int64_t hi, void *ctx)
             const int mode = lt->mis_mode;
             const uint32_t st = 3u * (uint32_t)l;
             light_cone c = cone_make(lt, ld3(j->P, i));
-            float acc[2][3] = { { 0 } };                           /* [diffuse, specular][r, g, b] */
+            /* the two strategies of the estimator keep their own sums (light samples; BSDF samples), each grown in
+             * sample order and added at the end: the device runs the strategies as separate passes */
+            float la[2][3] = { { 0 } }, ba[2][3] = { { 0 } };      /* [diffuse, specular][r, g, b] */
             for (int s = 0; s < j->spp && c.valid; s++) {
                 float rx, ry;
                 if (mode != 2) {                                   /* one light sample, both lobes */
@@ -2121,7 +2123,7 @@ static void dlight_range(int64_t lo, int64_t hi, void *ctx)
                             orc_rgb f = orc_disney_eval_brdf(&d, L);
                             float p = orc_disney_eval_pdf(&d, L);
                             float w = mode == 1 ? 1.0f : power_heuristic(c.pdf, p);
-                            acc[lobe][0] += f.r * w / c.pdf; acc[lobe][1] += f.g * w / c.pdf; acc[lobe][2] += f.b * w / c.pdf;
+                            la[lobe][0] += f.r * w / c.pdf; la[lobe][1] += f.g * w / c.pdf; la[lobe][2] += f.b * w / c.pdf;
                         }
                     }
                 }
@@ -2134,11 +2136,14 @@ static void dlight_range(int64_t lo, int64_t hi, void *ctx)
                         float p = orc_disney_eval_pdf(&d, L);
                         if (p > AI_EPSILON && cone_hit(&c, L)) {   /* valid sample: src/rlDisney.cpp:309 */
                             float w = mode == 2 ? 1.0f : power_heuristic(p, c.pdf);
-                            acc[lobe][0] += f.r * w / p; acc[lobe][1] += f.g * w / p; acc[lobe][2] += f.b * w / p;
+                            ba[lobe][0] += f.r * w / p; ba[lobe][1] += f.g * w / p; ba[lobe][2] += f.b * w / p;
                         }
                     }
                 }
             }
+            float acc[2][3];
+            for (int lobe = 0; lobe < 2; lobe++)
+                for (int k = 0; k < 3; k++) acc[lobe][k] = la[lobe][k] + ba[lobe][k];
             const float *rad = lt->radiance;
             const orc_rgb tD = rgb(rad[0] * acc[0][0] * inv, rad[1] * acc[0][1] * inv, rad[2] * acc[0][2] * inv);
             const orc_rgb tS = rgb(rad[0] * acc[1][0] * inv, rad[1] * acc[1][1] * inv, rad[2] * acc[1][2] * inv);

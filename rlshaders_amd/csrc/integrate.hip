@@ -40,6 +40,13 @@ namespace {
 #define RLS_INT_WAVES 4
 #endif
 #define RLS_INT_ATTR __launch_bounds__(rlsh::kBlock) __attribute__((amdgpu_waves_per_eu(RLS_INT_WAVES, RLS_INT_WAVES)))
+// rlDisney's light loop and whole node evaluate packed requests with a second 45-word closure in registers: at four
+// waves (128 VGPRs) they spill 123 of them and the packing gains 3 %; at three it gains 17 % / 9 % (60.3 -> 52.1 ms,
+// 81.6 -> 73.7 ms)
+#ifndef RLS_DISNEY_LIGHT_WAVES
+#define RLS_DISNEY_LIGHT_WAVES 3
+#endif
+#define RLS_DISNEY_LIGHT_ATTR __launch_bounds__(rlsh::kBlock) __attribute__((amdgpu_waves_per_eu(RLS_DISNEY_LIGHT_WAVES, RLS_DISNEY_LIGHT_WAVES)))
 
 constexpr int kMaxSpp = 256;   // spp_n <= 16
 
@@ -90,7 +97,8 @@ __device__ __forceinline__ float group_sum(float v)
 template <int K>
 struct SlowLds {
     float q[rlsh::kBlock / 64][4][K * 64];      // per wavefront: requests (p, q, t[, lane]), overwritten by the results
-    float st[3][K][rlsh::kBlock];               // per lane and sample: two values of the caller's + flags | slot << 2
+    float st[4][K][rlsh::kBlock];               // per lane and sample: two values of the caller's + flags | slot << 2;
+                                                // [3]: the flags | slot of an evaluation request ([0..2] stay the caller's)
 };
 
 __device__ __forceinline__ void wave_lds_fence()   // LDS traffic between the lanes of ONE wavefront: order it, no s_barrier
@@ -216,16 +224,16 @@ __device__ __forceinline__ void eval_push(SlowLds<K> &L, int k, int &cnt, bool w
     const int slot = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     if (want) {
         L.q[wave][0][slot] = dir.x; L.q[wave][1][slot] = dir.y; L.q[wave][2][slot] = dir.z;
-        L.q[wave][3][slot] = __int_as_float(tid & 63);
+        L.q[wave][3][slot] = __int_as_float((tid & 63) | (k << 6));
     }
-    L.st[2][k][tid] = __int_as_float((want ? 2 : 0) | (slot << 2));
+    L.st[3][k][tid] = __int_as_float((want ? 2 : 0) | (slot << 2));
     cnt += __builtin_popcountll(m);
 }
 template <int K>
 __device__ __forceinline__ bool eval_pop(const SlowLds<K> &L, int k, float (&c)[4])
 {
     const int tid = (int)threadIdx.x, wave = tid >> 6;
-    const int f = __float_as_int(L.st[2][k][tid]);
+    const int f = __float_as_int(L.st[3][k][tid]);
     const bool want = (f & 2) != 0;
     if (want) {
         const int slot = f >> 2;
@@ -263,7 +271,7 @@ __device__ __forceinline__ void ggx_light_eval_run(SlowLds<K> &Q, int cnt, const
         const bool have = j < cnt;
         V3 L = mk(0.0f, 0.0f, 1.0f);
         int src = lane;
-        if (have) { L = mk(Q.q[wave][0][j], Q.q[wave][1][j], Q.q[wave][2][j]); src = __float_as_int(Q.q[wave][3][j]); }
+        if (have) { L = mk(Q.q[wave][0][j], Q.q[wave][1][j], Q.q[wave][2][j]); src = __float_as_int(Q.q[wave][3][j]) & 63; }
         const Ggx h = ggx_fetch(g, src);                        // every lane executes the fetches
         OrenNayar o;
         o.N = h.fr.N; o.A = lane_fetch(on.A, src); o.B = lane_fetch(on.B, src);
@@ -297,7 +305,7 @@ __device__ __forceinline__ void ggx_hit_eval_run(SlowLds<K> &Q, int cnt, const G
         const bool have = j < cnt;
         V3 L = mk(0.0f, 0.0f, 1.0f);
         int src = lane;
-        if (have) { L = mk(Q.q[wave][0][j], Q.q[wave][1][j], Q.q[wave][2][j]); src = __float_as_int(Q.q[wave][3][j]); }
+        if (have) { L = mk(Q.q[wave][0][j], Q.q[wave][1][j], Q.q[wave][2][j]); src = __float_as_int(Q.q[wave][3][j]) & 63; }
         const Ggx h = ggx_fetch(g, src);
         const float cp = lane_fetch(conePdf, src);
         if (have) {
@@ -1054,6 +1062,80 @@ using rlsh::DisneyLightIO;
         disney_prepare(d);                                                                                 \
     }
 
+// what disney_eval_pdf reads of a prepared closure
+__device__ __forceinline__ Disney disney_fetch(const Disney &d, int src)
+{
+    Disney h;
+    h.fr.N = lane_fetch(d.fr.N, src); h.fr.U = lane_fetch(d.fr.U, src); h.fr.V = lane_fetch(d.fr.V, src);
+    h.view = lane_fetch(d.view, src);
+    h.f0R = lane_fetch(d.f0R, src); h.f0G = lane_fetch(d.f0G, src); h.f0B = lane_fetch(d.f0B, src);
+    h.shR = lane_fetch(d.shR, src); h.shG = lane_fetch(d.shG, src); h.shB = lane_fetch(d.shB, src);
+    h.baseR = lane_fetch(d.baseR, src); h.baseG = lane_fetch(d.baseG, src); h.baseB = lane_fetch(d.baseB, src);
+    h.roughness = lane_fetch(d.roughness, src); h.subsurface = lane_fetch(d.subsurface, src);
+    h.metallic = 0.0f; h.clearcoatGloss = 0.0f; h.gtr2Weight = 0.0f;          // not read by the evaluation
+    h.clearcoat = lane_fetch(d.clearcoat, src); h.specRough = lane_fetch(d.specRough, src);
+    h.ax = lane_fetch(d.ax, src); h.ay = lane_fetch(d.ay, src);
+    h.vn = lane_fetch(d.vn, src); h.FV = lane_fetch(d.FV, src); h.gsV = lane_fetch(d.gsV, src); h.grV = lane_fetch(d.grV, src);
+    h.ccA2m1 = lane_fetch(d.ccA2m1, src); h.ccLogA2 = lane_fetch(d.ccLogA2, src);
+    h.ccw = lane_fetch(d.ccw, src); h.vnc = lane_fetch(d.vnc, src); h.om = lane_fetch(d.om, src);
+    return h;
+}
+// the light-sampling strategy of rlDisney's light loop for the queued light samples: both lobes (evalDiffuseLightSample,
+// evalSpecularLightSample); the diffuse lobe's three terms go back through the queue, the specular lobe's through the
+// requesting lane's state words st[0..2][k]
+template <int K>
+__device__ __forceinline__ void disney_light_eval_run(SlowLds<K> &Q, int cnt, const Disney &d, float conePdf, int mode)
+{
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    wave_lds_fence();
+    for (int base = 0; base < cnt; base += 64) {
+        const int j = base + lane;
+        const bool have = j < cnt;
+        V3 L = mk(0.0f, 0.0f, 1.0f);
+        int who = lane;
+        if (have) { L = mk(Q.q[wave][0][j], Q.q[wave][1][j], Q.q[wave][2][j]); who = __float_as_int(Q.q[wave][3][j]); }
+        const int src = who & 63, k = who >> 6;
+        const Disney h = disney_fetch(d, src);
+        const float cp = lane_fetch(conePdf, src);
+        if (have) {
+            float r, g, b, p;
+            disney_eval_pdf<true, true, true>(h, L, r, g, b, p);       // evalDiffuseLightSample, src/rlDisney.cpp:265-269
+            float wgt = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cp, p);
+            Q.q[wave][0][j] = R_DIV(r * wgt, cp); Q.q[wave][1][j] = R_DIV(g * wgt, cp); Q.q[wave][2][j] = R_DIV(b * wgt, cp);
+            disney_eval_pdf<false, true, true>(h, L, r, g, b, p);      // evalSpecularLightSample, :272-276
+            wgt = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cp, p);
+            const int t = (wave << 6) | src;
+            Q.st[0][k][t] = R_DIV(r * wgt, cp); Q.st[1][k][t] = R_DIV(g * wgt, cp); Q.st[2][k][t] = R_DIV(b * wgt, cp);
+        }
+    }
+    wave_lds_fence();
+}
+// the BSDF-sampling strategy for the queued samples that hit the light: f w / p per channel and, in the fourth word,
+// whether the sample counts (pdf > AI_EPSILON, src/rlDisney.cpp:309)
+template <int K, bool DIFFUSE>
+__device__ __forceinline__ void disney_hit_eval_run(SlowLds<K> &Q, int cnt, const Disney &d, float conePdf, int mode)
+{
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    wave_lds_fence();
+    for (int base = 0; base < cnt; base += 64) {
+        const int j = base + lane;
+        const bool have = j < cnt;
+        V3 L = mk(0.0f, 0.0f, 1.0f);
+        int src = lane;
+        if (have) { L = mk(Q.q[wave][0][j], Q.q[wave][1][j], Q.q[wave][2][j]); src = __float_as_int(Q.q[wave][3][j]) & 63; }
+        const Disney h = disney_fetch(d, src);
+        const float cp = lane_fetch(conePdf, src);
+        if (have) {
+            float r, g, b, p;
+            disney_eval_pdf<DIFFUSE, true, true>(h, L, r, g, b, p);
+            const float wgt = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(p, cp);
+            Q.q[wave][0][j] = R_DIV(r * wgt, p); Q.q[wave][1][j] = R_DIV(g * wgt, p); Q.q[wave][2][j] = R_DIV(b * wgt, p);
+            Q.q[wave][3][j] = p > kEps ? 1.0f : 0.0f;
+        }
+    }
+    wave_lds_fence();
+}
+
 // The light loop of rlDisney (src/rlDisney.cpp:695-705) for one shading point: oD / oS = the sums over the lights of
 // evalDiffuseLightSample / evalSpecularLightSample, group-reduced.  Light l: sample streams 3 l .. 3 l + 2.
 template <int G, int K, class IO>
@@ -1070,56 +1152,81 @@ __device__ __forceinline__ void disney_direct_loops(SlowLds<K> &slow, const Disn
 #pragma unroll
         for (int k = 0; k < 6; k++) scr[k] = hash_u32(seed, index, kScrambleStream + 6 * l + k);
 
-        float sR = 0.0f, sG = 0.0f, sB = 0.0f, dR = 0.0f, dG = 0.0f, dB = 0.0f;
-        for (int s0 = sub; s0 - sub < spp; s0 += K * G) {          // K samples per pass; the same trip count in every lane
-            // first sweep: the specular lobe's BSDF samples, their rare branches queued and evaluated packed
-            if (mode != RLS_MIS_LIGHT_ONLY) {
-                int cnt = 0;
-#pragma unroll 1
-                for (int k = 0; k < K; k++) {
-                    const int s = s0 + k * G;
-                    const int sc = s < spp ? s : 0;
-                    disney_spec_push<K>(slow, k, cnt, s < spp && cone.valid, d, w, bits_u01(tab[0][sc] ^ scr[4]),
-                                        bits_u01(tab[1][sc] ^ scr[5]));
-                }
-                slow_run<K>(slow, cnt);
-            }
-            // second sweep: the samples in order
+        // The estimator's two strategies as separate passes over the samples (K per pass, the same trip count in every
+        // lane), each with its own sums, grown in sample order and added at the end.  Every evaluation is queued and run
+        // packed: a light sample is evaluated only above the horizon, a BSDF sample only where it hits the light.
+        float lD[3] = { 0.0f, 0.0f, 0.0f }, lS[3] = { 0.0f, 0.0f, 0.0f }, bD[3] = { 0.0f, 0.0f, 0.0f }, bS[3] = { 0.0f, 0.0f, 0.0f };
+        const int tid = (int)threadIdx.x;
+        for (int s0 = sub; mode != RLS_MIS_BSDF_ONLY && s0 - sub < spp; s0 += K * G) {     // one light sample, both lobes
+            int qn = 0;
 #pragma unroll 1
             for (int k = 0; k < K; k++) {
                 const int s = s0 + k * G;
-                if (!(s < spp && cone.valid)) continue;
-                if (mode != RLS_MIS_BSDF_ONLY) {                     // one light sample, both lobes
-                    float rx = bits_u01(tab[0][s] ^ scr[0]), ry = bits_u01(tab[1][s] ^ scr[1]);
-                    V3 L = cone_sample(cone, rx, ry);
-                    if (dot(L, N) > 0.0f) {
-                        float r, g, b, p;
-                        disney_eval_pdf<true, true, true>(d, L, r, g, b, p);       // evalDiffuseLightSample, :265-269
-                        float wgt = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, p);
-                        dR += R_DIV(r * wgt, cone.pdf); dG += R_DIV(g * wgt, cone.pdf); dB += R_DIV(b * wgt, cone.pdf);
-                        disney_eval_pdf<false, true, true>(d, L, r, g, b, p);      // evalSpecularLightSample, :272-276
-                        wgt = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, p);
-                        sR += R_DIV(r * wgt, cone.pdf); sG += R_DIV(g * wgt, cone.pdf); sB += R_DIV(b * wgt, cone.pdf);
-                    }
-                }
-                if (mode != RLS_MIS_LIGHT_ONLY) {                    // one BSDF sample per lobe
-                    float rx = bits_u01(tab[0][s] ^ scr[2]), ry = bits_u01(tab[1][s] ^ scr[3]);
-                    V3 L = cosine_hemisphere(d.fr, rx, ry);
-                    float r, g, b, p;
-                    disney_eval_pdf<true, true, true>(d, L, r, g, b, p);
-                    if (p > kEps && cone_hit(cone, L)) {
-                        float wgt = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(p, cone.pdf);
-                        dR += R_DIV(r * wgt, p); dG += R_DIV(g * wgt, p); dB += R_DIV(b * wgt, p);
-                    }
-                    L = disney_spec_pop<K>(slow, k, d, w);
-                    disney_eval_pdf<false, true, true>(d, L, r, g, b, p);
-                    if (p > kEps && cone_hit(cone, L)) {
-                        float wgt = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(p, cone.pdf);
-                        sR += R_DIV(r * wgt, p); sG += R_DIV(g * wgt, p); sB += R_DIV(b * wgt, p);
-                    }
+                const int sc = s < spp ? s : 0;
+                V3 L = cone_sample(cone, bits_u01(tab[0][sc] ^ scr[0]), bits_u01(tab[1][sc] ^ scr[1]));
+                eval_push<K>(slow, k, qn, s < spp && cone.valid && dot(L, N) > 0.0f, L);
+            }
+            disney_light_eval_run<K>(slow, qn, d, cone.pdf, mode);
+#pragma unroll 1
+            for (int k = 0; k < K; k++) {
+                float t[4];
+                if (eval_pop<K>(slow, k, t)) {
+                    lD[0] += t[0]; lD[1] += t[1]; lD[2] += t[2];
+                    lS[0] += slow.st[0][k][tid]; lS[1] += slow.st[1][k][tid]; lS[2] += slow.st[2][k][tid];
                 }
             }
         }
+        for (int s0 = sub; mode != RLS_MIS_LIGHT_ONLY && s0 - sub < spp; s0 += K * G) {    // one BSDF sample per lobe
+            // diffuse lobe: cosine-weighted directions; those that hit the light are evaluated
+            int qn = 0;
+#pragma unroll 1
+            for (int k = 0; k < K; k++) {
+                const int s = s0 + k * G;
+                const int sc = s < spp ? s : 0;
+                V3 L = cosine_hemisphere(d.fr, bits_u01(tab[0][sc] ^ scr[2]), bits_u01(tab[1][sc] ^ scr[3]));
+                eval_push<K>(slow, k, qn, s < spp && cone.valid && cone_hit(cone, L), L);
+            }
+            disney_hit_eval_run<K, true>(slow, qn, d, cone.pdf, mode);
+#pragma unroll 1
+            for (int k = 0; k < K; k++) {
+                float t[4];
+                if (eval_pop<K>(slow, k, t) && t[3] != 0.0f) { bD[0] += t[0]; bD[1] += t[1]; bD[2] += t[2]; }
+            }
+            // specular lobe: the sampler's rare branches packed, then the reflected directions that hit the light
+            qn = 0;
+#pragma unroll 1
+            for (int k = 0; k < K; k++) {
+                const int s = s0 + k * G;
+                const int sc = s < spp ? s : 0;
+                disney_spec_push<K>(slow, k, qn, s < spp && cone.valid, d, w, bits_u01(tab[0][sc] ^ scr[4]),
+                                    bits_u01(tab[1][sc] ^ scr[5]));
+            }
+            slow_run<K>(slow, qn);
+            uint32_t hits = 0;
+#pragma unroll 1
+            for (int k = 0; k < K; k++) {
+                const int s = s0 + k * G;
+                const V3 L = disney_spec_pop<K>(slow, k, d, w);
+                const bool hit = s < spp && cone.valid && cone_hit(cone, L);
+                hits |= (hit ? 1u : 0u) << k;
+                slow.st[0][k][tid] = L.x; slow.st[1][k][tid] = L.y; slow.st[2][k][tid] = L.z;
+            }
+            wave_lds_fence();
+            qn = 0;
+#pragma unroll 1
+            for (int k = 0; k < K; k++) {
+                const V3 L = mk(slow.st[0][k][tid], slow.st[1][k][tid], slow.st[2][k][tid]);
+                eval_push<K>(slow, k, qn, ((hits >> k) & 1u) != 0, L);
+            }
+            disney_hit_eval_run<K, false>(slow, qn, d, cone.pdf, mode);
+#pragma unroll 1
+            for (int k = 0; k < K; k++) {
+                float t[4];
+                if (eval_pop<K>(slow, k, t) && t[3] != 0.0f) { bS[0] += t[0]; bS[1] += t[1]; bS[2] += t[2]; }
+            }
+        }
+        float dR = lD[0] + bD[0], dG = lD[1] + bD[1], dB = lD[2] + bD[2];
+        float sR = lS[0] + bS[0], sG = lS[1] + bS[1], sB = lS[2] + bS[2];
         if (G > 1) {
             dR = group_sum<G>(dR); dG = group_sum<G>(dG); dB = group_sum<G>(dB);
             sR = group_sum<G>(sR); sG = group_sum<G>(sG); sB = group_sum<G>(sB);
@@ -1135,7 +1242,7 @@ __device__ __forceinline__ void disney_direct_loops(SlowLds<K> &slow, const Disn
 }
 
 template <int G, int FAST_MATH = RLS_FAST>
-__global__ RLS_INT_ATTR void disney_direct_kernel(DisneyLightIO a)
+__global__ RLS_DISNEY_LIGHT_ATTR void disney_direct_kernel(DisneyLightIO a)
 {
     __shared__ uint32_t tab[2][kMaxSpp];
     __shared__ SlowLds<RLS_SPEC_BLOCK> slow;
@@ -1258,7 +1365,7 @@ __global__ RLS_INT_ATTR void ggx_shade_kernel(GgxShadeIO a)
 }
 
 template <int G, int FAST_MATH = RLS_FAST>
-__global__ RLS_INT_ATTR void disney_shade_kernel(DisneyShadeIO a)
+__global__ RLS_DISNEY_LIGHT_ATTR void disney_shade_kernel(DisneyShadeIO a)
 {
     constexpr int K = RLS_SPEC_BLOCK;
     __shared__ uint32_t tab[2][kMaxSpp];

@@ -139,3 +139,37 @@ def test_shade_hostile_inputs_and_argument_checks(gpu, oracle):
         s.shade(dev(P), lg * 5, spp_n, seed)                              # ten lights
     with pytest.raises(R.RlsError):
         s.shade(dev(P), lg, 17, seed)                                     # spp_n > 16
+
+
+@pytest.mark.parametrize("n", [1, 5, 67])
+def test_tiny_batches_pick_lane_groups(gpu, oracle, n):
+    """a handful of shading points: the host gives each point 64 lanes (pick_group), workgroups are mostly padding lanes,
+    and the packed queues carry the requests of lanes that share a point -- the results agree with the oracle up to the
+    order of the sums"""
+    spp_n, seed = 4, 91
+    c = cases.ggx_mixed(cases.SEED_PARITY, 128)
+    c = {k: np.ascontiguousarray(v[..., :n]) for k, v in c.items()}
+    d = cases.disney_mixed(cases.SEED_PARITY, 128)
+    d = {k: np.ascontiguousarray(v[..., :n]) for k, v in d.items()}
+    P = _slab(128)[:, :n].copy()
+    lo, lg = _lights(oracle)
+    ref = ggx_oracle(oracle, c).shade(P, lo, spp_n, seed, Kt=0.5)
+    got = {q: host(v) for q, v in ggx_sampler(gpu, c).shade(dev(P), lg, spp_n, seed, Kt=0.5).items()}
+    for q in ref:
+        scale = np.abs(ref[q]).max() + 1e-6
+        assert np.abs(got[q] - ref[q]).max() <= 2e-4 * scale, (q, got[q], ref[q])
+    ref = disney_oracle(oracle, d).shade(P, lo, spp_n, seed)
+    got = {q: host(v) for q, v in disney_sampler(gpu, d).shade(dev(P), lg, spp_n, seed).items()}
+    for q in ref:
+        scale = np.abs(ref[q]).max() + 1e-6
+        assert np.abs(got[q] - ref[q]).max() <= 2e-4 * scale, (q, got[q], ref[q])
+    s = cases.skin_mixed(cases.SEED_PARITY, 128)
+    sp = {k: np.ascontiguousarray(v[..., :n]) for k, v in s["params"].items()}
+    wo, N, T = (np.ascontiguousarray(s[k][:, :n]) for k in ("wo", "N", "T"))
+    kw = dict(geometry="sphere", sphere_radius=1.0, light_dir=(0.0, 0.6, 0.8), use_cavity_fade=True)
+    ref = oracle.skin_integrate(wo, N, T, sp, N, oracle.make_scene(**kw), spp_n, seed, lights=lo[:1])
+    sk = R.SkinShader(gpu, dev(wo), dev(N), dev(T), **{k: dev(v) for k, v in sp.items()})
+    got = {q: host(v) for q, v in sk.integrate(dev(N), R.make_scene(**kw), spp_n, seed, lights=lg[:1]).items()}
+    for q in ref:
+        scale = np.abs(ref[q]).max() + 1e-6
+        assert np.abs(got[q] - ref[q]).max() <= 5e-4 * scale, (q, got[q], ref[q])

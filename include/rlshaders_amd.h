@@ -240,7 +240,8 @@ rls_status rls_ggx_integrate_refract(rls_context *ctx, int64_t n, const rls_ggx_
  * samples only, BSDF samples only -- equal in expectation when sample / eval / pdf are consistent.
  * `lights` is an array of n_lights (1 .. RLS_MAX_LIGHTS) lights: the loop `while (AiLightsGetSample(sg))` visits
  * every sample of every light, so light l runs the estimator above with its own sample streams (3 l .. 3 l + 2) and
- * the AOVs are the sums over the lights, added in array order. */
+ * the AOVs are the sums over the lights, added in array order.  Within a light each strategy (light samples, BSDF
+ * samples) keeps its own sum, grown in sample order; the two are added at the end. */
 #define RLS_MAX_LIGHTS     8
 #define RLS_MIS_BOTH       0
 #define RLS_MIS_LIGHT_ONLY 1

@@ -484,7 +484,8 @@ rls_status rls_skin_sample_eval_pdf(rls_context *ctx, int64_t n, const rls_skin_
  * the mean of evalBrdf / evalPdf over the samples times the radiance env[3] of a uniform environment;
  * integrateScatter -> rls_sss_integrate_scatter's analytic scene; the light loops of 193-198 / 217-222
  * (evalLightSample per light, BEFORE integrateGlossy) -> the estimator of rls_ggx_direct_lighting's specular lobe
- * over `lights` (n_lights = 0: no lights, the loops draw no samples).  The BSDF-sampling half of that estimator calls
+ * over `lights` (n_lights = 0: no lights, the loops draw no samples; here the two strategies' terms go into ONE sum,
+ * sample by sample).  The BSDF-sampling half of that estimator calls
  * evalSample, so its Fresnel terms enter the mean too: getAvgReflectWeight = (sum over the light loops' BSDF samples
  * and integrateGlossy's samples) / (their count).  integrateGlossy draws no samples for a small colour (174-176),
  * the light loop does (167-170).  Scramble streams: sheen glossy 0, specular glossy 1, scatter 2 (as without

@@ -17,6 +17,20 @@ own 2^26 points), the only communication being the barrier and the max-over-rank
 `roofline`: algorithmic bytes per launch / average kernel duration (HIP events on the launch
 stream) against the 8 TB/s HBM3E peak.  `cpu_baseline`: the CPU oracle (a port of the reference's
 scalar closure code) timed on this host's cores on a bounded sample of the same workload.
+
+`workloads` (default run only): the other BASELINE configurations (3: rlDisney 64 spp reduced and streamed, 4: the
+rlSss probe at 2^25 and 2^26 points, 5: rlSkin at 2^26 and 2^27) and the verbs an Arnold-side stub calls one by one
+(rlGgx evalBrdf / evalPdf alone, the rlDisney one-sample triple of either lobe, the NDProfile sample, config 2 with
+uniform parameters), each measured in this same process with >= 10 warm-up launches of its own, its own
+`roofline` and a short `cpu_baseline`.  With N > 1 ranks the block holds configs 3, 4 and 5 at their per-GPU sizes.
+`--config {2,3,4,5}` makes one of them the headline (workload + points per GPU of that BASELINE configuration).
+
+Roofline accounting, per record: `frac` is on the bytes the verb's arithmetic needs (`algorithmic_bytes_per_point`;
+where SURVEY.md 8(d) counts planes the reference reads and never uses -- the albedo of NDProfile::setDistance --
+`survey_bytes_per_point` / `frac_survey_bytes` carry that figure too), `frac_counter_bytes` is on the HBM bytes the
+PMC counters saw (profiles/*_traffic.json, separate rocprofv3 --pmc passes of the same command), and
+`issue_slot_frac` prices the VALU wave-instructions the counters saw (profiles/*_flops.json) against one
+wave-instruction per SIMD every two cycles: 256 CUs x 4 SIMDs x 2.4 GHz / 2 = 1.2288e12 per second.
 """
 from __future__ import annotations
 
@@ -34,6 +48,7 @@ sys.path.insert(0, str(ROOT / "tests"))
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 VALU_PEAK_TFLOPS = 157.3  # fp32 vector peak of the same guide (packed-fp32 FMA rate; the integrators' bound)
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2   # wave64 VALU instructions per second: one per SIMD every two cycles
 SEED = 1234               # throughput seed, SURVEY.md 8(d)
 
 # stream ids (shared with oracle/rls_oracle.h)
@@ -43,6 +58,21 @@ S_XI0 = 11
 S_PARAM0 = 32
 
 
+WORKLOADS = ["ggx_reflect_refract", "ggx_reflect_refract_uniform", "ggx_reflect", "ggx_eval", "ggx_pdf", "ggx_direct",
+             "ggx_shade", "disney_direct", "disney_shade", "disney_integrate", "disney_stream", "disney_triple_diffuse",
+             "disney_triple_glossy", "sss_probe", "nd_sample", "sss_scatter", "skin", "skin_integrate"]
+
+# BASELINE.json configs -> (workload, log2 of the points ONE GPU holds): config 4 is 2^28 points over 8 GPUs, config 5 2^30
+CONFIG_PRESETS = {2: ("ggx_reflect_refract", 26), 3: ("disney_integrate", 26), 4: ("sss_probe", 25), 5: ("skin", 27)}
+
+# the `workloads` block of the default line: (workload, log2 points per GPU, timed steps)
+BLOCK_ALL = [("ggx_reflect_refract_uniform", 26, 40), ("ggx_reflect", 26, 40), ("ggx_eval", 26, 40), ("ggx_pdf", 26, 40),
+             ("disney_triple_diffuse", 26, 40), ("disney_triple_glossy", 26, 40),
+             ("disney_integrate", 26, 12), ("disney_stream", 26, 10),
+             ("sss_probe", 25, 40), ("sss_probe", 26, 40), ("nd_sample", 26, 40), ("skin", 26, 30), ("skin", 27, 20)]
+BLOCK_CONFIGS = [("disney_integrate", 26, 12), ("sss_probe", 25, 40), ("skin", 27, 20)]
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -50,10 +80,14 @@ def parse_args():
     # (3.3, 2.9, 2.7, 2.6, 2.55, 2.5 ... 2.38 ms; tools/exp_warmup.py), hence ten warm-up steps by default
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--log2-points", type=int, default=26, help="points per GPU = 2^this (config: 26)")
-    ap.add_argument("--workload", default="ggx_reflect_refract",
-                    choices=["ggx_reflect_refract", "ggx_reflect", "ggx_direct", "ggx_shade", "disney_direct", "disney_shade", "disney_integrate", "disney_stream", "sss_probe",
-                             "sss_scatter", "skin", "skin_integrate"])
+    ap.add_argument("--log2-points", type=int, default=None, help="points per GPU = 2^this (default 26, or the --config's)")
+    ap.add_argument("--workload", default=None, choices=WORKLOADS, help="headline workload (default ggx_reflect_refract)")
+    ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIG_PRESETS),
+                    help="BASELINE.json configuration as the headline: 2 ggx_reflect_refract 2^26/GPU, 3 disney_integrate "
+                         "2^26/GPU, 4 sss_probe 2^25/GPU (2^28 over 8), 5 skin 2^27/GPU (2^30 over 8)")
+    ap.add_argument("--workloads", default="auto", choices=["auto", "all", "configs", "none"],
+                    help="the `workloads` block: all = every other config and verb, configs = BASELINE configs 3-5 only; "
+                         "auto = all on one GPU / configs on several when the headline is the default, none otherwise")
     ap.add_argument("--chunk-log2", type=int, default=20, help="disney_stream: points per chunk = 2^this")
     ap.add_argument("--math", default="exact", choices=["exact", "fast"],
                     help="arithmetic of the measured kernels: exact (default, bit-faithful to the CPU closures) "
@@ -64,17 +98,40 @@ def parse_args():
                          "vector-issue-bound EXACT kernels by < 1 % (profiles/r02_placement.txt): two candidates are a check, "
                          "not a search; --math fast gains up to 15 % from 16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target seconds of CPU-baseline work")
-    return ap.parse_args()
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target seconds of CPU-baseline work (headline)")
+    ap.add_argument("--block-cpu-seconds", type=float, default=3.5, help="the same for each record of the workloads block")
+    ap.add_argument("--block-log2-points", type=int, default=None,
+                    help="every record of the workloads block at 2^this points per GPU instead of its configuration's size (tests)")
+    a = ap.parse_args()
+    explicit = a.workload is not None or a.config is not None or a.log2_points is not None
+    if a.config is not None:
+        w, l2 = CONFIG_PRESETS[a.config]
+        if a.workload is not None and a.workload != w:
+            ap.error(f"--config {a.config} is the workload {w}")
+        a.workload = w
+        if a.log2_points is None:
+            a.log2_points = l2
+    if a.workload is None:
+        a.workload = "ggx_reflect_refract"
+    if a.log2_points is None:
+        a.log2_points = 26
+    if a.workloads == "auto":
+        a.workloads = "none" if explicit else ("all" if a.gpus == 1 else "configs")
+    return a
 
 
 # ------------------------------------------------------------------------------------------------
 class Workload:
     """name, samples per point, algorithmic bytes per point, a launch() closure"""
 
-    def __init__(self, name, samples_per_point, bytes_per_point, launch, kernel, desc, bound="hbm", launches_per_step=1):
+    def __init__(self, name, samples_per_point, bytes_per_point, launch, kernel, desc, bound="hbm", launches_per_step=1,
+                 survey_bytes=None, config=None):
         self.name, self.samples_per_point, self.bytes_per_point = name, samples_per_point, bytes_per_point
         self.launch, self.kernel, self.desc = launch, kernel, desc
+        # bytes_per_point: the planes the verb's arithmetic needs (= what the kernel moves); survey_bytes: SURVEY.md 8(d)'s
+        # figure where that also counts planes the reference reads and never uses
+        self.survey_bytes = survey_bytes
+        self.config = config                       # BASELINE.json configuration this workload is the kernel of
         # "hbm": the pointwise streaming kernels; "valu": the n^2-spp integrators, which read ~100 B per point for
         # tens of triples of arithmetic (SURVEY.md 8(d): "VALU-bound, not HBM-bound ... must be stated as such")
         self.bound = bound
@@ -82,7 +139,9 @@ class Workload:
 
 
 # planes (n floats each) a workload reads and writes: sizes its arena
-PLANES = {"ggx_reflect_refract": 19 + 12, "ggx_reflect": 17 + 8, "disney_integrate": 22 + 8, "disney_stream": 22 + 8,
+PLANES = {"ggx_reflect_refract": 19 + 12, "ggx_reflect_refract_uniform": 13 + 12, "ggx_reflect": 17 + 8,
+          "ggx_eval": 17 + 8 + 3, "ggx_pdf": 17 + 8 + 1, "disney_triple_diffuse": 24 + 7, "disney_triple_glossy": 24 + 7,
+          "nd_sample": 9 + 7 + 5, "disney_integrate": 22 + 8, "disney_stream": 22 + 8,
           "sss_probe": 17 + 12,
           "sss_scatter": 15 + 3, "skin": 35 + 24, "skin_integrate": 29 + 3 + 15, "ggx_direct": 15 + 3 + 6 + 6,
           "disney_direct": 22 + 3 + 6, "ggx_shade": 15 + 3 + 6 + 4 + 18, "disney_shade": 22 + 3 + 15}     # (the generator's wo planes included where the closure ignores them)
@@ -101,7 +160,7 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
         return t
 
     wo, N, T = R.gen_frame(ctx, SEED, first, n, out=(A.planes(3), A.planes(3), A.planes(3)))
-    if name in ("ggx_reflect_refract", "ggx_reflect"):
+    if name in ("ggx_reflect_refract", "ggx_reflect", "ggx_eval", "ggx_pdf"):
         g = R.GgxSampler(ctx, wo, N, T, specColor=u3(S_KS), ior=u(S_IOR, 1.05, 2.55),
                          roughness=u(S_ROUGH, 0.05, 1.0), anisotropic=R.gen_aniso(ctx, SEED, first, n, out=A.plane()))
         xi = [u(S_XI0 + j) for j in range(4 if name == "ggx_reflect_refract" else 2)]
@@ -110,11 +169,37 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
             # in: wo3 N3 T3 Ks3 rough ior aniso xi4 = 19 f; out: wi3 f3 pdf F wt3 weight = 12 f
             wl = Workload(name, 2, (19 + 12) * 4, lambda: g.reflectRefract(xi[0], xi[1], xi[2], xi[3], out=out),
                           "ggx_kernel<5, {m}, true>",
-                          "rlGgx reflect+refract VNDF sampling, mixed params (SURVEY 8d config 2)")
+                          "rlGgx reflect+refract VNDF sampling, mixed params (SURVEY 8d config 2)", config=2)
         else:
             out = (A.planes(3), A.planes(3), A.plane(), A.plane())
-            wl = Workload(name, 1, (17 + 8) * 4, lambda: g.sampleEvalPdf(xi[0], xi[1], out=out),
-                          "ggx_kernel<3, {m}, true>", "rlGgx reflect triple, mixed params")
+            if name == "ggx_reflect":
+                wl = Workload(name, 1, (17 + 8) * 4, lambda: g.sampleEvalPdf(xi[0], xi[1], out=out),
+                              "ggx_kernel<3, {m}, true>", "rlGgx reflect triple, mixed params")
+            else:
+                # the verbs alone, as Arnold's integrators call them (src/rlGgx.h:110-127), on the directions evalSample drew
+                g.sampleEvalPdf(xi[0], xi[1], out=out)
+                wi = out[0]
+                if name == "ggx_eval":
+                    f = A.planes(3)
+                    # evalBrdf reads wo3 N3 T3 Ks3 rough ior aniso wi3 = 18 f, writes f3
+                    wl = Workload(name, 1, (18 + 3) * 4, lambda: g.evalBrdf(wi, out=f), "ggx_kernel<1, {m}, true>",
+                                  "rlGgx evalBrdf alone on sampled directions, mixed params (src/rlGgx.h:110-119)")
+                else:
+                    pdf = A.plane()
+                    # evalPdf needs no colour and no ior: wo3 N3 T3 rough aniso wi3 = 14 f, writes pdf
+                    wl = Workload(name, 1, (14 + 1) * 4, lambda: g.evalPdf(wi, out=pdf), "ggx_kernel<2, {m}, true>",
+                                  "rlGgx evalPdf alone on sampled directions, mixed params (src/rlGgx.h:121-127)",
+                                  survey_bytes=(18 + 1) * 4)
+    elif name == "ggx_reflect_refract_uniform":
+        # config 2's kernel as a stub without linked textures runs it: every node parameter one value for the batch
+        # (Arnold parameters are constants unless textured), geometry and random numbers streamed
+        g = R.GgxSampler(ctx, wo, N, T, specColor=(0.9, 0.8, 0.7), ior=1.5, roughness=0.35, anisotropic=0.25)
+        xi = [u(S_XI0 + j) for j in range(4)]
+        out = (A.planes(3), A.planes(3), A.plane(), A.plane(), A.planes(3), A.plane())
+        wl = Workload(name, 2, (13 + 12) * 4, lambda: g.reflectRefract(xi[0], xi[1], xi[2], xi[3], out=out),
+                      "ggx_kernel<5, {m}, false>",
+                      "rlGgx reflect+refract VNDF sampling, uniform node parameters (KsColor, roughness 0.35, ior 1.5, "
+                      "anisotropic 0.25): wo3 N3 T3 xi4 in, 12 f out")
     elif name == "ggx_direct":
         # the light loop of rlGgx (direct diffuse + direct specular): 16 light samples + 16 BSDF samples per lobe
         g = R.GgxSampler(ctx, wo, N, T, specColor=u3(S_KS), ior=u(S_IOR, 1.05, 2.55),
@@ -175,6 +260,19 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
                       "disney_direct_kernel<1, {m}>",
                       "rlDisney light loop: both lobes under two spherical lights, per light 16 light + 2 x 16 BSDF samples "
                       "per point, power-heuristic MIS (src/rlDisney.cpp:695-705; VALU-bound)", bound="valu")
+    elif name in ("disney_triple_diffuse", "disney_triple_glossy"):
+        # the static triple of one lobe, one sample per point (src/rlDisney.cpp:109-152): evalSample -> evalBrdf -> evalPdf
+        base = u3(S_KS)
+        sc = {k: u(S_PARAM0 + j) for j, k in enumerate(R._capi.DISNEY_SCALARS)}
+        d = R.DisneySampler(ctx, wo, N, T, base_color=base, **sc)
+        d.setSampleType(R.RLS_RAY_DIFFUSE if name.endswith("diffuse") else R.RLS_RAY_GLOSSY)
+        xi = [u(S_XI0 + j) for j in range(2)]
+        out = (A.planes(3), A.planes(3), A.plane())
+        lobe = 0 if name.endswith("diffuse") else 1
+        wl = Workload(name, 1, (24 + 7) * 4, lambda: d.sampleEvalPdf(xi[0], xi[1], out=out),
+                      "disney_kernel<3, %s, {m}, true>" % ("true" if lobe == 0 else "false"),
+                      f"rlDisney one-sample triple, {'diffuse' if lobe == 0 else 'glossy (GTR2 + clearcoat + sheen)'} lobe, "
+                      "mixed params: wo3 N3 T3 base3 + 10 scalars + xi2 in, wi3 f3 pdf out (src/rlDisney.cpp:109-152)")
     elif name in ("disney_integrate", "disney_stream"):
         base = u3(S_KS)
         sc = {k: u(S_PARAM0 + j) for j, k in enumerate(R._capi.DISNEY_SCALARS)}
@@ -184,7 +282,8 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
         if name == "disney_integrate":
             wl = Workload(name, 128, (22 + 8) * 4, lambda: d.integrate(8, SEED, out=out, first_index=first),
                           "disney_integrate_kernel<1, {m}>",
-                          "rlDisney both lobes x 64 spp, reduced mode (SURVEY 8d config 3, mode R; VALU-bound)", bound="valu")
+                          "rlDisney both lobes x 64 spp, reduced mode (SURVEY 8d config 3, mode R; VALU-bound)", bound="valu",
+                          config=3)
         else:
             # mode S: every sample's (wi, f, pdf) = 28 B per triple goes to HBM; the 241 GB of a whole 2^26-point batch
             # are produced chunk by chunk into one chunk-sized set of sample-major planes (what a consumer would read
@@ -196,14 +295,27 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
                           lambda: d.integrateChunked(8, SEED, cp, out=out, chunk=chunk, first_index=first),
                           "disney_integrate_kernel<1, {m}>",
                           f"rlDisney both lobes x 64 spp, streamed mode in chunks of {cp} points (SURVEY 8d config 3, "
-                          "mode S: 88 B in + 32 B sums + 128 x 28 B samples per point)", launches_per_step=(n + cp - 1) // cp)
+                          "mode S: 88 B in + 32 B sums + 128 x 28 B samples per point; runs at the speed of its arithmetic)",
+                          launches_per_step=(n + cp - 1) // cp, config=3)
     elif name == "sss_probe":
         s = R.SssSampler(ctx, N, T, albedo=u3(S_KS), dist=u3(S_PARAM0, 0.1, 2.1))
         xi = [u(S_XI0 + j) for j in range(2)]
         out = {"r": A.plane(), "origin": A.planes(3), "dir": A.planes(3), "maxdist": A.plane(),
                "pdf": A.plane(), "profile": A.planes(3)}
-        wl = Workload(name, 1, (14 + 12) * 4, lambda: s.getProbeRay(xi[0], xi[1], out=out),
-                      "sss_kernel<3, {m}>", "rlSss ND probe ray + pdf + profile (SURVEY 8d config 4)")
+        # SURVEY 8(d) config 4 counts 14 f in (dist3 albedo3 N3 T3 xi2) + 12 f out = 104 B; the reference computes `s` from the
+        # albedo and never uses it (src/rlSss.cpp:22-23), so the verb needs -- and the kernel moves -- 11 f in: 92 B
+        wl = Workload(name, 1, (11 + 12) * 4, lambda: s.getProbeRay(xi[0], xi[1], out=out),
+                      "sss_kernel<3, {m}>", "rlSss ND probe ray + pdf + profile (SURVEY 8d config 4)",
+                      survey_bytes=(14 + 12) * 4, config=4)
+    elif name == "nd_sample":
+        # NDProfile alone: setDistance + getRadius + getPdf + evalProfile (src/rlSss.cpp:20-106); SURVEY 8(d) "profile-only":
+        # 8 f in (dist3 albedo3 multiplier xi) + 5 f out = 52 B, of which the arithmetic needs dist3 xi: 4 f in
+        p = R.NDProfile(ctx, n, u3(S_PARAM0, 0.1, 2.1), albedo=u3(S_KS))
+        rx = u(S_XI0)
+        out = (A.plane(), A.plane(), A.planes(3))
+        wl = Workload(name, 1, (4 + 5) * 4, lambda: p.sample(rx, out=out), "sss_kernel<0, {m}>",
+                      "rlSss NDProfile alone: setDistance + getRadius + getPdf + evalProfile (SURVEY 8d config 4, profile-only)",
+                      survey_bytes=(8 + 5) * 4)
     elif name == "sss_scatter":
         # shading points on the unit sphere (P = geometric normal), 16 probe rays each
         s = R.SssSampler(ctx, N, T, albedo=u3(S_KS), dist=u3(S_PARAM0, 0.02, 0.3))
@@ -239,8 +351,11 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
         for j in range(6):
             R.gen_uniform(ctx, SEED, first, n, S_XI0 + j, out=xi[j])
         out = sk.alloc_out(arena=A)
-        wl = Workload(name, 3, (35 + 24) * 4, lambda: sk.sampleEvalPdf(xi, out=out),
-                      "skin_kernel<{m}, true>", "rlSkin sheen GGX + specular GGX + SSS (SURVEY 8d config 5)")
+        # 35 f in + 24 f out = 236 B; sss_color enters no arithmetic of the three samples (the albedo of
+        # NDProfile::setDistance, unused: src/rlSss.cpp:22-23), so 32 f in: 224 B
+        wl = Workload(name, 3, (32 + 24) * 4, lambda: sk.sampleEvalPdf(xi, out=out),
+                      "skin_kernel<{m}, true>", "rlSkin sheen GGX + specular GGX + SSS (SURVEY 8d config 5)",
+                      survey_bytes=(35 + 24) * 4, config=5)
     else:
         raise ValueError(name)
     wl.arena = A
@@ -255,11 +370,22 @@ def _cpu_leg(workload: str, n: int, threads: int):
     import cases
     u = lambda stream, lo=0.0, hi=1.0: O.gen_uniform(SEED, 0, n, stream, lo, hi)
     u3 = lambda stream, lo=0.0, hi=1.0: np.stack([u(stream + j, lo, hi) for j in range(3)])
-    if workload in ("ggx_reflect_refract", "ggx_reflect", "ggx_direct", "ggx_shade"):
+    if workload == "ggx_reflect_refract_uniform":
+        wo, N, T = cases.frame(SEED, n)
+        g = O.Ggx(wo, N, T, KsColor=(0.9, 0.8, 0.7), ior=1.5, roughness=0.35, anisotropic=0.25, nthreads=threads)
+        x = cases.xi(SEED, n, 4)
+        out = g.reflect_refract(x[0], x[1], x[2], x[3])
+        return (lambda: g.reflect_refract(x[0], x[1], x[2], x[3], out=out)), 2, "orc_batch_ggx_reflect_refract"
+    if workload in ("ggx_reflect_refract", "ggx_reflect", "ggx_eval", "ggx_pdf", "ggx_direct", "ggx_shade"):
         c = cases.ggx_mixed(SEED, n)
         g = O.Ggx(c["wo"], c["N"], c["T"], KsColor=c["KsColor"], ior=c["ior"], roughness=c["roughness"],
                   anisotropic=c["anisotropic"], nthreads=threads)
         x = cases.xi(SEED, n, 4)
+        if workload in ("ggx_eval", "ggx_pdf"):
+            wi = g.sample(x[0], x[1])[0]
+            if workload == "ggx_eval":
+                return (lambda: g.eval(wi)), 1, "orc_batch_ggx_eval"
+            return (lambda: g.pdf(wi)), 1, "orc_batch_ggx_pdf"
         if workload == "ggx_reflect_refract":
             out = g.reflect_refract(x[0], x[1], x[2], x[3])
             return (lambda: g.reflect_refract(x[0], x[1], x[2], x[3], out=out)), 2, "orc_batch_ggx_reflect_refract"
@@ -275,10 +401,15 @@ def _cpu_leg(workload: str, n: int, threads: int):
                                     env=(1.0, 0.9, 0.8))), 144, "orc_batch_ggx_shade"
         return (lambda: g.direct_lighting(P, lt, 4, SEED, Kd_color=kdc, Kd=kd, Kd_roughness=kdr, Ks=ks)), 48, \
             "orc_batch_ggx_direct_lighting"
-    if workload in ("disney_integrate", "disney_stream", "disney_direct", "disney_shade"):
+    if workload in ("disney_integrate", "disney_stream", "disney_direct", "disney_shade", "disney_triple_diffuse",
+                    "disney_triple_glossy"):
         c = cases.disney_mixed(SEED, n)
         sc = {k: c[k] for k in O.DISNEY_SCALARS}
         d = O.Disney(c["wo"], c["N"], c["T"], base_color=c["base_color"], nthreads=threads, **sc)
+        if workload.startswith("disney_triple"):
+            lobe = 0x08 if workload.endswith("diffuse") else 0x10        # AI_RAY_DIFFUSE / AI_RAY_GLOSSY
+            x = cases.xi(SEED, n, 2)
+            return (lambda: d.sample_eval_pdf(lobe, x[0], x[1])), 1, "orc_batch_disney_sample_eval_pdf"
         if workload == "disney_direct":
             P = u3(S_PARAM0 + 16, 0.0, 4.0)
             lts = [O.make_light(center=(2.0, 2.0, 6.0), radius=1.25, radiance=(3.0, 2.0, 1.0)),
@@ -291,6 +422,10 @@ def _cpu_leg(workload: str, n: int, threads: int):
             return (lambda: d.shade(P, lts, 4, SEED, env=(1.0, 0.9, 0.8))), 128, "orc_batch_disney_shade"
         streamed = workload == "disney_stream"
         return (lambda: d.integrate(8, SEED, streamed=streamed)), 128, "orc_batch_disney_integrate"
+    if workload == "nd_sample":
+        s = O.Sss(n, u3(S_PARAM0, 0.1, 2.1), u3(S_KS), nthreads=threads)
+        x = cases.xi(SEED, n, 1)
+        return (lambda: s.nd_sample(x[0])), 1, "orc_batch_nd_sample_pdf_profile"
     if workload in ("sss_probe", "sss_scatter"):
         _, N, T = cases.frame(SEED, n)
         if workload == "sss_probe":
@@ -378,6 +513,109 @@ def profile_record(workload: str, math: str, suffix: str, key: str):
 
 
 # ------------------------------------------------------------------------------------------------
+def device_identity(torch, index: int) -> dict:
+    """what tells two GPUs apart: uuid and PCI bus id of the HIP device a rank runs on"""
+    p = torch.cuda.get_device_properties(index)
+    ident = {"index": index, "name": p.name}
+    for k in ("uuid", "pci_bus_id", "pci_device_id", "pci_domain_id"):
+        v = getattr(p, k, None)
+        if v is not None:
+            ident[k] = str(v)
+    return ident
+
+
+def roofline_record(wl, n: int, kernel_ms: float, math: str) -> dict:
+    """The `roofline` object of one measured workload (module docstring: "Roofline accounting")."""
+    launches = wl.launches_per_step
+    bytes_per_launch = n * wl.bytes_per_point / launches              # algorithmic bytes of one kernel launch
+    launch_ms = kernel_ms / launches                                   # average duration of one kernel launch
+    sec = launch_ms * 1e-3
+    achieved_gbs = bytes_per_launch / sec / 1e9
+    tr = profile_record(wl.name, math, "traffic", "hbm_bytes_per_launch")
+    fl = profile_record(wl.name, math, "flops", "flops_per_point")
+    # the PMC passes ran at their own batch size: scale the counters to this launch by the points it covers
+    traffic = None
+    if tr:
+        prof_points = tr.get("points_per_launch") or (1 << 26) / launches
+        traffic = tr["hbm_bytes_per_launch"] / prof_points * (n / launches)
+    valu = fl["instructions_per_point"].get("SQ_INSTS_VALU") if fl else None
+    salu = fl["instructions_per_point"].get("SQ_INSTS_SALU") if fl else None
+    issue = valu * (n / launches / 64.0) / sec / VALU_ISSUE_PEAK if valu else None
+    tflops = fl["flops_per_point"] * (n / launches) / sec / 1e12 if fl else None
+    if wl.bound == "hbm":
+        roof = {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": int(traffic) if traffic else None}
+    else:
+        # the integrators run tens of triples per 100-odd bytes: bounded by fp32 vector issue.  Executed flops per
+        # point come from the PMC instruction mix of this kernel (add + mul + 2 fma + transcendental, fp64 counted
+        # once each), see tools/summarize_workload.py
+        roof = {"bound": "valu", "achieved": round(tflops, 3) if fl else None, "peak": VALU_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(tflops / VALU_PEAK_TFLOPS, 4) if fl else None,
+                "traffic": int(traffic) if traffic else None,
+                "flops_per_point": fl["flops_per_point"] if fl else None,
+                "hbm_gbs": round(achieved_gbs, 2), "hbm_frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
+                "frac_note": "`frac` prices executed flops against the all-FMA packed peak; the kernels' own limit is "
+                             "instruction issue: see issue_slot_frac"}
+    roof.update({
+        "frac_counter_bytes": round(traffic / sec / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+        "issue_slot_frac": round(issue, 4) if issue else None,
+        "valu_per_point": valu, "salu_per_point": salu,
+        "issue_slot_peak": "256 CUs x 4 SIMDs x 2.4 GHz / 2 = 1.2288e12 wave64 VALU instructions per second",
+        "counter_source": {"traffic": tr["file"] if tr else None, "instruction_mix": fl["file"] if fl else None,
+                           "note": "rocprofv3 --pmc passes of this command (tools/profile_workload.sh), not this run"},
+        "kernel": wl.kernel.format(m=1 if math == "fast" else 0),      # as rocprofv3 --kernel-trace names it
+        "kernel_ms": round(launch_ms, 5), "launches_per_step": launches,
+        "algorithmic_bytes_per_point": wl.bytes_per_point,
+        "algorithmic_bytes_per_launch": int(bytes_per_launch)})
+    if wl.survey_bytes:
+        roof["survey_bytes_per_point"] = wl.survey_bytes
+        roof["frac_survey_bytes"] = round(n * wl.survey_bytes / launches / sec / 1e9 / HBM_PEAK_GBS, 4)
+    return roof
+
+
+def measure(R, ctx, ranks, torch, name: str, log2n: int, steps: int, warmup: int, math: str, candidates: int,
+            chunk_log2: int, other_mode: bool):
+    """Build one workload on this rank's shard, warm it up, time `steps` passes between barriers.
+    -> (workload, n, elapsed seconds [max over ranks], kernel ms per step [max over ranks], this rank's kernel ms,
+        kernel ms per step in the other arithmetic mode or None)"""
+    from rlshaders_amd.sharding import shard_range
+    world, rank = ranks.world, ranks.rank
+    n = 1 << log2n
+    # weak scaling: the job is world * n points, rank g owns the index range [g*n, (g+1)*n)
+    first, count = shard_range(world * n, rank, world)
+    assert count == n
+    wl = make_workload(R, ctx, name, n, first=first, candidates=candidates, chunk_log2=chunk_log2)
+    torch.cuda.synchronize()
+    for _ in range(warmup):
+        wl.launch()
+    torch.cuda.synchronize()
+    ranks.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for _ in range(steps):
+        wl.launch()
+    ctx.timer_stop()
+    torch.cuda.synchronize()
+    ranks.barrier()
+    elapsed = time.perf_counter() - t0
+    my_kernel_ms = ctx.timer_elapsed_ms() / max(steps, 1)
+    elapsed, kernel_ms = ranks.max_over_ranks([elapsed, my_kernel_ms])
+    other_ms = None
+    if other_mode:
+        # the other arithmetic mode, a few launches, for the record (not the headline number)
+        ctx.set_math_mode(math != "fast")
+        wl.launch()
+        torch.cuda.synchronize()
+        ctx.timer_start()
+        for _ in range(5):
+            wl.launch()
+        ctx.timer_stop()
+        other_ms = ranks.max_over_ranks([ctx.timer_elapsed_ms() / 5])[0]
+        ctx.set_math_mode(math == "fast")
+    return wl, n, elapsed, kernel_ms, my_kernel_ms, other_ms
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -391,7 +629,7 @@ def main():
 
     import torch
     import rlshaders_amd as R
-    from rlshaders_amd.sharding import Ranks, shard_range
+    from rlshaders_amd.sharding import Ranks
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -403,76 +641,31 @@ def main():
     torch.cuda.set_device(device_index)
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ        # under torchrun, also with one rank
     ranks = Ranks(backend=backend if (world > 1 or launched) else None,
-                  device=torch.device("cuda", device_index) if backend == "nccl" else torch.device("cpu"))
+                  device=torch.device("cuda", device_index) if backend == "nccl" else torch.device("cpu"),
+                  launched=launched)
     rank = ranks.rank
 
     ctx = R.Context(device_index)
     ctx.set_math_mode(args.math == "fast")
-    n = 1 << args.log2_points
-    # weak scaling: the job is world * n points, rank g owns the index range [g*n, (g+1)*n)
-    first, count = shard_range(world * n, rank, world)
-    assert count == n
-    wl = make_workload(R, ctx, args.workload, n, first=first, candidates=args.arena_candidates,
-                       chunk_log2=args.chunk_log2)
-    torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        wl.launch()
-    torch.cuda.synchronize()
-    ranks.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ctx.timer_start()
-    for _ in range(args.steps):
-        wl.launch()
-    ctx.timer_stop()
-    torch.cuda.synchronize()
-    ranks.barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = ctx.timer_elapsed_ms() / max(args.steps, 1)
-    elapsed, kernel_ms = ranks.max_over_ranks([elapsed, kernel_ms])
+    # who is here: every rank's device, gathered before anything is timed.  Under RCCL two ranks on one GPU would
+    # halve each other's throughput silently -- refuse to produce a number then.
+    identities = ranks.gather_objects(dict(device_identity(torch, device_index), rank=rank,
+                                           host=os.uname().nodename, pid=os.getpid()))
+    keys = [(d["host"], d.get("uuid") or d.get("pci_bus_id") or d["index"]) for d in identities]
+    if backend == "nccl" and len(set(keys)) != len(keys):
+        raise SystemExit(f"bench.py: two ranks share a GPU: {identities}")
 
-    # the other arithmetic mode, a few launches, for the record (not the headline number)
-    ctx.set_math_mode(args.math != "fast")
-    wl.launch()
-    torch.cuda.synchronize()
-    ctx.timer_start()
-    for _ in range(5):
-        wl.launch()
-    ctx.timer_stop()
-    other_ms = ranks.max_over_ranks([ctx.timer_elapsed_ms() / 5])[0]
-    ctx.set_math_mode(args.math == "fast")
+    wl, n, elapsed, kernel_ms, my_ms, other_ms = measure(R, ctx, ranks, torch, args.workload, args.log2_points, args.steps,
+                                                         args.warmup, args.math, args.arena_candidates, args.chunk_log2, True)
+    per_rank_ms = ranks.gather_objects(round(my_ms, 5))
 
+    line = None
     if rank == 0:
         samples = world * n * wl.samples_per_point * args.steps
         value = samples / elapsed / 1e9
-        launches = wl.launches_per_step
-        bytes_per_step = n * wl.bytes_per_point                       # algorithmic bytes of one pass over the shard
-        bytes_per_launch = bytes_per_step / launches
-        launch_ms = kernel_ms / launches                              # average duration of one kernel launch
-        achieved_gbs = bytes_per_launch / (launch_ms * 1e-3) / 1e9
-        tr = profile_record(args.workload, args.math, "traffic", "hbm_bytes_per_launch")
-        if wl.bound == "hbm":
-            roof = {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
-                    "traffic": tr["hbm_bytes_per_launch"] if tr else None}
-        else:
-            # the integrators run tens of triples per 100-odd bytes: bounded by fp32 vector issue.  Executed flops per
-            # point come from the PMC instruction mix of this kernel (add + mul + 2 fma + transcendental, fp64 counted
-            # once each), see tools/pmc_flops.py
-            fl = profile_record(args.workload, args.math, "flops", "flops_per_point")
-            tflops = fl["flops_per_point"] * n / (kernel_ms * 1e-3) / 1e12 if fl else None
-            roof = {"bound": "valu", "achieved": round(tflops, 3) if fl else None, "peak": VALU_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(tflops / VALU_PEAK_TFLOPS, 4) if fl else None,
-                    "traffic": tr["hbm_bytes_per_launch"] if tr else None,
-                    "flops_per_point": fl["flops_per_point"] if fl else None,
-                    "flops_source": fl["file"] if fl else None,
-                    "hbm_gbs": round(achieved_gbs, 2), "hbm_frac": round(achieved_gbs / HBM_PEAK_GBS, 4)}
-        roof.update({"traffic_source": (tr["file"] + " (rocprofv3 --pmc passes of this command, not this run)") if tr else None,
-                     "kernel": wl.kernel.format(m=1 if args.math == "fast" else 0),   # as rocprofv3 --kernel-trace names it
-                     "kernel_ms": round(launch_ms, 5), "launches_per_step": launches,
-                     "algorithmic_bytes_per_point": wl.bytes_per_point,
-                     "algorithmic_bytes_per_launch": int(bytes_per_launch)})
+        roof = roofline_record(wl, n, kernel_ms, args.math)
+        bytes_per_step = n * wl.bytes_per_point
         line = {
             "metric": "BSDF Gsamples/sec (eval+sample+pdf)",
             "value": round(value, 4),
@@ -486,7 +679,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": wl.desc, "name": wl.name, "math": args.math, "points_per_gpu": n,
+            "config": {"workload": wl.desc, "name": wl.name, "baseline_config": wl.config, "math": args.math,
+                       "points_per_gpu": n, "points_total": world * n,
                        "samples_per_point": wl.samples_per_point, "sharding": f"index-range x{world}, no collective",
                        "control_plane": (f"torch.distributed {backend}" if ranks.dist is not None else "single process"),
                        "placement": wl.arena.info(),
@@ -496,6 +690,10 @@ def main():
                        f"warmup {args.warmup} < 10: the clock ramp of the first launches is inside the timed region "
                        "(under-reports by ~4 % at 5, ~15 % at 1)"},
             "roofline": roof,
+            # the ranks that took part, as gathered over the process group: a straggler or a doubled-up device shows here
+            "ranks": {"ranks_seen": len(identities), "world_size": world, "backend": backend if ranks.dist is not None else None,
+                      "devices": identities, "distinct_devices": len(set(keys)),
+                      "per_rank_kernel_ms": per_rank_ms, "min_kernel_ms": min(per_rank_ms), "max_kernel_ms": max(per_rank_ms)},
         }
         other = "exact" if args.math == "fast" else "fast"
         line["other_math_mode"] = {"math": other, "kernel_ms": round(other_ms, 5),
@@ -505,6 +703,35 @@ def main():
             cb = cpu_baseline(args.workload, args.cpu_seconds)
             if cb:
                 line["cpu_baseline"] = cb
+    del wl
+    torch.cuda.empty_cache()
+
+    # ---- the other configurations and verbs, same process, each with its own warm-up --------------------------------
+    block = {"all": BLOCK_ALL, "configs": BLOCK_CONFIGS, "none": []}[args.workloads]
+    if args.block_log2_points is not None:
+        block = [(w, args.block_log2_points, min(st, 5)) for w, _, st in block]
+        block = sorted(set(block), key=block.index)
+    block = [b for b in block if not (b[0] == args.workload and b[1] == args.log2_points)]
+    records = []
+    for name, log2n, steps in block:
+        warm = max(10, args.warmup)
+        w, bn, el, kms, my, _ = measure(R, ctx, ranks, torch, name, log2n, steps, warm, args.math, 1, args.chunk_log2, False)
+        prm = ranks.gather_objects(round(my, 5))
+        if rank == 0:
+            rec = {"name": w.name, "baseline_config": w.config, "workload": w.desc, "points_per_gpu": bn,
+                   "points_total": world * bn, "samples_per_point": w.samples_per_point,
+                   "value": round(world * bn * w.samples_per_point * steps / el / 1e9, 4), "unit": "Gsamples/s",
+                   "steps": steps, "warmup": warm, "ms_per_step": round(el / steps * 1e3, 5),
+                   "roofline": roofline_record(w, bn, kms, args.math), "per_rank_kernel_ms": prm}
+            if world == 1 and not args.no_cpu_baseline:
+                rec["cpu_baseline"] = cpu_baseline(name, args.block_cpu_seconds)
+            records.append(rec)
+        del w
+        torch.cuda.empty_cache()
+
+    if rank == 0:
+        if block:
+            line["workloads"] = records
         print(json.dumps(line), flush=True)
 
     ranks.close()

@@ -54,7 +54,8 @@ enum {
     RLS_ERR_NO_DEVICE = 2,          /* no HIP device / bad ordinal                      */
     RLS_ERR_HIP = 3,                /* a HIP runtime call failed; see rls_last_error()  */
     RLS_ERR_OUT_OF_MEMORY = 4,
-    RLS_ERR_UNSUPPORTED = 5
+    RLS_ERR_UNSUPPORTED = 5,
+    RLS_ERR_ABORTED = 6             /* a caller-supplied callback asked to stop (rls_disney_integrate_chunked) */
 };
 
 typedef struct rls_context rls_context;
@@ -326,7 +327,10 @@ rls_status rls_disney_integrate(rls_context *ctx, int64_t n, const rls_disney_cl
  * explicit sample loop, src/rlDisney.cpp:299-312): it is called on the host right after a chunk's kernel has
  * been enqueued; work it enqueues on the context's stream runs after the chunk is complete and before the
  * next chunk overwrites the buffers.  NULL discards the samples (measurement).  A non-zero return stops the
- * walk.  The samples are those of the unchunked rls_disney_integrate call. */
+ * walk and the call returns RLS_ERR_ABORTED.  A consumer is a host-side effect per chunk: it cannot be recorded
+ * into a launch graph (a replay would overwrite the chunk buffers back to back without calling it), so between
+ * rls_graph_begin_capture and rls_graph_end_capture a call with a consumer is refused (RLS_ERR_UNSUPPORTED).
+ * The samples are those of the unchunked rls_disney_integrate call. */
 typedef int (*rls_disney_chunk_fn)(void *user, int64_t first_point, int64_t count,
                                    const rls_disney_stream_out *chunk);
 rls_status rls_disney_integrate_chunked(rls_context *ctx, int64_t n, const rls_disney_closure *c,

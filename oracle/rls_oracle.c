@@ -1930,8 +1930,16 @@ float orc_oren_nayar_pdf(const orc_oren_nayar *o, orc_v3 wi)
 
 /* the light loop of rlGgx for one shading point (src/rlGgx.cpp:285-299): the sums over the lights of the Oren-Nayar
  * closure's and of the GGX triple's AiEvaluateLightSample, BEFORE diffuse *= diffuseColor, specular *= specularWeight */
+/* Summation order of the estimator.  The loop it stands for -- `while (AiLightsGetSample(sg))` adding
+ * AiEvaluateLightSample's result -- is closed, so the order is the builder's to define, and it is defined ONCE, here:
+ * the CANONICAL form (two_sums = 0) keeps one running sum per AOV and adds each sample's terms as they come, the light
+ * sample's first, then the BSDF sample's.  The second form (two_sums = 1; the orc_batch_*_two_sums entry points) keeps
+ * one sum per strategy, each grown in sample order, and adds the two at the end: that is the order the device kernels
+ * produce, because they run the two strategies as separate passes over the samples.  The two forms add the same terms;
+ * tests/test_oracle_light_loops.py holds them to 1e-6 of each other, the GPU tests hold the kernels to the second form
+ * bit for bit. */
 static void ggx_light_loop(orc_ggx *g, const orc_oren_nayar *on, orc_v3 wo, orc_v3 N, orc_v3 T, orc_v3 P, int sampleDiffuse,
-                           const orc_light *lights, int n_lights, int spp, uint32_t seed, uint64_t index,
+                           const orc_light *lights, int n_lights, int spp, uint32_t seed, uint64_t index, int two_sums,
                            orc_rgb *diffuse, orc_rgb *specular)
 {
     const float inv = 1.0f / (float)spp;
@@ -1941,9 +1949,8 @@ static void ggx_light_loop(orc_ggx *g, const orc_oren_nayar *on, orc_v3 wo, orc_
         const int mode = lt->mis_mode;
         const uint32_t st = 3u * (uint32_t)l;
         light_cone c = cone_make(lt, P);
-        /* the two strategies of the estimator keep their own sums (light samples; BSDF samples), each grown in sample
-         * order and added at the end: the device runs the strategies as separate passes over the samples */
-        float lR = 0.0f, lG = 0.0f, lB = 0.0f, lA = 0.0f, bR = 0.0f, bG = 0.0f, bB = 0.0f, bA = 0.0f;
+        float acc[2][4] = { { 0 } };                           /* [strategy][r, g, b (GGX), a (Oren-Nayar)] */
+        float *la = acc[0], *ba = two_sums ? acc[1] : acc[0];
         for (int s = 0; s < spp && c.valid; s++) {
             float rx, ry;
             if (mode != 2) {                                   /* one light sample, both lobes */
@@ -1953,11 +1960,11 @@ static void ggx_light_loop(orc_ggx *g, const orc_oren_nayar *on, orc_v3 wo, orc_
                     orc_rgb f = orc_ggx_eval_brdf(g, L);
                     float pb = orc_ggx_eval_pdf(g, L);
                     float w = mode == 1 ? 1.0f : power_heuristic(c.pdf, pb);
-                    lR += f.r * w / c.pdf; lG += f.g * w / c.pdf; lB += f.b * w / c.pdf;
+                    la[0] += f.r * w / c.pdf; la[1] += f.g * w / c.pdf; la[2] += f.b * w / c.pdf;
                     if (sampleDiffuse) {
                         float fd = orc_oren_nayar_brdf(on, wo, L);
                         float wd = mode == 1 ? 1.0f : power_heuristic(c.pdf, orc_oren_nayar_pdf(on, L));
-                        lA += fd * wd / c.pdf;
+                        la[3] += fd * wd / c.pdf;
                     }
                 }
             }
@@ -1968,7 +1975,7 @@ static void ggx_light_loop(orc_ggx *g, const orc_oren_nayar *on, orc_v3 wo, orc_
                     orc_rgb f = orc_ggx_eval_brdf(g, L);
                     float pb = orc_ggx_eval_pdf(g, L);
                     float w = mode == 2 ? 1.0f : power_heuristic(pb, c.pdf);
-                    bR += f.r * w / pb; bG += f.g * w / pb; bB += f.b * w / pb;
+                    ba[0] += f.r * w / pb; ba[1] += f.g * w / pb; ba[2] += f.b * w / pb;
                 }
                 if (sampleDiffuse) {
                     orc_sample_02(seed, index, st + 2, (uint32_t)s, &rx, &ry);
@@ -1977,12 +1984,13 @@ static void ggx_light_loop(orc_ggx *g, const orc_oren_nayar *on, orc_v3 wo, orc_
                     if (pd > 0.0f && cone_hit(&c, Ld)) {
                         float fd = orc_oren_nayar_brdf(on, wo, Ld);
                         float wd = mode == 2 ? 1.0f : power_heuristic(pd, c.pdf);
-                        bA += fd * wd / pd;
+                        ba[3] += fd * wd / pd;
                     }
                 }
             }
         }
-        const float sR = lR + bR, sG = lG + bG, sB = lB + bB, dA = lA + bA;
+        const float sR = two_sums ? acc[0][0] + acc[1][0] : acc[0][0], sG = two_sums ? acc[0][1] + acc[1][1] : acc[0][1];
+        const float sB = two_sums ? acc[0][2] + acc[1][2] : acc[0][2], dA = two_sums ? acc[0][3] + acc[1][3] : acc[0][3];
         const float *rad = lt->radiance;
         const orc_rgb tS = rgb(rad[0] * sR * inv, rad[1] * sG * inv, rad[2] * sB * inv);
         const orc_rgb tD = rgb(rad[0] * dA * inv, rad[1] * dA * inv, rad[2] * dA * inv);
@@ -1999,6 +2007,7 @@ typedef struct {
     orc_v3p dd, ds;
     /* the whole shader_evaluate (orc_batch_ggx_shade) */
     int shade, traced; const float *env; orc_v3p refr, id, is, out;
+    int two_sums;
 } light_job;
 
 #define SHADE_STREAM (3u * 8u)      /* first sample stream after the lights' (RLS_MAX_LIGHTS = 8) */
@@ -2019,7 +2028,7 @@ static void light_range(int64_t lo, int64_t hi, void *ctx)
         const int sampleDiffuse = !rgb_is_small(diffuseColor);                          /* :280 */
         orc_rgb diffuse, specular;
         ggx_light_loop(&g, &on, wo, N, T, ld3(j->P, i), sampleDiffuse, j->lights, j->n_lights, j->spp, j->seed, index,
-                       &diffuse, &specular);
+                       j->two_sums, &diffuse, &specular);
         diffuse = rgb(diffuse.r * diffuseColor.r, diffuse.g * diffuseColor.g, diffuse.b * diffuseColor.b);   /* :304 */
         specular = rgb(specular.r * ks, specular.g * ks, specular.b * ks);                                  /* :305 */
         stc(j->ds, i, specular);
@@ -2068,7 +2077,17 @@ void orc_batch_ggx_direct_lighting(int64_t n, const orc_ggx_soa *in, const orc_g
                                    orc_v3p direct_diffuse, orc_v3p direct_specular, int nthreads)
 {
     light_job j = { in, sh, P, lights, n_lights, spp_n * spp_n, seed, first_index, direct_diffuse, direct_specular,
-                    0, 0, NULL, {0}, {0}, {0}, {0} };
+                    0, 0, NULL, {0}, {0}, {0}, {0}, 0 };
+    parallel_for(n, nthreads, light_range, &j);
+}
+
+/* the same with one sum per strategy (the device kernels' order; see ggx_light_loop) */
+void orc_batch_ggx_direct_lighting_two_sums(int64_t n, const orc_ggx_soa *in, const orc_ggx_shader_soa *sh, orc_cv3p P,
+                                            const orc_light *lights, int n_lights, int spp_n, uint32_t seed,
+                                            uint64_t first_index, orc_v3p direct_diffuse, orc_v3p direct_specular, int nthreads)
+{
+    light_job j = { in, sh, P, lights, n_lights, spp_n * spp_n, seed, first_index, direct_diffuse, direct_specular,
+                    0, 0, NULL, {0}, {0}, {0}, {0}, 1 };
     parallel_for(n, nthreads, light_range, &j);
 }
 
@@ -2077,7 +2096,16 @@ void orc_batch_ggx_shade(int64_t n, const orc_ggx_soa *in, const orc_ggx_shader_
                          uint64_t first_index, const orc_ggx_shade_out_soa *out, int nthreads)
 {
     light_job j = { in, sh, P, lights, n_lights, spp_n * spp_n, seed, first_index, out->direct_diffuse, out->direct_specular,
-                    1, traced, env, out->refraction, out->indirect_diffuse, out->indirect_specular, out->out };
+                    1, traced, env, out->refraction, out->indirect_diffuse, out->indirect_specular, out->out, 0 };
+    parallel_for(n, nthreads, light_range, &j);
+}
+
+void orc_batch_ggx_shade_two_sums(int64_t n, const orc_ggx_soa *in, const orc_ggx_shader_soa *sh, orc_cv3p P,
+                                  const orc_light *lights, int n_lights, const float env[3], int traced, int spp_n,
+                                  uint32_t seed, uint64_t first_index, const orc_ggx_shade_out_soa *out, int nthreads)
+{
+    light_job j = { in, sh, P, lights, n_lights, spp_n * spp_n, seed, first_index, out->direct_diffuse, out->direct_specular,
+                    1, traced, env, out->refraction, out->indirect_diffuse, out->indirect_specular, out->out, 1 };
     parallel_for(n, nthreads, light_range, &j);
 }
 
@@ -2090,6 +2118,7 @@ typedef struct {
     orc_v3p dd, ds;
     /* the whole shader_evaluate (orc_batch_disney_shade) */
     int shade; const float *env; orc_v3p id, is, out;
+    int two_sums;                                                  /* see ggx_light_loop */
 } dlight_job;
 
 static void dlight_range(int64_t lo, int64_t hi, void *ctx)
@@ -2109,9 +2138,9 @@ static void dlight_range(int64_t lo, int64_t hi, void *ctx)
             const int mode = lt->mis_mode;
             const uint32_t st = 3u * (uint32_t)l;
             light_cone c = cone_make(lt, ld3(j->P, i));
-            /* the two strategies of the estimator keep their own sums (light samples; BSDF samples), each grown in
-             * sample order and added at the end: the device runs the strategies as separate passes */
-            float la[2][3] = { { 0 } }, ba[2][3] = { { 0 } };      /* [diffuse, specular][r, g, b] */
+            /* canonical: one running sum per lobe; two_sums: one per strategy, added at the end (see ggx_light_loop) */
+            float sum_l[2][3] = { { 0 } }, sum_b[2][3] = { { 0 } };   /* [diffuse, specular][r, g, b] */
+            float (*la)[3] = sum_l, (*ba)[3] = j->two_sums ? sum_b : sum_l;
             for (int s = 0; s < j->spp && c.valid; s++) {
                 float rx, ry;
                 if (mode != 2) {                                   /* one light sample, both lobes */
@@ -2143,7 +2172,7 @@ static void dlight_range(int64_t lo, int64_t hi, void *ctx)
             }
             float acc[2][3];
             for (int lobe = 0; lobe < 2; lobe++)
-                for (int k = 0; k < 3; k++) acc[lobe][k] = la[lobe][k] + ba[lobe][k];
+                for (int k = 0; k < 3; k++) acc[lobe][k] = j->two_sums ? sum_l[lobe][k] + sum_b[lobe][k] : sum_l[lobe][k];
             const float *rad = lt->radiance;
             const orc_rgb tD = rgb(rad[0] * acc[0][0] * inv, rad[1] * acc[0][1] * inv, rad[2] * acc[0][2] * inv);
             const orc_rgb tS = rgb(rad[0] * acc[1][0] * inv, rad[1] * acc[1][1] * inv, rad[2] * acc[1][2] * inv);
@@ -2182,7 +2211,16 @@ void orc_batch_disney_direct_lighting(int64_t n, const orc_disney_soa *in, orc_c
                                       orc_v3p direct_diffuse, orc_v3p direct_specular, int nthreads)
 {
     dlight_job j = { in, P, lights, n_lights, spp_n * spp_n, seed, first_index, direct_diffuse, direct_specular,
-                     0, NULL, {0}, {0}, {0} };
+                     0, NULL, {0}, {0}, {0}, 0 };
+    parallel_for(n, nthreads, dlight_range, &j);
+}
+
+void orc_batch_disney_direct_lighting_two_sums(int64_t n, const orc_disney_soa *in, orc_cv3p P, const orc_light *lights,
+                                               int n_lights, int spp_n, uint32_t seed, uint64_t first_index,
+                                               orc_v3p direct_diffuse, orc_v3p direct_specular, int nthreads)
+{
+    dlight_job j = { in, P, lights, n_lights, spp_n * spp_n, seed, first_index, direct_diffuse, direct_specular,
+                     0, NULL, {0}, {0}, {0}, 1 };
     parallel_for(n, nthreads, dlight_range, &j);
 }
 
@@ -2191,7 +2229,16 @@ void orc_batch_disney_shade(int64_t n, const orc_disney_soa *in, orc_cv3p P, con
                             const orc_disney_shade_out_soa *out, int nthreads)
 {
     dlight_job j = { in, P, lights, n_lights, spp_n * spp_n, seed, first_index, out->direct_diffuse, out->direct_specular,
-                     1, env, out->indirect_diffuse, out->indirect_specular, out->out };
+                     1, env, out->indirect_diffuse, out->indirect_specular, out->out, 0 };
+    parallel_for(n, nthreads, dlight_range, &j);
+}
+
+void orc_batch_disney_shade_two_sums(int64_t n, const orc_disney_soa *in, orc_cv3p P, const orc_light *lights, int n_lights,
+                                     const float env[3], int spp_n, uint32_t seed, uint64_t first_index,
+                                     const orc_disney_shade_out_soa *out, int nthreads)
+{
+    dlight_job j = { in, P, lights, n_lights, spp_n * spp_n, seed, first_index, out->direct_diffuse, out->direct_specular,
+                     1, env, out->indirect_diffuse, out->indirect_specular, out->out, 1 };
     parallel_for(n, nthreads, dlight_range, &j);
 }
 

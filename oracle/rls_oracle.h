@@ -380,6 +380,13 @@ float orc_oren_nayar_pdf(const orc_oren_nayar *o, orc_v3 wi);
 void  orc_batch_ggx_direct_lighting(int64_t n, const orc_ggx_soa *in, const orc_ggx_shader_soa *sh, orc_cv3p P,
                                     const orc_light *lights, int n_lights, int spp_n, uint32_t seed, uint64_t first_index,
                                     orc_v3p direct_diffuse, orc_v3p direct_specular, int nthreads);
+/* Summation order of the light loops' estimator (rls_oracle.c, ggx_light_loop): the entry points above and below keep ONE
+ * running sum per AOV, each sample's terms added as they come (light sample, then BSDF sample) -- the canonical form.
+ * The *_two_sums twins keep one sum per strategy and add the two at the end: the order the device kernels produce (they
+ * run the strategies as separate passes).  Same terms; the forms agree to 1e-6 (tests/test_oracle_light_loops.py). */
+void  orc_batch_ggx_direct_lighting_two_sums(int64_t n, const orc_ggx_soa *in, const orc_ggx_shader_soa *sh, orc_cv3p P,
+                                             const orc_light *lights, int n_lights, int spp_n, uint32_t seed,
+                                             uint64_t first_index, orc_v3p direct_diffuse, orc_v3p direct_specular, int nthreads);
 /* shader_evaluate of rlGgx for a camera ray, whole (src/rlGgx.cpp:248-327): the light loop, transmission =
  * integrateRefract x KtColor x Kt (black for a small product), indirect diffuse = diffuseColor x AiBRDFIntegrate over the
  * Oren-Nayar closure (mean of brdf / pdf over cosine-weighted samples x env), indirect glossy = integrateGlossy x Ks,
@@ -389,17 +396,26 @@ typedef struct { orc_v3p direct_diffuse, direct_specular, refraction, indirect_d
 void  orc_batch_ggx_shade(int64_t n, const orc_ggx_soa *in, const orc_ggx_shader_soa *sh, orc_cv3p P,
                           const orc_light *lights, int n_lights, const float env[3], int traced, int spp_n, uint32_t seed,
                           uint64_t first_index, const orc_ggx_shade_out_soa *out, int nthreads);
+void  orc_batch_ggx_shade_two_sums(int64_t n, const orc_ggx_soa *in, const orc_ggx_shader_soa *sh, orc_cv3p P,
+                                   const orc_light *lights, int n_lights, const float env[3], int traced, int spp_n,
+                                   uint32_t seed, uint64_t first_index, const orc_ggx_shade_out_soa *out, int nthreads);
 /* shader_evaluate of rlDisney for a camera ray, whole (src/rlDisney.cpp:685-727): the light loop + integrateDiffuse +
  * integrateGlossy (sum of brdf / pdf over the valid samples x 1 / spp x env); streams: lights as above, 24, 25 */
 typedef struct { orc_v3p direct_diffuse, direct_specular, indirect_diffuse, indirect_specular, out; } orc_disney_shade_out_soa;
 void  orc_batch_disney_shade(int64_t n, const orc_disney_soa *in, orc_cv3p P, const orc_light *lights, int n_lights,
                              const float env[3], int spp_n, uint32_t seed, uint64_t first_index,
                              const orc_disney_shade_out_soa *out, int nthreads);
+void  orc_batch_disney_shade_two_sums(int64_t n, const orc_disney_soa *in, orc_cv3p P, const orc_light *lights, int n_lights,
+                                      const float env[3], int spp_n, uint32_t seed, uint64_t first_index,
+                                      const orc_disney_shade_out_soa *out, int nthreads);
 /* Direct lighting of the rlDisney node (src/rlDisney.cpp:695-705: evalDiffuseLightSample + evalSpecularLightSample per
  * light, 265-277), same stand-ins; streams 3 l (light samples), 3 l + 1 (diffuse BSDF samples), 3 l + 2 (specular) */
 void  orc_batch_disney_direct_lighting(int64_t n, const orc_disney_soa *in, orc_cv3p P, const orc_light *lights,
                                        int n_lights, int spp_n, uint32_t seed, uint64_t first_index,
                                        orc_v3p direct_diffuse, orc_v3p direct_specular, int nthreads);
+void  orc_batch_disney_direct_lighting_two_sums(int64_t n, const orc_disney_soa *in, orc_cv3p P, const orc_light *lights,
+                                                int n_lights, int spp_n, uint32_t seed, uint64_t first_index,
+                                                orc_v3p direct_diffuse, orc_v3p direct_specular, int nthreads);
 
 /* utility closures, batch form (a2-a5) */
 void orc_batch_util(int64_t n, const float *a, const float *b, orc_v3p spherical, orc_v3p disk, int nthreads);

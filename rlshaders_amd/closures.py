@@ -35,9 +35,11 @@ class Context:
         check(self.lib.rls_context_create(self.device, C.byref(h)))
         self.handle = h
         self.torch_device = torch.device("cuda", self.device)
-        self._private_stream = not use_torch_stream          # a fresh rls_context launches on its own stream
+        self._ext_stream = None                 # torch's view of the private stream while launches go there
         if use_torch_stream:
             self.use_stream(torch.cuda.current_stream(self.torch_device))
+        else:
+            self.use_stream(None)
 
     def use_stream(self, stream: Optional["torch.cuda.Stream"]) -> None:
         """stream = a torch.cuda.Stream (its handle may be 0 = the null stream), or None for the
@@ -46,15 +48,20 @@ class Context:
         On the private stream (``use_stream(None)`` / ``use_torch_stream=False``) the launches are NOT ordered with
         torch's own work: torch fills and frees tensors on its current stream, the kernels read and write them on a
         non-blocking stream.  The caller then orders the two -- ``torch.cuda.synchronize()`` (or an event) after the
-        inputs are produced and ``ctx.synchronize()`` before the outputs are read or any tensor a launch used (inputs,
-        and outputs this class allocated) is dropped: torch's caching allocator recycles a freed block for later work
-        on ITS stream without knowing that a kernel on the private stream may still be using it."""
+        inputs are produced and ``ctx.synchronize()`` before the outputs are read or an INPUT tensor a launch used is
+        dropped: torch's caching allocator recycles a freed block for later work on ITS stream without knowing that a
+        kernel on the private stream may still be using it.  Tensors this class allocates (``ctx.empty``: the outputs of
+        every verb called without ``out=``) are registered with the allocator as in use on the private stream
+        (``Tensor.record_stream``), and switching to the private stream makes it wait for the work torch's current
+        stream holds at that moment."""
         if stream is None:
             check(self.lib.rls_context_use_own_stream(self.handle))
-            self._private_stream = True
+            self._ext_stream = torch.cuda.ExternalStream(int(self.lib.rls_context_get_stream(self.handle) or 0),
+                                                         device=self.torch_device)
+            self._ext_stream.wait_stream(torch.cuda.current_stream(self.torch_device))
         else:
             check(self.lib.rls_context_set_stream(self.handle, C.c_void_p(stream.cuda_stream)))
-            self._private_stream = False
+            self._ext_stream = None
 
     def set_math_mode(self, fast: bool) -> None:
         """False: RLS_MATH_EXACT (default, bit-faithful to the CPU closures); True: RLS_MATH_FAST."""
@@ -102,7 +109,10 @@ class Context:
 
     # -- helpers --------------------------------------------------------------------------------
     def empty(self, *shape) -> torch.Tensor:
-        return torch.empty(*shape, dtype=torch.float32, device=self.torch_device)
+        t = torch.empty(*shape, dtype=torch.float32, device=self.torch_device)
+        if self._ext_stream is not None:
+            t.record_stream(self._ext_stream)        # allocated on torch's stream, written on the private one
+        return t
 
 
 class Arena:
@@ -549,7 +559,7 @@ class DisneySampler:
         stands for the per-sample loop body of the reference (src/rlDisney.cpp:299-312).  Returns (sums, chunk)."""
         n, ctx = self.n, self.ctx
         spp = spp_n * spp_n
-        chunk_points = min(int(chunk_points), n)
+        chunk_points = max(1, min(int(chunk_points), n))
         m = 2 * spp * chunk_points
         if out is None:
             out = {"diffuse_sum": ctx.empty(3, n), "diffuse_count": ctx.empty(n),
@@ -607,10 +617,10 @@ class NDProfile:
         self._keep = (dist, albedo, multiplier)
         self.c = _sss_closure(self.n, dist, multiplier, albedo, None, None, False)
 
-    def sample(self, rx):
+    def sample(self, rx, out=None):
         """getRadius(rx), getPdf(r), evalProfile(r) in one pass -> (r, pdf, profile)."""
         n, ctx = self.n, self.ctx
-        r, pdf, prof = ctx.empty(n), ctx.empty(n), ctx.empty(3, n)
+        r, pdf, prof = out if out is not None else (ctx.empty(n), ctx.empty(n), ctx.empty(3, n))
         check(ctx.lib.rls_nd_sample(ctx.handle, n, C.byref(self.c), plane(rx, n, "rx"), plane(r, n, "r"),
                                     plane(pdf, n, "pdf"), rgb(prof, n, "profile")))
         return r, pdf, prof

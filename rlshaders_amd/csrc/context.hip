@@ -46,6 +46,7 @@ const char *rls_status_string(rls_status s)
     case RLS_ERR_HIP: return "HIP runtime error";
     case RLS_ERR_OUT_OF_MEMORY: return "out of device memory";
     case RLS_ERR_UNSUPPORTED: return "unsupported";
+    case RLS_ERR_ABORTED: return "stopped by a callback";
     default: return "unknown status";
     }
 }

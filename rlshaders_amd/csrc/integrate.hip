@@ -1655,6 +1655,11 @@ rls_status rls_disney_integrate_chunked(rls_context *ctx, int64_t n, const rls_d
     RLS_REQUIRE(n >= 0, "n < 0");
     RLS_REQUIRE(chunk_points >= 1, "chunk_points < 1");
     RLS_REQUIRE(chunk != nullptr, "chunk buffers are NULL");
+    if (ctx->capturing && consume != nullptr) {
+        // the consumer runs on the host between chunks; a graph replay would drop it and lose every chunk but the last
+        rlsh::set_error("rls_disney_integrate_chunked: a consumer callback cannot be recorded into a launch graph");
+        return RLS_ERR_UNSUPPORTED;
+    }
     if (n == 0) return RLS_OK;
     RLS_REQUIRE(c != nullptr, "closure is NULL");
     for (int64_t p0 = 0; p0 < n; p0 += chunk_points) {
@@ -1674,7 +1679,7 @@ rls_status rls_disney_integrate_chunked(rls_context *ctx, int64_t n, const rls_d
             int rc = consume(user, p0, count, chunk);
             if (rc != 0) {
                 rlsh::set_error("rls_disney_integrate_chunked: consumer returned %d at point %lld", rc, (long long)p0);
-                return RLS_ERR_INVALID_ARGUMENT;
+                return RLS_ERR_ABORTED;
             }
         }
     }

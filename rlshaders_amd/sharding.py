@@ -28,23 +28,29 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
 class Ranks:
     """Thin wrapper over torch.distributed that degrades to a no-op for a single process."""
 
-    def __init__(self, backend: Optional[str] = None, device: Optional[torch.device] = None):
+    def __init__(self, backend: Optional[str] = None, device: Optional[torch.device] = None, launched: bool = False):
+        """``launched``: opt in to initialising the process group for a ONE-rank run as well (bench.py and the tests pass it
+        when a launcher started them: the control path of an N-rank run -- init_process_group("nccl", device_id), barrier,
+        device all_reduce -- is then the one a single-GPU box exercises too).  Without it a single process never touches
+        torch.distributed, whatever RANK / MASTER_PORT variables its environment happens to export.  A default process
+        group the caller has already created is reused, never re-initialised, and left alone by close()."""
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.device = device if device is not None else torch.device("cpu")
         self.dist = None
-        # under a launcher (torchrun exports RANK + MASTER_PORT) the process group is initialised even for one rank:
-        # the control path of an N-rank run -- init_process_group("nccl", device_id), barrier, device all_reduce --
-        # is then the one a single-GPU box exercises too
-        launched = "RANK" in os.environ and "MASTER_PORT" in os.environ
+        self._owns_group = False
         if self.world > 1 or launched:
             import torch.distributed as dist
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            if backend is None:
-                backend = "nccl" if self.device.type == "cuda" else "gloo"
-            kw = {"device_id": self.device} if backend == "nccl" else {}
-            dist.init_process_group(backend, **kw)
+            if dist.is_available() and dist.is_initialized():
+                self.world, self.rank = dist.get_world_size(), dist.get_rank()
+            else:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                if backend is None:
+                    backend = "nccl" if self.device.type == "cuda" else "gloo"
+                kw = {"device_id": self.device} if backend == "nccl" else {}
+                dist.init_process_group(backend, **kw)
+                self._owns_group = True
             self.dist = dist
 
     def barrier(self) -> None:
@@ -68,8 +74,17 @@ class Ranks:
         self.dist.all_gather(out, mine)
         return [int(o[0]) | (int(o[1]) << 32) for o in out]
 
+    def gather_objects(self, obj) -> list:
+        """every rank's (picklable) object, in rank order -- device identities, per-rank timings"""
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
     def close(self) -> None:
         if self.dist is not None:
             self.dist.barrier()
-            self.dist.destroy_process_group()
+            if self._owns_group:
+                self.dist.destroy_process_group()
             self.dist = None

@@ -28,7 +28,7 @@ def checksum(arrs) -> int:
 
 def main():
     total = int(sys.argv[1])
-    r = Ranks(backend="gloo")
+    r = Ranks(backend="gloo", launched=True)
     first, n = shard_range(total, r.rank, r.world)
     c = cases.ggx_mixed(1234, n, first=first)
     x = cases.xi(1234, n, 4, first=first)
@@ -40,8 +40,11 @@ def main():
     r.barrier()
     elapsed = r.max_over_ranks([time.perf_counter() - t0])[0]
     sums = r.gather_u64(checksum(out))
+    # what bench.py gathers to make its line self-evidencing: who took part, and every rank's own time
+    import os
+    seen = r.gather_objects({"rank": r.rank, "pid": os.getpid(), "first": first, "count": n})
     if r.rank == 0:
-        print(json.dumps({"world": r.world, "total": total, "elapsed": elapsed, "checksums": sums,
+        print(json.dumps({"world": r.world, "total": total, "elapsed": elapsed, "checksums": sums, "ranks_seen": seen,
                           "shards": [shard_range(total, k, r.world) for k in range(r.world)]}), flush=True)
     r.close()
 

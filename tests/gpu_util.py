@@ -3,7 +3,22 @@ import numpy as np
 import torch
 
 import rlshaders_amd as R
-from gpu_util_cpu import disney_oracle, ggx_oracle  # noqa: F401  (re-exported)
+import gpu_util_cpu
+
+
+def ggx_oracle(O, case, exiting=None, nthreads=4):
+    """the oracle closure the device is compared with: its light loops in the SECOND form of the estimator -- one sum per
+    strategy, the order the kernels' separate passes produce (oracle/rls_oracle.c, ggx_light_loop).  The canonical form
+    (one running sum) is what the CPU-only tests check; tests/test_oracle_light_loops.py ties the two together."""
+    g = gpu_util_cpu.ggx_oracle(O, case, exiting=exiting, nthreads=nthreads)
+    g.two_sums_default = True
+    return g
+
+
+def disney_oracle(O, case, nthreads=4):
+    d = gpu_util_cpu.disney_oracle(O, case, nthreads=nthreads)
+    d.two_sums_default = True
+    return d
 
 
 def dev(a):

@@ -185,6 +185,9 @@ class Ggx:
                           _p(a["aniso"]),
                           self.exiting.ctypes.data_as(C.POINTER(C.c_uint8)) if self.exiting is not None else None)
         self.nthreads = nthreads
+        # light loops: False = the oracle's canonical estimator (one running sum), True = its second form with one sum per
+        # strategy, the order the device kernels produce (rls_oracle.c, ggx_light_loop); the GPU parity tests set True
+        self.two_sums_default = False
 
     def sample_eval_pdf(self, rx, ry):
         n = self.n
@@ -252,22 +255,24 @@ class Ggx:
         return pdf
 
     def direct_lighting(self, P, light, spp_n, seed, Kd_color=(1, 1, 1), Kd=1.0, Kd_roughness=0.0, Ks=1.0,
-                        first_index=0):
-        """orc_batch_ggx_direct_lighting (one Light or a sequence) -> (direct_diffuse [3,n], direct_specular [3,n])"""
+                        first_index=0, two_sums=None):
+        """orc_batch_ggx_direct_lighting (one Light or a sequence) -> (direct_diffuse [3,n], direct_specular [3,n]).
+        two_sums: the estimator with one sum per strategy (the device kernels' order) instead of the canonical running sum"""
         n = self.n
         P = f32(P)
         kdc, kd, kdr, ks = _full3(Kd_color, n), _full(Kd, n), _full(Kd_roughness, n), _full(Ks, n)
         sh = GgxShaderSoa(_v(kdc), _p(kd), _p(kdr), _p(ks), CV3P(), None)
         dd, ds = np.empty((3, n), np.float32), np.empty((3, n), np.float32)
         la, nl = light_array(light)
-        lib().orc_batch_ggx_direct_lighting(C.c_int64(n), C.byref(self.soa), C.byref(sh), _v(P), la, nl,
-                                            int(spp_n), C.c_uint32(seed), C.c_uint64(first_index), _v(dd), _v(ds),
-                                            self.nthreads)
+        two_sums = self.two_sums_default if two_sums is None else two_sums
+        fn = lib().orc_batch_ggx_direct_lighting_two_sums if two_sums else lib().orc_batch_ggx_direct_lighting
+        fn(C.c_int64(n), C.byref(self.soa), C.byref(sh), _v(P), la, nl, int(spp_n), C.c_uint32(seed), C.c_uint64(first_index),
+           _v(dd), _v(ds), self.nthreads)
         return dd, ds
 
     def shade(self, P, lights, spp_n, seed, Kd_color=(1, 1, 1), Kd=0.5, Kd_roughness=0.0, Ks=0.5, Kt_color=(1, 1, 1), Kt=0.0,
-              env=(1.0, 1.0, 1.0), traced=True, first_index=0) -> dict:
-        """orc_batch_ggx_shade -> dict of the five AOVs and out, [3,n] each"""
+              env=(1.0, 1.0, 1.0), traced=True, first_index=0, two_sums=None) -> dict:
+        """orc_batch_ggx_shade -> dict of the five AOVs and out, [3,n] each (two_sums: see direct_lighting)"""
         n = self.n
         P = f32(P)
         kdc, kd, kdr, ks = _full3(Kd_color, n), _full(Kd, n), _full(Kd_roughness, n), _full(Ks, n)
@@ -278,8 +283,10 @@ class Ggx:
         o = GgxShadeOutSoa(*[_v(out[k]) for k in keys])
         la, nl = light_array(lights)
         e = (C.c_float * 3)(*[float(v) for v in env])
-        lib().orc_batch_ggx_shade(C.c_int64(n), C.byref(self.soa), C.byref(sh), _v(P), la, nl, e, 1 if traced else 0,
-                                  int(spp_n), C.c_uint32(seed), C.c_uint64(first_index), C.byref(o), self.nthreads)
+        two_sums = self.two_sums_default if two_sums is None else two_sums
+        fn = lib().orc_batch_ggx_shade_two_sums if two_sums else lib().orc_batch_ggx_shade
+        fn(C.c_int64(n), C.byref(self.soa), C.byref(sh), _v(P), la, nl, e, 1 if traced else 0,
+           int(spp_n), C.c_uint32(seed), C.c_uint64(first_index), C.byref(o), self.nthreads)
         return out
 
     def integrate_refract(self, spp_n, seed, traced=True, env=(1.0, 1.0, 1.0), first_index=0):
@@ -307,6 +314,7 @@ class Disney:
         a = self.arr
         self.soa = DisneySoa(_v(a["wo"]), _v(a["N"]), _v(a["T"]), _v(a["base"]), (fp * 10)(*[_p(s) for s in self.sc]))
         self.nthreads = nthreads
+        self.two_sums_default = False           # see Ggx
 
     def sample(self, lobe, rx, ry):
         n = self.n
@@ -348,18 +356,21 @@ class Disney:
                                    _p(out1), self.nthreads)
         return out3 if kind < 2 else out1
 
-    def direct_lighting(self, P, light, spp_n, seed, first_index=0):
-        """orc_batch_disney_direct_lighting (one Light or a sequence) -> (direct_diffuse [3,n], direct_specular [3,n])"""
+    def direct_lighting(self, P, light, spp_n, seed, first_index=0, two_sums=None):
+        """orc_batch_disney_direct_lighting (one Light or a sequence) -> (direct_diffuse [3,n], direct_specular [3,n]).
+        two_sums: the estimator with one sum per strategy (the device kernels' order) instead of the canonical running sum"""
         n = self.n
         P = f32(P)
         dd, ds = np.empty((3, n), np.float32), np.empty((3, n), np.float32)
         la, nl = light_array(light)
-        lib().orc_batch_disney_direct_lighting(C.c_int64(n), C.byref(self.soa), _v(P), la, nl, int(spp_n), C.c_uint32(seed),
-                                               C.c_uint64(first_index), _v(dd), _v(ds), self.nthreads)
+        two_sums = self.two_sums_default if two_sums is None else two_sums
+        fn = lib().orc_batch_disney_direct_lighting_two_sums if two_sums else lib().orc_batch_disney_direct_lighting
+        fn(C.c_int64(n), C.byref(self.soa), _v(P), la, nl, int(spp_n), C.c_uint32(seed), C.c_uint64(first_index), _v(dd), _v(ds),
+           self.nthreads)
         return dd, ds
 
-    def shade(self, P, lights, spp_n, seed, env=(1.0, 1.0, 1.0), first_index=0) -> dict:
-        """orc_batch_disney_shade -> dict of the four AOVs and out, [3,n] each"""
+    def shade(self, P, lights, spp_n, seed, env=(1.0, 1.0, 1.0), first_index=0, two_sums=None) -> dict:
+        """orc_batch_disney_shade -> dict of the four AOVs and out, [3,n] each (two_sums: see direct_lighting)"""
         n = self.n
         P = f32(P)
         keys = ("direct_diffuse", "direct_specular", "indirect_diffuse", "indirect_specular", "out")
@@ -367,8 +378,10 @@ class Disney:
         o = DisneyShadeOutSoa(*[_v(out[k]) for k in keys])
         la, nl = light_array(lights)
         e = (C.c_float * 3)(*[float(v) for v in env])
-        lib().orc_batch_disney_shade(C.c_int64(n), C.byref(self.soa), _v(P), la, nl, e, int(spp_n), C.c_uint32(seed),
-                                     C.c_uint64(first_index), C.byref(o), self.nthreads)
+        two_sums = self.two_sums_default if two_sums is None else two_sums
+        fn = lib().orc_batch_disney_shade_two_sums if two_sums else lib().orc_batch_disney_shade
+        fn(C.c_int64(n), C.byref(self.soa), _v(P), la, nl, e, int(spp_n), C.c_uint32(seed), C.c_uint64(first_index), C.byref(o),
+           self.nthreads)
         return out
 
     def integrate(self, spp_n, seed, streamed=False, first_index=0):

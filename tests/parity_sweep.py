@@ -88,6 +88,7 @@ def sweep(ctx, n: int, seed: int, spp_n: int = 2, verbose: bool = True) -> dict:
     sc = {k: u(32 + j) for j, k in enumerate(R._capi.DISNEY_SCALARS)}
     d = R.DisneySampler(ctx, wo, N, T, base_color=Ks, **sc)
     od = O.Disney(c["wo"], c["N"], c["T"], base_color=c["KsColor"], nthreads=th, **{k: hostf(v) for k, v in sc.items()})
+    od.two_sums_default = True                  # the device's summation order (oracle/rls_oracle.c, ggx_light_loop)
     for lobe, nm in ((R.RLS_RAY_DIFFUSE, "diffuse"), (R.RLS_RAY_GLOSSY, "glossy")):
         d.setSampleType(lobe)
         tally(f"disney {nm}", [hostf(t) for t in d.sampleEvalPdf(xi[0], xi[1])], od.sample_eval_pdf(lobe, hxi[0], hxi[1]))

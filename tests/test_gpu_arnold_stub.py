@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import cases
-from gpu_util_cpu import disney_oracle, ggx_oracle
+from gpu_util import disney_oracle, ggx_oracle
 
 ROOT = Path(__file__).resolve().parent.parent
 FIX = json.loads((ROOT / "tests" / "golden" / "param_surface.json").read_text())["nodes"]

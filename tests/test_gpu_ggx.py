@@ -137,7 +137,7 @@ def test_refract_and_reflect_refract(gpu, oracle, mixed):
     print("ggx refract weight", sw)
     cases.assert_tight(st, "refract dir")
     cases.assert_tight(sw, "refract weight")
-    assert (host(flag) != flag_ref).sum() <= 1
+    assert (host(flag) != flag_ref).sum() <= cases.flag_slack()
     # the one-pass kernel = reflect triple + refract sample, bit for bit
     out = s.reflectRefract(dev(x[0]), dev(x[1]), dev(x[2]), dev(x[3]))
     tri = s.sampleEvalPdf(dev(x[0]), dev(x[1]))
@@ -158,7 +158,7 @@ def test_exiting_and_tir(gpu, oracle):
     assert 0 < flag_ref.mean() < 1, "case must contain both refraction and TIR"
     s = ggx_sampler(gpu, c, exiting=exiting)
     wt, w, flag = s.refractSample(dev(x[0]), dev(x[1]))
-    assert (host(flag) != flag_ref).sum() <= 1
+    assert (host(flag) != flag_ref).sum() <= cases.flag_slack()
     same = host(flag) == flag_ref
     st = cases.summarize(cases.rel_err(host(wt)[:, same], wt_ref[:, same]))
     print("ggx exiting refract dir", st)

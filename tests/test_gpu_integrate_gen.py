@@ -123,4 +123,5 @@ def test_large_parity_sweep(gpu, oracle):
     report = parity_sweep.sweep(gpu, 1 << 22, 4242)
     assert len(report) == 14
     for name, r in report.items():
-        assert r["words_differing"] <= 4 and r["beyond_1e5"] == 0, (name, r)
+        # the soaks count 0 differing words of 2.2e11: on a host whose glibc is the build the device libm follows, so does this
+        assert r["words_differing"] <= (0 if cases.strict_parity() else 4) and r["beyond_1e5"] == 0, (name, r)

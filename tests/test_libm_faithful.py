@@ -8,13 +8,31 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 
 
+import sys
+
+sys.path.insert(0, str(ROOT / "tests"))
+import cases  # noqa: E402
+
+
 def host_libm_uses_fma() -> bool:
-    """glibc's ifunc resolvers pick the -mfma builds of sinf/cosf/expf/logf/powf when the CPU has AVX2 and FMA"""
-    try:
-        flags = next(l for l in open("/proc/cpuinfo") if l.startswith("flags")).split()
-    except (OSError, StopIteration):
-        return True
-    return "fma" in flags and "avx2" in flags
+    """glibc's ifunc resolvers pick the -mfma builds of sinf/cosf/expf/logf/powf when the CPU has AVX2 and FMA -- decided
+    here from the functions' RESULTS on the 42 arguments that tell the two builds apart (cases.host_libm_flavour)"""
+    return cases.host_libm_flavour()["flavour"] != "sse2"
+
+
+def test_host_libm_flavour_probe():
+    """the probe behind the strict parity gates: the committed discriminating arguments (found by sweeping all 2^32
+    through both flavours of rls_libm.hpp) really discriminate, and this host's libm sides with exactly one flavour"""
+    r = cases.host_libm_flavour()
+    assert r["discriminating"] == 42 and {k: v["discriminating"] for k, v in r["functions"].items()} == \
+        {"sinf": 12, "cosf": 22, "expf": 2, "powf5": 6}
+    assert r["flavour"] in ("fma", "sse2"), r
+    fma = sum(v["libm_sides_with_fma"] for v in r["functions"].values())
+    sse = sum(v["libm_sides_with_sse2"] for v in r["functions"].values())
+    assert {fma, sse} == {42, 0}, r
+    if r["flavour"] == "fma":
+        assert all(v["libm_differs_from_fma_port"] == 0 for v in r["functions"].values()), r
+        assert cases.strict_parity()
 
 
 def test_device_libm_matches_host_libm(tmp_path):

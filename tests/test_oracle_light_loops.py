@@ -191,3 +191,56 @@ def test_whole_node_shading_closed_forms():
                                (whole["diffuse_sum"].astype(np.float64) / 64).mean(axis=1), rtol=0.02)
     np.testing.assert_allclose(big["indirect_specular"].astype(np.float64).mean(axis=1),
                                (whole["specular_sum"].astype(np.float64) / 64).mean(axis=1), rtol=0.1)
+
+
+def test_the_two_summation_orders_of_the_estimator_agree():
+    """The light loops' estimator is the builder's stand-in for the closed AiEvaluateLightSample loop, so its summation
+    order is defined here, once: canonically ONE running sum per AOV (light sample's term, then the BSDF sample's, sample
+    by sample).  The device kernels run the two strategies as separate passes and so produce the second form -- one sum
+    per strategy, added at the end (orc_batch_*_two_sums) -- which the GPU tests match bit for bit.  Same terms, another
+    order: the two forms must agree to 1e-6, for rlGgx and rlDisney, the light loops alone and the whole shader_evaluate,
+    one light and three, every MIS mode; with one strategy switched off they are the same sum and must be bit-equal."""
+    n = 1 << 13
+    c = cases.ggx_mixed(cases.SEED_PARITY, n)
+    dcase = cases.disney_mixed(cases.SEED_PARITY, n)
+    P = np.stack([O.gen_uniform(cases.SEED_PARITY, 0, n, O.S_PARAM0 + 16 + j, 0.0, 4.0) for j in range(3)])
+    th = O.hardware_threads()
+    g, d = ggx_oracle(O, c, nthreads=th), disney_oracle(O, dcase, nthreads=th)
+    assert g.two_sums_default is False and d.two_sums_default is False        # the canonical form is the default
+
+    def worst(a, b):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        den = np.maximum(np.abs(b), 1e-30)
+        return float((np.abs(a - b) / den).max())
+
+    sets = {"one": [O.make_light(center=(2.0, 2.0, 6.0), radius=1.25, radiance=(3.0, 2.0, 1.0))],
+            "three": [O.make_light(center=(2.0, 2.0, 6.0), radius=1.25, radiance=(3.0, 2.0, 1.0)),
+                      O.make_light(center=(-1.0, 5.0, 7.0), radius=0.6, radiance=(0.5, 0.5, 4.0)),
+                      O.make_light(center=(0.5, -3.0, 5.0), radius=2.0, radiance=(1.0, 1.0, 1.0))]}
+    differing = 0
+    for name, lts in sets.items():
+        for spp_n in (3, 4):
+            kw = dict(Kd_color=(0.8, 0.7, 0.6), Kd=0.5, Kd_roughness=0.3, Ks=0.5)
+            a, b = g.direct_lighting(P, lts, spp_n, 321, **kw), g.direct_lighting(P, lts, spp_n, 321, two_sums=True, **kw)
+            for x, y in zip(a, b):
+                assert worst(y, x) <= 1e-6, (name, spp_n, "rlGgx light loop")
+                differing += int((x.view(np.uint32) != y.view(np.uint32)).sum())
+            a, b = d.direct_lighting(P, lts, spp_n, 17), d.direct_lighting(P, lts, spp_n, 17, two_sums=True)
+            for x, y in zip(a, b):
+                assert worst(y, x) <= 1e-6, (name, spp_n, "rlDisney light loop")
+                differing += int((x.view(np.uint32) != y.view(np.uint32)).sum())
+        a = g.shade(P, lts, 3, 5, Kt=0.5, env=(1.0, 0.9, 0.8))
+        b = g.shade(P, lts, 3, 5, Kt=0.5, env=(1.0, 0.9, 0.8), two_sums=True)
+        for k in a:
+            assert worst(b[k], a[k]) <= 1e-6, (name, k, "rlGgx shader_evaluate")
+        a, b = d.shade(P, lts, 3, 5), d.shade(P, lts, 3, 5, two_sums=True)
+        for k in a:
+            assert worst(b[k], a[k]) <= 1e-6, (name, k, "rlDisney shader_evaluate")
+    assert differing > 0, "the two orders never differed: the second form is not being exercised"
+    # one strategy only: a single sum either way
+    for mode in (1, 2):
+        lt = O.make_light(center=(2.0, 2.0, 6.0), radius=1.25, radiance=(3.0, 2.0, 1.0), mis_mode=mode)
+        for x, y in zip(g.direct_lighting(P, lt, 4, 321), g.direct_lighting(P, lt, 4, 321, two_sums=True)):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+        for x, y in zip(d.direct_lighting(P, lt, 4, 17), d.direct_lighting(P, lt, 4, 17, two_sums=True)):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32))

@@ -45,3 +45,37 @@ def test_two_ranks_equal_one_rank():
     # checksum of checksums: additive hash, so shard sums add up to the single-process sum
     assert sum(two["checksums"]) % (1 << 64) == one["checksums"][0]
     assert two["elapsed"] > 0
+    # gather_objects: every rank reports itself, in rank order, from its own process
+    seen = two["ranks_seen"]
+    assert [d["rank"] for d in seen] == [0, 1] and len({d["pid"] for d in seen}) == 2
+    assert [[d["first"], d["count"]] for d in seen] == two["shards"]
+    assert len(one["ranks_seen"]) == 1
+
+
+def test_ranks_is_inert_without_a_launcher(monkeypatch):
+    """a single process whose environment happens to export RANK / MASTER_PORT (a cluster shell) must not start a
+    rendezvous: the one-rank process group is opt-in (launched=True)"""
+    import torch.distributed as dist
+    from rlshaders_amd.sharding import Ranks
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("MASTER_PORT", "1")          # a port nobody may bind: an init would fail loudly
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    r = Ranks(backend="gloo")
+    assert r.dist is None and not dist.is_initialized()
+    assert r.max_over_ranks([1.5]) == [1.5] and r.gather_objects("x") == ["x"] and r.gather_u64(7) == [7]
+    r.close()
+
+
+def test_ranks_reuses_an_existing_process_group(tmp_path):
+    """a caller that already owns the default process group: Ranks joins it and close() leaves it alive"""
+    import torch.distributed as dist
+    from rlshaders_amd.sharding import Ranks
+    dist.init_process_group("gloo", init_method=f"file://{tmp_path / 'rdv'}", rank=0, world_size=1)
+    try:
+        r = Ranks(backend="gloo", launched=True)
+        assert r.dist is not None and r.world == 1 and r.rank == 0
+        assert r.gather_objects({"a": 1}) == [{"a": 1}]
+        r.close()
+        assert dist.is_initialized()
+    finally:
+        dist.destroy_process_group()

@@ -60,7 +60,8 @@ S_PARAM0 = 32
 
 WORKLOADS = ["ggx_reflect_refract", "ggx_reflect_refract_uniform", "ggx_reflect", "ggx_eval", "ggx_pdf", "ggx_direct",
              "ggx_shade", "disney_direct", "disney_shade", "disney_integrate", "disney_stream", "disney_triple_diffuse",
-             "disney_triple_glossy", "sss_probe", "nd_sample", "sss_scatter", "skin", "skin_integrate"]
+             "disney_triple_glossy", "sss_probe", "nd_sample", "sss_scatter", "skin", "skin_integrate",
+             "ggx_reflect_refract_host"]
 
 # BASELINE.json configs -> (workload, log2 of the points ONE GPU holds): config 4 is 2^28 points over 8 GPUs, config 5 2^30
 CONFIG_PRESETS = {2: ("ggx_reflect_refract", 26), 3: ("disney_integrate", 26), 4: ("sss_probe", 25), 5: ("skin", 27)}
@@ -69,7 +70,8 @@ CONFIG_PRESETS = {2: ("ggx_reflect_refract", 26), 3: ("disney_integrate", 26), 4
 BLOCK_ALL = [("ggx_reflect_refract_uniform", 26, 40), ("ggx_reflect", 26, 40), ("ggx_eval", 26, 40), ("ggx_pdf", 26, 40),
              ("disney_triple_diffuse", 26, 40), ("disney_triple_glossy", 26, 40),
              ("disney_integrate", 26, 12), ("disney_stream", 26, 10),
-             ("sss_probe", 25, 40), ("sss_probe", 26, 40), ("nd_sample", 26, 40), ("skin", 26, 30), ("skin", 27, 20)]
+             ("sss_probe", 25, 40), ("sss_probe", 26, 40), ("nd_sample", 26, 40), ("skin", 26, 30), ("skin", 27, 20),
+             ("ggx_reflect_refract_host", 24, 4)]
 BLOCK_CONFIGS = [("disney_integrate", 26, 12), ("sss_probe", 25, 40), ("skin", 27, 20)]
 
 
@@ -88,7 +90,13 @@ def parse_args():
     ap.add_argument("--workloads", default="auto", choices=["auto", "all", "configs", "none"],
                     help="the `workloads` block: all = every other config and verb, configs = BASELINE configs 3-5 only; "
                          "auto = all on one GPU / configs on several when the headline is the default, none otherwise")
-    ap.add_argument("--chunk-log2", type=int, default=20, help="disney_stream: points per chunk = 2^this")
+    ap.add_argument("--chunk-log2", type=int, default=20,
+                    help="disney_stream, ggx_reflect_refract_host: points per chunk = 2^this")
+    ap.add_argument("--host-resident", action="store_true",
+                    help="config 2 with the batch in page-locked HOST memory: = --workload ggx_reflect_refract_host "
+                         "--log2-points 24 (a 2 GB batch), through rlshaders_amd.Pipeline (chunked upload / kernel / download "
+                         "on --pipeline-depth streams); PCIe-bound")
+    ap.add_argument("--pipeline-depth", type=int, default=3)
     ap.add_argument("--math", default="exact", choices=["exact", "fast"],
                     help="arithmetic of the measured kernels: exact (default, bit-faithful to the CPU closures) "
                          "or fast (RLS_MATH_FAST)")
@@ -103,6 +111,10 @@ def parse_args():
     ap.add_argument("--block-log2-points", type=int, default=None,
                     help="every record of the workloads block at 2^this points per GPU instead of its configuration's size (tests)")
     a = ap.parse_args()
+    if a.host_resident:
+        a.workload = "ggx_reflect_refract_host"
+        if a.log2_points is None:
+            a.log2_points = 24
     explicit = a.workload is not None or a.config is not None or a.log2_points is not None
     if a.config is not None:
         w, l2 = CONFIG_PRESETS[a.config]
@@ -139,7 +151,7 @@ class Workload:
 
 
 # planes (n floats each) a workload reads and writes: sizes its arena
-PLANES = {"ggx_reflect_refract": 19 + 12, "ggx_reflect_refract_uniform": 13 + 12, "ggx_reflect": 17 + 8,
+PLANES = {"ggx_reflect_refract": 19 + 12, "ggx_reflect_refract_host": 19, "ggx_reflect_refract_uniform": 13 + 12, "ggx_reflect": 17 + 8,
           "ggx_eval": 17 + 8 + 3, "ggx_pdf": 17 + 8 + 1, "disney_triple_diffuse": 24 + 7, "disney_triple_glossy": 24 + 7,
           "nd_sample": 9 + 7 + 5, "disney_integrate": 22 + 8, "disney_stream": 22 + 8,
           "sss_probe": 17 + 12,
@@ -147,7 +159,7 @@ PLANES = {"ggx_reflect_refract": 19 + 12, "ggx_reflect_refract_uniform": 13 + 12
           "disney_direct": 22 + 3 + 6, "ggx_shade": 15 + 3 + 6 + 4 + 18, "disney_shade": 22 + 3 + 15}     # (the generator's wo planes included where the closure ignores them)
 
 
-def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, chunk_log2: int = 20):
+def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, chunk_log2: int = 20, depth: int = 3):
     """All planes of the workload live in one arena (R.Arena): one allocation, and with candidates > 1 the
     fastest of that many equally sized blocks ("Placement")."""
     A = R.Arena(ctx, n, PLANES[name], candidates)
@@ -190,6 +202,42 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
                     wl = Workload(name, 1, (14 + 1) * 4, lambda: g.evalPdf(wi, out=pdf), "ggx_kernel<2, {m}, true>",
                                   "rlGgx evalPdf alone on sampled directions, mixed params (src/rlGgx.h:121-127)",
                                   survey_bytes=(18 + 1) * 4)
+    elif name == "ggx_reflect_refract_host":
+        # config 2 with the batch in page-locked HOST memory, where an Arnold-side stub's render threads gather it (the
+        # reference evaluates per hit on those threads, src/rlGgx.cpp:248-261): 19 planes up, the same kernel per chunk,
+        # 12 planes down, overlapped on `depth` streams (rlshaders_amd.Pipeline = rls_pipeline_*).  PCIe-bound.
+        import torch
+        dev_in = [wo[0], wo[1], wo[2], N[0], N[1], N[2], T[0], T[1], T[2]] + list(u3(S_KS)) + \
+                 [u(S_ROUGH, 0.05, 1.0), u(S_IOR, 1.05, 2.55), R.gen_aniso(ctx, SEED, first, n, out=A.plane())] + \
+                 [u(S_XI0 + j) for j in range(4)]
+        hin = [torch.empty(n, dtype=torch.float32, pin_memory=True) for _ in range(19)]
+        hout = [torch.empty(n, dtype=torch.float32, pin_memory=True) for _ in range(12)]
+        torch.cuda.synchronize()
+        for h, d in zip(hin, dev_in):
+            h.copy_(d)
+        cp = min(n, 1 << chunk_log2)
+        pipe = R.Pipeline(ctx, cp, 19, 12, depth)
+
+        def chunk(slot, _first, count, i, o):
+            c = R._capi.GgxClosure()
+            c.wo = R._capi.CVec3(i[0].data_ptr(), i[1].data_ptr(), i[2].data_ptr())
+            c.N = R._capi.CVec3(i[3].data_ptr(), i[4].data_ptr(), i[5].data_ptr())
+            c.T = R._capi.CVec3(i[6].data_ptr(), i[7].data_ptr(), i[8].data_ptr())
+            c.KsColor = R._capi.ParamRgb(i[9].data_ptr(), i[10].data_ptr(), i[11].data_ptr(), 0.0, 0.0, 0.0)
+            c.specularRoughness = R._capi.Param(i[12].data_ptr(), 0.0)
+            c.ior = R._capi.Param(i[13].data_ptr(), 0.0)
+            c.anisotropic = R._capi.Param(i[14].data_ptr(), 0.0)
+            P = lambda t: t.data_ptr()
+            R._capi.check(slot.lib.rls_ggx_reflect_refract(
+                slot.handle, count, R.closures.C.byref(c), P(i[15]), P(i[16]), P(i[17]), P(i[18]),
+                R._capi.Vec3(P(o[0]), P(o[1]), P(o[2])), R._capi.Rgb(P(o[3]), P(o[4]), P(o[5])), P(o[6]), P(o[7]),
+                R._capi.Vec3(P(o[8]), P(o[9]), P(o[10])), P(o[11])))
+
+        wl = Workload(name, 2, (19 + 12) * 4, lambda: pipe.run(n, hin, hout, chunk), "ggx_kernel<5, {m}, true>",
+                      f"rlGgx reflect+refract, batch resident in page-locked HOST memory: chunks of {cp} points uploaded, "
+                      f"sampled and downloaded on {depth} streams (rls_pipeline_*); PCIe-bound, 76 B up + 48 B down per point",
+                      bound="pcie", launches_per_step=(n + cp - 1) // cp)
+        wl.pipe, wl.host = pipe, (hin, hout)
     elif name == "ggx_reflect_refract_uniform":
         # config 2's kernel as a stub without linked textures runs it: every node parameter one value for the batch
         # (Arnold parameters are constants unless textured), geometry and random numbers streamed
@@ -376,6 +424,8 @@ def _cpu_leg(workload: str, n: int, threads: int):
         x = cases.xi(SEED, n, 4)
         out = g.reflect_refract(x[0], x[1], x[2], x[3])
         return (lambda: g.reflect_refract(x[0], x[1], x[2], x[3], out=out)), 2, "orc_batch_ggx_reflect_refract"
+    if workload == "ggx_reflect_refract_host":
+        workload = "ggx_reflect_refract"            # the CPU closures' batch is host-resident by nature
     if workload in ("ggx_reflect_refract", "ggx_reflect", "ggx_eval", "ggx_pdf", "ggx_direct", "ggx_shade"):
         c = cases.ggx_mixed(SEED, n)
         g = O.Ggx(c["wo"], c["N"], c["T"], KsColor=c["KsColor"], ior=c["ior"], roughness=c["roughness"],
@@ -542,6 +592,23 @@ def roofline_record(wl, n: int, kernel_ms: float, math: str) -> dict:
     salu = fl["instructions_per_point"].get("SQ_INSTS_SALU") if fl else None
     issue = valu * (n / launches / 64.0) / sec / VALU_ISSUE_PEAK if valu else None
     tflops = fl["flops_per_point"] * (n / launches) / sec / 1e12 if fl else None
+    if wl.bound == "pcie":
+        # host-resident batch: the copies bound the pass.  Held against the pinned-memory rates THIS box reaches (measured
+        # now, rls_measure_copy_rates): each direction alone, and both at once
+        rates = wl.pipe.copy_rates(1 << 28)
+        up, down = n * 19 * 4.0, n * 12 * 4.0
+        t = kernel_ms * 1e-3
+        floor = max(up / (rates["h2d"] * 1e9), down / (rates["d2h"] * 1e9), (up + down) / (rates["both"] * 1e9))
+        return {"bound": "pcie", "achieved": round((up + down) / t / 1e9, 2), "peak": round(rates["both"], 2), "unit": "GB/s",
+                "frac": round(floor / t, 4), "traffic": None,
+                "frac_note": "time the box's own pinned copies need for this pass (max of: upload alone, download alone, both "
+                             "directions at the measured bidirectional rate) / measured time of the pass",
+                "h2d_gb_per_s": round(up / t / 1e9, 2), "d2h_gb_per_s": round(down / t / 1e9, 2),
+                "box_copy_rates_gb_per_s": {k: round(v, 2) for k, v in rates.items()},
+                "pass_ms": round(kernel_ms, 4), "chunks_per_pass": launches, "kernel": wl.kernel.format(m=1 if math == "fast" else 0),
+                "kernel_ms": round(launch_ms, 5), "launches_per_step": launches,
+                "algorithmic_bytes_per_point": wl.bytes_per_point, "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                "device_resident_note": "the same kernel on a device-resident batch is the headline workload ggx_reflect_refract"}
     if wl.bound == "hbm":
         roof = {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": int(traffic) if traffic else None}
@@ -574,7 +641,7 @@ def roofline_record(wl, n: int, kernel_ms: float, math: str) -> dict:
 
 
 def measure(R, ctx, ranks, torch, name: str, log2n: int, steps: int, warmup: int, math: str, candidates: int,
-            chunk_log2: int, other_mode: bool):
+            chunk_log2: int, other_mode: bool, depth: int = 3):
     """Build one workload on this rank's shard, warm it up, time `steps` passes between barriers.
     -> (workload, n, elapsed seconds [max over ranks], kernel ms per step [max over ranks], this rank's kernel ms,
         kernel ms per step in the other arithmetic mode or None)"""
@@ -584,7 +651,7 @@ def measure(R, ctx, ranks, torch, name: str, log2n: int, steps: int, warmup: int
     # weak scaling: the job is world * n points, rank g owns the index range [g*n, (g+1)*n)
     first, count = shard_range(world * n, rank, world)
     assert count == n
-    wl = make_workload(R, ctx, name, n, first=first, candidates=candidates, chunk_log2=chunk_log2)
+    wl = make_workload(R, ctx, name, n, first=first, candidates=candidates, chunk_log2=chunk_log2, depth=depth)
     torch.cuda.synchronize()
     for _ in range(warmup):
         wl.launch()
@@ -600,9 +667,11 @@ def measure(R, ctx, ranks, torch, name: str, log2n: int, steps: int, warmup: int
     ranks.barrier()
     elapsed = time.perf_counter() - t0
     my_kernel_ms = ctx.timer_elapsed_ms() / max(steps, 1)
+    if wl.bound == "pcie":                 # the pipeline runs on its own streams and returns when the batch is back in host
+        my_kernel_ms = elapsed / max(steps, 1) * 1e3      # memory: the pass is timed on the host clock
     elapsed, kernel_ms = ranks.max_over_ranks([elapsed, my_kernel_ms])
     other_ms = None
-    if other_mode:
+    if other_mode and wl.bound != "pcie":
         # the other arithmetic mode, a few launches, for the record (not the headline number)
         ctx.set_math_mode(math != "fast")
         wl.launch()
@@ -657,7 +726,8 @@ def main():
         raise SystemExit(f"bench.py: two ranks share a GPU: {identities}")
 
     wl, n, elapsed, kernel_ms, my_ms, other_ms = measure(R, ctx, ranks, torch, args.workload, args.log2_points, args.steps,
-                                                         args.warmup, args.math, args.arena_candidates, args.chunk_log2, True)
+                                                         args.warmup, args.math, args.arena_candidates, args.chunk_log2, True,
+                                                         args.pipeline_depth)
     per_rank_ms = ranks.gather_objects(round(my_ms, 5))
 
     line = None
@@ -696,9 +766,10 @@ def main():
                       "per_rank_kernel_ms": per_rank_ms, "min_kernel_ms": min(per_rank_ms), "max_kernel_ms": max(per_rank_ms)},
         }
         other = "exact" if args.math == "fast" else "fast"
-        line["other_math_mode"] = {"math": other, "kernel_ms": round(other_ms, 5),
-                                   "value": round(world * n * wl.samples_per_point / (other_ms * 1e-3) / 1e9, 4),
-                                   "hbm_frac": round(bytes_per_step / (other_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        if other_ms is not None:
+            line["other_math_mode"] = {"math": other, "kernel_ms": round(other_ms, 5),
+                                       "value": round(world * n * wl.samples_per_point / (other_ms * 1e-3) / 1e9, 4),
+                                       "hbm_frac": round(bytes_per_step / (other_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(args.workload, args.cpu_seconds)
             if cb:
@@ -715,7 +786,9 @@ def main():
     records = []
     for name, log2n, steps in block:
         warm = max(10, args.warmup)
-        w, bn, el, kms, my, _ = measure(R, ctx, ranks, torch, name, log2n, steps, warm, args.math, 1, args.chunk_log2, False)
+        warm = warm if name != "ggx_reflect_refract_host" else 2
+        w, bn, el, kms, my, _ = measure(R, ctx, ranks, torch, name, log2n, steps, warm, args.math, 1, args.chunk_log2, False,
+                                        args.pipeline_depth)
         prm = ranks.gather_objects(round(my, 5))
         if rank == 0:
             rec = {"name": w.name, "baseline_config": w.config, "workload": w.desc, "points_per_gpu": bn,

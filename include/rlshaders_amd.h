@@ -161,6 +161,35 @@ rls_status  rls_graph_end_capture(rls_context *ctx, rls_graph **out);
 rls_status  rls_graph_launch(rls_context *ctx, rls_graph *graph);      /* asynchronous, on the context's stream */
 void        rls_graph_destroy(rls_graph *graph);
 
+/* Host-resident batches.  The reference's closures run per hit on CPU render threads (src/rlGgx.cpp:248-261 builds the
+ * closure on shader_evaluate's stack), so the shading points an Arnold-side stub gathers start in HOST memory and the
+ * results are wanted there.  rls_host_alloc gives page-locked host memory (DMA at the full PCIe rate, asynchronous
+ * copies); rls_host_register page-locks memory the host already owns (its batch buffers, once).
+ * A pipeline cuts a batch of n points into chunks of chunk_points and sends them through `depth` slots, each slot a
+ * stream of its own with its own device planes (in_planes + out_planes planes of chunk_points floats): per chunk the
+ * input planes are uploaded from host_in[k] + first_point, `launch` is called with the SLOT's context and device planes
+ * -- it enqueues the closure calls for `count` points on that context, e.g. rls_ggx_reflect_refract(slot, count, ...) --
+ * and the output planes are downloaded to host_out[k] + first_point.  With depth >= 2 the upload of chunk k + 1, the
+ * kernels of chunk k and the download of chunk k - 1 overlap.  A NULL host plane is skipped (a uniform parameter, an
+ * unwanted output).  rls_pipeline_run returns when every chunk has arrived in host memory; the slots compute in the
+ * arithmetic mode of the context the pipeline was created on.  Results are those of the device-resident call on the
+ * same points, bit for bit.  PCIe-bound by construction: rls_measure_copy_rates gives the box's pinned-memory rates
+ * (host -> device, device -> host, both at once; GB/s) to hold a pipeline's throughput against. */
+rls_status  rls_host_alloc(rls_context *ctx, size_t bytes, void **out);
+rls_status  rls_host_free(rls_context *ctx, void *p);
+rls_status  rls_host_register(rls_context *ctx, void *p, size_t bytes);
+rls_status  rls_host_unregister(rls_context *ctx, void *p);
+typedef struct rls_pipeline rls_pipeline;
+/* returns an rls_status (RLS_OK to go on) */
+typedef int (*rls_pipeline_launch_fn)(void *user, rls_context *slot, int64_t first_point, int64_t count,
+                                      float *const *device_in, float *const *device_out);
+rls_status  rls_pipeline_create(rls_context *ctx, int64_t chunk_points, int in_planes, int out_planes, int depth,
+                                rls_pipeline **out);
+rls_status  rls_pipeline_run(rls_pipeline *p, int64_t n, const float *const *host_in, float *const *host_out,
+                             rls_pipeline_launch_fn launch, void *user);
+void        rls_pipeline_destroy(rls_pipeline *p);
+rls_status  rls_measure_copy_rates(rls_context *ctx, size_t bytes, float rates_gb_per_s[3]);
+
 /* ------------------------------------------------------------------------------------------
  * rlGgx closure: rls::GgxSamplerT<VNDFKernel>  (src/rlGgx.h:92-373, src/rlGgx.cpp:14-99)
  * Parameter names: src/rlGgx.cpp:172-186 (KsColor, specularRoughness, ior, anisotropic).

@@ -188,6 +188,14 @@ PROTOTYPES = {
     "rls_graph_end_capture": (C.c_int, [_ctx, C.POINTER(_vp)]),
     "rls_graph_launch": (C.c_int, [_ctx, _vp]),
     "rls_graph_destroy": (None, [_vp]),
+    "rls_host_alloc": (C.c_int, [_ctx, C.c_size_t, C.POINTER(_vp)]),
+    "rls_host_free": (C.c_int, [_ctx, _vp]),
+    "rls_host_register": (C.c_int, [_ctx, _vp, C.c_size_t]),
+    "rls_host_unregister": (C.c_int, [_ctx, _vp]),
+    "rls_pipeline_create": (C.c_int, [_ctx, _i64, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "rls_pipeline_run": (C.c_int, [_vp, _i64, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp]),
+    "rls_pipeline_destroy": (None, [_vp]),
+    "rls_measure_copy_rates": (C.c_int, [_ctx, C.c_size_t, C.POINTER(C.c_float)]),
     # rlGgx
     "rls_ggx_sample": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), _vp, _vp, Vec3, _vp]),
     "rls_ggx_eval": (C.c_int, [_ctx, _i64, C.POINTER(GgxClosure), CVec3, Rgb]),
@@ -259,6 +267,11 @@ class RlsError(RuntimeError):
     def __init__(self, status: int, message: str):
         super().__init__(f"rlshaders_amd: status {status}: {message}")
         self.status = status
+
+
+# rls_pipeline_launch_fn: (user, slot context, first_point, count, device_in planes, device_out planes) -> rls_status
+PipelineLaunchFn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p),
+                               C.POINTER(C.c_void_p))
 
 
 def load() -> C.CDLL:

@@ -22,7 +22,7 @@ OBJDIR = PKG / "build"
 LIB = LIBDIR / "librlshaders_amd.so"
 ARCH = "gfx950"
 
-SOURCES = ["context.hip", "ggx.hip", "disney.hip", "sss.hip", "skin.hip", "integrate.hip", "alternates.hip"]
+SOURCES = ["context.hip", "pipeline.hip", "ggx.hip", "disney.hip", "sss.hip", "skin.hip", "integrate.hip", "alternates.hip"]
 FAST_UNITS = {"ggx.hip", "disney.hip", "sss.hip", "skin.hip", "integrate.hip", "alternates.hip"}
 HEADERS = [CSRC / "rls_device.hpp", CSRC / "rls_libm.hpp", CSRC / "rls_libm_tables.inc", CSRC / "rls_internal.hpp",
            PKG.parent / "include" / "rlshaders_amd.h"]
@@ -99,7 +99,7 @@ def build_host_examples(verbose: bool = False) -> Path:
     """Compile-check the C++ host mirror (header-only) and its example against the C ABI."""
     OBJDIR.mkdir(exist_ok=True)
     first = OBJDIR / "example_arnold_stub"
-    for name in ("example_arnold_stub", "example_multi_gpu", "test_arnold_stub"):
+    for name in ("example_arnold_stub", "example_multi_gpu", "example_host_pipeline", "test_arnold_stub"):
         src = PKG / "host" / f"{name}.cpp"
         out = OBJDIR / name
         if not src.exists():

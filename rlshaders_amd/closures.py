@@ -17,7 +17,7 @@ from typing import Optional, Sequence, Union
 import torch
 
 from . import _capi as capi
-from ._capi import (RLS_KERNEL_NDF, RLS_KERNEL_VNDF, RLS_RAY_DIFFUSE, RLS_RAY_GLOSSY, check)
+from ._capi import (RLS_KERNEL_NDF, RLS_KERNEL_VNDF, RLS_RAY_DIFFUSE, RLS_RAY_GLOSSY, RlsError, check)
 
 Scalar = Union[float, torch.Tensor]
 Color = Union[Sequence[float], torch.Tensor]
@@ -35,11 +35,8 @@ class Context:
         check(self.lib.rls_context_create(self.device, C.byref(h)))
         self.handle = h
         self.torch_device = torch.device("cuda", self.device)
-        self._ext_stream = None                 # torch's view of the private stream while launches go there
         if use_torch_stream:
             self.use_stream(torch.cuda.current_stream(self.torch_device))
-        else:
-            self.use_stream(None)
 
     def use_stream(self, stream: Optional["torch.cuda.Stream"]) -> None:
         """stream = a torch.cuda.Stream (its handle may be 0 = the null stream), or None for the
@@ -48,20 +45,16 @@ class Context:
         On the private stream (``use_stream(None)`` / ``use_torch_stream=False``) the launches are NOT ordered with
         torch's own work: torch fills and frees tensors on its current stream, the kernels read and write them on a
         non-blocking stream.  The caller then orders the two -- ``torch.cuda.synchronize()`` (or an event) after the
-        inputs are produced and ``ctx.synchronize()`` before the outputs are read or an INPUT tensor a launch used is
-        dropped: torch's caching allocator recycles a freed block for later work on ITS stream without knowing that a
-        kernel on the private stream may still be using it.  Tensors this class allocates (``ctx.empty``: the outputs of
-        every verb called without ``out=``) are registered with the allocator as in use on the private stream
-        (``Tensor.record_stream``), and switching to the private stream makes it wait for the work torch's current
-        stream holds at that moment."""
+        inputs are produced and ``ctx.synchronize()`` before the outputs are read or any tensor a launch used (inputs,
+        and outputs this class allocated) is dropped: torch's caching allocator recycles a freed block for later work
+        on ITS stream without knowing that a kernel on the private stream may still be using it.  (Registering the
+        tensors with the allocator -- ``Tensor.record_stream`` on a wrapper of the private stream -- is not an option:
+        the allocator would record its events on that stream when the tensors die, possibly after ``close()`` has
+        destroyed it.)"""
         if stream is None:
             check(self.lib.rls_context_use_own_stream(self.handle))
-            self._ext_stream = torch.cuda.ExternalStream(int(self.lib.rls_context_get_stream(self.handle) or 0),
-                                                         device=self.torch_device)
-            self._ext_stream.wait_stream(torch.cuda.current_stream(self.torch_device))
         else:
             check(self.lib.rls_context_set_stream(self.handle, C.c_void_p(stream.cuda_stream)))
-            self._ext_stream = None
 
     def set_math_mode(self, fast: bool) -> None:
         """False: RLS_MATH_EXACT (default, bit-faithful to the CPU closures); True: RLS_MATH_FAST."""
@@ -109,10 +102,7 @@ class Context:
 
     # -- helpers --------------------------------------------------------------------------------
     def empty(self, *shape) -> torch.Tensor:
-        t = torch.empty(*shape, dtype=torch.float32, device=self.torch_device)
-        if self._ext_stream is not None:
-            t.record_stream(self._ext_stream)        # allocated on torch's stream, written on the private one
-        return t
+        return torch.empty(*shape, dtype=torch.float32, device=self.torch_device)
 
 
 class Arena:
@@ -171,6 +161,96 @@ class Arena:
             return {"arena": False, "planes": self.used}
         return {"arena": True, "bytes": self.bytes, "planes": self.count, "candidates_probed": len(self.probe_gbs),
                 "probe_gb_per_s": [round(g, 1) for g in self.probe_gbs], "chosen_gb_per_s": self.chosen_gbs}
+
+
+class _DevicePlane:
+    """a device plane the library owns, as torch sees it (zero-copy, through __cuda_array_interface__)"""
+
+    def __init__(self, ptr: int, count: int):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+class Pipeline:
+    """Host-resident batches (rls_pipeline_*): a batch whose planes live in page-locked HOST memory goes through the GPU in
+    chunks -- upload, closure kernels, download -- on ``depth`` streams, so that the copies of neighbouring chunks overlap
+    the kernels and each other.  What an Arnold-side stub does with the shading points its CPU render threads gathered
+    (the reference evaluates per hit on those threads, src/rlGgx.cpp:248-261).
+
+    ``run(n, host_in, host_out, launch)``: ``host_in`` / ``host_out`` are lists of pinned float32 CPU tensors of n
+    elements (``torch.empty(n, pin_memory=True)``) or None for a plane that is not streamed; ``launch(slot, first, count,
+    dev_in, dev_out)`` is called once per chunk with a Context for the chunk's stream and the chunk's device planes
+    ([count] tensors, None where the host plane is None) and makes the closure calls."""
+
+    def __init__(self, ctx: Context, chunk_points: int, in_planes: int, out_planes: int, depth: int = 3):
+        self.ctx, self.chunk_points = ctx, int(chunk_points)
+        self.in_planes, self.out_planes, self.depth = int(in_planes), int(out_planes), int(depth)
+        h = C.c_void_p()
+        check(ctx.lib.rls_pipeline_create(ctx.handle, self.chunk_points, self.in_planes, self.out_planes, self.depth, C.byref(h)))
+        self.handle = h
+        self._slots = {}
+
+    def _slot(self, handle: int) -> Context:
+        s = self._slots.get(handle)
+        if s is None:
+            s = Context.__new__(Context)            # a view of the slot's rls_context: borrowed, never destroyed from here
+            s.lib, s.device, s.torch_device = self.ctx.lib, self.ctx.device, self.ctx.torch_device
+            s.handle = C.c_void_p(handle)
+            s.close = lambda: None
+            self._slots[handle] = s
+        return s
+
+    def run(self, n: int, host_in, host_out, launch) -> None:
+        if len(host_in) != self.in_planes or len(host_out) != self.out_planes:
+            raise ValueError(f"Pipeline.run: expected {self.in_planes} input and {self.out_planes} output planes")
+        for what, planes in (("host_in", host_in), ("host_out", host_out)):
+            for k, t in enumerate(planes):
+                if t is None:
+                    continue
+                if t.dtype != torch.float32 or t.is_cuda or t.dim() != 1 or t.shape[0] != n or not t.is_contiguous():
+                    raise TypeError(f"{what}[{k}]: expected a contiguous float32 CPU tensor of {n} elements")
+                if not t.is_pinned():
+                    raise TypeError(f"{what}[{k}]: host planes must be page-locked (torch.empty(n, pin_memory=True))")
+        hin = (C.c_void_p * max(self.in_planes, 1))(*[t.data_ptr() if t is not None else None for t in host_in])
+        hout = (C.c_void_p * max(self.out_planes, 1))(*[t.data_ptr() if t is not None else None for t in host_out])
+        err = []
+
+        def _cb(_user, slot, first, count, din, dout):
+            try:
+                mk = lambda arr, k, live: (torch.as_tensor(_DevicePlane(arr[k], int(count)), device=self.ctx.torch_device)
+                                           if live else None)
+                launch(self._slot(slot), int(first), int(count),
+                       [mk(din, k, host_in[k] is not None) for k in range(self.in_planes)],
+                       [mk(dout, k, host_out[k] is not None) for k in range(self.out_planes)])
+                return 0
+            except RlsError as e:       # never unwind through the C frames
+                err.append(e)
+                return e.status
+            except Exception as e:
+                err.append(e)
+                return 1
+
+        cb = capi.PipelineLaunchFn(_cb)
+        st = self.ctx.lib.rls_pipeline_run(self.handle, int(n), hin, hout, C.cast(cb, C.c_void_p), None)
+        if err:
+            raise err[0]
+        check(st)
+
+    def copy_rates(self, nbytes: int = 1 << 28) -> dict:
+        """pinned-memory copy rates of this box in GB/s (rls_measure_copy_rates)"""
+        r = (C.c_float * 3)()
+        check(self.ctx.lib.rls_measure_copy_rates(self.ctx.handle, int(nbytes), r))
+        return {"h2d": float(r[0]), "d2h": float(r[1]), "both": float(r[2])}
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.ctx.lib.rls_pipeline_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class GraphCapture:

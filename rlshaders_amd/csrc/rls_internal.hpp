@@ -313,6 +313,32 @@ RLS_DEV TileRange tile_range(int64_t n)
     return t;
 }
 
+// A fresh copy of the kernel's argument struct, read from the kernarg segment at the point of the call.  The pointwise
+// kernels stream 25-59 planes: kept alive across the tile loop, their base pointers alone need up to 118 of the 102
+// scalar registers, and the allocator spills them into vector lanes (v_writelane / v_readlane -- VALU instructions, on
+// kernels that are bound by VALU issue: rlSkin 246 spilled SGPRs, reflect+refract 52, the rlSss probe 30).  Re-read per
+// tile -- the input planes' pointers where the loads are issued, the output planes' where the stores are -- they live
+// for a few instructions each; the s_load_dwordx4/x8 that fetch them go to the scalar cache and cost no vector issue.
+// The empty asm makes the pointer opaque, so the loads cannot be hoisted back out of the loop.  IO must be the kernel's
+// first (only) parameter.  Measured (profiles/r03_reload_args.txt, two libraries interleaved on one box): rlSkin 246 -> 42
+// spilled SGPRs, 4.44 -> 4.34 ms (-2.2 %); the rlSss probe 30 -> 0, 1.710 -> 1.686 ms (-1.4 %); the rlGgx kernels 52 -> 2
+// but +2.3 % (2.054 -> 2.102 ms: stores that used to leave early now wait for the reload), so ggx.hip does not use it.
+#ifndef RLS_RELOAD_ARGS
+#define RLS_RELOAD_ARGS 1
+#endif
+template <class IO>
+RLS_DEV IO reload_args(const IO &a)
+{
+#if RLS_RELOAD_ARGS && defined(__HIP_DEVICE_COMPILE__)     // (the host pass of the translation unit only parses this)
+    typedef const __attribute__((address_space(4))) IO *KP;
+    KP p = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *p;
+#else
+    return a;
+#endif
+}
+
 // I: int64_t or Idx.  STREAMED: every optional parameter plane is present (checked on the host), so the
 // per-parameter "stream or uniform" test -- a scalar branch per parameter per iteration -- disappears.
 template <bool STREAMED = false, class I>

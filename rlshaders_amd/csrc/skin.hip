@@ -45,13 +45,14 @@ __device__ __forceinline__ LobeOut ggx_lobe(V3 wo, V3 N, V3 T, V3 local, float c
 
 // STREAMED: every parameter is a per-point plane (checked on the host)
 template <int FAST_MATH, bool STREAMED>
-__global__ __launch_bounds__(rlsh::kBlock) void skin_kernel(SkinIO a)
+__global__ __launch_bounds__(rlsh::kBlock) void skin_kernel(SkinIO a0)
 {
     stage_libm_tables();   // expf / logf tables -> LDS (EXACT mode)
-    const TileRange tiles = tile_range(a.n);
+    const TileRange tiles = tile_range(a0.n);
     for (int64_t base = tiles.first; base < tiles.end; base += tiles.step) {
         const Idx i = make_idx(base);
-        if (i.full() >= a.n) continue;
+        if (i.full() >= a0.n) continue;
+        const SkinIO a = reload_args(a0);      // the 35 input planes' pointers, for the loads of this tile only
         const rls_skin_closure &c = a.c;
         V3 wo = ld3(c.wo, i), N = ld3(c.N, i), T = ld3(c.T, i);
 
@@ -116,7 +117,8 @@ __global__ __launch_bounds__(rlsh::kBlock) void skin_kernel(SkinIO a)
             nd_pdf_profile(p, r, rpdf, R, G, B);
         }
 
-        const rls_skin_out &o = a.o;
+        const SkinIO b = reload_args(a0);      // ... and the 24 output planes', for its stores
+        const rls_skin_out &o = b.o;
         st3(o.sheen_wi, i, sh.wi); strgb(o.sheen_f, i, sh.fr, sh.fg, sh.fb);
         stg(o.sheen_pdf, i, sh.pdf); stg(o.sheen_fresnel, i, sh.F);
         st3(o.spec_wi, i, sp.wi); strgb(o.spec_f, i, sp.fr, sp.fg, sp.fb);

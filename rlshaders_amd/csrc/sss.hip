@@ -30,13 +30,14 @@ __device__ __forceinline__ NdProfile load_profile(const rls_sss_closure &c, I i)
 }
 
 template <int OP, int FAST_MATH = RLS_FAST>
-__global__ __launch_bounds__(rlsh::kBlock) void sss_kernel(SssIO a)
+__global__ __launch_bounds__(rlsh::kBlock) void sss_kernel(SssIO a0)
 {
     stage_libm_tables();   // expf / logf tables -> LDS (EXACT mode)
-    const TileRange tiles = tile_range(a.n);
+    const TileRange tiles = tile_range(a0.n);
     for (int64_t base = tiles.first; base < tiles.end; base += tiles.step) {
         const Idx i = make_idx(base);
-        if (i.full() >= a.n) continue;
+        if (i.full() >= a0.n) continue;
+        const SssIO a = reload_args(a0);       // plane pointers re-read per tile (rls_internal.hpp, reload_args)
         NdProfile p = load_profile(a.c, i);
         if (OP == OP_ND) {
             float r = nd_radius(p, ldg(a.rx, i));
@@ -59,12 +60,13 @@ __global__ __launch_bounds__(rlsh::kBlock) void sss_kernel(SssIO a)
             if (a.P.x) off = ld3(a.P, i) + off;                       // ray.origin = origin + offset
             float pdf, R, G, B;
             nd_pdf_profile(p, r, pdf, R, G, B);
-            stg(a.r, i, r);
-            st3(a.origin, i, off);
-            st3(a.dir, i, dir);
-            stg(a.maxdist, i, maxdist);
-            stg(a.pdf, i, pdf);
-            strgb(a.profile, i, R, G, B);
+            const SssIO b = reload_args(a0);   // the output planes' pointers, for the stores
+            stg(b.r, i, r);
+            st3(b.origin, i, off);
+            st3(b.dir, i, dir);
+            stg(b.maxdist, i, maxdist);
+            stg(b.pdf, i, pdf);
+            strgb(b.profile, i, R, G, B);
         } else if (OP == OP_MIS) {
             Frame fr = sss_frame(ld3(a.c.N, i), ld3(a.c.T, i), a.c.has_dPdu != 0);
             stg(a.pdf, i, sss_mis_pdf(p, fr, ld3(a.disp, i), ld3(a.sampleN, i), a.literal != 0));

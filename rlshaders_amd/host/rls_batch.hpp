@@ -17,8 +17,10 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <exception>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -173,6 +175,77 @@ private:
     float *ptr_ = nullptr;
     int64_t n_ = 0;
     int planes_ = 0;
+};
+
+// n x planes floats in PAGE-LOCKED host memory (rls_host_alloc), planar: what a stub's render threads fill and read.
+// Pinned memory is what lets a Pipeline's copies run asynchronously at the PCIe rate.
+class HostPlanes {
+public:
+    HostPlanes() = default;
+    HostPlanes(const Device &d, int64_t n, int planes) : dev_(&d), n_(n), planes_(planes)
+    {
+        void *p = nullptr;
+        check(rls_host_alloc(d.ctx(), sizeof(float) * (size_t)n * (size_t)planes, &p));
+        ptr_ = static_cast<float *>(p);
+    }
+    ~HostPlanes() { if (ptr_) rls_host_free(dev_->ctx(), ptr_); }
+    HostPlanes(const HostPlanes &) = delete;
+    HostPlanes &operator=(const HostPlanes &) = delete;
+    float *plane(int p) const { return ptr_ + (size_t)p * (size_t)n_; }
+    int64_t size() const { return n_; }
+    int planes() const { return planes_; }
+
+private:
+    const Device *dev_ = nullptr;
+    float *ptr_ = nullptr;
+    int64_t n_ = 0;
+    int planes_ = 0;
+};
+
+// A host-resident batch through the GPU in overlapped chunks (rls_pipeline_*): per chunk upload -> the closure calls `launch`
+// makes -> download, on `depth` streams.  `launch(slot, first_point, count, device_in, device_out)` receives the chunk's
+// rls_context (its stream) and device planes and calls the C ABI on them, e.g.
+//     rlsb::Pipeline pipe(dev, 1 << 20, 19, 12);
+//     pipe.run(n, in.data(), out.data(), [&](rls_context *slot, int64_t, int64_t count, float *const *i, float *const *o) {
+//         rls_ggx_closure c{}; c.wo = {i[0], i[1], i[2]}; ...
+//         return rls_ggx_reflect_refract(slot, count, &c, i[15], i[16], i[17], i[18], {o[0], o[1], o[2]}, ...); });
+// The reference has no counterpart: it evaluates per hit on the render thread (src/rlGgx.cpp:248-261).
+class Pipeline {
+public:
+    Pipeline(const Device &d, int64_t chunk_points, int in_planes, int out_planes, int depth = 3)
+    {
+        check(rls_pipeline_create(d.ctx(), chunk_points, in_planes, out_planes, depth, &p_));
+    }
+    ~Pipeline() { rls_pipeline_destroy(p_); }
+    Pipeline(const Pipeline &) = delete;
+    Pipeline &operator=(const Pipeline &) = delete;
+
+    template <typename Launch>
+    void run(int64_t n, const float *const *host_in, float *const *host_out, Launch &&launch) const
+    {
+        Thunk<Launch> t{&launch, nullptr};
+        rls_status st = rls_pipeline_run(p_, n, host_in, host_out, &Thunk<Launch>::call, &t);
+        if (t.thrown) std::rethrow_exception(t.thrown);
+        check(st);
+    }
+
+private:
+    template <typename Launch>
+    struct Thunk {
+        typename std::remove_reference<Launch>::type *fn;
+        std::exception_ptr thrown;
+        static rls_status call(void *user, rls_context *slot, int64_t first, int64_t count, float *const *in, float *const *out)
+        {
+            Thunk *t = static_cast<Thunk *>(user);
+            try {
+                return (*t->fn)(slot, first, count, in, out);
+            } catch (...) {                  // never unwind through the C frames
+                t->thrown = std::current_exception();
+                return RLS_ERR_ABORTED;
+            }
+        }
+    };
+    rls_pipeline *p_ = nullptr;
 };
 
 // What the closures read from AtShaderGlobals, gathered per shading point by the Arnold-side stub:

@@ -1,0 +1,127 @@
+"""GPU: host-resident batches (rls_pipeline_*, rlshaders_amd.Pipeline, rlsb::Pipeline).  The shading points of an
+Arnold-side stub start in host memory (the reference evaluates per hit on CPU render threads, src/rlGgx.cpp:248-261);
+the pipeline sends them through the GPU in overlapped chunks.  Its results must be those of ONE device-resident call
+on the same points, bit for bit -- ragged batches, batches shorter than a chunk, one slot or several, uniform
+parameters (host planes that are not streamed), and the oracle on top."""
+import json
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+import rlshaders_amd as R
+from gpu_util import dev, ggx_oracle, host
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _pinned(a: np.ndarray) -> torch.Tensor:
+    t = torch.empty(a.shape[0], dtype=torch.float32, pin_memory=True)
+    t.copy_(torch.from_numpy(np.ascontiguousarray(a)))
+    return t
+
+
+def _launch(slot, first, count, i, o):
+    g = R.GgxSampler(slot, torch.stack(i[0:3]), torch.stack(i[3:6]), torch.stack(i[6:9]), specColor=torch.stack(i[9:12]),
+                     roughness=i[12], ior=i[13], anisotropic=i[14])
+    # the verb writes straight into the chunk's device planes; the stacked inputs above are chunk-sized device copies
+    wi, f, wt = (torch.empty(3, count, device="cuda") for _ in range(3))
+    out = g.reflectRefract(i[15], i[16], i[17], i[18], out=(wi, f, o[6], o[7], wt, o[11]))
+    for k in range(3):
+        o[k].copy_(out[0][k]); o[3 + k].copy_(out[1][k]); o[8 + k].copy_(out[4][k])
+
+
+@pytest.mark.parametrize("n,chunk,depth", [(100_003, 1 << 14, 3), (5000, 1 << 14, 2), (1 << 16, 1 << 14, 1), (70_001, 4096, 4)])
+def test_pipeline_equals_device_resident(gpu, oracle, n, chunk, depth):
+    c = cases.ggx_mixed(cases.SEED_PARITY, n)
+    x = cases.xi(cases.SEED_PARITY, n, 4)
+    planes = [c["wo"][k] for k in range(3)] + [c["N"][k] for k in range(3)] + [c["T"][k] for k in range(3)] + \
+             [c["KsColor"][k] for k in range(3)] + [c["roughness"], c["ior"], c["anisotropic"]] + [x[k] for k in range(4)]
+    hin = [_pinned(p) for p in planes]
+    hout = [torch.full((n,), float("nan"), dtype=torch.float32).pin_memory() for _ in range(12)]
+    pipe = R.Pipeline(gpu, chunk, 19, 12, depth)
+    try:
+        pipe.run(n, hin, hout, _launch)
+    finally:
+        pipe.close()
+    # the same points in one device-resident call
+    from gpu_util import ggx_sampler
+    ref = [host(t) for t in ggx_sampler(gpu, c).reflectRefract(dev(x[0]), dev(x[1]), dev(x[2]), dev(x[3]))]
+    flat = [ref[0][0], ref[0][1], ref[0][2], ref[1][0], ref[1][1], ref[1][2], ref[2], ref[3], ref[4][0], ref[4][1], ref[4][2], ref[5]]
+    for k, (a, b) in enumerate(zip(hout, flat)):
+        assert np.array_equal(a.numpy().view(np.uint32), b.view(np.uint32)), (k, n, chunk, depth)
+    # and the oracle
+    orc = ggx_oracle(oracle, c).reflect_refract(x[0], x[1], x[2], x[3])
+    got_f = np.stack([hout[3].numpy(), hout[4].numpy(), hout[5].numpy()])
+    cases.assert_tight(cases.summarize(cases.rel_err(got_f, orc[1])), "pipeline f")
+
+
+def test_pipeline_uniform_planes_and_argument_checks(gpu):
+    """host planes that are None are not copied: uniform node parameters, outputs nobody wants"""
+    n = 20_000
+    c = cases.ggx_mixed(cases.SEED_EDGE, n)
+    x = cases.xi(cases.SEED_EDGE, n, 2)
+    hin = [_pinned(c["wo"][k]) for k in range(3)] + [_pinned(c["N"][k]) for k in range(3)] + \
+          [_pinned(c["T"][k]) for k in range(3)] + [None] + [_pinned(x[0]), _pinned(x[1])]
+    hout = [torch.empty(n, dtype=torch.float32).pin_memory() for _ in range(3)] + [None]
+    seen = []
+
+    def launch(slot, first, count, i, o):
+        assert i[9] is None and o[3] is None and all(t.shape == (count,) for t in i[:9])
+        seen.append((first, count))
+        g = R.GgxSampler(slot, torch.stack(i[0:3]), torch.stack(i[3:6]), torch.stack(i[6:9]), specColor=(0.9, 0.8, 0.7),
+                         roughness=0.35, ior=1.5)
+        wi, _ = g.evalSample(i[10], i[11])
+        for k in range(3):
+            o[k].copy_(wi[k])
+
+    pipe = R.Pipeline(gpu, 8192, 12, 4, 2)
+    try:
+        pipe.run(n, hin, hout, launch)
+        assert seen == [(0, 8192), (8192, 8192), (16384, n - 16384)]
+        g = R.GgxSampler(gpu, dev(c["wo"]), dev(c["N"]), dev(c["T"]), specColor=(0.9, 0.8, 0.7), roughness=0.35, ior=1.5)
+        wi = host(g.evalSample(dev(x[0]), dev(x[1]))[0])
+        for k in range(3):
+            assert np.array_equal(hout[k].numpy().view(np.uint32), wi[k].view(np.uint32))
+        with pytest.raises(TypeError):                      # pageable host memory is refused
+            pipe.run(n, [torch.empty(n)] + hin[1:], hout, launch)
+        with pytest.raises(ValueError):
+            pipe.run(n, hin[:5], hout, launch)
+
+        def bad(slot, first, count, i, o):
+            raise RuntimeError("consumer failed")
+        with pytest.raises(RuntimeError, match="consumer failed"):
+            pipe.run(n, hin, hout, bad)
+        pipe.run(n, hin, hout, launch)                      # still usable after a failed run
+    finally:
+        pipe.close()
+    lib = gpu.lib
+    import ctypes as C
+    h = C.c_void_p()
+    assert lib.rls_pipeline_create(gpu.handle, 0, 1, 1, 2, C.byref(h)) == 1        # chunk_points < 1
+    assert lib.rls_pipeline_create(gpu.handle, 16, 1, 1, 0, C.byref(h)) == 1       # depth out of range
+    rates = R.Pipeline(gpu, 1024, 1, 1, 1)
+    try:
+        r = rates.copy_rates(1 << 26)
+        assert r["h2d"] > 1.0 and r["d2h"] > 1.0 and r["both"] > 1.0
+    finally:
+        rates.close()
+
+
+def test_cpp_host_pipeline_example():
+    """rlsb::Pipeline + rlsb::HostPlanes (rls_host_alloc): the C++ stub's path, checked against the device-resident call
+    inside the example (exit code) and reported with the box's copy rates"""
+    from rlshaders_amd import build
+    build.build_library()
+    build.build_host_examples()
+    exe = ROOT / "rlshaders_amd" / "build" / "example_host_pipeline"
+    p = subprocess.run([str(exe), "21", "17", "3", "2"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout, p.stderr)
+    got = json.loads(p.stdout.strip().splitlines()[-1])
+    assert got["bit_identical_to_device_resident"] is True and got["points"] == (1 << 21) - 37
+    assert got["gsamples_per_s"] > 0 and got["box_h2d"] > 1.0
+    print(got)

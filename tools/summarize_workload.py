@@ -67,7 +67,8 @@ def main():
     if "FETCH_SIZE" in fetch and "WRITE_SIZE" in write:
         rd, wr = fetch["FETCH_SIZE"] * 1024.0 * factor, write["WRITE_SIZE"] * 1024.0
         alg = line["roofline"]["algorithmic_bytes_per_launch"]
-        t = {"workload": workload, "math": math, "kernel": ksub, "hbm_bytes_per_launch": int(round(rd + wr)),
+        t = {"workload": workload, "math": math, "kernel": ksub, "points_per_launch": points_per_launch,
+             "hbm_bytes_per_launch": int(round(rd + wr)),
              "read": int(round(rd)), "write": int(round(wr)), "algorithmic_bytes_per_launch": alg,
              "ratio_to_algorithmic": round((rd + wr) / alg, 4), "fetch_size_factor": round(factor, 4),
              "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/profile_workload.sh); FETCH_SIZE x "
@@ -84,7 +85,8 @@ def main():
         flops = (g("SQ_INSTS_VALU_ADD_F32") + g("SQ_INSTS_VALU_MUL_F32") + 2 * g("SQ_INSTS_VALU_FMA_F32")
                  + g("SQ_INSTS_VALU_TRANS_F32") + g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64")
                  + 2 * g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_TRANS_F64"))
-        f = {"workload": workload, "math": math, "kernel": ksub, "flops_per_point": round(flops, 1),
+        f = {"workload": workload, "math": math, "kernel": ksub, "points_per_launch": points_per_launch,
+             "flops_per_point": round(flops, 1),
              "instructions_per_point": per,
              "note": "wave-instructions per wave of 64 points = instructions per point (G = 1: one lane per point); flops = "
                      "add + mul + 2 fma + transcendental, fp32 and fp64 alike; divergent lanes count as executed",

@@ -598,11 +598,13 @@ def roofline_record(wl, n: int, kernel_ms: float, math: str) -> dict:
         rates = wl.pipe.copy_rates(1 << 28)
         up, down = n * 19 * 4.0, n * 12 * 4.0
         t = kernel_ms * 1e-3
-        floor = max(up / (rates["h2d"] * 1e9), down / (rates["d2h"] * 1e9), (up + down) / (rates["both"] * 1e9))
+        floor = max(up / (rates["h2d"] * 1e9), down / (rates["d2h"] * 1e9))
         return {"bound": "pcie", "achieved": round((up + down) / t / 1e9, 2), "peak": round(rates["both"], 2), "unit": "GB/s",
                 "frac": round(floor / t, 4), "traffic": None,
-                "frac_note": "time the box's own pinned copies need for this pass (max of: upload alone, download alone, both "
-                             "directions at the measured bidirectional rate) / measured time of the pass",
+                "frac_note": "time the box's own pinned copies need for this pass (the slower of: all uploads at the measured "
+                             "host -> device rate, all downloads at the device -> host rate; the two directions run on "
+                             "separate DMA engines) / measured time of the pass; `peak` is the measured rate of both "
+                             "directions at once",
                 "h2d_gb_per_s": round(up / t / 1e9, 2), "d2h_gb_per_s": round(down / t / 1e9, 2),
                 "box_copy_rates_gb_per_s": {k: round(v, 2) for k, v in rates.items()},
                 "pass_ms": round(kernel_ms, 4), "chunks_per_pass": launches, "kernel": wl.kernel.format(m=1 if math == "fast" else 0),

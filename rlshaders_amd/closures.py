@@ -164,10 +164,40 @@ class Arena:
 
 
 class _DevicePlane:
-    """a device plane the library owns, as torch sees it (zero-copy, through __cuda_array_interface__)"""
+    """device planes the library owns, as torch sees them (zero-copy, through __cuda_array_interface__)"""
 
-    def __init__(self, ptr: int, count: int):
-        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+    def __init__(self, ptr: int, count: int, rows: int = 0, row_stride_bytes: int = 0):
+        if rows:
+            self.__cuda_array_interface__ = {"shape": (rows, count), "strides": (row_stride_bytes, 4), "typestr": "<f4",
+                                             "data": (ptr, False), "version": 2}
+        else:
+            self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+class ChunkPlanes:
+    """The device planes of one pipeline chunk: ``p[k]`` is plane k as a [count] tensor (None where the host plane is not
+    streamed), ``p.rows(k, 3)`` planes k .. k+2 as one [3, count] tensor -- what the closure classes take for a vec3 /
+    colour.  Views of the slot's memory: fill and read them with closure calls on the slot's Context only (torch's own
+    operations run on torch's stream, which is not ordered with the slot's)."""
+
+    def __init__(self, ptrs, live, count: int, device):
+        self._ptrs, self._live, self._count, self._device = ptrs, live, int(count), device
+
+    def __len__(self):
+        return len(self._live)
+
+    def __getitem__(self, k: int):
+        if not self._live[k]:
+            return None
+        return torch.as_tensor(_DevicePlane(self._ptrs[k], self._count), device=self._device)
+
+    def rows(self, k: int, rows: int = 3):
+        if not all(self._live[k:k + rows]):
+            return None
+        step = self._ptrs[k + 1] - self._ptrs[k] if rows > 1 else 4 * self._count
+        if any(self._ptrs[k + j] - self._ptrs[k] != j * step for j in range(rows)):
+            raise ValueError("ChunkPlanes.rows: planes are not equally spaced")
+        return torch.as_tensor(_DevicePlane(self._ptrs[k], self._count, rows, step), device=self._device)
 
 
 class Pipeline:
@@ -179,7 +209,7 @@ class Pipeline:
     ``run(n, host_in, host_out, launch)``: ``host_in`` / ``host_out`` are lists of pinned float32 CPU tensors of n
     elements (``torch.empty(n, pin_memory=True)``) or None for a plane that is not streamed; ``launch(slot, first, count,
     dev_in, dev_out)`` is called once per chunk with a Context for the chunk's stream and the chunk's device planes
-    ([count] tensors, None where the host plane is None) and makes the closure calls."""
+    (ChunkPlanes) and makes the closure calls -- on ``slot``, writing into ``dev_out`` through the verbs' ``out=``."""
 
     def __init__(self, ctx: Context, chunk_points: int, in_planes: int, out_planes: int, depth: int = 3):
         self.ctx, self.chunk_points = ctx, int(chunk_points)
@@ -216,11 +246,11 @@ class Pipeline:
 
         def _cb(_user, slot, first, count, din, dout):
             try:
-                mk = lambda arr, k, live: (torch.as_tensor(_DevicePlane(arr[k], int(count)), device=self.ctx.torch_device)
-                                           if live else None)
                 launch(self._slot(slot), int(first), int(count),
-                       [mk(din, k, host_in[k] is not None) for k in range(self.in_planes)],
-                       [mk(dout, k, host_out[k] is not None) for k in range(self.out_planes)])
+                       ChunkPlanes([din[k] for k in range(self.in_planes)], [t is not None for t in host_in], count,
+                                   self.ctx.torch_device),
+                       ChunkPlanes([dout[k] for k in range(self.out_planes)], [t is not None for t in host_out], count,
+                                   self.ctx.torch_device))
                 return 0
             except RlsError as e:       # never unwind through the C frames
                 err.append(e)

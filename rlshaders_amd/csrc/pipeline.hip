@@ -213,9 +213,14 @@ rls_status rls_measure_copy_rates(rls_context *ctx, size_t bytes, float rates_gb
         };
         float warm;
         e = pass(true, true, &warm);
-        if (e == hipSuccess) e = pass(true, false, &rates_gb_per_s[0]);
-        if (e == hipSuccess) e = pass(false, true, &rates_gb_per_s[1]);
-        if (e == hipSuccess) e = pass(true, true, &rates_gb_per_s[2]);
+        rates_gb_per_s[0] = rates_gb_per_s[1] = rates_gb_per_s[2] = 0.0f;
+        for (int rep = 0; e == hipSuccess && rep < 2; rep++) {          // best of two: a pass now and then runs at half rate
+            float g[3] = {0.0f, 0.0f, 0.0f};
+            e = pass(true, false, &g[0]);
+            if (e == hipSuccess) e = pass(false, true, &g[1]);
+            if (e == hipSuccess) e = pass(true, true, &g[2]);
+            for (int k = 0; k < 3; k++) if (g[k] > rates_gb_per_s[k]) rates_gb_per_s[k] = g[k];
+        }
     }
     if (a) (void)hipEventDestroy(a);
     if (b) (void)hipEventDestroy(b);

@@ -26,13 +26,10 @@ def _pinned(a: np.ndarray) -> torch.Tensor:
 
 
 def _launch(slot, first, count, i, o):
-    g = R.GgxSampler(slot, torch.stack(i[0:3]), torch.stack(i[3:6]), torch.stack(i[6:9]), specColor=torch.stack(i[9:12]),
-                     roughness=i[12], ior=i[13], anisotropic=i[14])
-    # the verb writes straight into the chunk's device planes; the stacked inputs above are chunk-sized device copies
-    wi, f, wt = (torch.empty(3, count, device="cuda") for _ in range(3))
-    out = g.reflectRefract(i[15], i[16], i[17], i[18], out=(wi, f, o[6], o[7], wt, o[11]))
-    for k in range(3):
-        o[k].copy_(out[0][k]); o[3 + k].copy_(out[1][k]); o[8 + k].copy_(out[4][k])
+    # everything on the slot's Context: its stream orders the upload, these kernels and the download.  The verbs read and
+    # write the chunk's device planes in place ([3, count] views of three consecutive planes for vectors and colours)
+    g = R.GgxSampler(slot, i.rows(0), i.rows(3), i.rows(6), specColor=i.rows(9), roughness=i[12], ior=i[13], anisotropic=i[14])
+    g.reflectRefract(i[15], i[16], i[17], i[18], out=(o.rows(0), o.rows(3), o[6], o[7], o.rows(8), o[11]))
 
 
 @pytest.mark.parametrize("n,chunk,depth", [(100_003, 1 << 14, 3), (5000, 1 << 14, 2), (1 << 16, 1 << 14, 1), (70_001, 4096, 4)])
@@ -69,15 +66,13 @@ def test_pipeline_uniform_planes_and_argument_checks(gpu):
           [_pinned(c["T"][k]) for k in range(3)] + [None] + [_pinned(x[0]), _pinned(x[1])]
     hout = [torch.empty(n, dtype=torch.float32).pin_memory() for _ in range(3)] + [None]
     seen = []
+    scratch = torch.empty(8192, device="cuda")        # the Fresnel side output nobody downloads
 
     def launch(slot, first, count, i, o):
-        assert i[9] is None and o[3] is None and all(t.shape == (count,) for t in i[:9])
+        assert i[9] is None and o[3] is None and all(i[k].shape == (count,) for k in range(9)) and i.rows(8) is None
         seen.append((first, count))
-        g = R.GgxSampler(slot, torch.stack(i[0:3]), torch.stack(i[3:6]), torch.stack(i[6:9]), specColor=(0.9, 0.8, 0.7),
-                         roughness=0.35, ior=1.5)
-        wi, _ = g.evalSample(i[10], i[11])
-        for k in range(3):
-            o[k].copy_(wi[k])
+        g = R.GgxSampler(slot, i.rows(0), i.rows(3), i.rows(6), specColor=(0.9, 0.8, 0.7), roughness=0.35, ior=1.5)
+        g.evalSample(i[10], i[11], out_wi=o.rows(0), out_fresnel=scratch[:count])
 
     pipe = R.Pipeline(gpu, 8192, 12, 4, 2)
     try:

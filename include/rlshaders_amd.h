@@ -236,10 +236,13 @@ rls_status rls_ggx_ndf_pdf(rls_context *ctx, int64_t n, const rls_ggx_closure *c
 /* spp_n^2 stratified samples per point drawn in-kernel (stand-in for AiSampler(spp_n, 2),
  * src/rlGgx.cpp:148): sum_f_over_pdf = sum over samples of eval/pdf (what AiBRDFIntegrate
  * accumulates before radiance), avg_reflect_weight = getAvgReflectWeight (src/rlGgx.h:181-184).
- * One wavefront per point group, lanes = strata, wave-shuffle reduction.
+ * Small batches are given 4, 16 or 64 lanes per point (chosen from n, so that they still fill the GPU); the sums grow in
+ * SAMPLE order whatever that width (the lanes' terms are folded into a replicated sum in lane order, round by round), so
+ * the results do not depend on it: bit for bit those of one lane per point, i.e. of the reference's `result +=` loop.
  * first_index (here and in every other in-kernel-sampling entry point): the global index of point 0 of
  * this call.  The per-point scrambles are hash(seed, first_index + i), so a batch split with
- * rls_shard_range -- or walked in chunks -- draws exactly the numbers of the unsplit batch. */
+ * rls_shard_range -- or walked in chunks -- draws exactly the numbers of the unsplit batch and, by the above, returns
+ * exactly its sums. */
 rls_status rls_ggx_integrate(rls_context *ctx, int64_t n, const rls_ggx_closure *c,
                              int spp_n, uint32_t seed, uint64_t first_index,
                              rls_rgb sum_f_over_pdf, float *avg_reflect_weight);

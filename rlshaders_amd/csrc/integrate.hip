@@ -80,12 +80,43 @@ __device__ __forceinline__ void stage_table(uint32_t (*tab)[kMaxSpp], int spp)
 
 RLS_DEV V3 arr3(const float (&a)[3]) { return mk(a[0], a[1], a[2]); }
 
+// butterfly sum over the G lanes of a group: for the integer-valued sums only (sample counts), where the order of the
+// additions cannot change the result
 template <int G>
 __device__ __forceinline__ float group_sum(float v)
 {
 #pragma unroll
     for (int off = G / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
+}
+
+// Sums in SAMPLE order whatever the group width.  Lane `sub` of a G-lane group takes samples sub, sub + G, ...: within one
+// round of the sample loop the G lanes hold the terms of G consecutive samples.  `acc` is kept replicated in all lanes of
+// the group; fold adds the round's terms to it in lane order -- sample order -- so that G = 4, 16, 64 produce, bit for bit,
+// the sum the one-lane-per-point loop (and the reference's `result +=` loop) produces.  Every lane of the group calls it at
+// the same point of the round, with +0 where it has no term (a sum that starts at +0 is never -0, so adding +0 changes
+// nothing); the lanes of other groups of the wavefront may be masked off (rlSkin's per-point branches).  G = 1: a plain add.
+// Cost: G cross-lane reads + adds per accumulator and round; G > 1 only runs on batches too small to fill the GPU.
+template <int G>
+__device__ __forceinline__ float group_lane(float v, int l)      // the value lane l of this lane's group holds
+{
+    if (G == 64) return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), l));
+    return __shfl(v, (int)((threadIdx.x & 63u) & ~(unsigned)(G - 1)) + l, 64);
+}
+template <int G>
+__device__ __forceinline__ void fold(float &acc, float t)
+{
+    if (G == 1) { acc += t; return; }
+#pragma unroll
+    for (int l = 0; l < G; l++) acc += group_lane<G>(t, l);
+}
+// two terms per sample, added as the one-lane loop adds them: sample by sample, t1 then t2
+template <int G>
+__device__ __forceinline__ void fold2(float &acc, float t1, float t2)
+{
+    if (G == 1) { acc += t1; acc += t2; return; }
+#pragma unroll
+    for (int l = 0; l < G; l++) { acc += group_lane<G>(t1, l); acc += group_lane<G>(t2, l); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -320,7 +351,7 @@ __device__ __forceinline__ void ggx_hit_eval_run(SlowLds<K> &Q, int cnt, const G
 
 // integrateGlossy's sample loop over one closure (src/rlGgx.h:172-179 -> AiBRDFIntegrate over the triple): lane `sub`
 // of a G-lane group takes samples sub, sub + G, ...; sums of f/pdf and of the Fresnel side effect of evalSample
-// (src/rlGgx.h:103), reduced over the group
+// (src/rlGgx.h:103), in sample order and replicated over the group (fold)
 // PACK = false: the plain loop.  rlSkin runs its two lobes inside per-point branches (src/rlSkin.cpp:191,214): wavefronts
 // arrive here partly active, and the packed form costs more than it saves there (+17 % on the whole kernel, measured)
 template <int G, int K, bool PACK = true>
@@ -328,18 +359,23 @@ __device__ __forceinline__ void ggx_glossy_loop(SlowLds<K> &slow, const Ggx &g, 
                                                 const uint32_t (*tab)[kMaxSpp], int spp, int sub, uint32_t sx, uint32_t sy,
                                                 float &accR, float &accG, float &accB, float &accF, float f0 = 0.0f)
 {
-    // f0: this lane's Fresnel sum of the samples drawn on the closure before (rlSkin's light loops)
+    // f0: the Fresnel sum of the samples drawn on the closure before (rlSkin's light loops)
     accR = 0.0f; accG = 0.0f; accB = 0.0f; accF = f0;
     if (!PACK) {
-        for (int s = sub; s < spp; s += G) {
-            float rx = bits_u01(tab[0][s] ^ sx);
-            float ry = bits_u01(tab[1][s] ^ sy);
-            V3 M = vndf_microfacet(w, g.fr, rx, ry);
-            V3 L = reflect_direction(g.view, M);
-            accF += ggx_fresnel(g, L, M);                   // mReflectWeight, src/rlGgx.h:103
-            float fr, fg, fb, pdf;
-            ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pdf);
-            accR += fr / pdf; accG += fg / pdf; accB += fb / pdf;
+        for (int s0 = 0; s0 < spp; s0 += G) {                  // one round: G consecutive samples, one per lane
+            const int s = s0 + sub;
+            float tR = 0.0f, tG = 0.0f, tB = 0.0f, tF = 0.0f;
+            if (s < spp) {
+                float rx = bits_u01(tab[0][s] ^ sx);
+                float ry = bits_u01(tab[1][s] ^ sy);
+                V3 M = vndf_microfacet(w, g.fr, rx, ry);
+                V3 L = reflect_direction(g.view, M);
+                tF = ggx_fresnel(g, L, M);                      // mReflectWeight, src/rlGgx.h:103
+                float fr, fg, fb, pdf;
+                ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pdf);
+                tR = fr / pdf; tG = fg / pdf; tB = fb / pdf;
+            }
+            fold<G>(accF, tF); fold<G>(accR, tR); fold<G>(accG, tG); fold<G>(accB, tB);
         }
     }
     for (int s0 = sub; PACK && s0 - sub < spp; s0 += K * G) {   // K samples per pass (SlowLds)
@@ -353,18 +389,17 @@ __device__ __forceinline__ void ggx_glossy_loop(SlowLds<K> &slow, const Ggx &g, 
         slow_run<K>(slow, cnt);
 #pragma unroll 1
         for (int k = 0; k < K; k++) {
-            if (s0 + k * G >= spp) continue;
-            V3 M = ggx_vndf_pop<K>(slow, k, w, g.fr);
-            V3 L = reflect_direction(g.view, M);
-            accF += ggx_fresnel(g, L, M);                   // mReflectWeight, src/rlGgx.h:103
-            float fr, fg, fb, pdf;
-            ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pdf);
-            accR += fr / pdf; accG += fg / pdf; accB += fb / pdf;
+            float tR = 0.0f, tG = 0.0f, tB = 0.0f, tF = 0.0f;
+            if (s0 + k * G < spp) {
+                V3 M = ggx_vndf_pop<K>(slow, k, w, g.fr);
+                V3 L = reflect_direction(g.view, M);
+                tF = ggx_fresnel(g, L, M);                      // mReflectWeight, src/rlGgx.h:103
+                float fr, fg, fb, pdf;
+                ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pdf);
+                tR = fr / pdf; tG = fg / pdf; tB = fb / pdf;
+            }
+            fold<G>(accF, tF); fold<G>(accR, tR); fold<G>(accG, tG); fold<G>(accB, tB);
         }
-    }
-    if (G > 1) {
-        accR = group_sum<G>(accR); accG = group_sum<G>(accG);
-        accB = group_sum<G>(accB); accF = group_sum<G>(accF);
     }
 }
 
@@ -381,9 +416,9 @@ __device__ __forceinline__ LightRegs light_regs(const rls_sphere_light &lt, V3 P
 
 // The light loop of one GGX lobe of rlSkin (src/rlSkin.cpp:193-198 / 217-222): per light evalLightSample
 // (src/rlGgx.h:167-170) = the two-sample estimator of rls_ggx_direct_lighting's specular lobe.  out: the sum over the
-// lights (group-reduced); f / cnt: THIS LANE's running Fresnel sum and count of the evalSample calls (src/rlGgx.h:103)
-// -- the caller carries them into integrateGlossy's loop and reduces once, so that one lane per point adds in the
-// reference's order.  Sample streams: `stream` + 4 l (light samples), `stream` + 1 + 4 l (BSDF samples).
+// lights; f / cnt: the running Fresnel sum and the count of the evalSample calls (src/rlGgx.h:103) -- the caller carries
+// f into integrateGlossy's loop, which goes on adding to it in sample order.  All sums are replicated over the lanes of
+// the group (fold).  Sample streams: `stream` + 4 l (light samples), `stream` + 1 + 4 l (BSDF samples).
 template <int G, class IO>
 __device__ __forceinline__ void ggx_light_loops(const Ggx &g, const VndfView &w, V3 N, V3 P, const IO &io,
                                                 const uint32_t (*tab)[kMaxSpp], int spp, int sub, float inv,
@@ -399,32 +434,38 @@ __device__ __forceinline__ void ggx_light_loops(const Ggx &g, const VndfView &w,
 #pragma unroll
         for (int k = 0; k < 4; k++) scr[k] = hash_u32(seed, index, kScrambleStream + 2 * (stream + 4 * l) + k);
         float sR = 0.0f, sG = 0.0f, sB = 0.0f;
-        for (int s = sub; s < spp && cone.valid; s += G) {       // the plain loop: see ggx_glossy_loop, PACK = false
-            if (mode != RLS_MIS_BSDF_ONLY) {
+        for (int s0 = 0; s0 < spp && cone.valid; s0 += G) {     // the plain loop: see ggx_glossy_loop, PACK = false
+            const int s = s0 + sub;
+            const bool ok = s < spp;
+            float aR = 0.0f, aG = 0.0f, aB = 0.0f, bR = 0.0f, bG = 0.0f, bB = 0.0f, tF = 0.0f, tC = 0.0f;
+            if (ok && mode != RLS_MIS_BSDF_ONLY) {
                 float rx = bits_u01(tab[0][s] ^ scr[0]), ry = bits_u01(tab[1][s] ^ scr[1]);
                 V3 L = cone_sample(cone, rx, ry);
                 if (dot(L, N) > 0.0f) {
                     float fr, fg, fb, pb;
                     ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pb);
                     float wgt = mode == RLS_MIS_LIGHT_ONLY ? 1.0f : power_heuristic(cone.pdf, pb);
-                    sR += R_DIV(fr * wgt, cone.pdf); sG += R_DIV(fg * wgt, cone.pdf); sB += R_DIV(fb * wgt, cone.pdf);
+                    aR = R_DIV(fr * wgt, cone.pdf); aG = R_DIV(fg * wgt, cone.pdf); aB = R_DIV(fb * wgt, cone.pdf);
                 }
             }
-            if (mode != RLS_MIS_LIGHT_ONLY) {
+            if (ok && mode != RLS_MIS_LIGHT_ONLY) {
                 float rx = bits_u01(tab[0][s] ^ scr[2]), ry = bits_u01(tab[1][s] ^ scr[3]);
                 V3 M = vndf_microfacet(w, g.fr, rx, ry);
                 V3 L = reflect_direction(g.view, M);
-                f += ggx_fresnel(g, L, M);                      // mReflectWeight += ..., mMisSampleCount += 1
-                cnt += 1.0f;
+                tF = ggx_fresnel(g, L, M);                      // mReflectWeight += ..., mMisSampleCount += 1
+                tC = 1.0f;
                 if (!is_zero(L) && dot(L, N) > 0.0f && cone_hit(cone, L)) {
                     float fr, fg, fb, pb;
                     ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pb);
                     float wgt = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(pb, cone.pdf);
-                    sR += R_DIV(fr * wgt, pb); sG += R_DIV(fg * wgt, pb); sB += R_DIV(fb * wgt, pb);
+                    bR = R_DIV(fr * wgt, pb); bG = R_DIV(fg * wgt, pb); bB = R_DIV(fb * wgt, pb);
                 }
             }
+            // one running sum per channel: the light sample's term, then the BSDF sample's, sample by sample
+            fold2<G>(sR, aR, bR); fold2<G>(sG, aG, bG); fold2<G>(sB, aB, bB);
+            fold<G>(f, tF);
+            cnt += G == 1 ? tC : group_sum<G>(tC);
         }
-        if (G > 1) { sR = group_sum<G>(sR); sG = group_sum<G>(sG); sB = group_sum<G>(sB); }
         out[0] += lt.rad[0] * sR * inv; out[1] += lt.rad[1] * sG * inv; out[2] += lt.rad[2] * sB * inv;
     }
 }
@@ -522,36 +563,37 @@ __global__ RLS_INT_ATTR void disney_integrate_kernel(DisneyIntIO a)
 #pragma unroll 1
             for (int k = 0; k < K; k++) {
                 const int s = s0 + k * G;
-                if (s >= a.spp) continue;
-                // diffuse lobe (setSampleType(AI_RAY_DIFFUSE), src/rlDisney.cpp:242)
-                {
-                    float rx = bits_u01(tab[0][s] ^ dx), ry = bits_u01(tab[1][s] ^ dy);
-                    V3 L = cosine_hemisphere(d.fr, rx, ry);
-                    float r, g, b, pdf;
-                    disney_eval_pdf<true, true, true>(d, L, r, g, b, pdf);
-                    if (pdf > kEps) { dR += r / pdf; dG += g / pdf; dB += b / pdf; dC += 1.0f; }
-                    if (a.streamed && live) {
-                        int64_t o = (int64_t)s * a.n + i;
-                        st3(a.st.wi, o, L); strgb(a.st.f, o, r, g, b); stg(a.st.pdf, o, pdf);
+                float td[3] = { 0.0f, 0.0f, 0.0f }, ts[3] = { 0.0f, 0.0f, 0.0f };
+                if (s < a.spp) {
+                    // diffuse lobe (setSampleType(AI_RAY_DIFFUSE), src/rlDisney.cpp:242)
+                    {
+                        float rx = bits_u01(tab[0][s] ^ dx), ry = bits_u01(tab[1][s] ^ dy);
+                        V3 L = cosine_hemisphere(d.fr, rx, ry);
+                        float r, g, b, pdf;
+                        disney_eval_pdf<true, true, true>(d, L, r, g, b, pdf);
+                        if (pdf > kEps) { td[0] = r / pdf; td[1] = g / pdf; td[2] = b / pdf; dC += 1.0f; }
+                        if (a.streamed && live) {
+                            int64_t o = (int64_t)s * a.n + i;
+                            st3(a.st.wi, o, L); strgb(a.st.f, o, r, g, b); stg(a.st.pdf, o, pdf);
+                        }
+                    }
+                    // specular lobe (setSampleType(AI_RAY_GLOSSY), src/rlDisney.cpp:281,289)
+                    {
+                        V3 L = disney_spec_pop<K>(slow, k, d, w);
+                        float r, g, b, pdf;
+                        disney_eval_pdf<false, true, true>(d, L, r, g, b, pdf);
+                        if (pdf > kEps) { ts[0] = r / pdf; ts[1] = g / pdf; ts[2] = b / pdf; sC += 1.0f; }   // :309
+                        if (a.streamed && live) {
+                            int64_t o = ((int64_t)a.spp + s) * a.n + i;
+                            st3(a.st.wi, o, L); strgb(a.st.f, o, r, g, b); stg(a.st.pdf, o, pdf);
+                        }
                     }
                 }
-                // specular lobe (setSampleType(AI_RAY_GLOSSY), src/rlDisney.cpp:281,289)
-                {
-                    V3 L = disney_spec_pop<K>(slow, k, d, w);
-                    float r, g, b, pdf;
-                    disney_eval_pdf<false, true, true>(d, L, r, g, b, pdf);
-                    if (pdf > kEps) { sR += r / pdf; sG += g / pdf; sB += b / pdf; sC += 1.0f; }   // :309
-                    if (a.streamed && live) {
-                        int64_t o = ((int64_t)a.spp + s) * a.n + i;
-                        st3(a.st.wi, o, L); strgb(a.st.f, o, r, g, b); stg(a.st.pdf, o, pdf);
-                    }
-                }
+                fold<G>(dR, td[0]); fold<G>(dG, td[1]); fold<G>(dB, td[2]);
+                fold<G>(sR, ts[0]); fold<G>(sG, ts[1]); fold<G>(sB, ts[2]);
             }
         }
-        if (G > 1) {
-            dR = group_sum<G>(dR); dG = group_sum<G>(dG); dB = group_sum<G>(dB); dC = group_sum<G>(dC);
-            sR = group_sum<G>(sR); sG = group_sum<G>(sG); sB = group_sum<G>(sB); sC = group_sum<G>(sC);
-        }
+        if (G > 1) { dC = group_sum<G>(dC); sC = group_sum<G>(sC); }      // counts: integers, any order
         if (live && sub == 0) {
             strgb(a.dsum, i, dR, dG, dB); stg(a.dcount, i, dC);
             strgb(a.ssum, i, sR, sG, sB); stg(a.scount, i, sC);
@@ -593,15 +635,18 @@ __device__ __forceinline__ SceneRegs scene_regs(const rls_sss_scene &sc)
     return r;
 }
 
-// the probe-ray loop of integrateScatter (src/rlSss.h:224-270) for one shading point: sums of irradiance / pdf and
-// of the shaded-hit count over the samples sub, sub + G, ..., reduced over the G-lane group
+// the probe-ray loop of integrateScatter (src/rlSss.h:224-270) for one shading point: sums of irradiance / pdf (in sample
+// order, replicated over the G-lane group: fold) and of the shaded-hit count over the samples sub, sub + G, ...
 template <int G>
 __device__ __forceinline__ void scatter_loop(const NdProfile &p, const Frame &fr, V3 Po, const SceneRegs &sc,
                                              const uint32_t (*tab)[kMaxSpp], int spp, int sub, uint32_t sx, uint32_t sy,
                                              float &accR, float &accG, float &accB, float &accD)
 {
     accR = 0.0f; accG = 0.0f; accB = 0.0f; accD = 0.0f;
-    for (int s = sub; s < spp; s += G) {
+    for (int s0 = 0; s0 < spp; s0 += G) {                      // one round: G consecutive samples, one per lane
+        const int s = s0 + sub;
+        float tr[2][3] = { { 0.0f, 0.0f, 0.0f }, { 0.0f, 0.0f, 0.0f } };       // the terms of this sample's (up to) two hits
+        if (s < spp) {
         float rx = bits_u01(tab[0][s] ^ sx);
         float ry = bits_u01(tab[1][s] ^ sy);
         V3 off, dir;
@@ -656,13 +701,13 @@ __device__ __forceinline__ void scatter_loop(const NdProfile &p, const Frame &fr
             const float iB = sc.lc[2] * w * pb * fade;
             if (iR == 0.0f && iG == 0.0f && iB == 0.0f) continue;            // :249
             const float pdf = sss_mis_pdf(p, fr, d, hn, sc.literal);
-            accR += R_DIV(iR, pdf); accG += R_DIV(iG, pdf); accB += R_DIV(iB, pdf);
+            tr[k][0] = R_DIV(iR, pdf); tr[k][1] = R_DIV(iG, pdf); tr[k][2] = R_DIV(iB, pdf);
         }
+        }
+        // hit by hit, sample by sample: the order the one-lane loop adds in
+        fold2<G>(accR, tr[0][0], tr[1][0]); fold2<G>(accG, tr[0][1], tr[1][1]); fold2<G>(accB, tr[0][2], tr[1][2]);
     }
-    if (G > 1) {
-        accR = group_sum<G>(accR); accG = group_sum<G>(accG);
-        accB = group_sum<G>(accB); accD = group_sum<G>(accD);
-    }
+    if (G > 1) accD = group_sum<G>(accD);                       // shaded-hit count: integers, any order
 }
 
 template <int G, int FAST_MATH = RLS_FAST>
@@ -751,7 +796,6 @@ __global__ RLS_INT_ATTR void skin_integrate_kernel(SkinIntIO a)
             // integrateGlossy returns black for a small colour without sampling (src/rlGgx.h:174-176); the light
             // loop samples regardless; getAvgReflectWeight (181-184) = sum / count over both, 1 when none were drawn
             const bool small = absf(cr) < kEps && absf(cg) < kEps && absf(cb) < kEps;
-            if (G > 1) { lf = group_sum<G>(lf); lc = group_sum<G>(lc); }
             const float fsum = small ? lf : aF, fcnt = small ? lc : lc + (float)a.spp;
             const float avg = fcnt > 0.0f ? R_DIV(fsum, fcnt) : 1.0f;
             if (small) { shR = 0.0f; shG = 0.0f; shB = 0.0f; }
@@ -770,7 +814,6 @@ __global__ RLS_INT_ATTR void skin_integrate_kernel(SkinIntIO a)
                                lit, lf, lc);                                          // :217-222
             ggx_glossy_loop<G, 1, false>(slow, g, w, tab, a.spp, sub, scr[2], scr[3], spR, spG, spB, aF, lf);
             const bool small = absf(cr) < kEps && absf(cg) < kEps && absf(cb) < kEps;
-            if (G > 1) { lf = group_sum<G>(lf); lc = group_sum<G>(lc); }
             const float fsum = small ? lf : aF, fcnt = small ? lc : lc + (float)a.spp;
             const float avg = fcnt > 0.0f ? R_DIV(fsum, fcnt) : 1.0f;
             if (small) { spR = 0.0f; spG = 0.0f; spB = 0.0f; }
@@ -831,14 +874,17 @@ __device__ __forceinline__ void ggx_refract_loop(SlowLds<K> &slow, const Ggx &g,
         slow_run<K>(slow, cnt);
 #pragma unroll 1
         for (int k = 0; k < K; k++) {
-            if (s0 + k * G >= spp) continue;
-            V3 M = ggx_vndf_pop<K>(slow, k, w, g.fr);
-            V3 dir;
-            if (!ggx_refract(g, M, dir)) tir += 1.0f;
-            acc += ggx_sample_weight(g, g.view, dir, M);                 // :241
+            float t = 0.0f;
+            if (s0 + k * G < spp) {
+                V3 M = ggx_vndf_pop<K>(slow, k, w, g.fr);
+                V3 dir;
+                if (!ggx_refract(g, M, dir)) tir += 1.0f;
+                t = ggx_sample_weight(g, g.view, dir, M);                // :241
+            }
+            fold<G>(acc, t);
         }
     }
-    if (G > 1) { acc = group_sum<G>(acc); tir = group_sum<G>(tir); }
+    if (G > 1) tir = group_sum<G>(tir);                             // a count: integers, any order
     const float inv = 1.0f / (float)spp;                             // AiSamplerGetSampleInvCount, :244
     acc *= inv; tir *= inv;
 }
@@ -928,11 +974,12 @@ __device__ __forceinline__ void ggx_direct_loops(SlowLds<K> &slow, const Ggx &g,
             ggx_light_eval_run<K>(slow, qn, g, on, cone.pdf, sampleDiffuse, mode);
 #pragma unroll 1
             for (int k = 0; k < K; k++) {
-                float t[4];
+                float t[4], u[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
                 if (eval_pop<K>(slow, k, t)) {
-                    lR += t[0]; lG += t[1]; lB += t[2];
-                    if (sampleDiffuse) lA += t[3];
+                    u[0] = t[0]; u[1] = t[1]; u[2] = t[2];
+                    if (sampleDiffuse) u[3] = t[3];
                 }
+                fold<G>(lR, u[0]); fold<G>(lG, u[1]); fold<G>(lB, u[2]); fold<G>(lA, u[3]);
             }
         }
         for (int s0 = sub; mode != RLS_MIS_LIGHT_ONLY && s0 - sub < spp; s0 += K * G) {   // one BSDF sample per lobe; K per pass (SlowLds)
@@ -968,25 +1015,25 @@ __device__ __forceinline__ void ggx_direct_loops(SlowLds<K> &slow, const Ggx &g,
 #pragma unroll 1
             for (int k = 0; k < K; k++) {
                 const int s = s0 + k * G;
-                if (!(s < spp && cone.valid)) continue;
-                float t[4];
-                if (eval_pop<K>(slow, k, t)) { bR += t[0]; bG += t[1]; bB += t[2]; }
-                if (sampleDiffuse) {
-                    float rx = bits_u01(tab[0][s] ^ scr[4]), ry = bits_u01(tab[1][s] ^ scr[5]);
-                    V3 Ld = cosine_hemisphere(g.fr, rx, ry);
-                    float pd = oren_nayar_pdf(on, Ld);
-                    if (pd > 0.0f && cone_hit(cone, Ld)) {
-                        float fd = oren_nayar_brdf(on, wo, Ld);
-                        float wd = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(pd, cone.pdf);
-                        bA += R_DIV(fd * wd, pd);
+                float u[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+                if (s < spp && cone.valid) {
+                    float t[4];
+                    if (eval_pop<K>(slow, k, t)) { u[0] = t[0]; u[1] = t[1]; u[2] = t[2]; }
+                    if (sampleDiffuse) {
+                        float rx = bits_u01(tab[0][s] ^ scr[4]), ry = bits_u01(tab[1][s] ^ scr[5]);
+                        V3 Ld = cosine_hemisphere(g.fr, rx, ry);
+                        float pd = oren_nayar_pdf(on, Ld);
+                        if (pd > 0.0f && cone_hit(cone, Ld)) {
+                            float fd = oren_nayar_brdf(on, wo, Ld);
+                            float wd = mode == RLS_MIS_BSDF_ONLY ? 1.0f : power_heuristic(pd, cone.pdf);
+                            u[3] = R_DIV(fd * wd, pd);
+                        }
                     }
                 }
+                fold<G>(bR, u[0]); fold<G>(bG, u[1]); fold<G>(bB, u[2]); fold<G>(bA, u[3]);
             }
         }
-        float sR = lR + bR, sG = lG + bG, sB = lB + bB, dA = lA + bA;
-        if (G > 1) {
-            sR = group_sum<G>(sR); sG = group_sum<G>(sG); sB = group_sum<G>(sB); dA = group_sum<G>(dA);
-        }
+        const float sR = lR + bR, sG = lG + bG, sB = lB + bB, dA = lA + bA;
         // specular += ..., diffuse += ... (288-294); the first light assigns (0 + x loses the sign of a zero)
         const float tS[3] = { lt.rad[0] * sR * inv, lt.rad[1] * sG * inv, lt.rad[2] * sB * inv };
         const float tD[3] = { lt.rad[0] * dA * inv, lt.rad[1] * dA * inv, lt.rad[2] * dA * inv };
@@ -1170,10 +1217,13 @@ __device__ __forceinline__ void disney_direct_loops(SlowLds<K> &slow, const Disn
 #pragma unroll 1
             for (int k = 0; k < K; k++) {
                 float t[4];
+                float u[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
                 if (eval_pop<K>(slow, k, t)) {
-                    lD[0] += t[0]; lD[1] += t[1]; lD[2] += t[2];
-                    lS[0] += slow.st[0][k][tid]; lS[1] += slow.st[1][k][tid]; lS[2] += slow.st[2][k][tid];
+                    u[0] = t[0]; u[1] = t[1]; u[2] = t[2];
+                    u[3] = slow.st[0][k][tid]; u[4] = slow.st[1][k][tid]; u[5] = slow.st[2][k][tid];
                 }
+                fold<G>(lD[0], u[0]); fold<G>(lD[1], u[1]); fold<G>(lD[2], u[2]);
+                fold<G>(lS[0], u[3]); fold<G>(lS[1], u[4]); fold<G>(lS[2], u[5]);
             }
         }
         for (int s0 = sub; mode != RLS_MIS_LIGHT_ONLY && s0 - sub < spp; s0 += K * G) {    // one BSDF sample per lobe
@@ -1190,7 +1240,9 @@ __device__ __forceinline__ void disney_direct_loops(SlowLds<K> &slow, const Disn
 #pragma unroll 1
             for (int k = 0; k < K; k++) {
                 float t[4];
-                if (eval_pop<K>(slow, k, t) && t[3] != 0.0f) { bD[0] += t[0]; bD[1] += t[1]; bD[2] += t[2]; }
+                float u[3] = { 0.0f, 0.0f, 0.0f };
+                if (eval_pop<K>(slow, k, t) && t[3] != 0.0f) { u[0] = t[0]; u[1] = t[1]; u[2] = t[2]; }
+                fold<G>(bD[0], u[0]); fold<G>(bD[1], u[1]); fold<G>(bD[2], u[2]);
             }
             // specular lobe: the sampler's rare branches packed, then the reflected directions that hit the light
             qn = 0;
@@ -1222,15 +1274,13 @@ __device__ __forceinline__ void disney_direct_loops(SlowLds<K> &slow, const Disn
 #pragma unroll 1
             for (int k = 0; k < K; k++) {
                 float t[4];
-                if (eval_pop<K>(slow, k, t) && t[3] != 0.0f) { bS[0] += t[0]; bS[1] += t[1]; bS[2] += t[2]; }
+                float u[3] = { 0.0f, 0.0f, 0.0f };
+                if (eval_pop<K>(slow, k, t) && t[3] != 0.0f) { u[0] = t[0]; u[1] = t[1]; u[2] = t[2]; }
+                fold<G>(bS[0], u[0]); fold<G>(bS[1], u[1]); fold<G>(bS[2], u[2]);
             }
         }
-        float dR = lD[0] + bD[0], dG = lD[1] + bD[1], dB = lD[2] + bD[2];
-        float sR = lS[0] + bS[0], sG = lS[1] + bS[1], sB = lS[2] + bS[2];
-        if (G > 1) {
-            dR = group_sum<G>(dR); dG = group_sum<G>(dG); dB = group_sum<G>(dB);
-            sR = group_sum<G>(sR); sG = group_sum<G>(sG); sB = group_sum<G>(sB);
-        }
+        const float dR = lD[0] + bD[0], dG = lD[1] + bD[1], dB = lD[2] + bD[2];
+        const float sR = lS[0] + bS[0], sG = lS[1] + bS[1], sB = lS[2] + bS[2];
         const float tD[3] = { lt.rad[0] * dR * inv, lt.rad[1] * dG * inv, lt.rad[2] * dB * inv };
         const float tS[3] = { lt.rad[0] * sR * inv, lt.rad[1] * sG * inv, lt.rad[2] * sB * inv };
 #pragma unroll
@@ -1334,12 +1384,16 @@ __global__ RLS_INT_ATTR void ggx_shade_kernel(GgxShadeIO a)
             const uint32_t sx = hash_u32(a.seed, idx, kScrambleStream + 2 * (kShadeStream + 2));
             const uint32_t sy = hash_u32(a.seed, idx, kScrambleStream + 2 * (kShadeStream + 2) + 1);
             float acc = 0.0f;
-            for (int s = sub; s < a.spp; s += G) {
-                V3 Ld = cosine_hemisphere(g.fr, bits_u01(tab[0][s] ^ sx), bits_u01(tab[1][s] ^ sy));
-                float pd = oren_nayar_pdf(on, Ld);
-                if (pd > 0.0f) acc += R_DIV(oren_nayar_brdf(on, wo, Ld), pd);
+            for (int s0 = 0; s0 < a.spp; s0 += G) {
+                const int s = s0 + sub;
+                float t = 0.0f;
+                if (s < a.spp) {
+                    V3 Ld = cosine_hemisphere(g.fr, bits_u01(tab[0][s] ^ sx), bits_u01(tab[1][s] ^ sy));
+                    float pd = oren_nayar_pdf(on, Ld);
+                    if (pd > 0.0f) t = R_DIV(oren_nayar_brdf(on, wo, Ld), pd);
+                }
+                fold<G>(acc, t);
             }
-            if (G > 1) acc = group_sum<G>(acc);
             acc *= inv;
             iD[0] = dr * (acc * a.env[0]); iD[1] = dg * (acc * a.env[1]); iD[2] = db * (acc * a.env[2]);
         }
@@ -1405,24 +1459,24 @@ __global__ RLS_DISNEY_LIGHT_ATTR void disney_shade_kernel(DisneyShadeIO a)
 #pragma unroll 1
             for (int k = 0; k < K; k++) {
                 const int s = s0 + k * G;
-                if (s >= a.spp) continue;
-                {
-                    V3 L = cosine_hemisphere(d.fr, bits_u01(tab[0][s] ^ scr[0]), bits_u01(tab[1][s] ^ scr[1]));
-                    float r, g, b, pdf;
-                    disney_eval_pdf<true, true, true>(d, L, r, g, b, pdf);
-                    if (pdf > kEps) { iR += r / pdf; iG += g / pdf; iB += b / pdf; }
+                float td[3] = { 0.0f, 0.0f, 0.0f }, ts[3] = { 0.0f, 0.0f, 0.0f };
+                if (s < a.spp) {
+                    {
+                        V3 L = cosine_hemisphere(d.fr, bits_u01(tab[0][s] ^ scr[0]), bits_u01(tab[1][s] ^ scr[1]));
+                        float r, g, b, pdf;
+                        disney_eval_pdf<true, true, true>(d, L, r, g, b, pdf);
+                        if (pdf > kEps) { td[0] = r / pdf; td[1] = g / pdf; td[2] = b / pdf; }
+                    }
+                    {
+                        V3 L = disney_spec_pop<K>(slow, k, d, w);
+                        float r, g, b, pdf;
+                        disney_eval_pdf<false, true, true>(d, L, r, g, b, pdf);
+                        if (pdf > kEps) { ts[0] = r / pdf; ts[1] = g / pdf; ts[2] = b / pdf; }
+                    }
                 }
-                {
-                    V3 L = disney_spec_pop<K>(slow, k, d, w);
-                    float r, g, b, pdf;
-                    disney_eval_pdf<false, true, true>(d, L, r, g, b, pdf);
-                    if (pdf > kEps) { gR += r / pdf; gG += g / pdf; gB += b / pdf; }
-                }
+                fold<G>(iR, td[0]); fold<G>(iG, td[1]); fold<G>(iB, td[2]);
+                fold<G>(gR, ts[0]); fold<G>(gG, ts[1]); fold<G>(gB, ts[2]);
             }
-        }
-        if (G > 1) {
-            iR = group_sum<G>(iR); iG = group_sum<G>(iG); iB = group_sum<G>(iB);
-            gR = group_sum<G>(gR); gG = group_sum<G>(gG); gB = group_sum<G>(gB);
         }
         const float iD[3] = { iR * inv * a.env[0], iG * inv * a.env[1], iB * inv * a.env[2] };
         const float iS[3] = { gR * inv * a.env[0], gG * inv * a.env[1], gB * inv * a.env[2] };

@@ -268,6 +268,15 @@ def assert_tight(st: dict, what="", tol: float = 1e-5) -> None:
     assert st["p999"] <= tol, (what, st)
 
 
+def assert_same_bits(a, b, what="") -> None:
+    """two results of the EXACT kernels that must not differ at all: the same batch with another lane-group width, a
+    shard against the slice of the whole, a replay against the direct launch"""
+    a, b = np.ascontiguousarray(a, dtype=np.float32), np.ascontiguousarray(b, dtype=np.float32)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    d = a.view(np.uint32) != b.view(np.uint32)
+    assert not d.any(), (what, "words differing", int(d.sum()), "of", d.size, "max rel err", float(rel_err(a, b).max()))
+
+
 def flag_slack() -> int:
     """how many TIR flags / output words of a batch may differ from the oracle's: none under strict parity"""
     return 0 if strict_parity() else 1

@@ -128,8 +128,7 @@ def test_integrate_reduced_and_streamed(gpu, oracle):
         for k in ("diffuse_count", "specular_count"):
             assert np.array_equal(alt[k], base[k]), (g, k)
         for k in ("diffuse_sum", "specular_sum"):
-            e = cases.rel_err(alt[k], base[k])
-            assert np.quantile(e, 0.999) <= 1e-4, (g, k, float(e.max()))     # summation order only
+            cases.assert_same_bits(alt[k], base[k], (g, k))    # sums in sample order whatever the group width
 
 
 def test_unselected_alternates(gpu, oracle, mixed):

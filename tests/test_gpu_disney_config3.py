@@ -45,12 +45,11 @@ def test_integrate_8x8_against_oracle(gpu, oracle):
         for k in COUNTS:
             assert np.array_equal(alt[k], base[k]), (g, k)
         for k in SUMS:
-            e = cases.rel_err(alt[k], base[k])
-            assert np.quantile(e, 0.999) <= 1e-4, (g, k, float(e.max()))
+            cases.assert_same_bits(alt[k], base[k], (g, k))    # sums in sample order whatever the group width
     # the automatic width (small batch -> several lanes per point)
     auto = {k: host(v) for k, v in s.integrate(spp_n, seed).items()}
-    for k in COUNTS:
-        assert np.array_equal(auto[k], base[k]), k
+    for k in COUNTS + SUMS:
+        cases.assert_same_bits(auto[k], base[k], ("auto", k))
 
 
 def test_streamed_chunked_equals_unchunked(gpu, oracle):
@@ -122,9 +121,8 @@ def test_full_size_config3(gpu, oracle):
     alt = _with_group(4, lambda: d.integrate(spp_n, seed))
     for k in COUNTS:
         assert torch.equal(alt[k], out[k]), k
-    for k in SUMS:
-        rel = (alt[k] - out[k]).abs() / out[k].abs().clamp_min(1e-20)
-        assert torch.quantile(rel.flatten()[:: 257].float(), 0.999).item() <= 1e-4, k
+    # four lanes per point: the sums grow in sample order all the same (fold, integrate.hip) -- every word of 2^26 points
+    assert ck == {k: R.checksum(ctx, alt[k]) for k in SUMS + COUNTS}
     del alt
     # oracle on eight windows of 256 points; first_index aligns the oracle's scrambles with the batch's
     for w in range(8):

@@ -63,11 +63,11 @@ def test_ggx_integrate(gpu, oracle):
             sm2, av2 = (host(t) for t in s.integrate(spp_n, 777))
         finally:
             del os.environ["RLS_INTEGRATE_GROUP"]
-        assert np.quantile(cases.rel_err(av2, av), 0.999) <= 1e-5, g
-        assert np.quantile(cases.rel_err(sm2, sm), 0.999) <= 1e-4, g
+        cases.assert_same_bits(av2, av, g)    # sums in sample order whatever the group width
+        cases.assert_same_bits(sm2, sm, g)    # sums in sample order whatever the group width
     # the automatic choice (small batch -> several lanes per point) agrees too
     sm3, av3 = (host(t) for t in s.integrate(spp_n, 777))
-    assert np.quantile(cases.rel_err(av3, av), 0.999) <= 1e-5
+    cases.assert_same_bits(av3, av, 'group width')    # sums in sample order whatever the group width
 
 
 def test_full_size_properties(gpu, oracle):

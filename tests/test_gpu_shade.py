@@ -80,8 +80,7 @@ def test_ggx_shade_matches_oracle(gpu, oracle, traced):
     for g in (4, 16):
         alt = _with_group(g, run)
         for q in ref:
-            e = cases.rel_err(alt[q], got[q])
-            assert np.quantile(e, 0.999) <= 2e-4, (g, q, float(e.max()))      # summation order only
+            cases.assert_same_bits(alt[q], got[q], (g, q))    # sums in sample order whatever the group width
 
 
 def test_disney_shade_matches_oracle(gpu, oracle):
@@ -107,8 +106,7 @@ def test_disney_shade_matches_oracle(gpu, oracle):
     for g in (4, 16, 64):
         alt = _with_group(g, run)
         for q in ref:
-            e = cases.rel_err(alt[q], got[q])
-            assert np.quantile(e, 0.999) <= 2e-4, (g, q, float(e.max()))
+            cases.assert_same_bits(alt[q], got[q], (g, q))    # sums in sample order whatever the group width
 
 
 def test_shade_hostile_inputs_and_argument_checks(gpu, oracle):

@@ -61,8 +61,7 @@ def test_skin_integrate_matches_oracle(gpu, oracle, geometry):
         alt = _with_group(g, lambda: {k: host(v) for k, v in sk.integrate(dev(P), scene, spp_n, seed, env=env,
                                                                           first_index=first).items()})
         for k in KEYS:
-            e = cases.rel_err(alt[k], got[k])
-            assert np.quantile(e, 0.999) <= 2e-4, (g, k, float(e.max()))     # summation order only
+            cases.assert_same_bits(alt[k], got[k], (g, k))    # sums in sample order whatever the group width
 
 
 def test_skin_integrate_layer_gates_and_presets(gpu, oracle):
@@ -112,7 +111,7 @@ def test_integrate_refract_matches_oracle(gpu, oracle, traced):
             alt, atir = _with_group(g, lambda: [host(t) for t in s.integrateRefract(spp_n, seed, traced=True, env=env,
                                                                                    want_tir=True, first_index=first)])
             assert np.array_equal(atir, tir)
-            assert np.quantile(cases.rel_err(alt, got), 0.999) <= 1e-4, g
+            cases.assert_same_bits(alt, got, g)    # sums in sample order whatever the group width
 
 
 @pytest.mark.parametrize("spp_n", [3, 4])
@@ -162,5 +161,4 @@ def test_skin_integrate_with_light_loops(gpu, oracle, spp_n):
         alt = _with_group(g, lambda: {k: host(v) for k, v in sk.integrate(dev(P), scene, spp_n, seed, env=env,
                                                                           first_index=first, lights=lg).items()})
         for k in KEYS:
-            e = cases.rel_err(alt[k], got[k])
-            assert np.quantile(e, 0.999) <= 2e-4, (g, k, float(e.max()))
+            cases.assert_same_bits(alt[k], got[k], (g, k))    # sums in sample order whatever the group width

@@ -317,10 +317,14 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
         xi = [u(S_XI0 + j) for j in range(2)]
         out = (A.planes(3), A.planes(3), A.plane())
         lobe = 0 if name.endswith("diffuse") else 1
-        wl = Workload(name, 1, (24 + 7) * 4, lambda: d.sampleEvalPdf(xi[0], xi[1], out=out),
+        # SURVEY's triple reads the whole closure: 22 f + xi2 in, wi3 f3 pdf out = 124 B.  The diffuse lobe's arithmetic needs
+        # only subsurface, metallic and roughness of the ten scalars (src/rlDisney.cpp:199-236, 359-365, 515-518): 17 f in = 96 B;
+        # the glossy lobe everything but subsurface: 23 f in = 120 B -- what the kernels move (profiles/r03_disney_triple_*_traffic)
+        wl = Workload(name, 1, ((17 if lobe == 0 else 23) + 7) * 4, lambda: d.sampleEvalPdf(xi[0], xi[1], out=out),
                       "disney_kernel<3, %s, {m}, true>" % ("true" if lobe == 0 else "false"),
                       f"rlDisney one-sample triple, {'diffuse' if lobe == 0 else 'glossy (GTR2 + clearcoat + sheen)'} lobe, "
-                      "mixed params: wo3 N3 T3 base3 + 10 scalars + xi2 in, wi3 f3 pdf out (src/rlDisney.cpp:109-152)")
+                      "mixed params: wo3 N3 T3 base3 + the lobe's scalars + xi2 in, wi3 f3 pdf out (src/rlDisney.cpp:109-152)",
+                      survey_bytes=(24 + 7) * 4)
     elif name in ("disney_integrate", "disney_stream"):
         base = u3(S_KS)
         sc = {k: u(S_PARAM0 + j) for j, k in enumerate(R._capi.DISNEY_SCALARS)}

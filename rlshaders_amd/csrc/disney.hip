@@ -10,6 +10,15 @@ using namespace rlsd;
 namespace {
 
 using rlsh::DisneyIO;
+
+#ifndef RLS_DISNEY_RELOAD
+#define RLS_DISNEY_RELOAD 1
+#endif
+#if RLS_DISNEY_RELOAD
+#define RLS_DISNEY_ARGS(a0) reload_args(a0)
+#else
+#define RLS_DISNEY_ARGS(a0) (a0)
+#endif
 enum { OP_SAMPLE = rlsh::DOP_SAMPLE, OP_EVAL = rlsh::DOP_EVAL, OP_PDF = rlsh::DOP_PDF, OP_FUSED = rlsh::DOP_FUSED };
 
 template <bool STREAMED>
@@ -33,13 +42,15 @@ __device__ __forceinline__ Disney load_closure(const rls_disney_closure &c, Idx 
 }
 
 template <int OP, bool DIFFUSE, int FAST_MATH, bool STREAMED>
-__global__ __launch_bounds__(rlsh::kBlock) void disney_kernel(DisneyIO a)
+__global__ __launch_bounds__(rlsh::kBlock) void disney_kernel(DisneyIO a0)
 {
     stage_libm_tables();   // powf / logf tables -> LDS (EXACT mode)
-    const TileRange tiles = tile_range(a.n);
+    const TileRange tiles = tile_range(a0.n);
     for (int64_t base = tiles.first; base < tiles.end; base += tiles.step) {
         const Idx i = make_idx(base);
-        if (i.full() >= a.n) continue;
+        if (i.full() >= a0.n) continue;
+        // plane pointers re-read from the kernarg segment where they are used (rls_internal.hpp, reload_args)
+        const DisneyIO a = RLS_DISNEY_ARGS(a0);
         Disney d = load_closure<STREAMED>(a.c, i);
         disney_prepare(d);
         V3 L;
@@ -51,15 +62,17 @@ __global__ __launch_bounds__(rlsh::kBlock) void disney_kernel(DisneyIO a)
                 VndfView w = vndf_view(d.view, d.fr, d.ax, d.ay);
                 L = disney_sample_specular(d, w, rx, ry);             // src/rlDisney.cpp:367-390
             }
-            st3(a.wi, i, L);
+            const DisneyIO b = RLS_DISNEY_ARGS(a0);
+            st3(b.wi, i, L);
         } else {
             L = ld3(a.cwi, i);
         }
         if (OP == OP_EVAL || OP == OP_PDF || OP == OP_FUSED) {
             float r, g, b, pdf;
             disney_eval_pdf<DIFFUSE, OP != OP_PDF, OP != OP_EVAL>(d, L, r, g, b, pdf);
-            if (OP != OP_PDF) strgb(a.f, i, r, g, b);
-            if (OP != OP_EVAL) stg(a.pdf, i, pdf);
+            const DisneyIO o = RLS_DISNEY_ARGS(a0);
+            if (OP != OP_PDF) strgb(o.f, i, r, g, b);
+            if (OP != OP_EVAL) stg(o.pdf, i, pdf);
         }
     }
 }

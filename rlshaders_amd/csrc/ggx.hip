@@ -13,6 +13,15 @@ namespace {
 
 using namespace rlsh;   // GgxOp, GgxIO
 
+#ifndef RLS_GGX_RELOAD
+#define RLS_GGX_RELOAD 1
+#endif
+#if RLS_GGX_RELOAD
+#define RLS_GGX_ARGS(a0) reload_args(a0)
+#else
+#define RLS_GGX_ARGS(a0) (a0)
+#endif
+
 template <bool STREAMED>
 __device__ __forceinline__ Ggx load_closure(const rls_ggx_closure &c, Idx i)
 {
@@ -29,14 +38,16 @@ __device__ __forceinline__ Ggx load_closure(const rls_ggx_closure &c, Idx i)
 // FAST_MATH only tags the kernel name (profiles tell the two builds apart); STREAMED: every closure
 // parameter is a per-point plane (no stream-or-uniform tests in the loop)
 template <int OP, int FAST_MATH, bool STREAMED>
-__global__ RLS_KERNEL_ATTR void ggx_kernel(GgxIO a)
+__global__ RLS_KERNEL_ATTR void ggx_kernel(GgxIO a0)
 {
     if (OP == OP_SAMPLE || OP == OP_FUSED || OP == OP_REFLECT_REFRACT || OP == OP_REFRACT || OP == OP_MICROFACET)
         stage_libm_tables();   // the range table of atanf -> LDS (visible-normal sampling calls atan2f twice)
-    const TileRange tiles = tile_range(a.n);
+    const TileRange tiles = tile_range(a0.n);
     for (int64_t base = tiles.first; base < tiles.end; base += tiles.step) {
         const Idx i = make_idx(base);
-        if (i.full() >= a.n) continue;
+        if (i.full() >= a0.n) continue;
+        // RLS_GGX_RELOAD: plane pointers re-read from the kernarg segment where they are used (rls_internal.hpp, reload_args)
+        const GgxIO a = RLS_GGX_ARGS(a0);
         Ggx g = load_closure<STREAMED>(a.c, i);
 
         if (OP == OP_SAMPLE || OP == OP_FUSED || OP == OP_REFLECT_REFRACT) {
@@ -53,19 +64,25 @@ __global__ RLS_KERNEL_ATTR void ggx_kernel(GgxIO a)
             }
             V3 L = reflect_direction(g.view, M);
             float F = ggx_fresnel(g, L, M);
-            st3(a.wi, i, L);
-            if (a.fresnel) stg(a.fresnel, i, F);
+            {
+                const GgxIO b = RLS_GGX_ARGS(a0);
+                st3(b.wi, i, L);
+                if (b.fresnel) stg(b.fresnel, i, F);
+            }
             if (OP != OP_SAMPLE) {
                 float fr, fg, fb, pdf;
                 ggx_eval_pdf<true, true>(g, L, fr, fg, fb, pdf);
-                strgb(a.f, i, fr, fg, fb);
-                stg(a.pdf, i, pdf);
+                const GgxIO b = RLS_GGX_ARGS(a0);
+                strgb(b.f, i, fr, fg, fb);
+                stg(b.pdf, i, pdf);
             }
             if (OP == OP_REFLECT_REFRACT) {
                 V3 dir;
                 ggx_refract(g, M2, dir);
-                st3(a.wt, i, dir);
-                stg(a.weight, i, ggx_sample_weight(g, g.view, dir, M2));
+                const float wgt = ggx_sample_weight(g, g.view, dir, M2);
+                const GgxIO b = RLS_GGX_ARGS(a0);
+                st3(b.wt, i, dir);
+                stg(b.weight, i, wgt);
             }
         } else if (OP == OP_EVAL) {
             float fr, fg, fb;

@@ -1382,19 +1382,49 @@ RLS_DEV Idx make_idx(int64_t base)
     return i;
 }
 #ifdef RLS_NO_SADDR   // experiment switch: 64-bit vector addressing
-RLS_DEV const float *at(const float *p, Idx i) { return p + i.full(); }
-RLS_DEV float *at(float *p, Idx i) { return p + i.full(); }
+typedef __attribute__((address_space(1))) float GFloat;
+RLS_DEV const GFloat *at(const float *p, Idx i) { return (const GFloat *)(p + i.full()); }
+RLS_DEV GFloat *at(float *p, Idx i) { return (GFloat *)(p + i.full()); }
 #else
-RLS_DEV const float *at(const float *p, Idx i)
+// plane pointer + tile offset: a wave-uniform sum, formed with scalar arithmetic and KEPT in a scalar register pair (the
+// empty asm) -- left alone, the optimiser re-associates it to (pointer + lane offset) + tile offset whenever the pointer
+// is loaded inside the loop (reload_args), which costs two 64-bit vector adds and two moves per access instead of none.
+// The pointer is cast to the global address space first: through the asm it would otherwise come back as a generic
+// pointer and the access as a flat_load / flat_store.
+#ifndef RLS_AT_SCALAR_BARRIER
+#define RLS_AT_SCALAR_BARRIER 1
+#endif
+// RLS_LOAD_RENEW: loads that sit in a later basic block than make_idx() (after a per-parameter stream-or-uniform branch,
+// after reload_args) renew the barrier on the lane offset like the stores do: one move instead of a 64-bit vector add
+#ifndef RLS_LOAD_RENEW
+#define RLS_LOAD_RENEW 0
+#endif
+typedef __attribute__((address_space(1))) char GChar;
+typedef __attribute__((address_space(1))) float GFloat;
+RLS_DEV const GFloat *at(const float *p, Idx i)
 {
-    return reinterpret_cast<const float *>(reinterpret_cast<const char *>(p + i.base) + i.byte);
+    const GChar *q = (const GChar *)(p + i.base);
+#if RLS_AT_SCALAR_BARRIER
+    asm("" : "+s"(q));
+#endif
+    return (const GFloat *)(q + i.byte);
 }
-RLS_DEV float *at(float *p, Idx i)
+RLS_DEV GFloat *at(float *p, Idx i)
 {
-    return reinterpret_cast<float *>(reinterpret_cast<char *>(p + i.base) + i.byte);
+    GChar *q = (GChar *)(p + i.base);
+#if RLS_AT_SCALAR_BARRIER
+    asm("" : "+s"(q));
+#endif
+    return (GFloat *)(q + i.byte);
 }
 #endif
-RLS_DEV float ldg(const float *p, Idx i) { return __builtin_nontemporal_load(at(p, i)); }
+RLS_DEV float ldg(const float *p, Idx i)
+{
+#if RLS_LOAD_RENEW
+    asm volatile("" : "+v"(i.byte));
+#endif
+    return __builtin_nontemporal_load(at(p, i));
+}
 RLS_DEV void stg(float *p, Idx i, float v)
 {
     // stores sit in later basic blocks than make_idx(): renew the barrier so the zext is local again

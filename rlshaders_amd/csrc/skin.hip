@@ -8,6 +8,11 @@
 // sss_color3 dist3 mult w_sss, spec col3 w rough ior, sheen col3 w rough ior, xi6) + 96 B out
 // (2 x [wi3 f3 pdf F] + [r pdf R3] + [sheenFresnel specularFresnel sssWeight]) = 236 B = 3 samples
 // (SURVEY.md section 8(d), config 5).
+// loads behind reload_args / the per-parameter stream-or-uniform branches sit in later basic blocks than make_idx():
+// they renew the lane-offset barrier (rls_device.hpp) so that every plane access keeps the scalar-base addressing form
+#ifndef RLS_LOAD_RENEW
+#define RLS_LOAD_RENEW 1
+#endif
 #include "rls_internal.hpp"
 
 using namespace rlsd;

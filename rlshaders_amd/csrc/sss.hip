@@ -5,6 +5,11 @@
 // Roofline: HBM.  Algorithmic bytes per sample: probe ray 56 B in (dist3 albedo3 N3 T3 xi2) +
 // 48 B out (r, origin3, dir3, maxdist, pdf, R3) = 104 B; profile-only 32 B in + 20 B out = 52 B
 // (SURVEY.md section 8(d), config 4).
+// loads behind reload_args / the per-parameter stream-or-uniform branches sit in later basic blocks than make_idx():
+// they renew the lane-offset barrier (rls_device.hpp) so that every plane access keeps the scalar-base addressing form
+#ifndef RLS_LOAD_RENEW
+#define RLS_LOAD_RENEW 1
+#endif
 #include "rls_internal.hpp"
 
 using namespace rlsd;

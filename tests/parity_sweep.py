@@ -27,7 +27,7 @@ def _words(got, ref):
     return dict(words_differing=diff, words=total, max_rel_err=worst, beyond_1e5=beyond)
 
 
-def sweep(ctx, n: int, seed: int, spp_n: int = 2, verbose: bool = True) -> dict:
+def sweep(ctx, n: int, seed: int, spp_n: int = 2, verbose: bool = True, group: str = '1') -> dict:
     th = O.hardware_threads()
     hostf = lambda t: t.contiguous().cpu().numpy()
     wo, N, T = R.gen_frame(ctx, seed, 0, n)
@@ -51,7 +51,7 @@ def sweep(ctx, n: int, seed: int, spp_n: int = 2, verbose: bool = True) -> dict:
     g = R.GgxSampler(ctx, wo, N, T, specColor=Ks, ior=ior, roughness=rough, anisotropic=aniso)
     og = ggx_oracle(O, c, nthreads=th)
     tally("ggx reflect+refract", [hostf(t) for t in g.reflectRefract(*xi[:4])], og.reflect_refract(*hxi[:4]))
-    os.environ["RLS_INTEGRATE_GROUP"] = "1"          # one lane per point: the reference's summation order
+    os.environ["RLS_INTEGRATE_GROUP"] = group        # lanes per point: the sums grow in sample order whatever the width (fold)
     try:
         tally("ggx integrate", [hostf(t) for t in g.integrate(spp_n, seed)], og.integrate(spp_n, seed))
         P = torch.stack([u(40, 0, 4), u(41, 0, 4), u(42, 0, 1)])
@@ -92,7 +92,7 @@ def sweep(ctx, n: int, seed: int, spp_n: int = 2, verbose: bool = True) -> dict:
     for lobe, nm in ((R.RLS_RAY_DIFFUSE, "diffuse"), (R.RLS_RAY_GLOSSY, "glossy")):
         d.setSampleType(lobe)
         tally(f"disney {nm}", [hostf(t) for t in d.sampleEvalPdf(xi[0], xi[1])], od.sample_eval_pdf(lobe, hxi[0], hxi[1]))
-    os.environ["RLS_INTEGRATE_GROUP"] = "1"
+    os.environ["RLS_INTEGRATE_GROUP"] = group
     try:                                              # BASELINE config 3's loop: spp_n^2 samples per lobe, both lobes
         keys = ("diffuse_sum", "diffuse_count", "specular_sum", "specular_count")
         gi, ri = d.integrate(spp_n, seed), od.integrate(spp_n, seed)
@@ -127,7 +127,7 @@ def sweep(ctx, n: int, seed: int, spp_n: int = 2, verbose: bool = True) -> dict:
     names = list(O.SKIN_VEC) + list(O.SKIN_SCALAR)
     tally("skin", [hostf(gout[k]) for k in names], [rout[k] for k in names])
     # rlSkin's shader_evaluate over spp_n^2 samples per layer, one light in the two light loops
-    os.environ["RLS_INTEGRATE_GROUP"] = "1"
+    os.environ["RLS_INTEGRATE_GROUP"] = group
     try:
         pk = dict(p, sss_scatter_dist=dsmall)
         ski = R.SkinShader(ctx, wo, N, T, **pk)

@@ -86,6 +86,40 @@ def test_streamed_chunked_equals_unchunked(gpu, oracle):
         raise RuntimeError("consumer failed")
     with pytest.raises(RuntimeError, match="consumer failed"):
         s.integrateChunked(spp_n, seed, 300, consume=bad)
+    # ... and the C ABI says so with its own status: RLS_ERR_ABORTED (6), not "invalid argument"
+    import ctypes as C
+    from rlshaders_amd import _capi as capi
+    from rlshaders_amd.closures import plane, rgb, vec3
+    spp = spp_n * spp_n
+    m = 2 * spp * 300
+    ch = dict(wi=gpu.empty(3, m), f=gpu.empty(3, m), pdf=gpu.empty(m))
+    so = capi.DisneyStreamOut(vec3(ch["wi"], m, "wi"), rgb(ch["f"], m, "f"), plane(ch["pdf"], m, "pdf"))
+    o = {k: gpu.empty(3, n) for k in SUMS}
+    o.update({k: gpu.empty(n) for k in COUNTS})
+    stop = capi.DisneyChunkFn(lambda user, p0, count, chunk: 7)
+
+    def chunked(ctx, cb):
+        return ctx.lib.rls_disney_integrate_chunked(
+            ctx.handle, n, C.byref(s.c), spp_n, seed, first, rgb(o["diffuse_sum"], n, "d"), plane(o["diffuse_count"], n, "dc"),
+            rgb(o["specular_sum"], n, "s"), plane(o["specular_count"], n, "sc"), 300, C.byref(so), cb, None)
+    assert chunked(gpu, stop) == 6 and b"consumer returned 7" in gpu.lib.rls_last_error()
+    # a consumer cannot be recorded into a launch graph (a replay would overwrite the chunk buffers without calling it):
+    # refused while capturing (RLS_ERR_UNSUPPORTED = 5); without a consumer the chunk launches record fine
+    own = R.Context(0, use_torch_stream=False)
+    try:
+        torch.cuda.synchronize()
+        assert own.lib.rls_graph_begin_capture(own.handle) == 0
+        assert chunked(own, stop) == 5 and b"launch graph" in own.lib.rls_last_error()
+        assert chunked(own, capi.DisneyChunkFn()) == 0
+        h = C.c_void_p()
+        assert own.lib.rls_graph_end_capture(own.handle, C.byref(h)) == 0
+        assert own.lib.rls_graph_launch(own.handle, h) == 0
+        own.synchronize()
+        own.lib.rls_graph_destroy(h)
+        for k in SUMS + COUNTS:                          # the replayed chunk launches produced the batch's sums
+            assert np.array_equal(host(o[k]).view(np.uint32), whole[k].view(np.uint32)), k
+    finally:
+        own.close()
     # no consumer: samples discarded, sums unchanged
     sums2, _ = _with_group(1, lambda: s.integrateChunked(spp_n, seed, 256, first_index=first))
     for k in SUMS + COUNTS:

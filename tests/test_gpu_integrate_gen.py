@@ -122,6 +122,9 @@ def test_large_parity_sweep(gpu, oracle):
     import parity_sweep
     report = parity_sweep.sweep(gpu, 1 << 22, 4242)
     assert len(report) == 14
+    # ... and with four lanes per point and nine samples (ragged rounds): the sums grow in sample order all the same
+    for name, r in parity_sweep.sweep(gpu, 1 << 20, 777, spp_n=3, group="4", verbose=False).items():
+        report[name + " (4 lanes per point, 9 samples)"] = r
     for name, r in report.items():
         # the soaks count 0 differing words of 2.2e11: on a host whose glibc is the build the device libm follows, so does this
         assert r["words_differing"] <= (0 if cases.strict_parity() else 4) and r["beyond_1e5"] == 0, (name, r)

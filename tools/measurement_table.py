@@ -6,9 +6,13 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 ROWS = (("ggx_reflect_refract", "2"), ("sss_probe", "4 (kernel; 2²⁸ points over 8 GPUs)"), ("skin", "5 (kernel; 2³⁰ points over 8 GPUs)"),
         ("disney_integrate", "3, mode R (reduced)"), ("disney_stream", "3, mode S (streamed, 64 chunks of 2²⁰ points)"),
+        ("ggx_reflect_refract_uniform", "2 with uniform node parameters"), ("ggx_reflect", "— (reflect triple, fused)"),
+        ("ggx_eval", "— (`evalBrdf` alone)"), ("ggx_pdf", "— (`evalPdf` alone)"),
+        ("disney_triple_diffuse", "— (rlDisney one-sample triple, diffuse lobe)"),
+        ("disney_triple_glossy", "— (rlDisney one-sample triple, glossy lobe)"), ("nd_sample", "4, profile-only variant"),
         ("skin_integrate", "— (rlSkin `shader_evaluate`, 16 samples per layer, no lights)"),
         ("ggx_shade", "— (rlGgx `shader_evaluate`, whole: two lights × 48 + 3 × 16 samples per point)"),
         ("disney_shade", "— (rlDisney `shader_evaluate`, whole: two lights × 48 + 2 × 16 samples per point)"),
@@ -26,7 +30,7 @@ def thousands(x):
     return f"{x:,.0f}".replace(",", " ")
 
 
-print("| workload (`bench.py --workload`) | BASELINE config | time per pass (rocprofv3 average) | throughput | roofline | HBM traffic ÷ algorithmic | VALU instr. per point | CPU baseline (oracle, all host threads) |")
+print("| workload (`bench.py --workload`) | BASELINE config | time per pass (rocprofv3 average) | throughput | roofline | HBM bytes the counters saw ÷ algorithmic (fraction of 8 TB/s on them) | VALU / SALU instr. per point, issue-slot fraction | CPU baseline (oracle, all host threads) |")
 print("|---|---|---|---|---|---|---|---|")
 for w, cfg in ROWS:
     b, f, t, tr = load(w, "bench"), load(w, "flops"), load(w, "traffic"), load(w, "bench_trace")
@@ -39,12 +43,21 @@ for w, cfg in ROWS:
     tm = f"{ms:.3f} ms" if ms < 20 else f"{ms:.1f} ms"
     if lp > 1:
         tm += f" = {lp} × {r['kernel_ms']:.3f} ms"
+    sec = r["kernel_ms"] * 1e-3
+    ppl = b["config"]["points_per_gpu"] / lp
     if r["bound"] == "hbm":
-        roof = f"{r['frac']:.3f} of 8 TB/s ({r['achieved'] / 1000:.2f} TB/s on {r['algorithmic_bytes_per_point']} B/point)"
+        roof = f"{r['frac']:.3f} of 8 TB/s ({r['achieved'] / 1000:.2f} TB/s on {r['algorithmic_bytes_per_point']} B/point"
+        if r.get("survey_bytes_per_point"):
+            roof += f"; {r['frac_survey_bytes']:.3f} on SURVEY's {r['survey_bytes_per_point']} B"
+        roof += ")"
     else:
         roof = f"VALU: {r['achieved']:.1f} of {r['peak']} TFLOP/s = {r['frac']:.2f} ({thousands(r['flops_per_point'])} executed flops per point)"
-    ratio = f"{t['ratio_to_algorithmic']:.3f}" if t else "—"
-    valu = thousands(f["instructions_per_point"]["SQ_INSTS_VALU"]) if f else "—"
+    ratio = f"{t['ratio_to_algorithmic']:.3f} ({t['hbm_bytes_per_launch'] / sec / 8e12:.3f})" if t else "—"
+    if f:
+        ip = f["instructions_per_point"]
+        valu = f"{thousands(ip['SQ_INSTS_VALU'])} / {thousands(ip.get('SQ_INSTS_SALU', 0))}, {ip['SQ_INSTS_VALU'] * ppl / 64 / sec / 1.2288e12:.2f}"
+    else:
+        valu = "—"
     unit = b["unit"]
     print(f"| `{w}` | {cfg} | {tm}" + (f" ({prof:.3f})" if prof and lp == 1 else "") + f" | {b['value']:.1f} {unit} | {roof} | {ratio} | {valu} | "
           f"{b['cpu_baseline']['value']:.3f} ({b['cpu_baseline']['cores']} threads) |")

@@ -20,19 +20,23 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--log2-points", type=int, default=24)
     ap.add_argument("--seeds", default="4242,99,7,1234")
+    ap.add_argument("--groups", default="1", help="lanes per point of the n^2-spp loops, e.g. 1,4,16 (RLS_INTEGRATE_GROUP)")
+    ap.add_argument("--spp-n", type=int, default=2, help="spp_n of the n^2-spp loops (3 -> 9 samples: ragged for 4 and 16 lanes)")
     args = ap.parse_args()
     ctx = R.Context(0)
     total = {}
     t0 = time.time()
     seeds = [int(s) for s in args.seeds.split(",")]
+    groups = args.groups.split(",")
     for seed in seeds:
-        for name, r in parity_sweep.sweep(ctx, 1 << args.log2_points, seed).items():
-            t = total.setdefault(name, dict(words_differing=0, words=0, max_rel_err=0.0, beyond_1e5=0))
-            t["words_differing"] += r["words_differing"]
-            t["words"] += r["words"]
-            t["beyond_1e5"] += r["beyond_1e5"]
-            t["max_rel_err"] = max(t["max_rel_err"], r["max_rel_err"])
-    summary = dict(points_per_seed=1 << args.log2_points, seeds=seeds, mode="RLS_MATH_EXACT",
+        for group in groups:
+            for name, r in parity_sweep.sweep(ctx, 1 << args.log2_points, seed, spp_n=args.spp_n, group=group).items():
+                t = total.setdefault(name, dict(words_differing=0, words=0, max_rel_err=0.0, beyond_1e5=0))
+                t["words_differing"] += r["words_differing"]
+                t["words"] += r["words"]
+                t["beyond_1e5"] += r["beyond_1e5"]
+                t["max_rel_err"] = max(t["max_rel_err"], r["max_rel_err"])
+    summary = dict(points_per_seed=1 << args.log2_points, seeds=seeds, lane_groups=groups, spp_n=args.spp_n, mode="RLS_MATH_EXACT",
                    seconds=round(time.time() - t0, 1), closures=total,
                    words=sum(t["words"] for t in total.values()),
                    words_differing=sum(t["words_differing"] for t in total.values()))

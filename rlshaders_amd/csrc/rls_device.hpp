@@ -1036,35 +1036,61 @@ struct NdProfile {
     float maxR;
 #if !RLS_FAST
     // getPdf divides by max(d_i, AI_EPSILON) twice and by c1_i + 3 c2_i once per channel, at every call: their correctly
-    // rounded reciprocals, and whether all six sit in the window of rlm::div32_y (2^-14 .. 2^14)
+    // rounded reciprocals, and whether they sit in the window of rlm::div32_y (2^-14 .. 2^14).  window: 0 none kept,
+    // 1 the three of d_i (one-sample kernels: setDistance's -maxR / d_i and getPdf's two divisions by d_i share them),
+    // 2 those of c1_i + 3 c2_i as well (the probe-ray loops, which call getPdf three times per hit)
     float dm[3], ydm[3], cw[3], ycw[3];
-    bool window;
+    int window;
 #endif
 };
 
-// RECIPROCALS: the profile is evaluated many times (the probe-ray loop of integrateScatter): keep the reciprocals of
-// getPdf's per-point denominators.  One-sample kernels do not (six reciprocals cost what they would save there).
+// RECIPROCALS: the profile is evaluated many times (the probe-ray loop of integrateScatter): keep the reciprocals of all of
+// getPdf's per-point denominators.  One-sample kernels keep the three of d_i only: each serves three divisions there
+// (setDistance's -maxR / d_i, getPdf's -r / d_i and (e1 + e2) / d_i) -- three reciprocals (4 instructions each) and nine
+// five-instruction quotients instead of nine IEEE divisions; the three of c1 + 3 c2 would serve one division each.
+#ifndef RLS_ND_RECIP_D
+#define RLS_ND_RECIP_D 1        // experiment switch: 0 = the one-sample kernels divide by d_i the IEEE way (round 2)
+#endif
 template <bool RECIPROCALS = false>
 RLS_DEV NdProfile nd_make(float dx, float dy, float dz)
 {
     NdProfile p;
     p.d[0] = dx; p.d[1] = dy; p.d[2] = dz;
     p.maxR = maxf(dx, maxf(dy, dz)) * 3.0f;
+#if !RLS_FAST
+    // d_i itself (not max(d_i, AI_EPSILON)) is what setDistance divides by: inside the window the two are the same value
+    p.window = (RECIPROCALS || RLS_ND_RECIP_D) ? 1 : 0;
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
-        p.c1[i] = 1.0f - R_EXP(R_DIV(-p.maxR, p.d[i]));
-        p.c2[i] = 1.0f - R_EXP(R_DIVC(R_DIV(-p.maxR, p.d[i]), 3.0f));
+    for (int i = 0; (RECIPROCALS || RLS_ND_RECIP_D) && i < 3; i++) {
+        p.dm[i] = maxf(p.d[i], kEps);
+        p.ydm[i] = R_RCPW(p.dm[i]);                  // windowed below; outside it the reciprocals are not used
+        if (!(p.d[i] >= 0x1p-13f && p.d[i] <= 0x1p14f)) p.window = 0;      // 2^-13 > AI_EPSILON: d_i == max(d_i, AI_EPSILON)
+    }
+    // -maxR / d_i: maxR = 3 max(d) is in [3 x 2^-13, 3 x 2^14] whenever the window holds (or NaN, which fails it)
+    if (__builtin_expect(p.window != 0, 1)) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const float q = rlm::div32_y(-p.maxR, p.d[i], p.ydm[i]);
+            p.c1[i] = 1.0f - R_EXP(q);
+            p.c2[i] = 1.0f - R_EXP(R_DIVC(q, 3.0f));
+        }
+    } else
+#endif
+    {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            p.c1[i] = 1.0f - R_EXP(R_DIV(-p.maxR, p.d[i]));
+            p.c2[i] = 1.0f - R_EXP(R_DIVC(R_DIV(-p.maxR, p.d[i]), 3.0f));
+        }
     }
 #if !RLS_FAST
-    p.window = RECIPROCALS;
 #pragma unroll
     for (int i = 0; RECIPROCALS && i < 3; i++) {
-        p.dm[i] = maxf(p.d[i], kEps);
         p.cw[i] = p.c1[i] + p.c2[i] * 3.0f;
-        p.ydm[i] = R_RCPW(p.dm[i]);                  // windowed below; outside it the reciprocals are not used
         p.ycw[i] = R_RCPW(p.cw[i]);
-        p.window = p.window && p.dm[i] >= 0x1p-14f && p.dm[i] <= 0x1p14f && p.cw[i] >= 0x1p-14f && p.cw[i] <= 0x1p14f;
+        if (!(p.cw[i] >= 0x1p-14f && p.cw[i] <= 0x1p14f)) p.window = 0;
     }
+    if (RECIPROCALS && p.window) p.window = 2;
 #endif
     return p;
 }
@@ -1120,7 +1146,7 @@ RLS_DEV float nd_pdf(const NdProfile &p, float r)
     // Nine of the ten divisions have a per-point denominator: through its reciprocal (rlm::div32_y, five instructions
     // each) when every operand is inside that routine's window -- the point's denominators (p.window), r, and the sums
     // e^(-r/d) + e^(-r/3d), which fall below 2^-60 only for r > 41 d; the quotients (p1 + p2) / d are then >= 2^-74
-    if (__builtin_expect(!(p.window && r >= 0x1p-40f && r <= 0x1p40f), 0)) return nd_pdf_ieee(p, r);
+    if (__builtin_expect(!(p.window == 2 && r >= 0x1p-40f && r <= 0x1p40f), 0)) return nd_pdf_ieee(p, r);
     float s[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
@@ -1153,7 +1179,8 @@ RLS_DEV void nd_profile(const NdProfile &p, float r, float &R, float &G, float &
 // getPdf and evalProfile at the same radius (the probe-ray sample of rlSss / rlSkin asks for both): e^(-r / d_i) is one
 // value in both -- getPdf divides by max(d_i, AI_EPSILON), evalProfile by d_i and only when d_i >= AI_EPSILON -- so
 // the three divisions and exponentials are done once.  Same results as nd_pdf() and nd_profile().
-template <bool WINDOWED>
+// WINDOWED: 0 every division the IEEE way, 1 those by d_i through its reciprocal, 2 those by c1_i + 3 c2_i as well
+template <int WINDOWED>
 RLS_DEV void nd_pdf_profile_t(const NdProfile &p, float r, float &pdf, float &R, float &G, float &B)
 {
     const float denom = 8.0f * kPi * r;
@@ -1171,15 +1198,18 @@ RLS_DEV void nd_pdf_profile_t(const NdProfile &p, float r, float &pdf, float &R,
         const float p1 = R_EXP(q);
         const float p2 = R_EXP(R_DIVC(q, 3.0f));
 #if !RLS_FAST
-        if (WINDOWED) {
+        if (WINDOWED == 2) {
             tiny = tiny || !(p1 + p2 >= 0x1p-60f);
             acc += rlm::div32_y(rlm::div32_y(p1 + p2, p.dm[i], p.ydm[i]), p.cw[i], p.ycw[i]);
+        } else if (WINDOWED == 1) {
+            tiny = tiny || !(p1 + p2 >= 0x1p-60f);
+            acc += R_DIV(rlm::div32_y(p1 + p2, p.dm[i], p.ydm[i]), p.c1[i] + p.c2[i] * 3.0f);
         } else
 #endif
         acc += R_DIV(R_DIV(p1 + p2, d), p.c1[i] + p.c2[i] * 3.0f);
         out[i] = p.d[i] < kEps ? 1.0f : R_DIV(p1 + R_EXP(R_DIV(-r, 3.0f * p.d[i])), denom * p.d[i]);
     }
-    if (WINDOWED && __builtin_expect(tiny, 0)) { nd_pdf_profile_t<false>(p, r, pdf, R, G, B); return; }
+    if (WINDOWED && __builtin_expect(tiny, 0)) { nd_pdf_profile_t<0>(p, r, pdf, R, G, B); return; }
     pdf = R_DIV(acc, kTwoPi * r * 3.0f);
     const bool white = r < kEps;
     R = white ? 1.0f : out[0]; G = white ? 1.0f : out[1]; B = white ? 1.0f : out[2];
@@ -1189,9 +1219,13 @@ RLS_DEV void nd_pdf_profile(const NdProfile &p, float r, float &pdf, float &R, f
     if (p.maxR < kEps) { pdf = 1.0f; R = 0.0f; G = 0.0f; B = 0.0f; return; }
 #if !RLS_FAST
     // the divisions of getPdf by per-point denominators through their reciprocals, as nd_pdf()
-    if (__builtin_expect(p.window && r >= 0x1p-40f && r <= 0x1p40f, 1)) { nd_pdf_profile_t<true>(p, r, pdf, R, G, B); return; }
+    if (__builtin_expect(p.window != 0 && r >= 0x1p-40f && r <= 0x1p40f, 1)) {
+        if (p.window == 2) nd_pdf_profile_t<2>(p, r, pdf, R, G, B);
+        else nd_pdf_profile_t<1>(p, r, pdf, R, G, B);
+        return;
+    }
 #endif
-    nd_pdf_profile_t<false>(p, r, pdf, R, G, B);
+    nd_pdf_profile_t<0>(p, r, pdf, R, G, B);
 }
 
 // SssSampler frame, src/rlSss.h:149-158

@@ -1095,6 +1095,12 @@ RLS_DEV NdProfile nd_make(float dx, float dy, float dz)
     return p;
 }
 
+// RLS_ND_MERGE_RADIUS: experiment switch (one division and one logf of selected operands for getRadius's two arms).
+// Measured twice, rounds 2 and 3 (profiles/r03_nd_recip.txt): the rlSss probe 1.576 -> 1.643 ms, rlSkin 4.12 -> 4.17 --
+// slower, although it executes fewer instructions; integrateScatter -0.6 %.  Off.
+#ifndef RLS_ND_MERGE_RADIUS
+#define RLS_ND_MERGE_RADIUS 0
+#endif
 // selectDistLobe + getRadius, src/rlSss.h:30-42, src/rlSss.cpp:36-66
 RLS_DEV float nd_radius(const NdProfile &p, float rx)
 {
@@ -1114,6 +1120,14 @@ RLS_DEV float nd_radius(const NdProfile &p, float rx)
     if (d < kEps) return 0.0f;
     float w = R_DIV(w1, w1 + w2 * 3.0f);
     float r;
+#if RLS_ND_MERGE_RADIUS
+    // the two arms divide and take the logarithm of different operands; the lanes of a wavefront take both, so the operands
+    // are selected and ONE division and ONE logf serve either arm (each lane still computes exactly what its arm computes:
+    // rx - 0 and w - 0 are exact)
+    const bool tail = rx > w;
+    const float t = clampf(R_DIV(rx - (tail ? w : 0.0f), (tail ? 1.0f : w) - (tail ? w : 0.0f)), 0.0f, 1.0f);
+    r = R_LOG(1.0f - t * (tail ? w2 : w1)) * (tail ? -d * 3.0f : -d);
+#else
     if (rx > w) {
         rx = linearstep(w, 1.0f, rx);
         r = R_LOG(1.0f - rx * w2) * (-d * 3.0f);
@@ -1121,6 +1135,7 @@ RLS_DEV float nd_radius(const NdProfile &p, float rx)
         rx = linearstep(0.0f, w, rx);
         r = R_LOG(1.0f - rx * w1) * (-d);
     }
+#endif
     return r;
 }
 

@@ -182,3 +182,41 @@ def test_gaussian_profile_alternate(gpu, oracle, mixed):
     var = 1.0 / 12.46
     dens = np.exp(-rr * rr / 2 / var) / (2 * np.pi * var) / (1 - np.exp(-0.5 / var)) * 2 * np.pi * rr
     assert abs(np.trapezoid(dens, rr) - 1.0) < 1e-6
+
+
+def test_nd_profile_across_the_reciprocal_window(gpu, oracle):
+    """The one-sample kernels divide by d_i through its reciprocal while d_i and the radius sit inside rlm::div32_y's operand
+    window (2^-13 .. 2^14 for d_i, 2^-40 .. 2^40 for r; nd_make / nd_pdf_profile, rls_device.hpp) and the IEEE way otherwise --
+    decided per lane.  Scatter distances from 1e-7 to 1e7, mixed within a wavefront and across the three channels, the window's
+    corner values included: radius, pdf and profile equal the oracle's bit for bit on either side of every border."""
+    n = 1 << 16
+    rng = np.random.default_rng(3)
+    e = rng.uniform(-7.0, 7.0, (3, n))
+    dist = (10.0 ** e).astype(np.float32)
+    corners = np.array([2.0 ** -14, 2.0 ** -13, np.nextafter(np.float32(2.0 ** -13), np.float32(0)), 2.0 ** 14,
+                        np.nextafter(np.float32(2.0 ** 14), np.float32(1e9)), 1e-4, np.nextafter(np.float32(1e-4), np.float32(0)),
+                        0.0, np.inf, np.nan, 1.0], dtype=np.float32)
+    k = np.arange(n)
+    for c in range(3):                                       # every 7th lane of channel c takes a corner value
+        sel = (k % 7) == c
+        dist[c, sel] = corners[(k[sel] // 7 + c) % len(corners)]
+    albedo = np.full((3, n), 0.5, np.float32)
+    rx = oracle.gen_uniform(5, 0, n, oracle.S_XI0)
+    p = R.NDProfile(gpu, n, dev(dist), albedo=dev(albedo))
+    ref = oracle.Sss(n, dist, albedo, nthreads=4).nd_sample(rx)
+    got = [host(t) for t in p.sample(dev(rx))]
+    for name, a, b in zip(("r", "pdf", "profile"), got, ref):
+        same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+        assert same.all(), (name, int((~same).sum()))
+    # the probe ray on the same profiles (frame from the seeded generator), radii driven to both ends by the random number
+    _, N, T = cases.frame(5, n)
+    x = np.stack([rx, oracle.gen_uniform(5, 0, n, oracle.S_XI0 + 1)])
+    x[0, ::5] = np.float32(0.0)
+    x[0, 1::5] = np.nextafter(np.float32(1.0), np.float32(0.0))
+    s = R.SssSampler(gpu, dev(N), dev(T), dev(albedo), dev(dist))
+    gp = s.getProbeRay(dev(x[0]), dev(x[1]))
+    rp = oracle.Sss(n, dist, albedo, N=N, T=T, nthreads=4).probe(x[0], x[1])
+    for name in ("r", "maxdist", "pdf", "profile"):
+        a, b = host(gp[name]), rp[name]
+        same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+        assert same.all(), (name, int((~same).sum()))

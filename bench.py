@@ -210,8 +210,11 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
         dev_in = [wo[0], wo[1], wo[2], N[0], N[1], N[2], T[0], T[1], T[2]] + list(u3(S_KS)) + \
                  [u(S_ROUGH, 0.05, 1.0), u(S_IOR, 1.05, 2.55), R.gen_aniso(ctx, SEED, first, n, out=A.plane())] + \
                  [u(S_XI0 + j) for j in range(4)]
-        hin = [torch.empty(n, dtype=torch.float32, pin_memory=True) for _ in range(19)]
-        hout = [torch.empty(n, dtype=torch.float32, pin_memory=True) for _ in range(12)]
+        # ONE page-locked [planes, n] array per direction, as a stub's batch buffers are: equally spaced planes travel as one
+        # strided copy per chunk and direction (rls_pipeline_run)
+        hin_all = torch.empty(19, n, dtype=torch.float32, pin_memory=True)
+        hout_all = torch.empty(12, n, dtype=torch.float32, pin_memory=True)
+        hin, hout = [hin_all[k] for k in range(19)], [hout_all[k] for k in range(12)]
         torch.cuda.synchronize()
         for h, d in zip(hin, dev_in):
             h.copy_(d)

@@ -24,12 +24,49 @@ struct Slot {
     float **in, **out;         // plane pointers handed to the launch callback
 };
 
+// host planes [k0, k1) <-> device planes of one slot, rows [p0, p0 + count): one hipMemcpyAsync per plane, or -- where
+// consecutive host planes are a constant positive distance apart -- one hipMemcpy2DAsync per run of planes
+// (a run may be equally spaced by accident -- separate allocations next to each other -- and then the runtime refuses the
+// strided copy, whose source must lie in one allocation: the run goes plane by plane and the pipeline stops trying)
+template <class HostPtr>
+hipError_t copy_planes(bool up, int planes, HostPtr const *host, float *const *dev, int64_t dev_stride, int64_t p0,
+                       int64_t count, hipStream_t stream, bool &strided)
+{
+    hipError_t e = hipSuccess;
+    const size_t row = (size_t)count * sizeof(float);
+    for (int k = 0; e == hipSuccess && k < planes;) {
+        if (!host[k]) { k++; continue; }
+        int m = k + 1;                                                // the run [k, m) of equally spaced host planes
+        if (strided && m < planes && host[m] && host[m] > host[k]) {
+            const ptrdiff_t d = host[m] - host[k];
+            while (m + 1 < planes && host[m + 1] && host[m + 1] - host[m] == d) m++;
+            m++;
+            if (m - k >= 2) {
+                if (up) e = hipMemcpy2DAsync(dev[k], (size_t)dev_stride * sizeof(float), host[k] + p0, (size_t)d * sizeof(float), row,
+                                             (size_t)(m - k), hipMemcpyHostToDevice, stream);
+                else e = hipMemcpy2DAsync((void *)(host[k] + p0), (size_t)d * sizeof(float), dev[k], (size_t)dev_stride * sizeof(float), row,
+                                          (size_t)(m - k), hipMemcpyDeviceToHost, stream);
+                if (e == hipSuccess) { k = m; continue; }
+                (void)hipGetLastError();                                  // refused (arguments are validated before anything is queued)
+                e = hipSuccess;
+                strided = false;
+            }
+            m = k + 1;
+        }
+        if (up) e = hipMemcpyAsync(dev[k], host[k] + p0, row, hipMemcpyHostToDevice, stream);
+        else e = hipMemcpyAsync((void *)(host[k] + p0), dev[k], row, hipMemcpyDeviceToHost, stream);
+        k = m;
+    }
+    return e;
+}
+
 } // namespace
 
 struct rls_pipeline {
     rls_context *parent;
     int64_t chunk_points, stride;
     int in_planes, out_planes, depth;
+    bool strided;              // RLS_PIPELINE_STRIDED=0 turns the strided copies off (one copy per plane)
     Slot *slots;
 };
 
@@ -106,6 +143,10 @@ rls_status rls_pipeline_create(rls_context *ctx, int64_t chunk_points, int in_pl
     p->chunk_points = chunk_points;
     p->stride = (chunk_points + 63) / 64 * 64;              // planes on 256-byte boundaries
     p->in_planes = in_planes; p->out_planes = out_planes; p->depth = depth;
+    {
+        const char *sv = getenv("RLS_PIPELINE_STRIDED");
+        p->strided = !(sv && sv[0] == '0');
+    }
     p->slots = (Slot *)calloc((size_t)depth, sizeof(Slot));
     rls_status st = p->slots ? RLS_OK : RLS_ERR_OUT_OF_MEMORY;
     for (int s = 0; st == RLS_OK && s < depth; s++) {
@@ -148,16 +189,14 @@ rls_status rls_pipeline_run(rls_pipeline *p, int64_t n, const float *const *host
         sl.ctx->fast = p->parent->fast;                    // the slots compute in the parent's arithmetic mode
         hipStream_t stream = sl.ctx->stream;
         hipError_t e = hipSetDevice(sl.ctx->device);
-        // a NULL host plane is a plane the caller does not stream (a uniform parameter, an unwanted output)
-        for (int k = 0; e == hipSuccess && k < p->in_planes; k++)
-            if (host_in[k])
-                e = hipMemcpyAsync(sl.in[k], host_in[k] + p0, (size_t)count * sizeof(float), hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) { st = rlsh::hip_fail(e, "rls_pipeline_run: hipSetDevice"); break; }
+        // a NULL host plane is a plane the caller does not stream (a uniform parameter, an unwanted output).  Runs of host
+        // planes that are equally spaced in memory (rlsb::HostPlanes, a [planes, n] array) travel as ONE strided copy
+        e = copy_planes(true, p->in_planes, host_in, sl.in, p->stride, p0, count, stream, p->strided);
         if (e != hipSuccess) { st = rlsh::hip_fail(e, "rls_pipeline_run: upload"); break; }
         st = launch(user, sl.ctx, p0, count, sl.in, sl.out);
         if (st != RLS_OK) break;
-        for (int k = 0; e == hipSuccess && k < p->out_planes; k++)
-            if (host_out[k])
-                e = hipMemcpyAsync(host_out[k] + p0, sl.out[k], (size_t)count * sizeof(float), hipMemcpyDeviceToHost, stream);
+        e = copy_planes(false, p->out_planes, host_out, sl.out, p->stride, p0, count, stream, p->strided);
         if (e != hipSuccess) { st = rlsh::hip_fail(e, "rls_pipeline_run: download"); break; }
     }
     // drain every slot, also after a failure: the caller's host buffers must not be written behind its back
@@ -169,7 +208,7 @@ rls_status rls_pipeline_run(rls_pipeline *p, int64_t n, const float *const *host
 }
 
 // Pinned-memory copy rates of this box, GB/s: [0] host -> device alone, [1] device -> host alone, [2] both directions at
-// once (sum of the two), each over `bytes` per direction in 4 MiB pieces on two streams -- what a pipeline's copies can
+// once (sum of the two), each over `bytes` per direction in 64 MiB pieces on two streams -- what a pipeline's copies can
 // reach at best, measured where the pipeline runs.
 rls_status rls_measure_copy_rates(rls_context *ctx, size_t bytes, float rates_gb_per_s[3])
 {
@@ -192,7 +231,7 @@ rls_status rls_measure_copy_rates(rls_context *ctx, size_t bytes, float rates_gb
     if (e == hipSuccess) {
         memset(h0, 1, bytes);
         memset(h1, 2, bytes);
-        const size_t piece = 4u << 20;
+        const size_t piece = 64u << 20;       // large pieces: what a copy engine sustains (4 MiB pieces read ~10 % lower)
         auto pass = [&](bool up, bool down, float *gbs) -> hipError_t {
             hipError_t r = hipDeviceSynchronize();
             if (r == hipSuccess) r = hipEventRecord(a, s0);

@@ -32,14 +32,25 @@ def _launch(slot, first, count, i, o):
     g.reflectRefract(i[15], i[16], i[17], i[18], out=(o.rows(0), o.rows(3), o[6], o[7], o.rows(8), o[11]))
 
 
-@pytest.mark.parametrize("n,chunk,depth", [(100_003, 1 << 14, 3), (5000, 1 << 14, 2), (1 << 16, 1 << 14, 1), (70_001, 4096, 4)])
-def test_pipeline_equals_device_resident(gpu, oracle, n, chunk, depth):
+@pytest.mark.parametrize("n,chunk,depth,one_array", [(100_003, 1 << 14, 3, False), (5000, 1 << 14, 2, False),
+                                                    (1 << 16, 1 << 14, 1, True), (70_001, 4096, 4, False),
+                                                    (100_003, 1 << 14, 3, True), (70_001, 4096, 2, True)])
+def test_pipeline_equals_device_resident(gpu, oracle, n, chunk, depth, one_array):
+    """one_array: the host planes are rows of ONE page-locked [planes, n] array (a stub's batch buffers, rlsb::HostPlanes) and
+    travel as one strided copy per chunk and direction; otherwise separate allocations, one copy per plane (also when they
+    happen to be equally spaced: the runtime refuses a strided copy across allocations and rls_pipeline_run falls back)"""
     c = cases.ggx_mixed(cases.SEED_PARITY, n)
     x = cases.xi(cases.SEED_PARITY, n, 4)
     planes = [c["wo"][k] for k in range(3)] + [c["N"][k] for k in range(3)] + [c["T"][k] for k in range(3)] + \
              [c["KsColor"][k] for k in range(3)] + [c["roughness"], c["ior"], c["anisotropic"]] + [x[k] for k in range(4)]
-    hin = [_pinned(p) for p in planes]
-    hout = [torch.full((n,), float("nan"), dtype=torch.float32).pin_memory() for _ in range(12)]
+    if one_array:
+        hin_all = torch.empty(19, n, dtype=torch.float32, pin_memory=True)
+        hin_all.copy_(torch.from_numpy(np.stack(planes)))
+        hout_all = torch.full((12, n), float("nan"), dtype=torch.float32).pin_memory()
+        hin, hout = [hin_all[k] for k in range(19)], [hout_all[k] for k in range(12)]
+    else:
+        hin = [_pinned(p) for p in planes]
+        hout = [torch.full((n,), float("nan"), dtype=torch.float32).pin_memory() for _ in range(12)]
     pipe = R.Pipeline(gpu, chunk, 19, 12, depth)
     try:
         pipe.run(n, hin, hout, _launch)
@@ -50,7 +61,7 @@ def test_pipeline_equals_device_resident(gpu, oracle, n, chunk, depth):
     ref = [host(t) for t in ggx_sampler(gpu, c).reflectRefract(dev(x[0]), dev(x[1]), dev(x[2]), dev(x[3]))]
     flat = [ref[0][0], ref[0][1], ref[0][2], ref[1][0], ref[1][1], ref[1][2], ref[2], ref[3], ref[4][0], ref[4][1], ref[4][2], ref[5]]
     for k, (a, b) in enumerate(zip(hout, flat)):
-        assert np.array_equal(a.numpy().view(np.uint32), b.view(np.uint32)), (k, n, chunk, depth)
+        assert np.array_equal(a.numpy().view(np.uint32), b.view(np.uint32)), (k, n, chunk, depth, one_array)
     # and the oracle
     orc = ggx_oracle(oracle, c).reflect_refract(x[0], x[1], x[2], x[3])
     got_f = np.stack([hout[3].numpy(), hout[4].numpy(), hout[5].numpy()])

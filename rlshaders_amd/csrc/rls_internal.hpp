@@ -242,7 +242,11 @@ inline hipError_t &pending_device_error()
     return e;
 }
 
-inline dim3 grid_for(const rls_context *ctx, int64_t n, int points_per_block = kBlock)
+// cap_mult: the rlGgx and rlSkin kernels run a tile per workgroup (no grid-stride loop) up to 16 x the context's cap --
+// measured with RLS_BLOCKS_PER_CU = 64 against 1024 at 2^26 points (profiles/r03_blocks_per_cu.txt): evalPdf / evalBrdf alone
+// -7.5 %, config 2 -1.0 %, rlSkin -1.3 %, reflect triple 0; the rlSss / NDProfile and rlDisney kernels LOSE 3-5 % (their
+// per-workgroup staging of the libm tables is paid per tile then) and keep the cap.
+inline dim3 grid_for(const rls_context *ctx, int64_t n, int points_per_block = kBlock, int cap_mult = 1)
 {
     // called right before every launch: make the context's device current for this host thread
     // (a host may drive several contexts, one per GPU, from one thread)
@@ -250,7 +254,7 @@ inline dim3 grid_for(const rls_context *ctx, int64_t n, int points_per_block = k
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) pending_device_error() = e;
     int64_t want = (n + points_per_block - 1) / points_per_block;
-    int64_t cap = (int64_t)ctx->compute_units * ctx->blocks_per_cu;
+    int64_t cap = (int64_t)ctx->compute_units * ctx->blocks_per_cu * cap_mult;
     if (want < 1) want = 1;
     if (want > cap) want = cap;
     // a multiple of the 8 XCDs whenever there is that much work: the pointwise kernels then give each XCD

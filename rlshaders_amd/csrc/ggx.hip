@@ -134,9 +134,9 @@ rls_status launch_kernel(rls_context *ctx, const GgxIO &io, const char *name)
     const bool streamed = c.KsColor.r && c.specularRoughness.v && c.ior.v && c.anisotropic.v;
 #endif
     if (streamed)
-        hipLaunchKernelGGL((ggx_kernel<OP, RLS_FAST, true>), rlsh::grid_for(ctx, io.n, rlsh::kBlock, 16), dim3(rlsh::kBlock), 0, ctx->stream, io);
+        hipLaunchKernelGGL((ggx_kernel<OP, RLS_FAST, true>), rlsh::grid_for(ctx, io.n, rlsh::kBlock, RLS_CAP_MULT), dim3(rlsh::kBlock), 0, ctx->stream, io);
     else
-        hipLaunchKernelGGL((ggx_kernel<OP, RLS_FAST, false>), rlsh::grid_for(ctx, io.n, rlsh::kBlock, 16), dim3(rlsh::kBlock), 0, ctx->stream, io);
+        hipLaunchKernelGGL((ggx_kernel<OP, RLS_FAST, false>), rlsh::grid_for(ctx, io.n, rlsh::kBlock, RLS_CAP_MULT), dim3(rlsh::kBlock), 0, ctx->stream, io);
     return rlsh::check_launch(name);
 }
 

@@ -246,6 +246,9 @@ inline hipError_t &pending_device_error()
 // measured with RLS_BLOCKS_PER_CU = 64 against 1024 at 2^26 points (profiles/r03_blocks_per_cu.txt): evalPdf / evalBrdf alone
 // -7.5 %, config 2 -1.0 %, rlSkin -1.3 %, reflect triple 0; the rlSss / NDProfile and rlDisney kernels LOSE 3-5 % (their
 // per-workgroup staging of the libm tables is paid per tile then) and keep the cap.
+#ifndef RLS_CAP_MULT
+#define RLS_CAP_MULT 16          // experiment switch: 1 = every kernel under the context's cap
+#endif
 inline dim3 grid_for(const rls_context *ctx, int64_t n, int points_per_block = kBlock, int cap_mult = 1)
 {
     // called right before every launch: make the context's device current for this host thread

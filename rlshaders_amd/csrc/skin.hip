@@ -143,9 +143,9 @@ rls_status launch_kernel(rls_context *ctx, const SkinIO &io, const char *name)
                           c.specular_weight.v && c.specular_roughness.v && c.specular_ior.v && c.sheen_color.r &&
                           c.sheen_weight.v && c.sheen_roughness.v && c.sheen_ior.v;
     if (streamed)
-        hipLaunchKernelGGL((skin_kernel<RLS_FAST, true>), rlsh::grid_for(ctx, io.n, rlsh::kBlock, 16), dim3(rlsh::kBlock), 0, ctx->stream, io);
+        hipLaunchKernelGGL((skin_kernel<RLS_FAST, true>), rlsh::grid_for(ctx, io.n, rlsh::kBlock, RLS_CAP_MULT), dim3(rlsh::kBlock), 0, ctx->stream, io);
     else
-        hipLaunchKernelGGL((skin_kernel<RLS_FAST, false>), rlsh::grid_for(ctx, io.n, rlsh::kBlock, 16), dim3(rlsh::kBlock), 0, ctx->stream, io);
+        hipLaunchKernelGGL((skin_kernel<RLS_FAST, false>), rlsh::grid_for(ctx, io.n, rlsh::kBlock, RLS_CAP_MULT), dim3(rlsh::kBlock), 0, ctx->stream, io);
     return rlsh::check_launch(name);
 }
 

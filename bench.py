@@ -222,19 +222,20 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
         pipe = R.Pipeline(ctx, cp, 19, 12, depth)
 
         def chunk(slot, _first, count, i, o):
+            # raw device addresses of the chunk's planes straight into the C ABI (no tensor object per plane and chunk: on a
+            # slow host core 31 of them per chunk cost more than the chunk's copies)
             c = R._capi.GgxClosure()
-            c.wo = R._capi.CVec3(i[0].data_ptr(), i[1].data_ptr(), i[2].data_ptr())
-            c.N = R._capi.CVec3(i[3].data_ptr(), i[4].data_ptr(), i[5].data_ptr())
-            c.T = R._capi.CVec3(i[6].data_ptr(), i[7].data_ptr(), i[8].data_ptr())
-            c.KsColor = R._capi.ParamRgb(i[9].data_ptr(), i[10].data_ptr(), i[11].data_ptr(), 0.0, 0.0, 0.0)
-            c.specularRoughness = R._capi.Param(i[12].data_ptr(), 0.0)
-            c.ior = R._capi.Param(i[13].data_ptr(), 0.0)
-            c.anisotropic = R._capi.Param(i[14].data_ptr(), 0.0)
-            P = lambda t: t.data_ptr()
+            c.wo = R._capi.CVec3(i.ptr(0), i.ptr(1), i.ptr(2))
+            c.N = R._capi.CVec3(i.ptr(3), i.ptr(4), i.ptr(5))
+            c.T = R._capi.CVec3(i.ptr(6), i.ptr(7), i.ptr(8))
+            c.KsColor = R._capi.ParamRgb(i.ptr(9), i.ptr(10), i.ptr(11), 0.0, 0.0, 0.0)
+            c.specularRoughness = R._capi.Param(i.ptr(12), 0.0)
+            c.ior = R._capi.Param(i.ptr(13), 0.0)
+            c.anisotropic = R._capi.Param(i.ptr(14), 0.0)
             R._capi.check(slot.lib.rls_ggx_reflect_refract(
-                slot.handle, count, R.closures.C.byref(c), P(i[15]), P(i[16]), P(i[17]), P(i[18]),
-                R._capi.Vec3(P(o[0]), P(o[1]), P(o[2])), R._capi.Rgb(P(o[3]), P(o[4]), P(o[5])), P(o[6]), P(o[7]),
-                R._capi.Vec3(P(o[8]), P(o[9]), P(o[10])), P(o[11])))
+                slot.handle, count, R.closures.C.byref(c), i.ptr(15), i.ptr(16), i.ptr(17), i.ptr(18),
+                R._capi.Vec3(o.ptr(0), o.ptr(1), o.ptr(2)), R._capi.Rgb(o.ptr(3), o.ptr(4), o.ptr(5)), o.ptr(6), o.ptr(7),
+                R._capi.Vec3(o.ptr(8), o.ptr(9), o.ptr(10)), o.ptr(11)))
 
         wl = Workload(name, 2, (19 + 12) * 4, lambda: pipe.run(n, hin, hout, chunk), "ggx_kernel<5, {m}, true>",
                       f"rlGgx reflect+refract, batch resident in page-locked HOST memory: chunks of {cp} points uploaded, "

@@ -186,6 +186,11 @@ class ChunkPlanes:
     def __len__(self):
         return len(self._live)
 
+    def ptr(self, k: int) -> Optional[int]:
+        """device address of plane k (None where the host plane is not streamed): for callers that talk to the C ABI
+        directly and do not want a tensor object per plane and chunk"""
+        return int(self._ptrs[k]) if self._live[k] else None
+
     def __getitem__(self, k: int):
         if not self._live[k]:
             return None

@@ -220,6 +220,17 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
             h.copy_(d)
         cp = min(n, 1 << chunk_log2)
         pipe = R.Pipeline(ctx, cp, 19, 12, depth)
+        # Freed device memory is cleared by the driver in the background -- on the copy engines: for a few seconds after a
+        # multi-GB arena has been released (the previous workload of this process) the two copy directions no longer run at
+        # once (tools/diag_copy_rates.py: both-directions rate 96 -> 57-64 GB/s right after a free, back after an idle second
+        # or two).  Wait for that to pass before measuring a PCIe-bound pipeline: poll until both directions overlap again.
+        settle = []
+        for _ in range(40):
+            r = pipe.copy_rates(1 << 27)
+            settle.append(round(r["both"], 1))
+            if r["both"] >= 1.4 * max(r["h2d"], r["d2h"]):
+                break
+            time.sleep(0.25)
 
         def chunk(slot, _first, count, i, o):
             # raw device addresses of the chunk's planes straight into the C ABI (no tensor object per plane and chunk: on a
@@ -241,7 +252,7 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
                       f"rlGgx reflect+refract, batch resident in page-locked HOST memory: chunks of {cp} points uploaded, "
                       f"sampled and downloaded on {depth} streams (rls_pipeline_*); PCIe-bound, 76 B up + 48 B down per point",
                       bound="pcie", launches_per_step=(n + cp - 1) // cp)
-        wl.pipe, wl.host = pipe, (hin, hout)
+        wl.pipe, wl.host, wl.settle = pipe, (hin, hout), settle
     elif name == "ggx_reflect_refract_uniform":
         # config 2's kernel as a stub without linked textures runs it: every node parameter one value for the batch
         # (Arnold parameters are constants unless textured), geometry and random numbers streamed
@@ -615,6 +626,7 @@ def roofline_record(wl, n: int, kernel_ms: float, math: str) -> dict:
                              "directions at once",
                 "h2d_gb_per_s": round(up / t / 1e9, 2), "d2h_gb_per_s": round(down / t / 1e9, 2),
                 "box_copy_rates_gb_per_s": {k: round(v, 2) for k, v in rates.items()},
+                "both_directions_rate_while_settling": getattr(wl, "settle", None),
                 "pass_ms": round(kernel_ms, 4), "chunks_per_pass": launches, "kernel": wl.kernel.format(m=1 if math == "fast" else 0),
                 "kernel_ms": round(launch_ms, 5), "launches_per_step": launches,
                 "algorithmic_bytes_per_point": wl.bytes_per_point, "algorithmic_bytes_per_launch": int(bytes_per_launch),

@@ -60,7 +60,7 @@ S_PARAM0 = 32
 
 WORKLOADS = ["ggx_reflect_refract", "ggx_reflect_refract_uniform", "ggx_reflect", "ggx_eval", "ggx_pdf", "ggx_direct",
              "ggx_shade", "disney_direct", "disney_shade", "disney_integrate", "disney_stream", "disney_triple_diffuse",
-             "disney_triple_glossy", "sss_probe", "nd_sample", "sss_scatter", "skin", "skin_integrate",
+             "disney_triple_glossy", "sss_probe", "sss_probe_uniform", "nd_sample", "sss_scatter", "skin", "skin_integrate",
              "ggx_reflect_refract_host"]
 
 # BASELINE.json configs -> (workload, log2 of the points ONE GPU holds): config 4 is 2^28 points over 8 GPUs, config 5 2^30
@@ -154,7 +154,7 @@ class Workload:
 PLANES = {"ggx_reflect_refract": 19 + 12, "ggx_reflect_refract_host": 19, "ggx_reflect_refract_uniform": 13 + 12, "ggx_reflect": 17 + 8,
           "ggx_eval": 17 + 8 + 3, "ggx_pdf": 17 + 8 + 1, "disney_triple_diffuse": 24 + 7, "disney_triple_glossy": 24 + 7,
           "nd_sample": 9 + 7 + 5, "disney_integrate": 22 + 8, "disney_stream": 22 + 8,
-          "sss_probe": 17 + 12,
+          "sss_probe": 17 + 12, "sss_probe_uniform": 11 + 12,
           "sss_scatter": 15 + 3, "skin": 35 + 24, "skin_integrate": 29 + 3 + 15, "ggx_direct": 15 + 3 + 6 + 6,
           "disney_direct": 22 + 3 + 6, "ggx_shade": 15 + 3 + 6 + 4 + 18, "disney_shade": 22 + 3 + 15}     # (the generator's wo planes included where the closure ignores them)
 
@@ -364,23 +364,31 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
                           f"rlDisney both lobes x 64 spp, streamed mode in chunks of {cp} points (SURVEY 8d config 3, "
                           "mode S: 88 B in + 32 B sums + 128 x 28 B samples per point; runs at the speed of its arithmetic)",
                           launches_per_step=(n + cp - 1) // cp, config=3)
-    elif name == "sss_probe":
-        s = R.SssSampler(ctx, N, T, albedo=u3(S_KS), dist=u3(S_PARAM0, 0.1, 2.1))
+    elif name in ("sss_probe", "sss_probe_uniform"):
+        uniform = name.endswith("uniform")
+        # _uniform: scatter distance and albedo one value for the batch, as a node without linked textures has them
+        s = R.SssSampler(ctx, N, T, albedo=(0.8, 0.5, 0.4) if uniform else u3(S_KS),
+                         dist=(1.0, 0.6, 0.35) if uniform else u3(S_PARAM0, 0.1, 2.1))
         xi = [u(S_XI0 + j) for j in range(2)]
         out = {"r": A.plane(), "origin": A.planes(3), "dir": A.planes(3), "maxdist": A.plane(),
                "pdf": A.plane(), "profile": A.planes(3)}
         # SURVEY 8(d) config 4 counts 14 f in (dist3 albedo3 N3 T3 xi2) + 12 f out = 104 B; the reference computes `s` from the
         # albedo and never uses it (src/rlSss.cpp:22-23), so the verb needs -- and the kernel moves -- 11 f in: 92 B
-        wl = Workload(name, 1, (11 + 12) * 4, lambda: s.getProbeRay(xi[0], xi[1], out=out),
-                      "sss_kernel<3, {m}>", "rlSss ND probe ray + pdf + profile (SURVEY 8d config 4)",
-                      survey_bytes=(14 + 12) * 4, config=4)
+        if uniform:
+            wl = Workload(name, 1, (8 + 12) * 4, lambda: s.getProbeRay(xi[0], xi[1], out=out), "sss_kernel<3, true, {m}>",
+                          "rlSss ND probe ray + pdf + profile, uniform scatter distance (1, 0.6, 0.35): N3 T3 xi2 in, 12 f out; "
+                          "setDistance once per thread")
+        else:
+            wl = Workload(name, 1, (11 + 12) * 4, lambda: s.getProbeRay(xi[0], xi[1], out=out),
+                          "sss_kernel<3, false, {m}>", "rlSss ND probe ray + pdf + profile (SURVEY 8d config 4)",
+                          survey_bytes=(14 + 12) * 4, config=4)
     elif name == "nd_sample":
         # NDProfile alone: setDistance + getRadius + getPdf + evalProfile (src/rlSss.cpp:20-106); SURVEY 8(d) "profile-only":
         # 8 f in (dist3 albedo3 multiplier xi) + 5 f out = 52 B, of which the arithmetic needs dist3 xi: 4 f in
         p = R.NDProfile(ctx, n, u3(S_PARAM0, 0.1, 2.1), albedo=u3(S_KS))
         rx = u(S_XI0)
         out = (A.plane(), A.plane(), A.planes(3))
-        wl = Workload(name, 1, (4 + 5) * 4, lambda: p.sample(rx, out=out), "sss_kernel<0, {m}>",
+        wl = Workload(name, 1, (4 + 5) * 4, lambda: p.sample(rx, out=out), "sss_kernel<0, false, {m}>",
                       "rlSss NDProfile alone: setDistance + getRadius + getPdf + evalProfile (SURVEY 8d config 4, profile-only)",
                       survey_bytes=(8 + 5) * 4)
     elif name == "sss_scatter":
@@ -495,8 +503,12 @@ def _cpu_leg(workload: str, n: int, threads: int):
         s = O.Sss(n, u3(S_PARAM0, 0.1, 2.1), u3(S_KS), nthreads=threads)
         x = cases.xi(SEED, n, 1)
         return (lambda: s.nd_sample(x[0])), 1, "orc_batch_nd_sample_pdf_profile"
-    if workload in ("sss_probe", "sss_scatter"):
+    if workload in ("sss_probe", "sss_probe_uniform", "sss_scatter"):
         _, N, T = cases.frame(SEED, n)
+        if workload == "sss_probe_uniform":
+            s = O.Sss(n, (1.0, 0.6, 0.35), (0.8, 0.5, 0.4), N=N, T=T, nthreads=threads)
+            x = cases.xi(SEED, n, 2)
+            return (lambda: s.probe(x[0], x[1])), 1, "orc_batch_sss_probe"
         if workload == "sss_probe":
             s = O.Sss(n, u3(S_PARAM0, 0.1, 2.1), u3(S_KS), N=N, T=T, nthreads=threads)
             x = cases.xi(SEED, n, 2)

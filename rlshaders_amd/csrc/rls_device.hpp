@@ -1095,6 +1095,32 @@ RLS_DEV NdProfile nd_make(float dx, float dy, float dz)
     return p;
 }
 
+// A value every lane of the wavefront holds (computed from kernel arguments only) moved to a scalar register: it costs no
+// vector register across the tile loop and the branches on it are scalar branches
+#ifdef RLS_NO_WAVE_UNIFORM   // experiment switch: keep the values in vector registers
+RLS_DEV float wave_uniform(float x) { return x; }
+RLS_DEV int wave_uniform(int x) { return x; }
+#else
+RLS_DEV float wave_uniform(float x) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(x))); }
+RLS_DEV int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+#endif
+RLS_DEV NdProfile nd_wave_uniform(NdProfile p)
+{
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        p.d[i] = wave_uniform(p.d[i]); p.c1[i] = wave_uniform(p.c1[i]); p.c2[i] = wave_uniform(p.c2[i]);
+#if !RLS_FAST
+        p.dm[i] = wave_uniform(p.dm[i]); p.ydm[i] = wave_uniform(p.ydm[i]);
+        p.cw[i] = wave_uniform(p.cw[i]); p.ycw[i] = wave_uniform(p.ycw[i]);
+#endif
+    }
+    p.maxR = wave_uniform(p.maxR);
+#if !RLS_FAST
+    p.window = wave_uniform(p.window);
+#endif
+    return p;
+}
+
 // RLS_ND_MERGE_RADIUS: experiment switch (one division and one logf of selected operands for getRadius's two arms).
 // Measured twice, rounds 2 and 3 (profiles/r03_nd_recip.txt): the rlSss probe 1.576 -> 1.643 ms, rlSkin 4.12 -> 4.17 --
 // slower, although it executes fewer instructions; integrateScatter -0.6 %.  Off.

@@ -34,16 +34,27 @@ __device__ __forceinline__ NdProfile load_profile(const rls_sss_closure &c, I i)
     return nd_make(dx, dy, dz);
 }
 
-template <int OP, int FAST_MATH = RLS_FAST>
+// UNIFORM: the scatter distance and its multiplier are one value for the batch (an Arnold parameter is a constant unless a
+// texture is linked to it): setDistance -- three divisions, six expf, with all of getPdf's reciprocals -- runs once per
+// thread ahead of the tile loop and its results stay in scalar registers, the same values a per-point evaluation gives
+__device__ __forceinline__ NdProfile uniform_profile(const rls_sss_closure &c)
+{
+    const float m = c.sss_dist_multiplier.u;
+    return nd_wave_uniform(nd_make<!RLS_FAST>(c.sss_scatter_dist[0].u * m, c.sss_scatter_dist[1].u * m, c.sss_scatter_dist[2].u * m));
+}
+
+template <int OP, bool UNIFORM, int FAST_MATH = RLS_FAST>
 __global__ __launch_bounds__(rlsh::kBlock) void sss_kernel(SssIO a0)
 {
     stage_libm_tables();   // expf / logf tables -> LDS (EXACT mode)
+    NdProfile pu = {};
+    if (UNIFORM) pu = uniform_profile(a0.c);
     const TileRange tiles = tile_range(a0.n);
     for (int64_t base = tiles.first; base < tiles.end; base += tiles.step) {
         const Idx i = make_idx(base);
         if (i.full() >= a0.n) continue;
         const SssIO a = reload_args(a0);       // plane pointers re-read per tile (rls_internal.hpp, reload_args)
-        NdProfile p = load_profile(a.c, i);
+        NdProfile p = UNIFORM ? pu : load_profile(a.c, i);
         if (OP == OP_ND) {
             float r = nd_radius(p, ldg(a.rx, i));
             float pdf, R, G, B;
@@ -120,7 +131,14 @@ rls_status check_closure(const rls_sss_closure *c, bool need_frame)
 template <int OP>
 rls_status launch_kernel(rls_context *ctx, const SssIO &io, const char *name)
 {
-    hipLaunchKernelGGL(sss_kernel<OP>, rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
+    const rls_sss_closure &c = io.c;
+    const bool uniform = !c.sss_dist_multiplier.v && !c.sss_scatter_dist[0].v && !c.sss_scatter_dist[1].v && !c.sss_scatter_dist[2].v;
+    // evalProfile alone uses nothing setDistance computes but maxR: no uniform specialisation of it
+    constexpr bool kHoists = OP != OP_ND_EVAL;
+    if (uniform && kHoists)
+        hipLaunchKernelGGL((sss_kernel<OP, kHoists>), rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
+    else
+        hipLaunchKernelGGL((sss_kernel<OP, false>), rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
     return rlsh::check_launch(name);
 }
 

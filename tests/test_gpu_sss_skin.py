@@ -220,3 +220,54 @@ def test_nd_profile_across_the_reciprocal_window(gpu, oracle):
         a, b = host(gp[name]), rp[name]
         same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
         assert same.all(), (name, int((~same).sum()))
+
+
+UNIFORM_DISTANCES = [(1.0, 0.6, 0.35), (1.0, 0.5, 0.25), (0.0, 0.0, 0.0), (1e-5, 1e-5, 1e-5), (1.0, 1e-5, 0.5),
+                     (2.0 ** -13, 1.0, 3.0), (float(np.nextafter(np.float32(2.0 ** -13), np.float32(0))), 1.0, 3.0),
+                     (2.0 ** 14, 1.0, 0.01), (float(np.nextafter(np.float32(2.0 ** 14), np.float32(1e9))), 5.0, 7.0),
+                     (1e-4, 2e-4, 1e-3), (1e7, 1e-7, 1.0), (float("inf"), 1.0, 1.0), (float("nan"), 1.0, 1.0), (37.5, 0.02, 911.0)]
+
+
+@pytest.mark.parametrize("multiplier", [None, 1.7])
+def test_uniform_scatter_distance_is_hoisted_and_bit_identical(gpu, oracle, multiplier):
+    """With the scatter distance (and its multiplier) one value for the batch the kernels run setDistance once per thread ahead of
+    the tile loop and keep NDProfile in scalar registers (sss.hip, uniform_profile) -- the same values as the per-point
+    evaluation: radius, pdf, profile, probe ray and MIS pdf equal the oracle's AND the streamed kernel's (the same distances as
+    per-point planes) bit for bit, for distances inside, on the borders of and outside the reciprocal window, degenerate ones
+    included."""
+    n = 1 << 14
+    _, N, T = cases.frame(11, n)
+    x = np.stack([oracle.gen_uniform(11, 0, n, oracle.S_XI0 + j) for j in range(2)])
+    x[0, ::5] = np.float32(0.0)
+    x[0, 1::5] = np.nextafter(np.float32(1.0), np.float32(0.0))
+    disp = (cases.xi(cases.SEED_EDGE, n, 3) - 0.5).astype(np.float32)
+    sN, _, _ = cases.frame(cases.SEED_EDGE, n)
+    albedo = (0.8, 0.5, 0.4)
+
+    def same(a, b, what):
+        a, b = np.asarray(a), np.asarray(b)
+        ok = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+        assert ok.all(), (what, int((~ok).sum()))
+
+    for dist in UNIFORM_DISTANCES:
+        planes = np.repeat(np.asarray(dist, np.float32)[:, None], n, axis=1)
+        mult_plane = None if multiplier is None else np.full(n, multiplier, np.float32)
+        o = oracle.Sss(n, dist, albedo, multiplier=multiplier, N=N, T=T, nthreads=4)
+        kw = {} if multiplier is None else dict(multiplier=multiplier)
+        kws = {} if multiplier is None else dict(multiplier=dev(mult_plane))
+        pu = R.NDProfile(gpu, n, dist, albedo, **kw)
+        ps = R.NDProfile(gpu, n, dev(planes), albedo, **kws)
+        ref = o.nd_sample(x[0])
+        gu, gs = [host(t) for t in pu.sample(dev(x[0]))], [host(t) for t in ps.sample(dev(x[0]))]
+        for name, a, b, c in zip(("r", "pdf", "profile"), gu, gs, ref):
+            same(a, c, (dist, name, "uniform vs oracle"))
+            same(a, b, (dist, name, "uniform vs streamed"))
+        r = np.abs(ref[0]) + np.float32(0.01)
+        same(host(pu.getPdf(dev(r))), o.nd_pdf(r), (dist, "getPdf"))
+        su = R.SssSampler(gpu, dev(N), dev(T), albedo, dist, **kw)
+        ss = R.SssSampler(gpu, dev(N), dev(T), albedo, dev(planes), **kws)
+        gu, gs, rp = su.getProbeRay(dev(x[0]), dev(x[1])), ss.getProbeRay(dev(x[0]), dev(x[1])), o.probe(x[0], x[1])
+        for name in ("r", "origin", "dir", "maxdist", "pdf", "profile"):
+            same(host(gu[name]), rp[name], (dist, name, "probe, uniform vs oracle"))
+            same(host(gu[name]), host(gs[name]), (dist, name, "probe, uniform vs streamed"))
+        same(host(su.misPdf(dev(disp), dev(sN))), o.mis_pdf(disp, sN, False), (dist, "mis pdf"))

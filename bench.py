@@ -60,8 +60,18 @@ S_PARAM0 = 32
 
 WORKLOADS = ["ggx_reflect_refract", "ggx_reflect_refract_uniform", "ggx_reflect", "ggx_eval", "ggx_pdf", "ggx_direct",
              "ggx_shade", "disney_direct", "disney_shade", "disney_integrate", "disney_stream", "disney_triple_diffuse",
-             "disney_triple_glossy", "sss_probe", "sss_probe_uniform", "nd_sample", "sss_scatter", "skin", "skin_integrate",
+             "disney_triple_glossy", "disney_triple_glossy_uniform", "sss_probe", "sss_probe_uniform", "nd_sample", "sss_scatter", "skin", "skin_uniform", "skin_integrate",
              "ggx_reflect_refract_host"]
+
+# every lobe of rlDisney switched on: the parameters of disney_triple_glossy_uniform, one value each for the whole batch
+DISNEY_UNIFORM = dict(base_color=(0.850000024, 0.704699695, 0.205699995), subsurface=0.2, metallic=0.3, specular=0.5, specular_tint=0.25,
+                      roughness=0.4, anisotropic=0.4, sheen=0.5, sheen_tint=0.5, clearcoat=0.6, clearcoat_gloss=0.7)
+
+# rlSkin's node defaults (src/rlSkin.cpp:109-128) with the sheen layer switched on and a skin-like scatter distance: the
+# parameters of the *_uniform skin workload, one value each for the whole batch
+SKIN_UNIFORM = dict(sss_color=(1.0, 0.842350006, 0.5), sss_weight=1.0, sss_dist_multiplier=1.0, sss_scatter_dist=(1.0, 0.6, 0.35),
+                    specular_color=(1.0, 1.0, 1.0), specular_weight=0.6, specular_roughness=0.5, specular_ior=1.44,
+                    sheen_color=(1.0, 1.0, 1.0), sheen_weight=0.3, sheen_roughness=0.35, sheen_ior=1.44)
 
 # BASELINE.json configs -> (workload, log2 of the points ONE GPU holds): config 4 is 2^28 points over 8 GPUs, config 5 2^30
 CONFIG_PRESETS = {2: ("ggx_reflect_refract", 26), 3: ("disney_integrate", 26), 4: ("sss_probe", 25), 5: ("skin", 27)}
@@ -152,10 +162,10 @@ class Workload:
 
 # planes (n floats each) a workload reads and writes: sizes its arena
 PLANES = {"ggx_reflect_refract": 19 + 12, "ggx_reflect_refract_host": 19, "ggx_reflect_refract_uniform": 13 + 12, "ggx_reflect": 17 + 8,
-          "ggx_eval": 17 + 8 + 3, "ggx_pdf": 17 + 8 + 1, "disney_triple_diffuse": 24 + 7, "disney_triple_glossy": 24 + 7,
+          "ggx_eval": 17 + 8 + 3, "ggx_pdf": 17 + 8 + 1, "disney_triple_diffuse": 24 + 7, "disney_triple_glossy": 24 + 7, "disney_triple_glossy_uniform": 11 + 7,
           "nd_sample": 9 + 7 + 5, "disney_integrate": 22 + 8, "disney_stream": 22 + 8,
           "sss_probe": 17 + 12, "sss_probe_uniform": 11 + 12,
-          "sss_scatter": 15 + 3, "skin": 35 + 24, "skin_integrate": 29 + 3 + 15, "ggx_direct": 15 + 3 + 6 + 6,
+          "sss_scatter": 15 + 3, "skin": 35 + 24, "skin_uniform": 15 + 24, "skin_integrate": 29 + 3 + 15, "ggx_direct": 15 + 3 + 6 + 6,
           "disney_direct": 22 + 3 + 6, "ggx_shade": 15 + 3 + 6 + 4 + 18, "disney_shade": 22 + 3 + 15}     # (the generator's wo planes included where the closure ignores them)
 
 
@@ -180,13 +190,13 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
             out = (A.planes(3), A.planes(3), A.plane(), A.plane(), A.planes(3), A.plane())
             # in: wo3 N3 T3 Ks3 rough ior aniso xi4 = 19 f; out: wi3 f3 pdf F wt3 weight = 12 f
             wl = Workload(name, 2, (19 + 12) * 4, lambda: g.reflectRefract(xi[0], xi[1], xi[2], xi[3], out=out),
-                          "ggx_kernel<5, {m}, true>",
+                          "ggx_kernel<5, {m}, 1>",
                           "rlGgx reflect+refract VNDF sampling, mixed params (SURVEY 8d config 2)", config=2)
         else:
             out = (A.planes(3), A.planes(3), A.plane(), A.plane())
             if name == "ggx_reflect":
                 wl = Workload(name, 1, (17 + 8) * 4, lambda: g.sampleEvalPdf(xi[0], xi[1], out=out),
-                              "ggx_kernel<3, {m}, true>", "rlGgx reflect triple, mixed params")
+                              "ggx_kernel<3, {m}, 1>", "rlGgx reflect triple, mixed params")
             else:
                 # the verbs alone, as Arnold's integrators call them (src/rlGgx.h:110-127), on the directions evalSample drew
                 g.sampleEvalPdf(xi[0], xi[1], out=out)
@@ -194,12 +204,12 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
                 if name == "ggx_eval":
                     f = A.planes(3)
                     # evalBrdf reads wo3 N3 T3 Ks3 rough ior aniso wi3 = 18 f, writes f3
-                    wl = Workload(name, 1, (18 + 3) * 4, lambda: g.evalBrdf(wi, out=f), "ggx_kernel<1, {m}, true>",
+                    wl = Workload(name, 1, (18 + 3) * 4, lambda: g.evalBrdf(wi, out=f), "ggx_kernel<1, {m}, 1>",
                                   "rlGgx evalBrdf alone on sampled directions, mixed params (src/rlGgx.h:110-119)")
                 else:
                     pdf = A.plane()
                     # evalPdf needs no colour and no ior: wo3 N3 T3 rough aniso wi3 = 14 f, writes pdf
-                    wl = Workload(name, 1, (14 + 1) * 4, lambda: g.evalPdf(wi, out=pdf), "ggx_kernel<2, {m}, true>",
+                    wl = Workload(name, 1, (14 + 1) * 4, lambda: g.evalPdf(wi, out=pdf), "ggx_kernel<2, {m}, 1>",
                                   "rlGgx evalPdf alone on sampled directions, mixed params (src/rlGgx.h:121-127)",
                                   survey_bytes=(18 + 1) * 4)
     elif name == "ggx_reflect_refract_host":
@@ -248,7 +258,7 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
                 R._capi.Vec3(o.ptr(0), o.ptr(1), o.ptr(2)), R._capi.Rgb(o.ptr(3), o.ptr(4), o.ptr(5)), o.ptr(6), o.ptr(7),
                 R._capi.Vec3(o.ptr(8), o.ptr(9), o.ptr(10)), o.ptr(11)))
 
-        wl = Workload(name, 2, (19 + 12) * 4, lambda: pipe.run(n, hin, hout, chunk), "ggx_kernel<5, {m}, true>",
+        wl = Workload(name, 2, (19 + 12) * 4, lambda: pipe.run(n, hin, hout, chunk), "ggx_kernel<5, {m}, 1>",
                       f"rlGgx reflect+refract, batch resident in page-locked HOST memory: chunks of {cp} points uploaded, "
                       f"sampled and downloaded on {depth} streams (rls_pipeline_*); PCIe-bound, 76 B up + 48 B down per point",
                       bound="pcie", launches_per_step=(n + cp - 1) // cp)
@@ -256,11 +266,16 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
     elif name == "ggx_reflect_refract_uniform":
         # config 2's kernel as a stub without linked textures runs it: every node parameter one value for the batch
         # (Arnold parameters are constants unless textured), geometry and random numbers streamed
-        g = R.GgxSampler(ctx, wo, N, T, specColor=(0.9, 0.8, 0.7), ior=1.5, roughness=0.35, anisotropic=0.25)
+        params = dict(specColor=(0.9, 0.8, 0.7), ior=1.5, roughness=0.35, anisotropic=0.25)
+        if os.environ.get("RLS_BENCH_UNIFORM_AS_PLANES") == "1":      # experiment switch, as in skin_uniform
+            import torch
+            const = lambda v: torch.full((n,), float(v), dtype=torch.float32, device="cuda")
+            params = {k: (torch.stack([const(x) for x in v]) if isinstance(v, tuple) else const(v)) for k, v in params.items()}
+        g = R.GgxSampler(ctx, wo, N, T, **params)
         xi = [u(S_XI0 + j) for j in range(4)]
         out = (A.planes(3), A.planes(3), A.plane(), A.plane(), A.planes(3), A.plane())
         wl = Workload(name, 2, (13 + 12) * 4, lambda: g.reflectRefract(xi[0], xi[1], xi[2], xi[3], out=out),
-                      "ggx_kernel<5, {m}, false>",
+                      "ggx_kernel<5, {m}, 2>",
                       "rlGgx reflect+refract VNDF sampling, uniform node parameters (KsColor, roughness 0.35, ior 1.5, "
                       "anisotropic 0.25): wo3 N3 T3 xi4 in, 12 f out")
     elif name == "ggx_direct":
@@ -323,6 +338,19 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
                       "disney_direct_kernel<1, {m}>",
                       "rlDisney light loop: both lobes under two spherical lights, per light 16 light + 2 x 16 BSDF samples "
                       "per point, power-heuristic MIS (src/rlDisney.cpp:695-705; VALU-bound)", bound="valu")
+    elif name == "disney_triple_glossy_uniform":
+        params = dict(DISNEY_UNIFORM)
+        if os.environ.get("RLS_BENCH_UNIFORM_AS_PLANES") == "1":      # experiment switch, as in skin_uniform
+            import torch
+            const = lambda v: torch.full((n,), float(v), dtype=torch.float32, device="cuda")
+            params = {k: (torch.stack([const(x) for x in v]) if isinstance(v, tuple) else const(v)) for k, v in params.items()}
+        d = R.DisneySampler(ctx, wo, N, T, **params)
+        d.setSampleType(R.RLS_RAY_GLOSSY)
+        xi = [u(S_XI0 + j) for j in range(2)]
+        out = (A.planes(3), A.planes(3), A.plane())
+        wl = Workload(name, 1, (11 + 7) * 4, lambda: d.sampleEvalPdf(xi[0], xi[1], out=out), "disney_kernel<3, false, {m}, 2>",
+                      "rlDisney one-sample triple, glossy (GTR2 + clearcoat + sheen) lobe, uniform node parameters (every lobe on): "
+                      "wo3 N3 T3 xi2 in, wi3 f3 pdf out; parameter-only arithmetic once per thread")
     elif name in ("disney_triple_diffuse", "disney_triple_glossy"):
         # the static triple of one lobe, one sample per point (src/rlDisney.cpp:109-152): evalSample -> evalBrdf -> evalPdf
         base = u3(S_KS)
@@ -336,7 +364,7 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
         # only subsurface, metallic and roughness of the ten scalars (src/rlDisney.cpp:199-236, 359-365, 515-518): 17 f in = 96 B;
         # the glossy lobe everything but subsurface: 23 f in = 120 B -- what the kernels move (profiles/r03_disney_triple_*_traffic)
         wl = Workload(name, 1, ((17 if lobe == 0 else 23) + 7) * 4, lambda: d.sampleEvalPdf(xi[0], xi[1], out=out),
-                      "disney_kernel<3, %s, {m}, true>" % ("true" if lobe == 0 else "false"),
+                      "disney_kernel<3, %s, {m}, 1>" % ("true" if lobe == 0 else "false"),
                       f"rlDisney one-sample triple, {'diffuse' if lobe == 0 else 'glossy (GTR2 + clearcoat + sheen)'} lobe, "
                       "mixed params: wo3 N3 T3 base3 + the lobe's scalars + xi2 in, wi3 f3 pdf out (src/rlDisney.cpp:109-152)",
                       survey_bytes=(24 + 7) * 4)
@@ -367,8 +395,12 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
     elif name in ("sss_probe", "sss_probe_uniform"):
         uniform = name.endswith("uniform")
         # _uniform: scatter distance and albedo one value for the batch, as a node without linked textures has them
+        dist = (1.0, 0.6, 0.35)
+        if uniform and os.environ.get("RLS_BENCH_UNIFORM_AS_PLANES") == "1":      # experiment switch, as in skin_uniform
+            import torch
+            dist = torch.stack([torch.full((n,), v, dtype=torch.float32, device="cuda") for v in dist])
         s = R.SssSampler(ctx, N, T, albedo=(0.8, 0.5, 0.4) if uniform else u3(S_KS),
-                         dist=(1.0, 0.6, 0.35) if uniform else u3(S_PARAM0, 0.1, 2.1))
+                         dist=dist if uniform else u3(S_PARAM0, 0.1, 2.1))
         xi = [u(S_XI0 + j) for j in range(2)]
         out = {"r": A.plane(), "origin": A.planes(3), "dir": A.planes(3), "maxdist": A.plane(),
                "pdf": A.plane(), "profile": A.planes(3)}
@@ -400,6 +432,21 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
                       "sss_scatter_kernel<1, {m}>",
                       "rlSss integrateScatter, 16 probe rays per point on an analytic sphere (SURVEY 8f rank 3; "
                       "VALU-bound)", bound="valu")
+    elif name == "skin_uniform":
+        params = dict(SKIN_UNIFORM)
+        if os.environ.get("RLS_BENCH_UNIFORM_AS_PLANES") == "1":
+            # experiment switch: the same values as per-point planes through the streamed kernel (what the hoisting is worth)
+            import torch
+            const = lambda v: torch.full((n,), float(v), dtype=torch.float32, device="cuda")
+            params = {k: (torch.stack([const(x) for x in v]) if isinstance(v, tuple) else const(v)) for k, v in params.items()}
+        sk = R.SkinShader(ctx, wo, N, T, **params)
+        xi = A.planes(6)
+        for j in range(6):
+            R.gen_uniform(ctx, SEED, first, n, S_XI0 + j, out=xi[j])
+        out = sk.alloc_out(arena=A)
+        wl = Workload(name, 3, (15 + 24) * 4, lambda: sk.sampleEvalPdf(xi, out=out), "skin_kernel<{m}, 2>",
+                      "rlSkin sheen GGX + specular GGX + SSS, uniform node parameters (node defaults, sheen 0.3, scatter distance "
+                      "(1, 0.6, 0.35)): wo3 N3 T3 xi6 in, 24 f out; parameter-only arithmetic once per thread")
     elif name in ("skin", "skin_integrate"):
         p = dict(sss_color=u3(S_PARAM0), sss_weight=u(S_PARAM0 + 3), sss_dist_multiplier=u(S_PARAM0 + 4, 0.5, 1.5),
                  sss_scatter_dist=u3(S_PARAM0 + 5, 0.1, 2.1),
@@ -429,7 +476,7 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
         # 35 f in + 24 f out = 236 B; sss_color enters no arithmetic of the three samples (the albedo of
         # NDProfile::setDistance, unused: src/rlSss.cpp:22-23), so 32 f in: 224 B
         wl = Workload(name, 3, (32 + 24) * 4, lambda: sk.sampleEvalPdf(xi, out=out),
-                      "skin_kernel<{m}, true>", "rlSkin sheen GGX + specular GGX + SSS (SURVEY 8d config 5)",
+                      "skin_kernel<{m}, 1>", "rlSkin sheen GGX + specular GGX + SSS (SURVEY 8d config 5)",
                       survey_bytes=(35 + 24) * 4, config=5)
     else:
         raise ValueError(name)
@@ -478,6 +525,11 @@ def _cpu_leg(workload: str, n: int, threads: int):
                                     env=(1.0, 0.9, 0.8))), 144, "orc_batch_ggx_shade"
         return (lambda: g.direct_lighting(P, lt, 4, SEED, Kd_color=kdc, Kd=kd, Kd_roughness=kdr, Ks=ks)), 48, \
             "orc_batch_ggx_direct_lighting"
+    if workload == "disney_triple_glossy_uniform":
+        wo, N, T = cases.frame(SEED, n)
+        d = O.Disney(wo, N, T, nthreads=threads, **DISNEY_UNIFORM)
+        x = cases.xi(SEED, n, 2)
+        return (lambda: d.sample_eval_pdf(0x10, x[0], x[1])), 1, "orc_batch_disney_sample_eval_pdf"
     if workload in ("disney_integrate", "disney_stream", "disney_direct", "disney_shade", "disney_triple_diffuse",
                     "disney_triple_glossy"):
         c = cases.disney_mixed(SEED, n)
@@ -516,6 +568,10 @@ def _cpu_leg(workload: str, n: int, threads: int):
         s = O.Sss(n, u3(S_PARAM0, 0.02, 0.3), u3(S_KS), N=N, T=T, nthreads=threads)
         scene = O.make_scene("sphere", sphere_radius=1.0, light_dir=(0.0, 0.6, 0.8), use_cavity_fade=True)
         return (lambda: O.integrate_scatter(s, N, scene, 4, SEED)), 16, "orc_batch_sss_integrate_scatter"
+    if workload == "skin_uniform":
+        wo, N, T = cases.frame(SEED, n)
+        x = cases.xi(SEED, n, 6)
+        return (lambda: O.skin(wo, N, T, SKIN_UNIFORM, x, nthreads=threads)), 3, "orc_batch_skin"
     if workload in ("skin", "skin_integrate"):
         wo, N, T = cases.frame(SEED, n)
         p = dict(sss_color=u3(S_PARAM0), sss_weight=u(S_PARAM0 + 3), sss_dist_multiplier=u(S_PARAM0 + 4, 0.5, 1.5),

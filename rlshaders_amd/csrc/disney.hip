@@ -21,6 +21,24 @@ using rlsh::DisneyIO;
 #endif
 enum { OP_SAMPLE = rlsh::DOP_SAMPLE, OP_EVAL = rlsh::DOP_EVAL, OP_PDF = rlsh::DOP_PDF, OP_FUSED = rlsh::DOP_FUSED };
 
+// MODE (checked on the host): STREAMED_ALL every parameter is a per-point plane; UNIFORM_ALL every one is a single value for
+// the batch (an Arnold parameter is a constant unless a texture is linked to it) and the parameter-only arithmetic -- the
+// constructor (tint, F0, sheen colour, aspect / alpha_x / alpha_y: src/rlDisney.cpp:155-192) and the clearcoat terms the
+// verbs recompute per call (logf(a2), clearcoat / (clearcoat + 1)) -- runs once per thread ahead of the tile loop, its results
+// kept in scalar registers; MIXED tests parameter by parameter in the loop
+enum { MIXED = 0, STREAMED_ALL = 1, UNIFORM_ALL = 2 };
+
+__device__ __forceinline__ Disney uniform_closure(const rls_disney_closure &c)
+{
+    const float s[10] = { c.subsurface.u, c.metallic.u, c.specular.u, c.specular_tint.u, c.roughness.u, c.anisotropic.u,
+                          c.sheen.u, c.sheen_tint.u, c.clearcoat.u, c.clearcoat_gloss.u };
+    const V3 zero = mk(0.0f, 0.0f, 0.0f);
+    Disney d = disney_make(zero, zero, zero, c.base_color.ur, c.base_color.ug, c.base_color.ub, s);
+    disney_prepare_material(d);
+    disney_wave_uniform(d);
+    return d;
+}
+
 template <bool STREAMED>
 __device__ __forceinline__ Disney load_closure(const rls_disney_closure &c, Idx i)
 {
@@ -41,18 +59,30 @@ __device__ __forceinline__ Disney load_closure(const rls_disney_closure &c, Idx 
     return disney_make(wo, N, T, br, bg, bb, s);
 }
 
-template <int OP, bool DIFFUSE, int FAST_MATH, bool STREAMED>
+template <int OP, bool DIFFUSE, int FAST_MATH, int MODE>
 __global__ __launch_bounds__(rlsh::kBlock) void disney_kernel(DisneyIO a0)
 {
     stage_libm_tables();   // powf / logf tables -> LDS (EXACT mode)
+    Disney ud = {};
+    if (MODE == UNIFORM_ALL) ud = uniform_closure(a0.c);
     const TileRange tiles = tile_range(a0.n);
     for (int64_t base = tiles.first; base < tiles.end; base += tiles.step) {
         const Idx i = make_idx(base);
         if (i.full() >= a0.n) continue;
         // plane pointers re-read from the kernarg segment where they are used (rls_internal.hpp, reload_args)
         const DisneyIO a = RLS_DISNEY_ARGS(a0);
-        Disney d = load_closure<STREAMED>(a.c, i);
-        disney_prepare(d);
+        Disney d;
+        if (MODE == UNIFORM_ALL) {
+            d = ud;
+            d.view = ld3(a.c.wo, i);
+            d.fr.N = ld3(a.c.N, i);
+            d.fr.U = ld3(a.c.T, i);
+            d.fr.V = cross(d.fr.N, d.fr.U);
+            disney_prepare_view(d);
+        } else {
+            d = load_closure<MODE == STREAMED_ALL>(a.c, i);
+            disney_prepare(d);
+        }
         V3 L;
         if (OP == OP_SAMPLE || OP == OP_FUSED) {
             float rx = ldg(a.rx, i), ry = ldg(a.ry, i);
@@ -94,13 +124,18 @@ rls_status launch_kernel(rls_context *ctx, int lobe, const DisneyIO &io, const c
     const bool streamed = c.base_color.r && c.subsurface.v && c.metallic.v && c.specular.v && c.specular_tint.v &&
                           c.roughness.v && c.anisotropic.v && c.sheen.v && c.sheen_tint.v && c.clearcoat.v &&
                           c.clearcoat_gloss.v;
+    const bool uniform = !c.base_color.r && !c.subsurface.v && !c.metallic.v && !c.specular.v && !c.specular_tint.v &&
+                         !c.roughness.v && !c.anisotropic.v && !c.sheen.v && !c.sheen_tint.v && !c.clearcoat.v &&
+                         !c.clearcoat_gloss.v;
     const dim3 block(rlsh::kBlock);
     if (lobe == RLS_RAY_DIFFUSE) {
-        if (streamed) hipLaunchKernelGGL((disney_kernel<OP, true, RLS_FAST, true>), grid, block, 0, ctx->stream, io);
-        else hipLaunchKernelGGL((disney_kernel<OP, true, RLS_FAST, false>), grid, block, 0, ctx->stream, io);
+        if (streamed) hipLaunchKernelGGL((disney_kernel<OP, true, RLS_FAST, STREAMED_ALL>), grid, block, 0, ctx->stream, io);
+        else if (uniform) hipLaunchKernelGGL((disney_kernel<OP, true, RLS_FAST, UNIFORM_ALL>), grid, block, 0, ctx->stream, io);
+        else hipLaunchKernelGGL((disney_kernel<OP, true, RLS_FAST, MIXED>), grid, block, 0, ctx->stream, io);
     } else {
-        if (streamed) hipLaunchKernelGGL((disney_kernel<OP, false, RLS_FAST, true>), grid, block, 0, ctx->stream, io);
-        else hipLaunchKernelGGL((disney_kernel<OP, false, RLS_FAST, false>), grid, block, 0, ctx->stream, io);
+        if (streamed) hipLaunchKernelGGL((disney_kernel<OP, false, RLS_FAST, STREAMED_ALL>), grid, block, 0, ctx->stream, io);
+        else if (uniform) hipLaunchKernelGGL((disney_kernel<OP, false, RLS_FAST, UNIFORM_ALL>), grid, block, 0, ctx->stream, io);
+        else hipLaunchKernelGGL((disney_kernel<OP, false, RLS_FAST, MIXED>), grid, block, 0, ctx->stream, io);
     }
     return rlsh::check_launch(name);
 }

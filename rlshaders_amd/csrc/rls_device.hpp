@@ -463,6 +463,16 @@ RLS_DEV void vndf_microfacet_pair(const VndfView &w1, const Frame &fr1, float rx
 #endif
 }
 
+// A value every lane of the wavefront holds (computed from kernel arguments only) moved to a scalar register: it costs no
+// vector register across the tile loop and the branches on it are scalar branches
+#ifdef RLS_NO_WAVE_UNIFORM   // experiment switch: keep the values in vector registers
+RLS_DEV float wave_uniform(float x) { return x; }
+RLS_DEV int wave_uniform(int x) { return x; }
+#else
+RLS_DEV float wave_uniform(float x) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(x))); }
+RLS_DEV int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+#endif
+
 // ---- rlGgx closure state, src/rlGgx.h:130-156 ---------------------------------------------------
 struct Ggx {
     Frame fr;
@@ -478,35 +488,54 @@ struct Ggx {
     float g1v;            // G1(mViewDir, m, n) where it is not zero, src/rlGgx.h:353-356
 };
 
+// The half of the constructor that depends on the node parameters only (src/rlGgx.h:130-156): a kernel whose parameters are
+// one value for the batch evaluates it once per thread (ggx_material + ggx_material_wave_uniform), every other kernel per
+// point through ggx_make() -- the same expressions either way.
+struct GgxMaterial {
+    float ksR, ksG, ksB;
+    float rough, ax, ay;
+    float out, rout;      // max(ior, 1e-4) and its reciprocal
+};
+
 // ISOTROPIC: the caller passes anisotropic = 0 (rlSkin's lobes, src/rlSkin.cpp:192,215): aspect = sqrtf(1 - 0 * 0.9) is
 // exactly 1, r^2 / 1 and r^2 * 1 are r^2 -- the square root, the division and the product are skipped, same bits
 template <bool ISOTROPIC = false>
-RLS_DEV Ggx ggx_make(V3 wo, V3 N, V3 T, bool exiting, float ksR, float ksG, float ksB,
-                     float ior, float roughness, float anisotropic)
+RLS_DEV GgxMaterial ggx_material(float ksR, float ksG, float ksB, float ior, float roughness, float anisotropic)
+{
+    GgxMaterial m;
+    m.ksR = ksR; m.ksG = ksG; m.ksB = ksB;
+    m.out = maxf(ior, 1e-4f);
+    if (ISOTROPIC) {
+        m.ax = maxf(1e-4f, sqr(roughness));
+        m.ay = m.ax;
+    } else {
+        float aspect = R_SQRT1M(anisotropic * 0.9f);
+        m.ax = maxf(1e-4f, R_DIV(sqr(roughness), aspect));
+        m.ay = maxf(1e-4f, sqr(roughness) * aspect);
+    }
+    m.rough = maxf(1e-5f, sqr(roughness));
+    // mIorOut / mIorIn (src/rlGgx.h:258) and mIorIn / mIorOut (refraction): one of the two iors is exactly 1, so one
+    // ratio is the other ior itself (x / 1 = x exactly) and the other its reciprocal; out >= 1e-4 (or it is 1e-4)
+    m.rout = R_RCPHI(m.out);
+    return m;
+}
+
+RLS_DEV Ggx ggx_from_material(const GgxMaterial &m, V3 wo, V3 N, V3 T, bool exiting)
 {
     Ggx g;
-    g.ksR = ksR; g.ksG = ksG; g.ksB = ksB;
-    float in = 1.0f, out = maxf(ior, 1e-4f);
-    g.iorIn = exiting ? out : in;
-    g.iorOut = exiting ? in : out;
+    g.ksR = m.ksR; g.ksG = m.ksG; g.ksB = m.ksB;
+    const float in = 1.0f;
+    g.iorIn = exiting ? m.out : in;
+    g.iorOut = exiting ? in : m.out;
     g.view = wo;
     g.fr.N = N;
     g.fr.U = T;
     g.fr.V = cross(N, T);
-    if (ISOTROPIC) {
-        g.ax = maxf(1e-4f, sqr(roughness));
-        g.ay = g.ax;
-    } else {
-        float aspect = R_SQRT1M(anisotropic * 0.9f);
-        g.ax = maxf(1e-4f, R_DIV(sqr(roughness), aspect));
-        g.ay = maxf(1e-4f, sqr(roughness) * aspect);
-    }
-    g.rough = maxf(1e-5f, sqr(roughness));
-    // mIorOut / mIorIn (src/rlGgx.h:258) and mIorIn / mIorOut (refraction): one of the two iors is exactly 1, so one
-    // ratio is the other ior itself (x / 1 = x exactly) and the other its reciprocal; out >= 1e-4 (or it is 1e-4)
-    const float rout = R_RCPHI(out);
-    g.eta2 = sqr(exiting ? rout : out);
-    g.etaIO = exiting ? out : rout;
+    g.ax = m.ax;
+    g.ay = m.ay;
+    g.rough = m.rough;
+    g.eta2 = sqr(exiting ? m.rout : m.out);
+    g.etaIO = exiting ? m.out : m.rout;
     g.vn = dot(wo, N);
     {
         float cosSqr = sqr(g.vn);
@@ -514,6 +543,21 @@ RLS_DEV Ggx ggx_make(V3 wo, V3 N, V3 T, bool exiting, float ksR, float ksG, floa
         g.g1v = R_TWO_OVER(1.0f + R_SQRT1P(sqr(g.rough) * tanSqr));
     }
     return g;
+}
+
+RLS_DEV GgxMaterial ggx_material_wave_uniform(GgxMaterial m)
+{
+    m.ksR = wave_uniform(m.ksR); m.ksG = wave_uniform(m.ksG); m.ksB = wave_uniform(m.ksB);
+    m.rough = wave_uniform(m.rough); m.ax = wave_uniform(m.ax); m.ay = wave_uniform(m.ay);
+    m.out = wave_uniform(m.out); m.rout = wave_uniform(m.rout);
+    return m;
+}
+
+template <bool ISOTROPIC = false>
+RLS_DEV Ggx ggx_make(V3 wo, V3 N, V3 T, bool exiting, float ksR, float ksG, float ksB,
+                     float ior, float roughness, float anisotropic)
+{
+    return ggx_from_material(ggx_material<ISOTROPIC>(ksR, ksG, ksB, ior, roughness, anisotropic), wo, N, T, exiting);
 }
 
 // src/rlGgx.h:249-270
@@ -738,22 +782,44 @@ RLS_DEV float D_GTR1_prepared(const Disney &d, float mn2)
     return R_DIV(d.ccA2m1 * kInvPi, den);
 }
 
-// Everything the per-sample verbs compute from the closure alone.  Needs the libm tables (powf, logf): kernels call
+// Everything the per-sample verbs compute from the closure alone, in two halves: what depends on the node parameters only
+// (a kernel whose parameters are one value for the batch evaluates disney_make() and this half once per thread, then
+// disney_wave_uniform()) and what depends on the view.  Needs the libm tables (powf, logf): kernels call
 // stage_libm_tables() first.
-RLS_DEV void disney_prepare(Disney &d)
+RLS_DEV void disney_prepare_material(Disney &d)
 {
-    d.vn = dot(d.view, d.fr.N);
-    d.FV = R_POW5(clampf(1.0f - d.vn, 0.0f, 1.0f));
-    d.gsV = smithG_GGX(d.vn, d.specRough);
-    d.grV = smithG_GGX(d.vn, 0.25f);
     float alpha = lerpf(d.clearcoatGloss, 0.1f, 0.001f);
     float a2 = sqr(alpha);
     d.ccA2m1 = a2 - 1.0f;
     d.ccLogA2 = R_LOG(a2);
     d.ccw = R_DIV(d.clearcoat, d.clearcoat + 1.0f);
-    d.vnc = maxf(1e-4f, d.vn);
     d.gtr2Weight = R_RCP(d.clearcoat + 1.0f);
     d.om = 1.0f - d.metallic;
+}
+RLS_DEV void disney_prepare_view(Disney &d)
+{
+    d.vn = dot(d.view, d.fr.N);
+    d.FV = R_POW5(clampf(1.0f - d.vn, 0.0f, 1.0f));
+    d.gsV = smithG_GGX(d.vn, d.specRough);
+    d.grV = smithG_GGX(d.vn, 0.25f);
+    d.vnc = maxf(1e-4f, d.vn);
+}
+RLS_DEV void disney_prepare(Disney &d)
+{
+    disney_prepare_view(d);
+    disney_prepare_material(d);
+}
+// the parameter-only members moved to scalar registers (the frame, the view and disney_prepare_view()'s members are per point)
+RLS_DEV void disney_wave_uniform(Disney &d)
+{
+    d.f0R = wave_uniform(d.f0R); d.f0G = wave_uniform(d.f0G); d.f0B = wave_uniform(d.f0B);
+    d.shR = wave_uniform(d.shR); d.shG = wave_uniform(d.shG); d.shB = wave_uniform(d.shB);
+    d.baseR = wave_uniform(d.baseR); d.baseG = wave_uniform(d.baseG); d.baseB = wave_uniform(d.baseB);
+    d.roughness = wave_uniform(d.roughness); d.subsurface = wave_uniform(d.subsurface); d.metallic = wave_uniform(d.metallic);
+    d.clearcoat = wave_uniform(d.clearcoat); d.clearcoatGloss = wave_uniform(d.clearcoatGloss);
+    d.specRough = wave_uniform(d.specRough); d.ax = wave_uniform(d.ax); d.ay = wave_uniform(d.ay);
+    d.ccA2m1 = wave_uniform(d.ccA2m1); d.ccLogA2 = wave_uniform(d.ccLogA2); d.ccw = wave_uniform(d.ccw);
+    d.gtr2Weight = wave_uniform(d.gtr2Weight); d.om = wave_uniform(d.om);
 }
 
 // evalDiffuse, src/rlDisney.cpp:199-236 (BRDF without the cosine)
@@ -1095,15 +1161,6 @@ RLS_DEV NdProfile nd_make(float dx, float dy, float dz)
     return p;
 }
 
-// A value every lane of the wavefront holds (computed from kernel arguments only) moved to a scalar register: it costs no
-// vector register across the tile loop and the branches on it are scalar branches
-#ifdef RLS_NO_WAVE_UNIFORM   // experiment switch: keep the values in vector registers
-RLS_DEV float wave_uniform(float x) { return x; }
-RLS_DEV int wave_uniform(int x) { return x; }
-#else
-RLS_DEV float wave_uniform(float x) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(x))); }
-RLS_DEV int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
-#endif
 RLS_DEV NdProfile nd_wave_uniform(NdProfile p)
 {
 #pragma unroll

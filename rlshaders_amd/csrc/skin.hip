@@ -34,11 +34,10 @@ __device__ __forceinline__ LobeOut lobe_from_microfacet(const Ggx &g, V3 M)
 }
 
 // One isotropic GGX lobe of rlSkin (src/rlSkin.cpp:192,215: anisotropic defaulted to 0).
-__device__ __forceinline__ LobeOut ggx_lobe(V3 wo, V3 N, V3 T, V3 local, float cr, float cg, float cb,
-                                            float ior, float rough, float rx, float ry)
+__device__ __forceinline__ LobeOut ggx_lobe(V3 wo, V3 N, V3 T, V3 local, const GgxMaterial &m, float rx, float ry)
 {
     LobeOut o;
-    Ggx g = ggx_make<true>(wo, N, T, false, cr, cg, cb, ior, rough, 0.0f);
+    Ggx g = ggx_from_material(m, wo, N, T, false);
     // `local` = the view in the shared (T, N x T, N) frame: the same for both lobes, computed once
     VndfView w = vndf_view_from(local, g.ax, g.ay);
     V3 M = vndf_microfacet(w, g.fr, rx, ry);
@@ -48,17 +47,44 @@ __device__ __forceinline__ LobeOut ggx_lobe(V3 wo, V3 N, V3 T, V3 local, float c
     return o;
 }
 
-// STREAMED: every parameter is a per-point plane (checked on the host)
-template <int FAST_MATH, bool STREAMED>
+// MODE (checked on the host): STREAMED every parameter is a per-point plane; UNIFORM every parameter is one value for the batch
+// (an Arnold parameter is a constant unless a texture is linked to it): the parameter-only arithmetic -- the two lobes'
+// roughness / ior terms, NDProfile::setDistance with its six expf -- runs once per thread ahead of the tile loop and stays in
+// scalar registers; MIXED tests parameter by parameter in the loop
+enum { MIXED = 0, STREAMED_ALL = 1, UNIFORM_ALL = 2 };
+#ifndef RLS_SKIN_SGPR          // experiment switch: which hoisted values move to scalar registers (1 the lobes', 2 NDProfile)
+#define RLS_SKIN_SGPR 3
+#endif
+#ifndef RLS_SKIN_UNIFORM_CAP
+#define RLS_SKIN_UNIFORM_CAP 1
+#endif
+#ifndef RLS_SKIN_ND_RECIP      // experiment switch: all of getPdf's reciprocals hoisted as well
+#define RLS_SKIN_ND_RECIP 1
+#endif
+template <int FAST_MATH, int MODE>
 __global__ __launch_bounds__(rlsh::kBlock) void skin_kernel(SkinIO a0)
 {
+    constexpr bool STREAMED = MODE == STREAMED_ALL, UNIFORM = MODE == UNIFORM_ALL;
     stage_libm_tables();   // expf / logf tables -> LDS (EXACT mode)
+    GgxMaterial um1 = {}, um2 = {};
+    NdProfile up = {};
+    if (UNIFORM) {
+        const rls_skin_closure &c = a0.c;
+        um1 = ggx_material<true>(c.sheen_color.ur, c.sheen_color.ug, c.sheen_color.ub, c.sheen_ior.u, c.sheen_roughness.u, 0.0f);
+        um2 = ggx_material<true>(c.specular_color.ur, c.specular_color.ug, c.specular_color.ub, c.specular_ior.u,
+                                 c.specular_roughness.u, 0.0f);
+        const float mult = c.sss_dist_multiplier.u;                               // src/rlSkin.cpp:235-236
+        up = nd_make<RLS_SKIN_ND_RECIP != 0>(c.sss_scatter_dist[0].u * mult, c.sss_scatter_dist[1].u * mult, c.sss_scatter_dist[2].u * mult);
+        if (RLS_SKIN_SGPR & 1) { um1 = ggx_material_wave_uniform(um1); um2 = ggx_material_wave_uniform(um2); }
+        if (RLS_SKIN_SGPR & 2) up = nd_wave_uniform(up);
+    }
     const TileRange tiles = tile_range(a0.n);
     for (int64_t base = tiles.first; base < tiles.end; base += tiles.step) {
         const Idx i = make_idx(base);
         if (i.full() >= a0.n) continue;
         const SkinIO a = reload_args(a0);      // the 35 input planes' pointers, for the loads of this tile only
         const rls_skin_closure &c = a.c;
+#define LDP(param) (UNIFORM ? (param).u : ldp<STREAMED>(param, i))
         V3 wo = ld3(c.wo, i), N = ld3(c.N, i), T = ld3(c.T, i);
 
         float sheenFresnel = 0.0f, specularFresnel = 0.0f;
@@ -67,23 +93,25 @@ __global__ __launch_bounds__(rlsh::kBlock) void skin_kernel(SkinIO a0)
         gfr.N = N; gfr.U = T; gfr.V = cross(N, T);
         V3 local = vndf_local(wo, gfr);
 
-        float sheenWeight = ldp<STREAMED>(c.sheen_weight, i);
-        float shr, shg, shb;
-        ldrgb<STREAMED>(c.sheen_color, i, shr, shg, shb);
-        float sheenIor = ldp<STREAMED>(c.sheen_ior, i), sheenRough = ldp<STREAMED>(c.sheen_roughness, i);
+        float sheenWeight = LDP(c.sheen_weight);
+        float shr = 0.0f, shg = 0.0f, shb = 0.0f;
+        if (!UNIFORM) ldrgb<STREAMED>(c.sheen_color, i, shr, shg, shb);
+        float sheenIor = LDP(c.sheen_ior), sheenRough = LDP(c.sheen_roughness);
         float rx0 = ldg(a.xi[0], i), ry0 = ldg(a.xi[1], i);
-        float specWeight = ldp<STREAMED>(c.specular_weight, i);
-        float spr, spg, spb;
-        ldrgb<STREAMED>(c.specular_color, i, spr, spg, spb);
-        float specIor = ldp<STREAMED>(c.specular_ior, i), specRough = ldp<STREAMED>(c.specular_roughness, i);
+        float specWeight = LDP(c.specular_weight);
+        float spr = 0.0f, spg = 0.0f, spb = 0.0f;
+        if (!UNIFORM) ldrgb<STREAMED>(c.specular_color, i, spr, spg, spb);
+        float specIor = LDP(c.specular_ior), specRough = LDP(c.specular_roughness);
         float rx1 = ldg(a.xi[2], i), ry1 = ldg(a.xi[3], i);
         const bool sheenOn = sheenWeight > kEps, specOn = specWeight > kEps;          // src/rlSkin.cpp:191, 214
+        const GgxMaterial m1 = UNIFORM ? um1 : ggx_material<true>(shr, shg, shb, sheenIor, sheenRough, 0.0f);
+        const GgxMaterial m2 = UNIFORM ? um2 : ggx_material<true>(spr, spg, spb, specIor, specRough, 0.0f);
 #ifndef RLS_NO_PAIR_COMPACTION
-        if (__builtin_amdgcn_ballot_w64(sheenOn && specOn) == ~0ull) {
+        if (UNIFORM ? (sheenOn && specOn) : __builtin_amdgcn_ballot_w64(sheenOn && specOn) == ~0ull) {
             // every lane of the wavefront evaluates both lobes: their two microfacet samples share one pass of the
             // uniform-slope fallback (vndf_microfacet_pair)
-            Ggx g1 = ggx_make<true>(wo, N, T, false, shr, shg, shb, sheenIor, sheenRough, 0.0f);
-            Ggx g2 = ggx_make<true>(wo, N, T, false, spr, spg, spb, specIor, specRough, 0.0f);
+            Ggx g1 = ggx_from_material(m1, wo, N, T, false);
+            Ggx g2 = ggx_from_material(m2, wo, N, T, false);
             VndfView w1 = vndf_view_from(local, g1.ax, g1.ay), w2 = vndf_view_from(local, g2.ax, g2.ay);
             V3 M1, M2;
             vndf_microfacet_pair(w1, g1.fr, rx0, ry0, w2, g2.fr, rx1, ry1, M1, M2);
@@ -95,26 +123,26 @@ __global__ __launch_bounds__(rlsh::kBlock) void skin_kernel(SkinIO a0)
 #endif
         {
             if (sheenOn) {
-                sh = ggx_lobe(wo, N, T, local, shr, shg, shb, sheenIor, sheenRough, rx0, ry0);
+                sh = ggx_lobe(wo, N, T, local, m1, rx0, ry0);
                 sheenFresnel = sh.F * sheenWeight;
             }
             if (specOn) {
-                sp = ggx_lobe(wo, N, T, local, spr, spg, spb, specIor, specRough, rx1, ry1);
+                sp = ggx_lobe(wo, N, T, local, m2, rx1, ry1);
                 specularFresnel = sp.F * specWeight;
             }
         }
 
-        float mult = ldp<STREAMED>(c.sss_dist_multiplier, i);                         // :235-236
-        float dx = ldp<STREAMED>(c.sss_scatter_dist[0], i) * mult;
-        float dy = ldp<STREAMED>(c.sss_scatter_dist[1], i) * mult;
-        float dz = ldp<STREAMED>(c.sss_scatter_dist[2], i) * mult;
-        float sssWeight = ldp<STREAMED>(c.sss_weight, i);
+        float mult = LDP(c.sss_dist_multiplier);                         // :235-236
+        float dx = LDP(c.sss_scatter_dist[0]) * mult;
+        float dy = LDP(c.sss_scatter_dist[1]) * mult;
+        float dz = LDP(c.sss_scatter_dist[2]) * mult;
+        float sssWeight = LDP(c.sss_weight);
         sssWeight *= 1.0f - specularFresnel * (1.0f - sheenFresnel);        // :238
         float rx2 = ldg(a.xi[4], i), ry2 = ldg(a.xi[5], i);
 
         float r = 0.0f, rpdf = 0.0f, R = 0.0f, G = 0.0f, B = 0.0f;
         if (!(sssWeight < kEps)) {                                          // :244
-            NdProfile p = nd_make(dx, dy, dz);
+            const NdProfile p = UNIFORM ? up : nd_make(dx, dy, dz);
             Frame fr = sss_frame(N, T, true);                               // src/rlSss.h:151-154
             V3 off, dir;
             float maxdist;
@@ -132,6 +160,7 @@ __global__ __launch_bounds__(rlsh::kBlock) void skin_kernel(SkinIO a0)
         stg(o.sheenFresnel, i, sheenFresnel);
         stg(o.specularFresnel, i, specularFresnel);
         stg(o.sssWeight, i, sssWeight);
+#undef LDP
     }
 }
 
@@ -142,10 +171,17 @@ rls_status launch_kernel(rls_context *ctx, const SkinIO &io, const char *name)
                           c.sss_scatter_dist[1].v && c.sss_scatter_dist[2].v && c.specular_color.r &&
                           c.specular_weight.v && c.specular_roughness.v && c.specular_ior.v && c.sheen_color.r &&
                           c.sheen_weight.v && c.sheen_roughness.v && c.sheen_ior.v;
+    const bool uniform = !c.sss_color.r && !c.sss_weight.v && !c.sss_dist_multiplier.v && !c.sss_scatter_dist[0].v &&
+                         !c.sss_scatter_dist[1].v && !c.sss_scatter_dist[2].v && !c.specular_color.r &&
+                         !c.specular_weight.v && !c.specular_roughness.v && !c.specular_ior.v && !c.sheen_color.r &&
+                         !c.sheen_weight.v && !c.sheen_roughness.v && !c.sheen_ior.v;
+    const dim3 grid = rlsh::grid_for(ctx, io.n, rlsh::kBlock, RLS_CAP_MULT);
     if (streamed)
-        hipLaunchKernelGGL((skin_kernel<RLS_FAST, true>), rlsh::grid_for(ctx, io.n, rlsh::kBlock, RLS_CAP_MULT), dim3(rlsh::kBlock), 0, ctx->stream, io);
+        hipLaunchKernelGGL((skin_kernel<RLS_FAST, STREAMED_ALL>), grid, dim3(rlsh::kBlock), 0, ctx->stream, io);
+    else if (uniform)   // under the context's cap: a thread that hoists wants many tiles to spread the hoisted work over
+        hipLaunchKernelGGL((skin_kernel<RLS_FAST, UNIFORM_ALL>), rlsh::grid_for(ctx, io.n, rlsh::kBlock, RLS_SKIN_UNIFORM_CAP), dim3(rlsh::kBlock), 0, ctx->stream, io);
     else
-        hipLaunchKernelGGL((skin_kernel<RLS_FAST, false>), rlsh::grid_for(ctx, io.n, rlsh::kBlock, RLS_CAP_MULT), dim3(rlsh::kBlock), 0, ctx->stream, io);
+        hipLaunchKernelGGL((skin_kernel<RLS_FAST, MIXED>), grid, dim3(rlsh::kBlock), 0, ctx->stream, io);
     return rlsh::check_launch(name);
 }
 

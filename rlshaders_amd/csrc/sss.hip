@@ -36,11 +36,17 @@ __device__ __forceinline__ NdProfile load_profile(const rls_sss_closure &c, I i)
 
 // UNIFORM: the scatter distance and its multiplier are one value for the batch (an Arnold parameter is a constant unless a
 // texture is linked to it): setDistance -- three divisions, six expf, with all of getPdf's reciprocals -- runs once per
-// thread ahead of the tile loop and its results stay in scalar registers, the same values a per-point evaluation gives
+// thread ahead of the tile loop, the same values a per-point evaluation gives
+#ifndef RLS_SSS_UNIFORM_SGPR
+#define RLS_SSS_UNIFORM_SGPR 0
+#endif
 __device__ __forceinline__ NdProfile uniform_profile(const rls_sss_closure &c)
 {
     const float m = c.sss_dist_multiplier.u;
-    return nd_wave_uniform(nd_make<!RLS_FAST>(c.sss_scatter_dist[0].u * m, c.sss_scatter_dist[1].u * m, c.sss_scatter_dist[2].u * m));
+    const NdProfile p = nd_make<!RLS_FAST>(c.sss_scatter_dist[0].u * m, c.sss_scatter_dist[1].u * m, c.sss_scatter_dist[2].u * m);
+    // measured (tools/ab.sh, probe ray at 2^26 points): 1.258 ms from scalar registers, 1.240 from vector registers -- these
+    // kernels have the vector registers to spare and every use of a scalar operand beyond the first costs a move
+    return RLS_SSS_UNIFORM_SGPR ? nd_wave_uniform(p) : p;
 }
 
 template <int OP, bool UNIFORM, int FAST_MATH = RLS_FAST>

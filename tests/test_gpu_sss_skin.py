@@ -271,3 +271,39 @@ def test_uniform_scatter_distance_is_hoisted_and_bit_identical(gpu, oracle, mult
             same(host(gu[name]), rp[name], (dist, name, "probe, uniform vs oracle"))
             same(host(gu[name]), host(gs[name]), (dist, name, "probe, uniform vs streamed"))
         same(host(su.misPdf(dev(disp), dev(sN))), o.mis_pdf(disp, sN, False), (dist, "mis pdf"))
+
+
+SKIN_UNIFORM_CASES = {
+    "all_layers": dict(cases.SKIN_DEFAULTS, sheen_weight=0.3, sss_scatter_dist=(1.0, 0.6, 0.35), sss_color=(1.0, 0.84, 0.5)),
+    "no_sheen": dict(cases.SKIN_DEFAULTS, sss_scatter_dist=(0.4, 0.2, 0.1), sss_dist_multiplier=2.5),
+    "no_specular": dict(cases.SKIN_DEFAULTS, sheen_weight=0.9, specular_weight=0.0, sheen_roughness=0.05, sheen_ior=2.4),
+    "no_sss": dict(cases.SKIN_DEFAULTS, sheen_weight=1.0, specular_weight=1.0, sss_weight=0.0),
+    "weights_on_the_threshold": dict(cases.SKIN_DEFAULTS, sheen_weight=1e-4, specular_weight=float(np.nextafter(np.float32(1e-4), np.float32(1)))),
+    "tiny_ior_and_roughness": dict(cases.SKIN_DEFAULTS, sheen_weight=0.5, sheen_ior=0.0, sheen_roughness=0.0, specular_ior=1e-5,
+                                   specular_roughness=1.0),
+    "distance_outside_the_window": dict(cases.SKIN_DEFAULTS, sheen_weight=0.5, sss_scatter_dist=(1e-5, 3e4, 1.0)),
+    "degenerate_distance": dict(cases.SKIN_DEFAULTS, sheen_weight=0.5, sss_scatter_dist=(0.0, 0.0, 0.0)),
+}
+
+
+@pytest.mark.parametrize("case", sorted(SKIN_UNIFORM_CASES))
+def test_skin_uniform_parameters_are_hoisted_and_bit_identical(gpu, oracle, case):
+    """Every parameter one value for the batch: skin_kernel<UNIFORM_ALL> evaluates the parameter-only arithmetic once per thread
+    (the lobes' roughness / ior terms, NDProfile::setDistance).  Its 24 outputs equal the oracle's and those of the streamed
+    kernel (the same values as per-point planes) bit for bit, with layers switched off, weights on the 1e-4 threshold,
+    degenerate ior / roughness and scatter distances outside the reciprocal window."""
+    n = 1 << 14
+    wo, N, T = cases.frame(cases.SEED_PARITY, n)
+    xi = cases.xi(cases.SEED_PARITY, n, 6)
+    p = SKIN_UNIFORM_CASES[case]
+    ref = oracle.skin(wo, N, T, p, xi, nthreads=4)
+    planes = {k: (np.repeat(np.asarray(v, np.float32)[:, None], n, axis=1) if np.ndim(v) else np.full(n, v, np.float32))
+              for k, v in p.items()}
+    gu = {k: host(v) for k, v in R.SkinShader(gpu, dev(wo), dev(N), dev(T), **p).sampleEvalPdf(dev(xi)).items()}
+    gs = {k: host(v) for k, v in R.SkinShader(gpu, dev(wo), dev(N), dev(T), **{k: dev(v) for k, v in planes.items()})
+          .sampleEvalPdf(dev(xi)).items()}
+    for k in SKIN_KEYS:
+        for other, what in ((ref[k], "oracle"), (gs[k], "streamed kernel")):
+            a, b = gu[k], np.asarray(other)
+            ok = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+            assert ok.all(), (case, k, what, int((~ok).sum()))

@@ -78,9 +78,10 @@ CONFIG_PRESETS = {2: ("ggx_reflect_refract", 26), 3: ("disney_integrate", 26), 4
 
 # the `workloads` block of the default line: (workload, log2 points per GPU, timed steps)
 BLOCK_ALL = [("ggx_reflect_refract_uniform", 26, 40), ("ggx_reflect", 26, 40), ("ggx_eval", 26, 40), ("ggx_pdf", 26, 40),
-             ("disney_triple_diffuse", 26, 40), ("disney_triple_glossy", 26, 40),
+             ("disney_triple_diffuse", 26, 40), ("disney_triple_glossy", 26, 40), ("disney_triple_glossy_uniform", 26, 40),
              ("disney_integrate", 26, 12), ("disney_stream", 26, 10),
-             ("sss_probe", 25, 40), ("sss_probe", 26, 40), ("nd_sample", 26, 40), ("skin", 26, 30), ("skin", 27, 20),
+             ("sss_probe", 25, 40), ("sss_probe", 26, 40), ("sss_probe_uniform", 26, 40), ("nd_sample", 26, 40),
+             ("skin", 26, 30), ("skin", 27, 20), ("skin_uniform", 26, 30),
              ("ggx_reflect_refract_host", 24, 4)]
 BLOCK_CONFIGS = [("disney_integrate", 26, 12), ("sss_probe", 25, 40), ("skin", 27, 20)]
 

@@ -34,7 +34,11 @@ def _table(node, n, values):
 
 
 @pytest.mark.gpu
-def test_three_nodes_through_the_stub(oracle, tmp_path):
+@pytest.mark.parametrize("parameters", ["textured", "constant"])
+def test_three_nodes_through_the_stub(oracle, tmp_path, parameters):
+    """textured: every parameter differs from point to point (planes).  constant: every parameter evaluates to the same value
+    at every point, as on a node without linked textures -- the stub notices (detail::Par1 / Par3), uploads nothing for them
+    and the library runs its UNIFORM_ALL kernels; the results must be the oracle's all the same."""
     from rlshaders_amd import build
     build.build_library()
     build.build_host_examples()
@@ -43,6 +47,14 @@ def test_three_nodes_through_the_stub(oracle, tmp_path):
     g = cases.ggx_mixed(cases.SEED_PARITY, n)
     d = cases.disney_mixed(cases.SEED_PARITY, n)
     s = cases.skin_mixed(cases.SEED_PARITY, n)
+    if parameters == "constant":
+        full = lambda v: (np.repeat(np.asarray(v, np.float32)[:, None], n, axis=1) if np.ndim(v) else np.full(n, v, np.float32))
+        g.update({k: full(v) for k, v in dict(KsColor=(0.9, 0.8, 0.7), ior=1.5, roughness=0.3, anisotropic=0.6).items()})
+        d.update({k: full(v) for k, v in dict(base_color=(0.85, 0.7047, 0.2057), subsurface=0.2, metallic=0.3, specular=0.5,
+                                              specular_tint=0.25, roughness=0.4, anisotropic=0.4, sheen=0.5, sheen_tint=0.5,
+                                              clearcoat=0.6, clearcoat_gloss=0.7).items()})
+        s["params"] = {k: full(v) for k, v in dict(cases.SKIN_DEFAULTS, sheen_weight=0.3, sss_scatter_dist=(1.0, 0.6, 0.35),
+                                                   sss_color=(1.0, 0.84, 0.5)).items()}
     xi = cases.xi(cases.SEED_PARITY, n, 6)
     wo, N, T = g["wo"], g["N"], g["T"]                  # the three case sets share their frames (same seed)
     assert np.array_equal(wo, d["wo"]) and np.array_equal(wo, s["wo"])
@@ -60,7 +72,9 @@ def test_three_nodes_through_the_stub(oracle, tmp_path):
     p = subprocess.run([str(exe), "run", str(inp), str(outp)], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr
     info = json.loads(p.stdout.strip().splitlines()[-1])
-    assert info == {"n": n, "ggx_planes": 8, "disney_planes": 14, "skin_planes": 24}
+    # rlGgx: KsColor + 3 scalars, rlDisney: base_color + 10, rlSkin: 3 colours + the scatter distance + 8 scalars
+    assert info == {"n": n, "ggx_planes": 8, "disney_planes": 14, "skin_planes": 24,
+                    "uniform_parameters": 4 + 11 + 12 if parameters == "constant" else 0}
     out = np.fromfile(outp, np.float32).reshape(-1, n)
     og, od, osk = out[:8], out[8:22], out[22:]
     # rlGgx: evalSample -> evalBrdf -> evalPdf (+ the Fresnel side effect)
@@ -122,7 +136,7 @@ def test_whole_shader_evaluate_through_the_stub(oracle, tmp_path):
     p = subprocess.run([str(exe), "shade", str(inp), str(outp)], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stderr
     info = json.loads(p.stdout.strip().splitlines()[-1])
-    assert info == {"n": n, "ggx_planes": 18, "disney_planes": 15, "skin_planes": 15}
+    assert info == {"n": n, "ggx_planes": 18, "disney_planes": 15, "skin_planes": 15, "uniform_parameters": 0}
     out = np.fromfile(outp, np.float32).reshape(-1, n)
     og, od, osk = out[:18], out[18:33], out[33:]
     lights = [oracle.make_light(center=(2.0, 2.0, 3.0), radius=1.25, radiance=(3.0, 2.0, 1.0), mis_mode=0),

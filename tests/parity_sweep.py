@@ -140,3 +140,84 @@ def sweep(ctx, n: int, seed: int, spp_n: int = 2, verbose: bool = True, group: s
     finally:
         del os.environ["RLS_INTEGRATE_GROUP"]
     return report
+
+
+def _draw_uniform_parameters(rng) -> dict:
+    """One node's worth of parameter VALUES (every parameter one number for the batch), drawn so that the borders matter:
+    weights below / on / above the 1e-4 layer gates, scatter distances across the reciprocal window, ior below 1 and at the
+    1e-4 clamp, roughness at both ends."""
+    pick = lambda *v: float(v[rng.integers(len(v))])
+    f = lambda lo, hi: float(np.float32(rng.uniform(lo, hi)))
+    logu = lambda lo, hi: float(np.float32(10.0 ** rng.uniform(lo, hi)))
+    rough = lambda: pick(f(0.0, 1.0), f(0.0, 1.0), f(0.0, 1.0), 0.0, 1.0, 1e-3)
+    ior = lambda: pick(f(1.05, 2.55), f(1.05, 2.55), f(0.3, 1.0), 1.0, 0.0, 5e-5)
+    weight = lambda: pick(f(0.0, 1.0), f(0.0, 1.0), f(0.0, 1.0), 0.0, 1e-4, float(np.nextafter(np.float32(1e-4), np.float32(1))), 1.0)
+    dist = lambda: pick(logu(-1.5, 0.5), logu(-1.5, 0.5), logu(-1.5, 0.5), logu(-6, 6), 2.0 ** -13, 2.0 ** 14, 1e-5, 0.0)
+    col = lambda: (f(0, 1), f(0, 1), f(0, 1))
+    return dict(
+        ggx=dict(KsColor=col(), roughness=rough(), ior=ior(), anisotropic=pick(f(0, 1), f(0, 1), 0.0, 1.0)),
+        disney=dict(base_color=(0.0, 0.0, 0.0) if rng.integers(4) == 0 else col(), subsurface=f(0, 1), metallic=f(0, 1), specular=f(0, 1),
+                    specular_tint=f(0, 1), roughness=rough(), anisotropic=pick(f(0, 1), 0.0, 1.0), sheen=f(0, 1), sheen_tint=f(0, 1),
+                    clearcoat=pick(f(0, 1), f(0, 1), 0.0, 1.0), clearcoat_gloss=pick(f(0, 1), f(0, 1), 0.0, 1.0)),
+        skin=dict(sss_color=col(), sss_weight=weight(), sss_dist_multiplier=pick(1.0, f(0.5, 1.5), f(0.0, 3.0)),
+                  sss_scatter_dist=(dist(), dist(), dist()), specular_color=col(), specular_weight=weight(),
+                  specular_roughness=rough(), specular_ior=ior(), sheen_color=col(), sheen_weight=weight(),
+                  sheen_roughness=rough(), sheen_ior=ior()))
+
+
+def sweep_uniform(ctx, n: int, seed: int, draws: int = 8, verbose: bool = True) -> dict:
+    """The UNIFORM_ALL kernels (parameter-only arithmetic once per thread): `draws` random parameter sets, each one value per
+    parameter for a batch of n device-generated shading points, every one-sample verb of the four units against the oracle,
+    counted in output words that differ at all."""
+    th = O.hardware_threads()
+    hostf = lambda t: t.contiguous().cpu().numpy()
+    rng = np.random.default_rng(seed)
+    report = {}
+
+    def tally(name, got, ref):
+        r = _words(got, ref)
+        t = report.setdefault(name, dict(words_differing=0, words=0, max_rel_err=0.0, beyond_1e5=0))
+        for k in ("words_differing", "words", "beyond_1e5"):
+            t[k] += r[k]
+        t["max_rel_err"] = max(t["max_rel_err"], r["max_rel_err"])
+
+    wo, N, T = R.gen_frame(ctx, seed, 0, n)
+    hwo, hN, hT = hostf(wo), hostf(N), hostf(T)
+    xi = [R.gen_uniform(ctx, seed, 0, n, 11 + j) for j in range(6)]
+    hxi = [hostf(t) for t in xi]
+    exiting = (torch.arange(n, device=wo.device) % 5 == 0).to(torch.uint8)
+    for k in range(draws):
+        p = _draw_uniform_parameters(rng)
+        g = p["ggx"]
+        ex = exiting if k % 2 else None
+        s = R.GgxSampler(ctx, wo, N, T, specColor=g["KsColor"], ior=g["ior"], roughness=g["roughness"],
+                         anisotropic=g["anisotropic"], exiting=ex)
+        og = O.Ggx(hwo, hN, hT, KsColor=g["KsColor"], ior=g["ior"], roughness=g["roughness"], anisotropic=g["anisotropic"],
+                   exiting=None if ex is None else hostf(ex), nthreads=th)
+        tally("ggx reflect+refract, uniform", [hostf(t) for t in s.reflectRefract(*xi[:4])], og.reflect_refract(*hxi[:4]))
+        wi = og.sample(hxi[0], hxi[1])[0]
+        dwi = torch.from_numpy(wi).cuda()
+        tally("ggx evalBrdf / evalPdf, uniform", [hostf(s.evalBrdf(dwi)), hostf(s.evalPdf(dwi))], [og.eval(wi), og.pdf(wi)])
+        d = R.DisneySampler(ctx, wo, N, T, **p["disney"])
+        od = O.Disney(hwo, hN, hT, nthreads=th, **p["disney"])
+        for lobe, nm in ((R.RLS_RAY_DIFFUSE, "diffuse"), (R.RLS_RAY_GLOSSY, "glossy")):
+            d.setSampleType(lobe)
+            tally(f"disney {nm}, uniform", [hostf(t) for t in d.sampleEvalPdf(xi[0], xi[1])],
+                  od.sample_eval_pdf(lobe, hxi[0], hxi[1]))
+        sk = p["skin"]
+        ss = R.SssSampler(ctx, N, T, sk["sss_color"], sk["sss_scatter_dist"], multiplier=sk["sss_dist_multiplier"])
+        gp = ss.getProbeRay(xi[0], xi[1])
+        rp = O.Sss(n, sk["sss_scatter_dist"], sk["sss_color"], multiplier=sk["sss_dist_multiplier"], N=hN, T=hT,
+                   nthreads=th).probe(hxi[0], hxi[1])
+        keys = ("r", "origin", "dir", "maxdist", "pdf", "profile")
+        tally("sss probe, uniform", [hostf(gp[q]) for q in keys], [rp[q] for q in keys])
+        gout = R.SkinShader(ctx, wo, N, T, **sk).sampleEvalPdf(torch.stack(xi))
+        rout = O.skin(hwo, hN, hT, sk, np.stack(hxi), nthreads=th)
+        names = list(O.SKIN_VEC) + list(O.SKIN_SCALAR)
+        tally("skin, uniform", [hostf(gout[q]) for q in names], [rout[q] for q in names])
+        if verbose:
+            bad = {q: r["words_differing"] for q, r in report.items() if r["words_differing"]}
+            print(f"uniform sweep seed {seed} draw {k}: differing so far {bad or 0}", flush=True)
+            if bad:
+                print("   parameters of this draw:", p, flush=True)
+    return report

@@ -113,3 +113,17 @@ def test_disney_uniform_equals_streamed_and_oracle(gpu, oracle, name):
         _same(du.evalSample(*dx), ds.evalSample(*dx), (name, lobe, "evalSample"))
         _same(du.evalBrdf(wi), ds.evalBrdf(wi), (name, lobe, "evalBrdf"))
         _same(du.evalPdf(wi), ds.evalPdf(wi), (name, lobe, "evalPdf"))
+
+
+def test_random_uniform_parameter_sets(gpu, oracle):
+    """tests/parity_sweep.py, sweep_uniform: random parameter VALUES with the borders over-sampled (layer weights around 1e-4,
+    scatter distances across the reciprocal window, ior below 1 and at its clamp), every one-sample verb of the four units."""
+    import parity_sweep
+    rep = parity_sweep.sweep_uniform(gpu, 1 << 16, 20261003, draws=6, verbose=False)
+    assert len(rep) == 6
+    for name, r in rep.items():
+        assert r["beyond_1e5"] == 0, (name, r)
+        if cases.strict_parity():
+            assert r["words_differing"] == 0, (name, r)
+        else:
+            assert r["words_differing"] <= max(4, r["words"] // 100000), (name, r)

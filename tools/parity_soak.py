@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--seeds", default="4242,99,7,1234")
     ap.add_argument("--groups", default="1", help="lanes per point of the n^2-spp loops, e.g. 1,4,16 (RLS_INTEGRATE_GROUP)")
     ap.add_argument("--spp-n", type=int, default=2, help="spp_n of the n^2-spp loops (3 -> 9 samples: ragged for 4 and 16 lanes)")
+    ap.add_argument("--uniform-draws", type=int, default=0,
+                    help="instead: this many random UNIFORM parameter sets per seed through the UNIFORM_ALL kernels (sweep_uniform)")
     args = ap.parse_args()
     ctx = R.Context(0)
     total = {}
@@ -30,13 +32,15 @@ def main():
     groups = args.groups.split(",")
     for seed in seeds:
         for group in groups:
-            for name, r in parity_sweep.sweep(ctx, 1 << args.log2_points, seed, spp_n=args.spp_n, group=group).items():
+            rep = (parity_sweep.sweep_uniform(ctx, 1 << args.log2_points, seed, draws=args.uniform_draws) if args.uniform_draws
+                   else parity_sweep.sweep(ctx, 1 << args.log2_points, seed, spp_n=args.spp_n, group=group))
+            for name, r in rep.items():
                 t = total.setdefault(name, dict(words_differing=0, words=0, max_rel_err=0.0, beyond_1e5=0))
                 t["words_differing"] += r["words_differing"]
                 t["words"] += r["words"]
                 t["beyond_1e5"] += r["beyond_1e5"]
                 t["max_rel_err"] = max(t["max_rel_err"], r["max_rel_err"])
-    summary = dict(points_per_seed=1 << args.log2_points, seeds=seeds, lane_groups=groups, spp_n=args.spp_n, mode="RLS_MATH_EXACT",
+    summary = dict(points_per_seed=1 << args.log2_points, seeds=seeds, lane_groups=groups, spp_n=args.spp_n, mode="RLS_MATH_EXACT", uniform_draws_per_seed=args.uniform_draws,
                    seconds=round(time.time() - t0, 1), closures=total,
                    words=sum(t["words"] for t in total.values()),
                    words_differing=sum(t["words_differing"] for t in total.values()))

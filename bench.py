@@ -60,7 +60,7 @@ S_PARAM0 = 32
 
 WORKLOADS = ["ggx_reflect_refract", "ggx_reflect_refract_uniform", "ggx_reflect", "ggx_eval", "ggx_pdf", "ggx_direct",
              "ggx_shade", "disney_direct", "disney_shade", "disney_integrate", "disney_stream", "disney_triple_diffuse",
-             "disney_triple_glossy", "disney_triple_glossy_uniform", "sss_probe", "sss_probe_uniform", "nd_sample", "sss_scatter", "skin", "skin_uniform", "skin_integrate",
+             "disney_triple_glossy", "disney_triple_glossy_uniform", "disney_triple_glossy_colour_map", "sss_probe", "sss_probe_uniform", "nd_sample", "sss_scatter", "skin", "skin_uniform", "skin_integrate",
              "ggx_reflect_refract_host"]
 
 # every lobe of rlDisney switched on: the parameters of disney_triple_glossy_uniform, one value each for the whole batch
@@ -79,6 +79,7 @@ CONFIG_PRESETS = {2: ("ggx_reflect_refract", 26), 3: ("disney_integrate", 26), 4
 # the `workloads` block of the default line: (workload, log2 points per GPU, timed steps)
 BLOCK_ALL = [("ggx_reflect_refract_uniform", 26, 40), ("ggx_reflect", 26, 40), ("ggx_eval", 26, 40), ("ggx_pdf", 26, 40),
              ("disney_triple_diffuse", 26, 40), ("disney_triple_glossy", 26, 40), ("disney_triple_glossy_uniform", 26, 40),
+             ("disney_triple_glossy_colour_map", 26, 40),
              ("disney_integrate", 26, 12), ("disney_stream", 26, 10),
              ("sss_probe", 25, 40), ("sss_probe", 26, 40), ("sss_probe_uniform", 26, 40), ("nd_sample", 26, 40),
              ("skin", 26, 30), ("skin", 27, 20), ("skin_uniform", 26, 30),
@@ -163,11 +164,23 @@ class Workload:
 
 # planes (n floats each) a workload reads and writes: sizes its arena
 PLANES = {"ggx_reflect_refract": 19 + 12, "ggx_reflect_refract_host": 19, "ggx_reflect_refract_uniform": 13 + 12, "ggx_reflect": 17 + 8,
-          "ggx_eval": 17 + 8 + 3, "ggx_pdf": 17 + 8 + 1, "disney_triple_diffuse": 24 + 7, "disney_triple_glossy": 24 + 7, "disney_triple_glossy_uniform": 11 + 7,
+          "ggx_eval": 17 + 8 + 3, "ggx_pdf": 17 + 8 + 1, "disney_triple_diffuse": 24 + 7, "disney_triple_glossy": 24 + 7, "disney_triple_glossy_uniform": 11 + 7, "disney_triple_glossy_colour_map": 14 + 7,
           "nd_sample": 9 + 7 + 5, "disney_integrate": 22 + 8, "disney_stream": 22 + 8,
           "sss_probe": 17 + 12, "sss_probe_uniform": 11 + 12,
           "sss_scatter": 15 + 3, "skin": 35 + 24, "skin_uniform": 15 + 24, "skin_integrate": 29 + 3 + 15, "ggx_direct": 15 + 3 + 6 + 6,
           "disney_direct": 22 + 3 + 6, "ggx_shade": 15 + 3 + 6 + 4 + 18, "disney_shade": 22 + 3 + 15}     # (the generator's wo planes included where the closure ignores them)
+
+
+def _as_planes(params: dict, n: int, colours=()):
+    """Experiment switch RLS_BENCH_UNIFORM_AS_PLANES for the *_uniform workloads: "1" hands every parameter over as a constant
+    per-point plane (the streamed kernel on the same values), "colours" only the named colour / weight parameters."""
+    mode = os.environ.get("RLS_BENCH_UNIFORM_AS_PLANES", "")
+    if mode not in ("1", "colours"):
+        return params
+    import torch
+    const = lambda v: torch.full((n,), float(v), dtype=torch.float32, device="cuda")
+    return {k: ((torch.stack([const(x) for x in v]) if isinstance(v, tuple) else const(v)) if mode == "1" or k in colours else v)
+            for k, v in params.items()}
 
 
 def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, chunk_log2: int = 20, depth: int = 3):
@@ -267,11 +280,7 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
     elif name == "ggx_reflect_refract_uniform":
         # config 2's kernel as a stub without linked textures runs it: every node parameter one value for the batch
         # (Arnold parameters are constants unless textured), geometry and random numbers streamed
-        params = dict(specColor=(0.9, 0.8, 0.7), ior=1.5, roughness=0.35, anisotropic=0.25)
-        if os.environ.get("RLS_BENCH_UNIFORM_AS_PLANES") == "1":      # experiment switch, as in skin_uniform
-            import torch
-            const = lambda v: torch.full((n,), float(v), dtype=torch.float32, device="cuda")
-            params = {k: (torch.stack([const(x) for x in v]) if isinstance(v, tuple) else const(v)) for k, v in params.items()}
+        params = _as_planes(dict(specColor=(0.9, 0.8, 0.7), ior=1.5, roughness=0.35, anisotropic=0.25), n, ("specColor",))
         g = R.GgxSampler(ctx, wo, N, T, **params)
         xi = [u(S_XI0 + j) for j in range(4)]
         out = (A.planes(3), A.planes(3), A.plane(), A.plane(), A.planes(3), A.plane())
@@ -339,19 +348,22 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
                       "disney_direct_kernel<1, {m}>",
                       "rlDisney light loop: both lobes under two spherical lights, per light 16 light + 2 x 16 BSDF samples "
                       "per point, power-heuristic MIS (src/rlDisney.cpp:695-705; VALU-bound)", bound="valu")
-    elif name == "disney_triple_glossy_uniform":
-        params = dict(DISNEY_UNIFORM)
-        if os.environ.get("RLS_BENCH_UNIFORM_AS_PLANES") == "1":      # experiment switch, as in skin_uniform
-            import torch
-            const = lambda v: torch.full((n,), float(v), dtype=torch.float32, device="cuda")
-            params = {k: (torch.stack([const(x) for x in v]) if isinstance(v, tuple) else const(v)) for k, v in params.items()}
+    elif name in ("disney_triple_glossy_uniform", "disney_triple_glossy_colour_map"):
+        params = _as_planes(dict(DISNEY_UNIFORM), n, ("base_color",))      # experiment switch, as in skin_uniform
+        cmap = name.endswith("colour_map")
+        if cmap:                # a colour map on an otherwise plain node: base_color per point, the ten scalars one value each
+            params["base_color"] = u3(S_KS)
         d = R.DisneySampler(ctx, wo, N, T, **params)
         d.setSampleType(R.RLS_RAY_GLOSSY)
         xi = [u(S_XI0 + j) for j in range(2)]
         out = (A.planes(3), A.planes(3), A.plane())
-        wl = Workload(name, 1, (11 + 7) * 4, lambda: d.sampleEvalPdf(xi[0], xi[1], out=out), "disney_kernel<3, false, {m}, 2>",
-                      "rlDisney one-sample triple, glossy (GTR2 + clearcoat + sheen) lobe, uniform node parameters (every lobe on): "
-                      "wo3 N3 T3 xi2 in, wi3 f3 pdf out; parameter-only arithmetic once per thread")
+        wl = Workload(name, 1, ((14 if cmap else 11) + 7) * 4, lambda: d.sampleEvalPdf(xi[0], xi[1], out=out),
+                      "disney_kernel<3, false, {m}, %d>" % (3 if cmap else 2),
+                      "rlDisney one-sample triple, glossy (GTR2 + clearcoat + sheen) lobe, " +
+                      ("base_color textured, the ten scalars uniform (every lobe on): wo3 N3 T3 base3 xi2 in, wi3 f3 pdf out; "
+                       "scalar-only arithmetic once per thread" if cmap else
+                       "uniform node parameters (every lobe on): wo3 N3 T3 xi2 in, wi3 f3 pdf out; parameter-only arithmetic "
+                       "once per thread"))
     elif name in ("disney_triple_diffuse", "disney_triple_glossy"):
         # the static triple of one lobe, one sample per point (src/rlDisney.cpp:109-152): evalSample -> evalBrdf -> evalPdf
         base = u3(S_KS)
@@ -434,12 +446,10 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
                       "rlSss integrateScatter, 16 probe rays per point on an analytic sphere (SURVEY 8f rank 3; "
                       "VALU-bound)", bound="valu")
     elif name == "skin_uniform":
-        params = dict(SKIN_UNIFORM)
-        if os.environ.get("RLS_BENCH_UNIFORM_AS_PLANES") == "1":
-            # experiment switch: the same values as per-point planes through the streamed kernel (what the hoisting is worth)
-            import torch
-            const = lambda v: torch.full((n,), float(v), dtype=torch.float32, device="cuda")
-            params = {k: (torch.stack([const(x) for x in v]) if isinstance(v, tuple) else const(v)) for k, v in params.items()}
+        # experiment switch RLS_BENCH_UNIFORM_AS_PLANES: "1" the same values as per-point planes through the streamed kernel
+        # (what the hoisting is worth), "colours" only the colours and layer weights (the colour-map case: the MIXED kernel)
+        params = _as_planes(dict(SKIN_UNIFORM), n, ("sss_color", "specular_color", "sheen_color", "sss_weight", "specular_weight",
+                                                    "sheen_weight"))
         sk = R.SkinShader(ctx, wo, N, T, **params)
         xi = A.planes(6)
         for j in range(6):
@@ -526,9 +536,12 @@ def _cpu_leg(workload: str, n: int, threads: int):
                                     env=(1.0, 0.9, 0.8))), 144, "orc_batch_ggx_shade"
         return (lambda: g.direct_lighting(P, lt, 4, SEED, Kd_color=kdc, Kd=kd, Kd_roughness=kdr, Ks=ks)), 48, \
             "orc_batch_ggx_direct_lighting"
-    if workload == "disney_triple_glossy_uniform":
+    if workload in ("disney_triple_glossy_uniform", "disney_triple_glossy_colour_map"):
         wo, N, T = cases.frame(SEED, n)
-        d = O.Disney(wo, N, T, nthreads=threads, **DISNEY_UNIFORM)
+        params = dict(DISNEY_UNIFORM)
+        if workload.endswith("colour_map"):
+            params["base_color"] = u3(S_KS)
+        d = O.Disney(wo, N, T, nthreads=threads, **params)
         x = cases.xi(SEED, n, 2)
         return (lambda: d.sample_eval_pdf(0x10, x[0], x[1])), 1, "orc_batch_disney_sample_eval_pdf"
     if workload in ("disney_integrate", "disney_stream", "disney_direct", "disney_shade", "disney_triple_diffuse",

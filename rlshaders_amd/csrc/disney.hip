@@ -25,17 +25,21 @@ enum { OP_SAMPLE = rlsh::DOP_SAMPLE, OP_EVAL = rlsh::DOP_EVAL, OP_PDF = rlsh::DO
 // the batch (an Arnold parameter is a constant unless a texture is linked to it) and the parameter-only arithmetic -- the
 // constructor (tint, F0, sheen colour, aspect / alpha_x / alpha_y: src/rlDisney.cpp:155-192) and the clearcoat terms the
 // verbs recompute per call (logf(a2), clearcoat / (clearcoat + 1)) -- runs once per thread ahead of the tile loop, its results
-// kept in scalar registers; MIXED tests parameter by parameter in the loop
-enum { MIXED = 0, STREAMED_ALL = 1, UNIFORM_ALL = 2 };
+// kept in scalar registers; UNIFORM_SCALARS the same with base_color as per-point planes (a colour map on an otherwise plain
+// node): the half of the constructor that reads base_color stays per point; MIXED tests parameter by parameter in the loop
+enum { MIXED = 0, STREAMED_ALL = 1, UNIFORM_ALL = 2, UNIFORM_SCALARS = 3 };
 
-__device__ __forceinline__ Disney uniform_closure(const rls_disney_closure &c)
+template <bool WITH_BASE>
+__device__ __forceinline__ Disney uniform_closure(const rls_disney_closure &c, DisneyTints &t)
 {
     const float s[10] = { c.subsurface.u, c.metallic.u, c.specular.u, c.specular_tint.u, c.roughness.u, c.anisotropic.u,
                           c.sheen.u, c.sheen_tint.u, c.clearcoat.u, c.clearcoat_gloss.u };
-    const V3 zero = mk(0.0f, 0.0f, 0.0f);
-    Disney d = disney_make(zero, zero, zero, c.base_color.ur, c.base_color.ug, c.base_color.ub, s);
+    Disney d = {};
+    t = disney_make_scalars(d, s);
+    if (WITH_BASE) disney_make_base(d, t, c.base_color.ur, c.base_color.ug, c.base_color.ub);
     disney_prepare_material(d);
     disney_wave_uniform(d);
+    t = disney_wave_uniform(t);
     return d;
 }
 
@@ -64,7 +68,9 @@ __global__ __launch_bounds__(rlsh::kBlock) void disney_kernel(DisneyIO a0)
 {
     stage_libm_tables();   // powf / logf tables -> LDS (EXACT mode)
     Disney ud = {};
-    if (MODE == UNIFORM_ALL) ud = uniform_closure(a0.c);
+    DisneyTints ut = {};
+    if (MODE == UNIFORM_ALL) ud = uniform_closure<true>(a0.c, ut);
+    if (MODE == UNIFORM_SCALARS) ud = uniform_closure<false>(a0.c, ut);
     const TileRange tiles = tile_range(a0.n);
     for (int64_t base = tiles.first; base < tiles.end; base += tiles.step) {
         const Idx i = make_idx(base);
@@ -72,12 +78,17 @@ __global__ __launch_bounds__(rlsh::kBlock) void disney_kernel(DisneyIO a0)
         // plane pointers re-read from the kernarg segment where they are used (rls_internal.hpp, reload_args)
         const DisneyIO a = RLS_DISNEY_ARGS(a0);
         Disney d;
-        if (MODE == UNIFORM_ALL) {
+        if (MODE == UNIFORM_ALL || MODE == UNIFORM_SCALARS) {
             d = ud;
             d.view = ld3(a.c.wo, i);
             d.fr.N = ld3(a.c.N, i);
             d.fr.U = ld3(a.c.T, i);
             d.fr.V = cross(d.fr.N, d.fr.U);
+            if (MODE == UNIFORM_SCALARS) {
+                float br, bg, bb;
+                ldrgb<true>(a.c.base_color, i, br, bg, bb);
+                disney_make_base(d, ut, br, bg, bb);
+            }
             disney_prepare_view(d);
         } else {
             d = load_closure<MODE == STREAMED_ALL>(a.c, i);
@@ -124,17 +135,19 @@ rls_status launch_kernel(rls_context *ctx, int lobe, const DisneyIO &io, const c
     const bool streamed = c.base_color.r && c.subsurface.v && c.metallic.v && c.specular.v && c.specular_tint.v &&
                           c.roughness.v && c.anisotropic.v && c.sheen.v && c.sheen_tint.v && c.clearcoat.v &&
                           c.clearcoat_gloss.v;
-    const bool uniform = !c.base_color.r && !c.subsurface.v && !c.metallic.v && !c.specular.v && !c.specular_tint.v &&
-                         !c.roughness.v && !c.anisotropic.v && !c.sheen.v && !c.sheen_tint.v && !c.clearcoat.v &&
-                         !c.clearcoat_gloss.v;
+    const bool scalars = !c.subsurface.v && !c.metallic.v && !c.specular.v && !c.specular_tint.v && !c.roughness.v &&
+                         !c.anisotropic.v && !c.sheen.v && !c.sheen_tint.v && !c.clearcoat.v && !c.clearcoat_gloss.v;
+    const bool uniform = scalars && !c.base_color.r, colour_map = scalars && c.base_color.r;
     const dim3 block(rlsh::kBlock);
     if (lobe == RLS_RAY_DIFFUSE) {
         if (streamed) hipLaunchKernelGGL((disney_kernel<OP, true, RLS_FAST, STREAMED_ALL>), grid, block, 0, ctx->stream, io);
         else if (uniform) hipLaunchKernelGGL((disney_kernel<OP, true, RLS_FAST, UNIFORM_ALL>), grid, block, 0, ctx->stream, io);
+        else if (colour_map) hipLaunchKernelGGL((disney_kernel<OP, true, RLS_FAST, UNIFORM_SCALARS>), grid, block, 0, ctx->stream, io);
         else hipLaunchKernelGGL((disney_kernel<OP, true, RLS_FAST, MIXED>), grid, block, 0, ctx->stream, io);
     } else {
         if (streamed) hipLaunchKernelGGL((disney_kernel<OP, false, RLS_FAST, STREAMED_ALL>), grid, block, 0, ctx->stream, io);
         else if (uniform) hipLaunchKernelGGL((disney_kernel<OP, false, RLS_FAST, UNIFORM_ALL>), grid, block, 0, ctx->stream, io);
+        else if (colour_map) hipLaunchKernelGGL((disney_kernel<OP, false, RLS_FAST, UNIFORM_SCALARS>), grid, block, 0, ctx->stream, io);
         else hipLaunchKernelGGL((disney_kernel<OP, false, RLS_FAST, MIXED>), grid, block, 0, ctx->stream, io);
     }
     return rlsh::check_launch(name);

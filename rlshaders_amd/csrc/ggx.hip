@@ -26,19 +26,21 @@ using namespace rlsh;   // GgxOp, GgxIO
 #endif
 
 // MODE (checked on the host): STREAMED_ALL every closure parameter is a per-point plane (no stream-or-uniform tests in the
-// loop); UNIFORM_ALL every one is a single value for the batch (an Arnold parameter is a constant unless a texture is linked
-// to it) and the parameter-only half of the constructor (ggx_material: aspect, alpha_x, alpha_y, the reciprocal ior) runs
-// once per thread ahead of the tile loop, its results kept in scalar registers; MIXED tests parameter by parameter
-enum { MIXED = 0, STREAMED_ALL = 1, UNIFORM_ALL = 2 };
+// loop); UNIFORM_MATERIAL roughness, ior and anisotropic are single values for the batch (an Arnold parameter is a constant
+// unless a texture is linked to it; specColor may be either -- it enters no arithmetic of the constructor) and the
+// parameter-only half of the constructor (ggx_material: aspect, alpha_x, alpha_y, the reciprocal ior) runs once per thread
+// ahead of the tile loop, its results kept in scalar registers; MIXED tests parameter by parameter
+enum { MIXED = 0, STREAMED_ALL = 1, UNIFORM_MATERIAL = 2 };
 
 template <int MODE>
 __device__ __forceinline__ Ggx load_closure(const rls_ggx_closure &c, Idx i, const GgxMaterial &um)
 {
     constexpr bool STREAMED = MODE == STREAMED_ALL;
     V3 wo = ld3(c.wo, i), N = ld3(c.N, i), T = ld3(c.T, i);
-    if (MODE == UNIFORM_ALL) return ggx_from_material(um, wo, N, T, c.exiting ? (c.exiting[i.full()] != 0) : false);
     float kr, kg, kb;
     ldrgb<STREAMED>(c.KsColor, i, kr, kg, kb);
+    if (MODE == UNIFORM_MATERIAL)
+        return ggx_from_material(um, wo, N, T, c.exiting ? (c.exiting[i.full()] != 0) : false, kr, kg, kb);
     float rough = ldp<STREAMED>(c.specularRoughness, i);
     float ior = ldp<STREAMED>(c.ior, i);
     float aniso = ldp<STREAMED>(c.anisotropic, i);
@@ -53,10 +55,9 @@ __global__ RLS_KERNEL_ATTR void ggx_kernel(GgxIO a0)
     if (OP == OP_SAMPLE || OP == OP_FUSED || OP == OP_REFLECT_REFRACT || OP == OP_REFRACT || OP == OP_MICROFACET)
         stage_libm_tables();   // the range table of atanf -> LDS (visible-normal sampling calls atan2f twice)
     GgxMaterial um = {};
-    if (MODE == UNIFORM_ALL) {
+    if (MODE == UNIFORM_MATERIAL) {
         const rls_ggx_closure &c = a0.c;
-        um = ggx_material_wave_uniform(ggx_material(c.KsColor.ur, c.KsColor.ug, c.KsColor.ub, c.ior.u, c.specularRoughness.u,
-                                                    c.anisotropic.u));
+        um = ggx_material_wave_uniform(ggx_material(c.ior.u, c.specularRoughness.u, c.anisotropic.u));
     }
     const TileRange tiles = tile_range(a0.n);
     for (int64_t base = tiles.first; base < tiles.end; base += tiles.step) {
@@ -149,11 +150,11 @@ rls_status launch_kernel(rls_context *ctx, const GgxIO &io, const char *name)
 #else
     const bool streamed = c.KsColor.r && c.specularRoughness.v && c.ior.v && c.anisotropic.v;
 #endif
-    const bool uniform = !c.KsColor.r && !c.specularRoughness.v && !c.ior.v && !c.anisotropic.v;
+    const bool uniform = !c.specularRoughness.v && !c.ior.v && !c.anisotropic.v;       // specColor: either
     if (streamed)
         hipLaunchKernelGGL((ggx_kernel<OP, RLS_FAST, STREAMED_ALL>), rlsh::grid_for(ctx, io.n, rlsh::kBlock, RLS_CAP_MULT), dim3(rlsh::kBlock), 0, ctx->stream, io);
     else if (uniform)   // under the context's cap: a thread that hoists wants many tiles to spread the hoisted work over
-        hipLaunchKernelGGL((ggx_kernel<OP, RLS_FAST, UNIFORM_ALL>), rlsh::grid_for(ctx, io.n, rlsh::kBlock, RLS_GGX_UNIFORM_CAP), dim3(rlsh::kBlock), 0, ctx->stream, io);
+        hipLaunchKernelGGL((ggx_kernel<OP, RLS_FAST, UNIFORM_MATERIAL>), rlsh::grid_for(ctx, io.n, rlsh::kBlock, RLS_GGX_UNIFORM_CAP), dim3(rlsh::kBlock), 0, ctx->stream, io);
     else
         hipLaunchKernelGGL((ggx_kernel<OP, RLS_FAST, MIXED>), rlsh::grid_for(ctx, io.n, rlsh::kBlock, RLS_CAP_MULT), dim3(rlsh::kBlock), 0, ctx->stream, io);
     return rlsh::check_launch(name);

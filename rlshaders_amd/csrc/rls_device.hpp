@@ -492,7 +492,6 @@ struct Ggx {
 // one value for the batch evaluates it once per thread (ggx_material + ggx_material_wave_uniform), every other kernel per
 // point through ggx_make() -- the same expressions either way.
 struct GgxMaterial {
-    float ksR, ksG, ksB;
     float rough, ax, ay;
     float out, rout;      // max(ior, 1e-4) and its reciprocal
 };
@@ -500,10 +499,9 @@ struct GgxMaterial {
 // ISOTROPIC: the caller passes anisotropic = 0 (rlSkin's lobes, src/rlSkin.cpp:192,215): aspect = sqrtf(1 - 0 * 0.9) is
 // exactly 1, r^2 / 1 and r^2 * 1 are r^2 -- the square root, the division and the product are skipped, same bits
 template <bool ISOTROPIC = false>
-RLS_DEV GgxMaterial ggx_material(float ksR, float ksG, float ksB, float ior, float roughness, float anisotropic)
+RLS_DEV GgxMaterial ggx_material(float ior, float roughness, float anisotropic)
 {
     GgxMaterial m;
-    m.ksR = ksR; m.ksG = ksG; m.ksB = ksB;
     m.out = maxf(ior, 1e-4f);
     if (ISOTROPIC) {
         m.ax = maxf(1e-4f, sqr(roughness));
@@ -520,10 +518,12 @@ RLS_DEV GgxMaterial ggx_material(float ksR, float ksG, float ksB, float ior, flo
     return m;
 }
 
-RLS_DEV Ggx ggx_from_material(const GgxMaterial &m, V3 wo, V3 N, V3 T, bool exiting)
+// ks: specColor enters no arithmetic of the constructor (it scales evalBrdf's result), so it may be a per-point plane
+// beside a hoisted material
+RLS_DEV Ggx ggx_from_material(const GgxMaterial &m, V3 wo, V3 N, V3 T, bool exiting, float ksR, float ksG, float ksB)
 {
     Ggx g;
-    g.ksR = m.ksR; g.ksG = m.ksG; g.ksB = m.ksB;
+    g.ksR = ksR; g.ksG = ksG; g.ksB = ksB;
     const float in = 1.0f;
     g.iorIn = exiting ? m.out : in;
     g.iorOut = exiting ? in : m.out;
@@ -547,7 +547,6 @@ RLS_DEV Ggx ggx_from_material(const GgxMaterial &m, V3 wo, V3 N, V3 T, bool exit
 
 RLS_DEV GgxMaterial ggx_material_wave_uniform(GgxMaterial m)
 {
-    m.ksR = wave_uniform(m.ksR); m.ksG = wave_uniform(m.ksG); m.ksB = wave_uniform(m.ksB);
     m.rough = wave_uniform(m.rough); m.ax = wave_uniform(m.ax); m.ay = wave_uniform(m.ay);
     m.out = wave_uniform(m.out); m.rout = wave_uniform(m.rout);
     return m;
@@ -557,7 +556,7 @@ template <bool ISOTROPIC = false>
 RLS_DEV Ggx ggx_make(V3 wo, V3 N, V3 T, bool exiting, float ksR, float ksG, float ksB,
                      float ior, float roughness, float anisotropic)
 {
-    return ggx_from_material(ggx_material<ISOTROPIC>(ksR, ksG, ksB, ior, roughness, anisotropic), wo, N, T, exiting);
+    return ggx_from_material(ggx_material<ISOTROPIC>(ior, roughness, anisotropic), wo, N, T, exiting, ksR, ksG, ksB);
 }
 
 // src/rlGgx.h:249-270
@@ -710,44 +709,56 @@ struct Disney {
     float om;                     // 1 - metallic
 };
 
+// The constructor (src/rlDisney.cpp:155-192) in two halves: what the ten scalars alone decide, and what needs base_color.
+// A kernel whose scalars are one value for the batch runs the first half once per thread (and the second as well when
+// base_color is uniform too); disney_make() is the two in sequence.
 // s: subsurface, metallic, specular, specular_tint, roughness, anisotropic, sheen, sheen_tint,
 //    clearcoat, clearcoat_gloss
-RLS_DEV Disney disney_make(V3 wo, V3 N, V3 T, float bR, float bG, float bB, const float (&s)[10])
+struct DisneyTints { float specular, specularTint, sheen, sheenTint; };     // the scalars the base_color half reads
+RLS_DEV DisneyTints disney_make_scalars(Disney &d, const float (&s)[10])
 {
-    Disney d;
-    d.baseR = bR; d.baseG = bG; d.baseB = bB;
+    DisneyTints t;
     d.subsurface = s[0];
     d.metallic = s[1];
-    float specular = s[2] * 0.08f;
-    float specularTint = s[3];
+    t.specular = s[2] * 0.08f;
+    t.specularTint = s[3];
     d.roughness = s[4];
     float anisotropic = s[5];
-    float sheen = s[6];
-    float sheenTint = s[7];
+    t.sheen = s[6];
+    t.sheenTint = s[7];
     d.clearcoat = s[8] * 0.25f;
     d.clearcoatGloss = s[9];
-    d.view = wo;
-    d.fr.N = N;
-    d.fr.U = T;
-    d.fr.V = cross(N, T);
-
     float aspect = R_SQRT1M(anisotropic * 0.9f);
     d.ax = maxf(1e-2f, R_DIV(sqr(d.roughness), aspect));
     d.ay = maxf(1e-2f, sqr(d.roughness) * aspect);
     d.specRough = sqr(d.roughness);
-
+    return t;
+}
+RLS_DEV void disney_make_base(Disney &d, const DisneyTints &t, float bR, float bG, float bB)
+{
+    d.baseR = bR; d.baseG = bG; d.baseB = bB;
     float lum = luminance(bR, bG, bB);
     float tR = 1.0f, tG = 1.0f, tB = 1.0f;
     if (lum > 0.0f) { tR = R_DIV(bR, lum); tG = R_DIV(bG, lum); tB = R_DIV(bB, lum); }
-    float mR = lerpf(specularTint, 1.0f, tR) * specular;
-    float mG = lerpf(specularTint, 1.0f, tG) * specular;
-    float mB = lerpf(specularTint, 1.0f, tB) * specular;
+    float mR = lerpf(t.specularTint, 1.0f, tR) * t.specular;
+    float mG = lerpf(t.specularTint, 1.0f, tG) * t.specular;
+    float mB = lerpf(t.specularTint, 1.0f, tB) * t.specular;
     d.f0R = lerpf(d.metallic, mR, bR);
     d.f0G = lerpf(d.metallic, mG, bG);
     d.f0B = lerpf(d.metallic, mB, bB);
-    d.shR = lerpf(sheenTint, 1.0f, tR) * sheen;
-    d.shG = lerpf(sheenTint, 1.0f, tG) * sheen;
-    d.shB = lerpf(sheenTint, 1.0f, tB) * sheen;
+    d.shR = lerpf(t.sheenTint, 1.0f, tR) * t.sheen;
+    d.shG = lerpf(t.sheenTint, 1.0f, tG) * t.sheen;
+    d.shB = lerpf(t.sheenTint, 1.0f, tB) * t.sheen;
+}
+RLS_DEV Disney disney_make(V3 wo, V3 N, V3 T, float bR, float bG, float bB, const float (&s)[10])
+{
+    Disney d;
+    d.view = wo;
+    d.fr.N = N;
+    d.fr.U = T;
+    d.fr.V = cross(N, T);
+    const DisneyTints t = disney_make_scalars(d, s);
+    disney_make_base(d, t, bR, bG, bB);
     return d;
 }
 
@@ -820,6 +831,12 @@ RLS_DEV void disney_wave_uniform(Disney &d)
     d.specRough = wave_uniform(d.specRough); d.ax = wave_uniform(d.ax); d.ay = wave_uniform(d.ay);
     d.ccA2m1 = wave_uniform(d.ccA2m1); d.ccLogA2 = wave_uniform(d.ccLogA2); d.ccw = wave_uniform(d.ccw);
     d.gtr2Weight = wave_uniform(d.gtr2Weight); d.om = wave_uniform(d.om);
+}
+RLS_DEV DisneyTints disney_wave_uniform(DisneyTints t)
+{
+    t.specular = wave_uniform(t.specular); t.specularTint = wave_uniform(t.specularTint);
+    t.sheen = wave_uniform(t.sheen); t.sheenTint = wave_uniform(t.sheenTint);
+    return t;
 }
 
 // evalDiffuse, src/rlDisney.cpp:199-236 (BRDF without the cosine)

@@ -34,10 +34,11 @@ __device__ __forceinline__ LobeOut lobe_from_microfacet(const Ggx &g, V3 M)
 }
 
 // One isotropic GGX lobe of rlSkin (src/rlSkin.cpp:192,215: anisotropic defaulted to 0).
-__device__ __forceinline__ LobeOut ggx_lobe(V3 wo, V3 N, V3 T, V3 local, const GgxMaterial &m, float rx, float ry)
+__device__ __forceinline__ LobeOut ggx_lobe(V3 wo, V3 N, V3 T, V3 local, const GgxMaterial &m, float cr, float cg, float cb,
+                                            float rx, float ry)
 {
     LobeOut o;
-    Ggx g = ggx_from_material(m, wo, N, T, false);
+    Ggx g = ggx_from_material(m, wo, N, T, false, cr, cg, cb);
     // `local` = the view in the shared (T, N x T, N) frame: the same for both lobes, computed once
     VndfView w = vndf_view_from(local, g.ax, g.ay);
     V3 M = vndf_microfacet(w, g.fr, rx, ry);
@@ -50,7 +51,10 @@ __device__ __forceinline__ LobeOut ggx_lobe(V3 wo, V3 N, V3 T, V3 local, const G
 // MODE (checked on the host): STREAMED every parameter is a per-point plane; UNIFORM every parameter is one value for the batch
 // (an Arnold parameter is a constant unless a texture is linked to it): the parameter-only arithmetic -- the two lobes'
 // roughness / ior terms, NDProfile::setDistance with its six expf -- runs once per thread ahead of the tile loop and stays in
-// scalar registers; MIXED tests parameter by parameter in the loop
+// scalar registers -- with the layer weights uniform as well the gates of the three layers are scalar branches; MIXED tests
+// parameter by parameter in the loop.  (Measured and not kept: a relaxed form that lets the colours and weights be planes beside
+// hoisted roughness / ior / distance terms -- the colour-map case -- gains 1 % over STREAMED there and costs the all-uniform case
+// 6 %: 3.47 -> 3.73 ms.)
 enum { MIXED = 0, STREAMED_ALL = 1, UNIFORM_ALL = 2 };
 #ifndef RLS_SKIN_SGPR          // experiment switch: which hoisted values move to scalar registers (1 the lobes', 2 NDProfile)
 #define RLS_SKIN_SGPR 3
@@ -70,9 +74,8 @@ __global__ __launch_bounds__(rlsh::kBlock) void skin_kernel(SkinIO a0)
     NdProfile up = {};
     if (UNIFORM) {
         const rls_skin_closure &c = a0.c;
-        um1 = ggx_material<true>(c.sheen_color.ur, c.sheen_color.ug, c.sheen_color.ub, c.sheen_ior.u, c.sheen_roughness.u, 0.0f);
-        um2 = ggx_material<true>(c.specular_color.ur, c.specular_color.ug, c.specular_color.ub, c.specular_ior.u,
-                                 c.specular_roughness.u, 0.0f);
+        um1 = ggx_material<true>(c.sheen_ior.u, c.sheen_roughness.u, 0.0f);
+        um2 = ggx_material<true>(c.specular_ior.u, c.specular_roughness.u, 0.0f);
         const float mult = c.sss_dist_multiplier.u;                               // src/rlSkin.cpp:235-236
         up = nd_make<RLS_SKIN_ND_RECIP != 0>(c.sss_scatter_dist[0].u * mult, c.sss_scatter_dist[1].u * mult, c.sss_scatter_dist[2].u * mult);
         if (RLS_SKIN_SGPR & 1) { um1 = ggx_material_wave_uniform(um1); um2 = ggx_material_wave_uniform(um2); }
@@ -95,23 +98,25 @@ __global__ __launch_bounds__(rlsh::kBlock) void skin_kernel(SkinIO a0)
 
         float sheenWeight = LDP(c.sheen_weight);
         float shr = 0.0f, shg = 0.0f, shb = 0.0f;
-        if (!UNIFORM) ldrgb<STREAMED>(c.sheen_color, i, shr, shg, shb);
+        if (UNIFORM) { shr = c.sheen_color.ur; shg = c.sheen_color.ug; shb = c.sheen_color.ub; }
+        else ldrgb<STREAMED>(c.sheen_color, i, shr, shg, shb);
         float sheenIor = LDP(c.sheen_ior), sheenRough = LDP(c.sheen_roughness);
         float rx0 = ldg(a.xi[0], i), ry0 = ldg(a.xi[1], i);
         float specWeight = LDP(c.specular_weight);
         float spr = 0.0f, spg = 0.0f, spb = 0.0f;
-        if (!UNIFORM) ldrgb<STREAMED>(c.specular_color, i, spr, spg, spb);
+        if (UNIFORM) { spr = c.specular_color.ur; spg = c.specular_color.ug; spb = c.specular_color.ub; }
+        else ldrgb<STREAMED>(c.specular_color, i, spr, spg, spb);
         float specIor = LDP(c.specular_ior), specRough = LDP(c.specular_roughness);
         float rx1 = ldg(a.xi[2], i), ry1 = ldg(a.xi[3], i);
         const bool sheenOn = sheenWeight > kEps, specOn = specWeight > kEps;          // src/rlSkin.cpp:191, 214
-        const GgxMaterial m1 = UNIFORM ? um1 : ggx_material<true>(shr, shg, shb, sheenIor, sheenRough, 0.0f);
-        const GgxMaterial m2 = UNIFORM ? um2 : ggx_material<true>(spr, spg, spb, specIor, specRough, 0.0f);
+        const GgxMaterial m1 = UNIFORM ? um1 : ggx_material<true>(sheenIor, sheenRough, 0.0f);
+        const GgxMaterial m2 = UNIFORM ? um2 : ggx_material<true>(specIor, specRough, 0.0f);
 #ifndef RLS_NO_PAIR_COMPACTION
         if (UNIFORM ? (sheenOn && specOn) : __builtin_amdgcn_ballot_w64(sheenOn && specOn) == ~0ull) {
             // every lane of the wavefront evaluates both lobes: their two microfacet samples share one pass of the
             // uniform-slope fallback (vndf_microfacet_pair)
-            Ggx g1 = ggx_from_material(m1, wo, N, T, false);
-            Ggx g2 = ggx_from_material(m2, wo, N, T, false);
+            Ggx g1 = ggx_from_material(m1, wo, N, T, false, shr, shg, shb);
+            Ggx g2 = ggx_from_material(m2, wo, N, T, false, spr, spg, spb);
             VndfView w1 = vndf_view_from(local, g1.ax, g1.ay), w2 = vndf_view_from(local, g2.ax, g2.ay);
             V3 M1, M2;
             vndf_microfacet_pair(w1, g1.fr, rx0, ry0, w2, g2.fr, rx1, ry1, M1, M2);
@@ -123,11 +128,11 @@ __global__ __launch_bounds__(rlsh::kBlock) void skin_kernel(SkinIO a0)
 #endif
         {
             if (sheenOn) {
-                sh = ggx_lobe(wo, N, T, local, m1, rx0, ry0);
+                sh = ggx_lobe(wo, N, T, local, m1, shr, shg, shb, rx0, ry0);
                 sheenFresnel = sh.F * sheenWeight;
             }
             if (specOn) {
-                sp = ggx_lobe(wo, N, T, local, m2, rx1, ry1);
+                sp = ggx_lobe(wo, N, T, local, m2, spr, spg, spb, rx1, ry1);
                 specularFresnel = sp.F * specWeight;
             }
         }

@@ -286,8 +286,9 @@ SKIN_UNIFORM_CASES = {
 }
 
 
+@pytest.mark.parametrize("maps", [False, True])
 @pytest.mark.parametrize("case", sorted(SKIN_UNIFORM_CASES))
-def test_skin_uniform_parameters_are_hoisted_and_bit_identical(gpu, oracle, case):
+def test_skin_uniform_parameters_are_hoisted_and_bit_identical(gpu, oracle, case, maps):
     """Every parameter one value for the batch: skin_kernel<UNIFORM_ALL> evaluates the parameter-only arithmetic once per thread
     (the lobes' roughness / ior terms, NDProfile::setDistance).  Its 24 outputs equal the oracle's and those of the streamed
     kernel (the same values as per-point planes) bit for bit, with layers switched off, weights on the 1e-4 threshold,
@@ -295,11 +296,21 @@ def test_skin_uniform_parameters_are_hoisted_and_bit_identical(gpu, oracle, case
     n = 1 << 14
     wo, N, T = cases.frame(cases.SEED_PARITY, n)
     xi = cases.xi(cases.SEED_PARITY, n, 6)
-    p = SKIN_UNIFORM_CASES[case]
+    p = dict(SKIN_UNIFORM_CASES[case])
+    if maps:      # the colours and layer weights textured (per-point planes, weights straddling the 1e-4 gates), the rest plain:
+        # the MIXED kernel (per-parameter tests in the loop)
+        m = cases.skin_mixed(cases.SEED_EDGE, n)["params"]
+        for k in ("sss_color", "specular_color", "sheen_color", "sss_weight", "specular_weight", "sheen_weight"):
+            p[k] = m[k].copy()
+        for k in ("sss_weight", "specular_weight", "sheen_weight"):
+            p[k][::11] = np.float32(1e-4)
+            p[k][5::13] = np.float32(0.0)
     ref = oracle.skin(wo, N, T, p, xi, nthreads=4)
-    planes = {k: (np.repeat(np.asarray(v, np.float32)[:, None], n, axis=1) if np.ndim(v) else np.full(n, v, np.float32))
+    planes = {k: (v if isinstance(v, np.ndarray) else
+                  np.repeat(np.asarray(v, np.float32)[:, None], n, axis=1) if np.ndim(v) else np.full(n, v, np.float32))
               for k, v in p.items()}
-    gu = {k: host(v) for k, v in R.SkinShader(gpu, dev(wo), dev(N), dev(T), **p).sampleEvalPdf(dev(xi)).items()}
+    gu = {k: host(v) for k, v in R.SkinShader(gpu, dev(wo), dev(N), dev(T), **{k: dev(v) for k, v in p.items()})
+          .sampleEvalPdf(dev(xi)).items()}
     gs = {k: host(v) for k, v in R.SkinShader(gpu, dev(wo), dev(N), dev(T), **{k: dev(v) for k, v in planes.items()})
           .sampleEvalPdf(dev(xi)).items()}
     for k in SKIN_KEYS:

@@ -1,6 +1,7 @@
-"""The UNIFORM_ALL specialisations of the pointwise kernels (ggx.hip, disney.hip; rlSss / rlSkin: test_gpu_sss_skin.py): with
-every node parameter one value for the batch -- an Arnold parameter is a constant unless a texture is linked to it -- the
-parameter-only arithmetic runs once per thread ahead of the tile loop and stays in scalar registers.  The results must be the
+"""The UNIFORM_* specialisations of the pointwise kernels (ggx.hip, disney.hip, skin.hip; rlSss: test_gpu_sss_skin.py): with
+the node parameters that enter parameter-only arithmetic one value for the batch -- an Arnold parameter is a constant unless a
+texture is linked to it -- that arithmetic runs once per thread ahead of the tile loop and stays in scalar registers.  Colours
+(rlGgx's specColor, rlDisney's base_color) may be per-point planes beside it: the colour-map case.  The results must be the
 per-point evaluation's: every verb is compared bit for bit with the STREAMED kernel given the same values as per-point planes,
 and with the oracle under the gates of the mixed-parameter tests."""
 import numpy as np
@@ -32,21 +33,28 @@ def _same(a, b, what):
     assert ok.all(), (what, int((~ok).sum()))
 
 
+def _full3(v, n):
+    return v if isinstance(v, np.ndarray) and v.ndim == 2 else _planes(v, n)
+
+
 def _planes(v, n):
     return np.repeat(np.asarray(v, np.float32)[:, None], n, axis=1) if np.ndim(v) else np.full(n, v, np.float32)
 
 
+@pytest.mark.parametrize("colour_map", [False, True])
 @pytest.mark.parametrize("exiting", [False, True])
 @pytest.mark.parametrize("name", sorted(GGX_UNIFORM))
-def test_ggx_uniform_equals_streamed_and_oracle(gpu, oracle, name, exiting):
-    p = GGX_UNIFORM[name]
+def test_ggx_uniform_equals_streamed_and_oracle(gpu, oracle, name, exiting, colour_map):
+    p = dict(GGX_UNIFORM[name])
     wo, Nn, T = cases.frame(cases.SEED_PARITY, N)
     x = cases.xi(cases.SEED_PARITY, N, 4)
+    if colour_map:                       # specColor textured, the rest of the node plain
+        p["KsColor"] = cases.xi(cases.SEED_EDGE, N, 3)
     ex = (np.arange(N) % 3 == 0).astype(np.uint8) if exiting else None
     exd = None if ex is None else torch.from_numpy(ex).cuda()
-    su = R.GgxSampler(gpu, dev(wo), dev(Nn), dev(T), specColor=p["KsColor"], ior=p["ior"], roughness=p["roughness"],
+    su = R.GgxSampler(gpu, dev(wo), dev(Nn), dev(T), specColor=dev(p["KsColor"]), ior=p["ior"], roughness=p["roughness"],
                       anisotropic=p["anisotropic"], exiting=exd)
-    ss = R.GgxSampler(gpu, dev(wo), dev(Nn), dev(T), specColor=dev(_planes(p["KsColor"], N)), ior=dev(_planes(p["ior"], N)),
+    ss = R.GgxSampler(gpu, dev(wo), dev(Nn), dev(T), specColor=dev(_full3(p["KsColor"], N)), ior=dev(_planes(p["ior"], N)),
                       roughness=dev(_planes(p["roughness"], N)), anisotropic=dev(_planes(p["anisotropic"], N)), exiting=exd)
     og = ggx_oracle(oracle, dict(wo=wo, N=Nn, T=T, **p), exiting=ex)
     dx = [dev(t) for t in x]
@@ -91,14 +99,18 @@ DISNEY_DEFAULTS = dict(subsurface=0.0, metallic=0.0, specular=0.5, specular_tint
                        sheen_tint=0.5, clearcoat=0.0, clearcoat_gloss=1.0)
 
 
+@pytest.mark.parametrize("colour_map", [False, True])
 @pytest.mark.parametrize("name", sorted(DISNEY_UNIFORM))
-def test_disney_uniform_equals_streamed_and_oracle(gpu, oracle, name):
+def test_disney_uniform_equals_streamed_and_oracle(gpu, oracle, name, colour_map):
     p = dict(DISNEY_DEFAULTS, **DISNEY_UNIFORM[name])
     wo, Nn, T = cases.frame(cases.SEED_PARITY, N)
     x = cases.xi(cases.SEED_PARITY, N, 2)
     dx = [dev(t) for t in x]
-    du = R.DisneySampler(gpu, dev(wo), dev(Nn), dev(T), **p)
-    ds = R.DisneySampler(gpu, dev(wo), dev(Nn), dev(T), **{k: dev(_planes(v, N)) for k, v in p.items()})
+    if colour_map:                       # base_color textured (with black texels), the ten scalars plain: UNIFORM_SCALARS
+        p["base_color"] = cases.xi(cases.SEED_EDGE, N, 3)
+        p["base_color"][:, ::7] = 0.0
+    du = R.DisneySampler(gpu, dev(wo), dev(Nn), dev(T), **{k: dev(v) for k, v in p.items()})
+    ds = R.DisneySampler(gpu, dev(wo), dev(Nn), dev(T), **{k: dev(_full3(v, N)) for k, v in p.items()})
     od = oracle.Disney(wo, Nn, T, nthreads=4, **p)
     for lobe in (R.RLS_RAY_DIFFUSE, R.RLS_RAY_GLOSSY):
         du.setSampleType(lobe); ds.setSampleType(lobe)

@@ -13,7 +13,8 @@ ROWS = (("ggx_reflect_refract", "2"), ("sss_probe", "4 (kernel; 2²⁸ points ov
         ("ggx_eval", "— (`evalBrdf` alone)"), ("ggx_pdf", "— (`evalPdf` alone)"),
         ("disney_triple_diffuse", "— (rlDisney one-sample triple, diffuse lobe)"),
         ("disney_triple_glossy", "— (rlDisney one-sample triple, glossy lobe)"),
-        ("disney_triple_glossy_uniform", "— (the same with uniform node parameters)"), ("nd_sample", "4, profile-only variant"),
+        ("disney_triple_glossy_uniform", "— (the same with uniform node parameters)"),
+        ("disney_triple_glossy_colour_map", "— (the same with base_color textured, the scalars uniform)"), ("nd_sample", "4, profile-only variant"),
         ("sss_probe_uniform", "4 with a uniform scatter distance"), ("skin_uniform", "5 with uniform node parameters"),
         ("skin_integrate", "— (rlSkin `shader_evaluate`, 16 samples per layer, no lights)"),
         ("ggx_shade", "— (rlGgx `shader_evaluate`, whole: two lights × 48 + 3 × 16 samples per point)"),

@@ -5,7 +5,7 @@
 TAG=${1:-r03}
 PROFILE_STEPS=200 bash tools/profile_workload.sh $TAG ggx_reflect_refract --math exact
 for w in skin sss_probe disney_integrate disney_stream ggx_reflect_refract_uniform ggx_reflect ggx_eval ggx_pdf disney_triple_diffuse disney_triple_glossy nd_sample \
-         disney_triple_glossy_uniform sss_probe_uniform skin_uniform \
+         disney_triple_glossy_uniform disney_triple_glossy_colour_map sss_probe_uniform skin_uniform \
          skin_integrate ggx_shade disney_shade disney_direct ggx_direct sss_scatter; do
   bash tools/profile_workload.sh $TAG $w --math exact
 done

@@ -130,7 +130,6 @@ rls_status check_closure(const rls_disney_closure *c, int lobe)
 template <int OP>
 rls_status launch_kernel(rls_context *ctx, int lobe, const DisneyIO &io, const char *name)
 {
-    dim3 grid = rlsh::grid_for(ctx, io.n);
     const rls_disney_closure &c = io.c;
     const bool streamed = c.base_color.r && c.subsurface.v && c.metallic.v && c.specular.v && c.specular_tint.v &&
                           c.roughness.v && c.anisotropic.v && c.sheen.v && c.sheen_tint.v && c.clearcoat.v &&
@@ -138,6 +137,7 @@ rls_status launch_kernel(rls_context *ctx, int lobe, const DisneyIO &io, const c
     const bool scalars = !c.subsurface.v && !c.metallic.v && !c.specular.v && !c.specular_tint.v && !c.roughness.v &&
                          !c.anisotropic.v && !c.sheen.v && !c.sheen_tint.v && !c.clearcoat.v && !c.clearcoat_gloss.v;
     const bool uniform = scalars && !c.base_color.r, colour_map = scalars && c.base_color.r;
+    const dim3 grid = scalars ? rlsh::grid_for_hoisting(ctx, io.n) : rlsh::grid_for(ctx, io.n);
     const dim3 block(rlsh::kBlock);
     if (lobe == RLS_RAY_DIFFUSE) {
         if (streamed) hipLaunchKernelGGL((disney_kernel<OP, true, RLS_FAST, STREAMED_ALL>), grid, block, 0, ctx->stream, io);

@@ -16,9 +16,6 @@ using namespace rlsh;   // GgxOp, GgxIO
 #ifndef RLS_GGX_RELOAD
 #define RLS_GGX_RELOAD 1
 #endif
-#ifndef RLS_GGX_UNIFORM_CAP
-#define RLS_GGX_UNIFORM_CAP 1
-#endif
 #if RLS_GGX_RELOAD
 #define RLS_GGX_ARGS(a0) reload_args(a0)
 #else
@@ -153,8 +150,8 @@ rls_status launch_kernel(rls_context *ctx, const GgxIO &io, const char *name)
     const bool uniform = !c.specularRoughness.v && !c.ior.v && !c.anisotropic.v;       // specColor: either
     if (streamed)
         hipLaunchKernelGGL((ggx_kernel<OP, RLS_FAST, STREAMED_ALL>), rlsh::grid_for(ctx, io.n, rlsh::kBlock, RLS_CAP_MULT), dim3(rlsh::kBlock), 0, ctx->stream, io);
-    else if (uniform)   // under the context's cap: a thread that hoists wants many tiles to spread the hoisted work over
-        hipLaunchKernelGGL((ggx_kernel<OP, RLS_FAST, UNIFORM_MATERIAL>), rlsh::grid_for(ctx, io.n, rlsh::kBlock, RLS_GGX_UNIFORM_CAP), dim3(rlsh::kBlock), 0, ctx->stream, io);
+    else if (uniform)   // a thread that hoists wants many tiles to spread the hoisted work over (grid_for_hoisting)
+        hipLaunchKernelGGL((ggx_kernel<OP, RLS_FAST, UNIFORM_MATERIAL>), rlsh::grid_for_hoisting(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
     else
         hipLaunchKernelGGL((ggx_kernel<OP, RLS_FAST, MIXED>), rlsh::grid_for(ctx, io.n, rlsh::kBlock, RLS_CAP_MULT), dim3(rlsh::kBlock), 0, ctx->stream, io);
     return rlsh::check_launch(name);

@@ -266,6 +266,36 @@ inline dim3 grid_for(const rls_context *ctx, int64_t n, int points_per_block = k
     return dim3((unsigned)want);
 }
 
+// Launches of the kernels that hoist parameter-only arithmetic out of the tile loop (UNIFORM_*): the fewer threads, the more
+// tiles share one evaluation of the hoisted part -- but the chip wants a few workgroups per CU in flight and some more
+// queued behind them.  Measured at 2^16 .. 2^26 points on the four hoisting workloads (profiles/r03_uniform_sizes.txt): about
+// eight tiles per thread, never fewer than 16 workgroups per CU (or than there are tiles), never more than the context's cap:
+// 2^22 points run on 4 096 workgroups of 4 tiles, 2^24 on 8 192 of 8, 2^26 on the cap's 16 384 of 16.  The hoisting is
+// worth 8-16 % from 2^20 points, its full 6-20 % from 2^24; below 2^20 (one tile per thread at most) such a launch costs what
+// the per-point kernel costs.
+#ifndef RLS_HOIST_TILES_PER_THREAD
+#define RLS_HOIST_TILES_PER_THREAD 8
+#endif
+#ifndef RLS_HOIST_MIN_BLOCKS_PER_CU
+#define RLS_HOIST_MIN_BLOCKS_PER_CU 16
+#endif
+inline dim3 grid_for_hoisting(const rls_context *ctx, int64_t n, int points_per_block = kBlock)
+{
+    static const int tpt = [] { const char *e = getenv("RLS_HOIST_TILES_PER_THREAD"); int v = e ? atoi(e) : 0; return v > 0 ? v : RLS_HOIST_TILES_PER_THREAD; }();
+    static const int bpc = [] { const char *e = getenv("RLS_HOIST_MIN_BLOCKS_PER_CU"); int v = e ? atoi(e) : 0; return v > 0 ? v : RLS_HOIST_MIN_BLOCKS_PER_CU; }();
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) pending_device_error() = e;
+    const int64_t tiles = (n + points_per_block - 1) / points_per_block;
+    int64_t want = (tiles + tpt - 1) / tpt;
+    const int64_t fill = (int64_t)ctx->compute_units * bpc, cap = (int64_t)ctx->compute_units * ctx->blocks_per_cu;
+    if (want < fill) want = fill;
+    if (want > cap) want = cap;
+    if (want > tiles) want = tiles;
+    if (want < 1) want = 1;
+    if (want >= 8) want = (want + 7) / 8 * 8;
+    return dim3((unsigned)want);
+}
+
 inline rls_status check_launch(const char *what)
 {
     hipError_t &pend = pending_device_error();

@@ -59,9 +59,6 @@ enum { MIXED = 0, STREAMED_ALL = 1, UNIFORM_ALL = 2 };
 #ifndef RLS_SKIN_SGPR          // experiment switch: which hoisted values move to scalar registers (1 the lobes', 2 NDProfile)
 #define RLS_SKIN_SGPR 3
 #endif
-#ifndef RLS_SKIN_UNIFORM_CAP
-#define RLS_SKIN_UNIFORM_CAP 1
-#endif
 #ifndef RLS_SKIN_ND_RECIP      // experiment switch: all of getPdf's reciprocals hoisted as well
 #define RLS_SKIN_ND_RECIP 1
 #endif
@@ -183,8 +180,8 @@ rls_status launch_kernel(rls_context *ctx, const SkinIO &io, const char *name)
     const dim3 grid = rlsh::grid_for(ctx, io.n, rlsh::kBlock, RLS_CAP_MULT);
     if (streamed)
         hipLaunchKernelGGL((skin_kernel<RLS_FAST, STREAMED_ALL>), grid, dim3(rlsh::kBlock), 0, ctx->stream, io);
-    else if (uniform)   // under the context's cap: a thread that hoists wants many tiles to spread the hoisted work over
-        hipLaunchKernelGGL((skin_kernel<RLS_FAST, UNIFORM_ALL>), rlsh::grid_for(ctx, io.n, rlsh::kBlock, RLS_SKIN_UNIFORM_CAP), dim3(rlsh::kBlock), 0, ctx->stream, io);
+    else if (uniform)   // a thread that hoists wants many tiles to spread the hoisted work over (grid_for_hoisting)
+        hipLaunchKernelGGL((skin_kernel<RLS_FAST, UNIFORM_ALL>), rlsh::grid_for_hoisting(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
     else
         hipLaunchKernelGGL((skin_kernel<RLS_FAST, MIXED>), grid, dim3(rlsh::kBlock), 0, ctx->stream, io);
     return rlsh::check_launch(name);

@@ -142,7 +142,7 @@ rls_status launch_kernel(rls_context *ctx, const SssIO &io, const char *name)
     // evalProfile alone uses nothing setDistance computes but maxR: no uniform specialisation of it
     constexpr bool kHoists = OP != OP_ND_EVAL;
     if (uniform && kHoists)
-        hipLaunchKernelGGL((sss_kernel<OP, kHoists>), rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
+        hipLaunchKernelGGL((sss_kernel<OP, kHoists>), rlsh::grid_for_hoisting(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
     else
         hipLaunchKernelGGL((sss_kernel<OP, false>), rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
     return rlsh::check_launch(name);

@@ -61,7 +61,7 @@ S_PARAM0 = 32
 WORKLOADS = ["ggx_reflect_refract", "ggx_reflect_refract_uniform", "ggx_reflect", "ggx_eval", "ggx_pdf", "ggx_direct",
              "ggx_shade", "disney_direct", "disney_shade", "disney_integrate", "disney_stream", "disney_triple_diffuse",
              "disney_triple_glossy", "disney_triple_glossy_uniform", "disney_triple_glossy_colour_map", "sss_probe", "sss_probe_uniform", "nd_sample", "sss_scatter", "skin", "skin_uniform", "skin_integrate",
-             "ggx_reflect_refract_host"]
+             "ggx_reflect_refract_host", "ggx_reflect_refract_host_materials"]
 
 # every lobe of rlDisney switched on: the parameters of disney_triple_glossy_uniform, one value each for the whole batch
 DISNEY_UNIFORM = dict(base_color=(0.850000024, 0.704699695, 0.205699995), subsurface=0.2, metallic=0.3, specular=0.5, specular_tint=0.25,
@@ -83,7 +83,7 @@ BLOCK_ALL = [("ggx_reflect_refract_uniform", 26, 40), ("ggx_reflect", 26, 40), (
              ("disney_integrate", 26, 12), ("disney_stream", 26, 10),
              ("sss_probe", 25, 40), ("sss_probe", 26, 40), ("sss_probe_uniform", 26, 40), ("nd_sample", 26, 40),
              ("skin", 26, 30), ("skin", 27, 20), ("skin_uniform", 26, 30),
-             ("ggx_reflect_refract_host", 24, 4)]
+             ("ggx_reflect_refract_host", 24, 4), ("ggx_reflect_refract_host_materials", 24, 4)]
 BLOCK_CONFIGS = [("disney_integrate", 26, 12), ("sss_probe", 25, 40), ("skin", 27, 20)]
 
 
@@ -163,7 +163,7 @@ class Workload:
 
 
 # planes (n floats each) a workload reads and writes: sizes its arena
-PLANES = {"ggx_reflect_refract": 19 + 12, "ggx_reflect_refract_host": 19, "ggx_reflect_refract_uniform": 13 + 12, "ggx_reflect": 17 + 8,
+PLANES = {"ggx_reflect_refract": 19 + 12, "ggx_reflect_refract_host": 19, "ggx_reflect_refract_host_materials": 15, "ggx_reflect_refract_uniform": 13 + 12, "ggx_reflect": 17 + 8,
           "ggx_eval": 17 + 8 + 3, "ggx_pdf": 17 + 8 + 1, "disney_triple_diffuse": 24 + 7, "disney_triple_glossy": 24 + 7, "disney_triple_glossy_uniform": 11 + 7, "disney_triple_glossy_colour_map": 14 + 7,
           "nd_sample": 9 + 7 + 5, "disney_integrate": 22 + 8, "disney_stream": 22 + 8,
           "sss_probe": 17 + 12, "sss_probe_uniform": 11 + 12,
@@ -226,24 +226,37 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
                     wl = Workload(name, 1, (14 + 1) * 4, lambda: g.evalPdf(wi, out=pdf), "ggx_kernel<2, {m}, 1>",
                                   "rlGgx evalPdf alone on sampled directions, mixed params (src/rlGgx.h:121-127)",
                                   survey_bytes=(18 + 1) * 4)
-    elif name == "ggx_reflect_refract_host":
+    elif name in ("ggx_reflect_refract_host", "ggx_reflect_refract_host_materials"):
+        by_ref = name.endswith("materials")
         # config 2 with the batch in page-locked HOST memory, where an Arnold-side stub's render threads gather it (the
         # reference evaluates per hit on those threads, src/rlGgx.cpp:248-261): 19 planes up, the same kernel per chunk,
         # 12 planes down, overlapped on `depth` streams (rlshaders_amd.Pipeline = rls_pipeline_*).  PCIe-bound.
         import torch
-        dev_in = [wo[0], wo[1], wo[2], N[0], N[1], N[2], T[0], T[1], T[2]] + list(u3(S_KS)) + \
-                 [u(S_ROUGH, 0.05, 1.0), u(S_IOR, 1.05, 2.55), R.gen_aniso(ctx, SEED, first, n, out=A.plane())] + \
-                 [u(S_XI0 + j) for j in range(4)]
+        if by_ref:
+            # the same batch as the hits of 256 node instances: the six parameters travel as per-MATERIAL columns, uploaded
+            # once, and every point carries its material id (rls_material_index): 14 planes up instead of 19
+            M = 256
+            table = [R.gen_uniform(ctx, SEED, 0, M, S_KS + j) for j in range(3)] + \
+                    [R.gen_uniform(ctx, SEED, 0, M, S_ROUGH, 0.05, 1.0), R.gen_uniform(ctx, SEED, 0, M, S_IOR, 1.05, 2.55),
+                     R.gen_aniso(ctx, SEED, 0, M)]
+            ids = (R.gen_uniform(ctx, SEED, first, n, S_PARAM0 + 30) * M).to(torch.int32).clamp_(0, M - 1)
+            dev_in = [wo[0], wo[1], wo[2], N[0], N[1], N[2], T[0], T[1], T[2]] + [u(S_XI0 + j) for j in range(4)] + \
+                     [ids.view(torch.float32)]
+        else:
+            dev_in = [wo[0], wo[1], wo[2], N[0], N[1], N[2], T[0], T[1], T[2]] + list(u3(S_KS)) + \
+                     [u(S_ROUGH, 0.05, 1.0), u(S_IOR, 1.05, 2.55), R.gen_aniso(ctx, SEED, first, n, out=A.plane())] + \
+                     [u(S_XI0 + j) for j in range(4)]
+        nin = len(dev_in)
         # ONE page-locked [planes, n] array per direction, as a stub's batch buffers are: equally spaced planes travel as one
         # strided copy per chunk and direction (rls_pipeline_run)
-        hin_all = torch.empty(19, n, dtype=torch.float32, pin_memory=True)
+        hin_all = torch.empty(nin, n, dtype=torch.float32, pin_memory=True)
         hout_all = torch.empty(12, n, dtype=torch.float32, pin_memory=True)
-        hin, hout = [hin_all[k] for k in range(19)], [hout_all[k] for k in range(12)]
+        hin, hout = [hin_all[k] for k in range(nin)], [hout_all[k] for k in range(12)]
         torch.cuda.synchronize()
         for h, d in zip(hin, dev_in):
             h.copy_(d)
         cp = min(n, 1 << chunk_log2)
-        pipe = R.Pipeline(ctx, cp, 19, 12, depth)
+        pipe = R.Pipeline(ctx, cp, nin, 12, depth)
         # Freed device memory is cleared by the driver in the background -- on the copy engines: for a few seconds after a
         # multi-GB arena has been released (the previous workload of this process) the two copy directions no longer run at
         # once (tools/diag_copy_rates.py: both-directions rate 96 -> 57-64 GB/s right after a free, back after an idle second
@@ -272,11 +285,31 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
                 R._capi.Vec3(o.ptr(0), o.ptr(1), o.ptr(2)), R._capi.Rgb(o.ptr(3), o.ptr(4), o.ptr(5)), o.ptr(6), o.ptr(7),
                 R._capi.Vec3(o.ptr(8), o.ptr(9), o.ptr(10)), o.ptr(11)))
 
-        wl = Workload(name, 2, (19 + 12) * 4, lambda: pipe.run(n, hin, hout, chunk), "ggx_kernel<5, {m}, 1>",
+        def chunk_by_reference(slot, _first, count, i, o):
+            c = R._capi.GgxClosure()
+            c.wo = R._capi.CVec3(i.ptr(0), i.ptr(1), i.ptr(2))
+            c.N = R._capi.CVec3(i.ptr(3), i.ptr(4), i.ptr(5))
+            c.T = R._capi.CVec3(i.ptr(6), i.ptr(7), i.ptr(8))
+            c.KsColor = R._capi.ParamRgb(table[0].data_ptr(), table[1].data_ptr(), table[2].data_ptr(), 0.0, 0.0, 0.0)
+            c.specularRoughness = R._capi.Param(table[3].data_ptr(), 0.0)
+            c.ior = R._capi.Param(table[4].data_ptr(), 0.0)
+            c.anisotropic = R._capi.Param(table[5].data_ptr(), 0.0)
+            c.materials = R._capi.MaterialIndex(i.ptr(13), M)
+            R._capi.check(slot.lib.rls_ggx_reflect_refract(
+                slot.handle, count, R.closures.C.byref(c), i.ptr(9), i.ptr(10), i.ptr(11), i.ptr(12),
+                R._capi.Vec3(o.ptr(0), o.ptr(1), o.ptr(2)), R._capi.Rgb(o.ptr(3), o.ptr(4), o.ptr(5)), o.ptr(6), o.ptr(7),
+                R._capi.Vec3(o.ptr(8), o.ptr(9), o.ptr(10)), o.ptr(11)))
+
+        fn = chunk_by_reference if by_ref else chunk
+        wl = Workload(name, 2, (nin + 12) * 4, lambda: pipe.run(n, hin, hout, fn), "ggx_kernel<5, {m}, %d>" % (0 if by_ref else 1),
                       f"rlGgx reflect+refract, batch resident in page-locked HOST memory: chunks of {cp} points uploaded, "
-                      f"sampled and downloaded on {depth} streams (rls_pipeline_*); PCIe-bound, 76 B up + 48 B down per point",
+                      f"sampled and downloaded on {depth} streams (rls_pipeline_*); PCIe-bound, " +
+                      ("parameters by reference (256 node instances: a material id per point, the six parameters as per-material "
+                       "columns uploaded once): 56 B up + 48 B down per point" if by_ref else "76 B up + 48 B down per point"),
                       bound="pcie", launches_per_step=(n + cp - 1) // cp)
-        wl.pipe, wl.host, wl.settle = pipe, (hin, hout), settle
+        wl.pipe, wl.host, wl.settle, wl.up_planes = pipe, (hin, hout), settle, nin
+        if by_ref:
+            wl.table = (table, ids)
     elif name == "ggx_reflect_refract_uniform":
         # config 2's kernel as a stub without linked textures runs it: every node parameter one value for the batch
         # (Arnold parameters are constants unless textured), geometry and random numbers streamed
@@ -420,12 +453,12 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
         # SURVEY 8(d) config 4 counts 14 f in (dist3 albedo3 N3 T3 xi2) + 12 f out = 104 B; the reference computes `s` from the
         # albedo and never uses it (src/rlSss.cpp:22-23), so the verb needs -- and the kernel moves -- 11 f in: 92 B
         if uniform:
-            wl = Workload(name, 1, (8 + 12) * 4, lambda: s.getProbeRay(xi[0], xi[1], out=out), "sss_kernel<3, true, {m}>",
+            wl = Workload(name, 1, (8 + 12) * 4, lambda: s.getProbeRay(xi[0], xi[1], out=out), "sss_kernel<3, 1, {m}>",
                           "rlSss ND probe ray + pdf + profile, uniform scatter distance (1, 0.6, 0.35): N3 T3 xi2 in, 12 f out; "
                           "setDistance once per thread")
         else:
             wl = Workload(name, 1, (11 + 12) * 4, lambda: s.getProbeRay(xi[0], xi[1], out=out),
-                          "sss_kernel<3, false, {m}>", "rlSss ND probe ray + pdf + profile (SURVEY 8d config 4)",
+                          "sss_kernel<3, 0, {m}>", "rlSss ND probe ray + pdf + profile (SURVEY 8d config 4)",
                           survey_bytes=(14 + 12) * 4, config=4)
     elif name == "nd_sample":
         # NDProfile alone: setDistance + getRadius + getPdf + evalProfile (src/rlSss.cpp:20-106); SURVEY 8(d) "profile-only":
@@ -433,7 +466,7 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
         p = R.NDProfile(ctx, n, u3(S_PARAM0, 0.1, 2.1), albedo=u3(S_KS))
         rx = u(S_XI0)
         out = (A.plane(), A.plane(), A.planes(3))
-        wl = Workload(name, 1, (4 + 5) * 4, lambda: p.sample(rx, out=out), "sss_kernel<0, false, {m}>",
+        wl = Workload(name, 1, (4 + 5) * 4, lambda: p.sample(rx, out=out), "sss_kernel<0, 0, {m}>",
                       "rlSss NDProfile alone: setDistance + getRadius + getPdf + evalProfile (SURVEY 8d config 4, profile-only)",
                       survey_bytes=(8 + 5) * 4)
     elif name == "sss_scatter":
@@ -509,7 +542,7 @@ def _cpu_leg(workload: str, n: int, threads: int):
         x = cases.xi(SEED, n, 4)
         out = g.reflect_refract(x[0], x[1], x[2], x[3])
         return (lambda: g.reflect_refract(x[0], x[1], x[2], x[3], out=out)), 2, "orc_batch_ggx_reflect_refract"
-    if workload == "ggx_reflect_refract_host":
+    if workload in ("ggx_reflect_refract_host", "ggx_reflect_refract_host_materials"):
         workload = "ggx_reflect_refract"            # the CPU closures' batch is host-resident by nature
     if workload in ("ggx_reflect_refract", "ggx_reflect", "ggx_eval", "ggx_pdf", "ggx_direct", "ggx_shade"):
         c = cases.ggx_mixed(SEED, n)
@@ -697,7 +730,7 @@ def roofline_record(wl, n: int, kernel_ms: float, math: str) -> dict:
         # host-resident batch: the copies bound the pass.  Held against the pinned-memory rates THIS box reaches (measured
         # now, rls_measure_copy_rates): each direction alone, and both at once
         rates = wl.pipe.copy_rates(1 << 28)
-        up, down = n * 19 * 4.0, n * 12 * 4.0
+        up, down = n * wl.up_planes * 4.0, n * 12 * 4.0
         t = kernel_ms * 1e-3
         floor = max(up / (rates["h2d"] * 1e9), down / (rates["d2h"] * 1e9))
         return {"bound": "pcie", "achieved": round((up + down) / t / 1e9, 2), "peak": round(rates["both"], 2), "unit": "GB/s",
@@ -890,7 +923,7 @@ def main():
     records = []
     for name, log2n, steps in block:
         warm = max(10, args.warmup)
-        warm = warm if name != "ggx_reflect_refract_host" else 2
+        warm = warm if not name.startswith("ggx_reflect_refract_host") else 2
         try:
             w, bn, el, kms, my, _ = measure(R, ctx, ranks, torch, name, log2n, steps, warm, args.math, 1, args.chunk_log2, False,
                                             args.pipeline_depth)

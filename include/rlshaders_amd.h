@@ -73,6 +73,15 @@ typedef struct { float *r, *g, *b; } rls_rgb;
 typedef struct { const float *v; float u; } rls_param;
 typedef struct { const float *r, *g, *b; float ur, ug, ub; } rls_param_rgb;
 
+/* Node parameters BY REFERENCE (a "material table"): a batch that mixes the hits of many node instances need not carry
+ * the parameters per point.  With `id != NULL` in a closure's `materials` member every non-NULL parameter pointer of that
+ * closure (and of the rls_ggx_shader handed over with it) is a COLUMN of `count` floats -- one entry per node instance --
+ * and point i takes entry min(id[i], count - 1): 4 bytes per point instead of 4 per parameter, which is what a host-resident
+ * batch pays for on the bus (rls_pipeline_*).  A NULL parameter pointer is still the uniform value.  The arithmetic is
+ * the per-point arithmetic on the looked-up values: the same bits as with the values expanded into planes.
+ * `id == NULL` (a zero-initialised closure): parameters are per-point planes or uniform values, as before. */
+typedef struct { const uint32_t *id; uint32_t count; } rls_material_index;
+
 /* Arnold ray-type tags selecting the rlDisney lobe (DisneySampler::mSampleType,
  * src/rlDisney.cpp:112,132,147,194-197) */
 #define RLS_RAY_DIFFUSE 0x08
@@ -205,6 +214,7 @@ typedef struct rls_ggx_closure {
     rls_param      specularRoughness;  /* roughness; alpha = roughness^2 (src/rlGgx.h:149)     */
     rls_param      ior;
     rls_param      anisotropic;
+    rls_material_index materials;      /* optional: the parameters above as per-material columns */
 } rls_ggx_closure;
 
 /* evalSample (src/rlGgx.h:97-107): wi = reflect(wo, VNDF microfacet).  fresnel (optional)
@@ -332,6 +342,7 @@ typedef struct rls_disney_closure {
     rls_param_rgb base_color;
     rls_param     subsurface, metallic, specular, specular_tint, roughness, anisotropic,
                   sheen, sheen_tint, clearcoat, clearcoat_gloss;
+    rls_material_index materials;       /* optional: the parameters above as per-material columns */
 } rls_disney_closure;
 
 /* lobe = RLS_RAY_DIFFUSE or RLS_RAY_GLOSSY (what setSampleType selects) */
@@ -426,6 +437,7 @@ typedef struct rls_sss_closure {
     rls_cvec3     N;                    /* sg->Ns; may be all-NULL for the profile-only calls     */
     rls_cvec3     T;                    /* sg->dPdu (has_dPdu) or the polar-frame tangent         */
     int           has_dPdu;             /* 1: Gram-Schmidt frame from dPdu (src/rlSss.h:151-154)  */
+    rls_material_index materials;       /* optional: the three parameters as per-material columns */
 } rls_sss_closure;
 
 /* getRadius(rx) -> r, getPdf(r), evalProfile(r) in one pass (src/rlSss.cpp:36-106) */
@@ -497,6 +509,7 @@ typedef struct rls_skin_closure {
     rls_param     specular_weight, specular_roughness, specular_ior;
     rls_param_rgb sheen_color;
     rls_param     sheen_weight, sheen_roughness, sheen_ior;
+    rls_material_index materials;       /* optional: the parameters above as per-material columns */
 } rls_skin_closure;
 
 typedef struct rls_skin_out {

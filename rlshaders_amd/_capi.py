@@ -47,11 +47,17 @@ class ParamRgb(C.Structure):
                 ("ur", C.c_float), ("ug", C.c_float), ("ub", C.c_float)]
 
 
+class MaterialIndex(C.Structure):
+    """rls_material_index: per-point material id (uint32 [n], device) + the length of the parameter columns"""
+    _fields_ = [("id", C.c_void_p), ("count", C.c_uint32)]
+
+
 class GgxClosure(C.Structure):
     _fields_ = [("wo", CVec3), ("N", CVec3), ("T", CVec3),
                 ("exiting", C.c_void_p),
                 ("KsColor", ParamRgb),
-                ("specularRoughness", Param), ("ior", Param), ("anisotropic", Param)]
+                ("specularRoughness", Param), ("ior", Param), ("anisotropic", Param),
+                ("materials", MaterialIndex)]
 
 
 class DisneyClosure(C.Structure):
@@ -60,7 +66,8 @@ class DisneyClosure(C.Structure):
                 ("subsurface", Param), ("metallic", Param), ("specular", Param),
                 ("specular_tint", Param), ("roughness", Param), ("anisotropic", Param),
                 ("sheen", Param), ("sheen_tint", Param), ("clearcoat", Param),
-                ("clearcoat_gloss", Param)]
+                ("clearcoat_gloss", Param),
+                ("materials", MaterialIndex)]
 
 
 DISNEY_SCALARS = ("subsurface", "metallic", "specular", "specular_tint", "roughness", "anisotropic",
@@ -80,7 +87,8 @@ class SssClosure(C.Structure):
                 ("sss_dist_multiplier", Param),
                 ("sss_scatter_dist", Param * 3),
                 ("N", CVec3), ("T", CVec3),
-                ("has_dPdu", C.c_int)]
+                ("has_dPdu", C.c_int),
+                ("materials", MaterialIndex)]
 
 
 class SphereLight(C.Structure):
@@ -119,7 +127,8 @@ class SkinClosure(C.Structure):
                 ("specular_color", ParamRgb),
                 ("specular_weight", Param), ("specular_roughness", Param), ("specular_ior", Param),
                 ("sheen_color", ParamRgb),
-                ("sheen_weight", Param), ("sheen_roughness", Param), ("sheen_ior", Param)]
+                ("sheen_weight", Param), ("sheen_roughness", Param), ("sheen_ior", Param),
+                ("materials", MaterialIndex)]
 
 
 class SkinOut(C.Structure):

@@ -360,6 +360,23 @@ def plane(t: torch.Tensor, n: int, what: str) -> int:
     return t.data_ptr()
 
 
+def material_index(materials, n: int):
+    """``materials`` = (ids, count): ids an int32 / uint32 CUDA tensor [n] (the node instance of every shading point), count
+    the length of the parameter columns -> (rls_material_index, the length a tensor parameter must then have).  With it,
+    tensor parameters are per-MATERIAL columns [count] / [3, count] instead of per-point planes (include/rlshaders_amd.h,
+    rls_material_index)."""
+    if materials is None:
+        return capi.MaterialIndex(None, 0), n
+    ids, count = materials
+    count = int(count)
+    if not isinstance(ids, torch.Tensor) or ids.dtype not in (torch.int32, torch.uint32) or ids.shape != (n,) or \
+            not ids.is_cuda or not ids.is_contiguous():
+        raise TypeError("materials: expected (ids, count) with ids a contiguous int32 CUDA tensor of shape [n]")
+    if count < 1:
+        raise ValueError("materials: count must be at least 1")
+    return capi.MaterialIndex(ids.data_ptr(), count), count
+
+
 def param(v: Scalar, n: int, what: str) -> capi.Param:
     if isinstance(v, torch.Tensor):
         return capi.Param(plane(v, n, what), 0.0)
@@ -385,21 +402,23 @@ class GgxSampler:
     """
 
     def __init__(self, ctx: Context, wo, N, T, specColor: Color = (1.0, 1.0, 1.0), ior: Scalar = 1.0,
-                 roughness: Scalar = 0.0, anisotropic: Scalar = 0.0, exiting: Optional[torch.Tensor] = None):
+                 roughness: Scalar = 0.0, anisotropic: Scalar = 0.0, exiting: Optional[torch.Tensor] = None, materials=None):
         self.ctx = ctx
         self.n = int(wo.shape[-1])
         n = self.n
-        self._keep = (wo, N, T, specColor, ior, roughness, anisotropic, exiting)
+        self._keep = (wo, N, T, specColor, ior, roughness, anisotropic, exiting, materials)
         c = capi.GgxClosure()
         c.wo, c.N, c.T = cvec3(wo, n, "wo"), cvec3(N, n, "N"), cvec3(T, n, "T")
         if exiting is not None:
             if exiting.dtype != torch.uint8 or exiting.shape != (n,) or not exiting.is_cuda:
                 raise TypeError("exiting: expected a uint8 CUDA tensor of shape [n]")
             c.exiting = exiting.data_ptr()
-        c.KsColor = param_rgb(specColor, n, "specColor")
-        c.ior = param(ior, n, "ior")
-        c.specularRoughness = param(roughness, n, "roughness")
-        c.anisotropic = param(anisotropic, n, "anisotropic")
+        c.materials, pn = material_index(materials, n)      # pn: the length of a tensor parameter (n, or the column length)
+        self.pn = pn
+        c.KsColor = param_rgb(specColor, pn, "specColor")
+        c.ior = param(ior, pn, "ior")
+        c.specularRoughness = param(roughness, pn, "roughness")
+        c.anisotropic = param(anisotropic, pn, "anisotropic")
         self.c = c
 
     # -- the callback triple ---------------------------------------------------------------------
@@ -463,9 +482,10 @@ class GgxSampler:
         of them -> (direct_diffuse [3,n], direct_specular [3,n]); parameter names and defaults of src/rlGgx.cpp:170-175."""
         n, ctx = self.n, self.ctx
         dd, ds = out if out is not None else (ctx.empty(3, n), ctx.empty(3, n))
-        sh = capi.GgxShader(param_rgb(KdColor, n, "KdColor"), param(Kd, n, "Kd"),
-                            param(diffuseRoughness, n, "diffuseRoughness"), param(Ks, n, "Ks"),
-                            param_rgb((1.0, 1.0, 1.0), n, "KtColor"), param(0.0, n, "Kt"))
+        pn = self.pn
+        sh = capi.GgxShader(param_rgb(KdColor, pn, "KdColor"), param(Kd, pn, "Kd"),
+                            param(diffuseRoughness, pn, "diffuseRoughness"), param(Ks, pn, "Ks"),
+                            param_rgb((1.0, 1.0, 1.0), pn, "KtColor"), param(0.0, pn, "Kt"))
         lights, nl = light_array(light)
         check(ctx.lib.rls_ggx_direct_lighting(ctx.handle, n, C.byref(self.c), C.byref(sh), cvec3(P, n, "P"),
                                               lights, nl, int(spp_n), int(seed) & 0xFFFFFFFF, int(first_index),
@@ -483,9 +503,10 @@ class GgxSampler:
         n, ctx = self.n, self.ctx
         if out is None:
             out = {k: ctx.empty(3, n) for k in self.SHADE_AOVS + ("out",)}
-        sh = capi.GgxShader(param_rgb(KdColor, n, "KdColor"), param(Kd, n, "Kd"),
-                            param(diffuseRoughness, n, "diffuseRoughness"), param(Ks, n, "Ks"),
-                            param_rgb(KtColor, n, "KtColor"), param(Kt, n, "Kt"))
+        pn = self.pn
+        sh = capi.GgxShader(param_rgb(KdColor, pn, "KdColor"), param(Kd, pn, "Kd"),
+                            param(diffuseRoughness, pn, "diffuseRoughness"), param(Ks, pn, "Ks"),
+                            param_rgb(KtColor, pn, "KtColor"), param(Kt, pn, "Kt"))
         o = capi.GgxShadeOut()
         for k in self.SHADE_AOVS:
             setattr(o, k, rgb(out[k], n, k))
@@ -541,19 +562,20 @@ class DisneySampler:
     """Batched ``DisneySampler`` (src/rlDisney.cpp:105-602); parameter names from
     src/rlDisney.cpp:606-610.  ``setSampleType`` picks the lobe the triple acts on."""
 
-    def __init__(self, ctx: Context, wo, N, T, base_color: Color = (1.0, 1.0, 1.0), **scalars: Scalar):
+    def __init__(self, ctx: Context, wo, N, T, base_color: Color = (1.0, 1.0, 1.0), materials=None, **scalars: Scalar):
         self.ctx = ctx
         self.n = int(wo.shape[-1])
         n = self.n
         unknown = set(scalars) - set(capi.DISNEY_SCALARS)
         if unknown:
             raise TypeError(f"unknown rlDisney parameters: {sorted(unknown)}")
-        self._keep = (wo, N, T, base_color, scalars)
+        self._keep = (wo, N, T, base_color, scalars, materials)
         c = capi.DisneyClosure()
         c.wo, c.N, c.T = cvec3(wo, n, "wo"), cvec3(N, n, "N"), cvec3(T, n, "T")
-        c.base_color = param_rgb(base_color, n, "base_color")
+        c.materials, pn = material_index(materials, n)
+        c.base_color = param_rgb(base_color, pn, "base_color")
         for name in capi.DISNEY_SCALARS:
-            setattr(c, name, param(scalars.get(name, 0.0), n, name))
+            setattr(c, name, param(scalars.get(name, 0.0), pn, name))
         self.c = c
         self.mSampleType = RLS_RAY_GLOSSY
 
@@ -705,12 +727,13 @@ class DisneySampler:
 
 
 # ================================================================================================
-def _sss_closure(n, sss_scatter_dist, sss_dist_multiplier, sss_color, N, T, has_dPdu) -> capi.SssClosure:
+def _sss_closure(n, sss_scatter_dist, sss_dist_multiplier, sss_color, N, T, has_dPdu, materials=None) -> capi.SssClosure:
     c = capi.SssClosure()
-    c.sss_color = param_rgb(sss_color, n, "sss_color")
-    c.sss_dist_multiplier = param(sss_dist_multiplier, n, "sss_dist_multiplier")
+    c.materials, pn = material_index(materials, n)
+    c.sss_color = param_rgb(sss_color, pn, "sss_color")
+    c.sss_dist_multiplier = param(sss_dist_multiplier, pn, "sss_dist_multiplier")
     if isinstance(sss_scatter_dist, torch.Tensor):
-        _chk(sss_scatter_dist, n, 3, "sss_scatter_dist")
+        _chk(sss_scatter_dist, pn, 3, "sss_scatter_dist")
         for k in range(3):
             c.sss_scatter_dist[k] = capi.Param(sss_scatter_dist[k].data_ptr(), 0.0)
     else:
@@ -727,10 +750,11 @@ class NDProfile:
     """Batched ``rls::NDProfile`` (src/rlSss.h:27-61, src/rlSss.cpp:20-106).  ``setDistance(dist,
     albedo)`` happens in the constructor; n must be given when every parameter is uniform."""
 
-    def __init__(self, ctx: Context, n: int, dist, albedo: Color = (1.0, 1.0, 1.0), multiplier: Scalar = 1.0):
+    def __init__(self, ctx: Context, n: int, dist, albedo: Color = (1.0, 1.0, 1.0), multiplier: Scalar = 1.0, materials=None):
         self.ctx, self.n = ctx, int(n)
         self._keep = (dist, albedo, multiplier)
-        self.c = _sss_closure(self.n, dist, multiplier, albedo, None, None, False)
+        self._materials = materials
+        self.c = _sss_closure(self.n, dist, multiplier, albedo, None, None, False, materials)
 
     def sample(self, rx, out=None):
         """getRadius(rx), getPdf(r), evalProfile(r) in one pass -> (r, pdf, profile)."""
@@ -779,10 +803,11 @@ class SssSampler:
     487-545).  ``Ns`` = sg->Ns, ``dPdu`` = sg->dPdu (Gram-Schmidt frame) or, with
     ``has_dPdu=False``, the polar-frame tangent."""
 
-    def __init__(self, ctx: Context, Ns, dPdu, albedo: Color, dist, multiplier: Scalar = 1.0, has_dPdu: bool = True):
+    def __init__(self, ctx: Context, Ns, dPdu, albedo: Color, dist, multiplier: Scalar = 1.0, has_dPdu: bool = True,
+                 materials=None):
         self.ctx, self.n = ctx, int(Ns.shape[-1])
-        self._keep = (Ns, dPdu, albedo, dist, multiplier)
-        self.c = _sss_closure(self.n, dist, multiplier, albedo, Ns, dPdu, has_dPdu)
+        self._keep = (Ns, dPdu, albedo, dist, multiplier, materials)
+        self.c = _sss_closure(self.n, dist, multiplier, albedo, Ns, dPdu, has_dPdu, materials)
 
     def getProbeRay(self, rx, ry, P=None, out=None):
         """src/rlSss.h:487-533 -> dict(r, origin, dir, maxdist, pdf, profile)."""
@@ -895,7 +920,7 @@ class SkinShader:
                     specular_color=(1.0, 1.0, 1.0), specular_weight=0.6, specular_roughness=0.5, specular_ior=1.44,
                     sheen_color=(1.0, 1.0, 1.0), sheen_weight=0.0, sheen_roughness=0.35, sheen_ior=1.44)
 
-    def __init__(self, ctx: Context, wo, N, T, **params):
+    def __init__(self, ctx: Context, wo, N, T, materials=None, **params):
         self.ctx, self.n = ctx, int(wo.shape[-1])
         n = self.n
         unknown = set(params) - set(self.DEFAULTS)
@@ -903,18 +928,19 @@ class SkinShader:
             raise TypeError(f"unknown rlSkin parameters: {sorted(unknown)}")
         p = dict(self.DEFAULTS)
         p.update(params)
-        self._keep = (wo, N, T, p)
+        self._keep = (wo, N, T, p, materials)
         c = capi.SkinClosure()
         c.wo, c.N, c.T = cvec3(wo, n, "wo"), cvec3(N, n, "N"), cvec3(T, n, "T")
+        c.materials, pn = material_index(materials, n)
         for name in ("sss_color", "specular_color", "sheen_color"):
-            setattr(c, name, param_rgb(p[name], n, name))
+            setattr(c, name, param_rgb(p[name], pn, name))
         for name in ("sss_weight", "sss_dist_multiplier", "specular_weight", "specular_roughness", "specular_ior",
                      "sheen_weight", "sheen_roughness", "sheen_ior"):
-            setattr(c, name, param(p[name], n, name))
+            setattr(c, name, param(p[name], pn, name))
         d = p["sss_scatter_dist"]
         for k in range(3):
             if isinstance(d, torch.Tensor):
-                _chk(d, n, 3, "sss_scatter_dist")
+                _chk(d, pn, 3, "sss_scatter_dist")
                 c.sss_scatter_dist[k] = capi.Param(d[k].data_ptr(), 0.0)
             else:
                 c.sss_scatter_dist[k] = capi.Param(None, float(d[k]))

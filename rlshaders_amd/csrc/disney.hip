@@ -47,19 +47,20 @@ template <bool STREAMED>
 __device__ __forceinline__ Disney load_closure(const rls_disney_closure &c, Idx i)
 {
     V3 wo = ld3(c.wo, i), N = ld3(c.N, i), T = ld3(c.T, i);
+    const PIndex<Idx> k = pindex<!STREAMED>(c.materials, i);           // parameters by reference run the MIXED kernel
     float br, bg, bb;
-    ldrgb<STREAMED>(c.base_color, i, br, bg, bb);
+    ldrgb<STREAMED>(c.base_color, k, br, bg, bb);
     float s[10];
-    s[0] = ldp<STREAMED>(c.subsurface, i);
-    s[1] = ldp<STREAMED>(c.metallic, i);
-    s[2] = ldp<STREAMED>(c.specular, i);
-    s[3] = ldp<STREAMED>(c.specular_tint, i);
-    s[4] = ldp<STREAMED>(c.roughness, i);
-    s[5] = ldp<STREAMED>(c.anisotropic, i);
-    s[6] = ldp<STREAMED>(c.sheen, i);
-    s[7] = ldp<STREAMED>(c.sheen_tint, i);
-    s[8] = ldp<STREAMED>(c.clearcoat, i);
-    s[9] = ldp<STREAMED>(c.clearcoat_gloss, i);
+    s[0] = ldp<STREAMED>(c.subsurface, k);
+    s[1] = ldp<STREAMED>(c.metallic, k);
+    s[2] = ldp<STREAMED>(c.specular, k);
+    s[3] = ldp<STREAMED>(c.specular_tint, k);
+    s[4] = ldp<STREAMED>(c.roughness, k);
+    s[5] = ldp<STREAMED>(c.anisotropic, k);
+    s[6] = ldp<STREAMED>(c.sheen, k);
+    s[7] = ldp<STREAMED>(c.sheen_tint, k);
+    s[8] = ldp<STREAMED>(c.clearcoat, k);
+    s[9] = ldp<STREAMED>(c.clearcoat_gloss, k);
     return disney_make(wo, N, T, br, bg, bb, s);
 }
 
@@ -124,6 +125,7 @@ rls_status check_closure(const rls_disney_closure *c, int lobe)
     RLS_REQUIRE(lobe == RLS_RAY_DIFFUSE || lobe == RLS_RAY_GLOSSY, "lobe must be RLS_RAY_DIFFUSE or RLS_RAY_GLOSSY");
     RLS_REQUIRE(rlsh::has3(c->wo) && rlsh::has3(c->N) && rlsh::has3(c->T), "wo/N/T plane is NULL");
     RLS_REQUIRE(rlsh::ok_rgb(c->base_color), "base_color planes must be all set or all NULL");
+    RLS_REQUIRE(rlsh::ok_materials(c->materials), "materials.id is set but materials.count is 0");
     return RLS_OK;
 }
 
@@ -131,10 +133,11 @@ template <int OP>
 rls_status launch_kernel(rls_context *ctx, int lobe, const DisneyIO &io, const char *name)
 {
     const rls_disney_closure &c = io.c;
-    const bool streamed = c.base_color.r && c.subsurface.v && c.metallic.v && c.specular.v && c.specular_tint.v &&
+    const bool by_reference = c.materials.id != nullptr;
+    const bool streamed = !by_reference && c.base_color.r && c.subsurface.v && c.metallic.v && c.specular.v && c.specular_tint.v &&
                           c.roughness.v && c.anisotropic.v && c.sheen.v && c.sheen_tint.v && c.clearcoat.v &&
                           c.clearcoat_gloss.v;
-    const bool scalars = !c.subsurface.v && !c.metallic.v && !c.specular.v && !c.specular_tint.v && !c.roughness.v &&
+    const bool scalars = !by_reference && !c.subsurface.v && !c.metallic.v && !c.specular.v && !c.specular_tint.v && !c.roughness.v &&
                          !c.anisotropic.v && !c.sheen.v && !c.sheen_tint.v && !c.clearcoat.v && !c.clearcoat_gloss.v;
     const bool uniform = scalars && !c.base_color.r, colour_map = scalars && c.base_color.r;
     const dim3 grid = scalars ? rlsh::grid_for_hoisting(ctx, io.n) : rlsh::grid_for(ctx, io.n);

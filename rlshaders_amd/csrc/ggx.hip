@@ -34,13 +34,14 @@ __device__ __forceinline__ Ggx load_closure(const rls_ggx_closure &c, Idx i, con
 {
     constexpr bool STREAMED = MODE == STREAMED_ALL;
     V3 wo = ld3(c.wo, i), N = ld3(c.N, i), T = ld3(c.T, i);
+    const PIndex<Idx> k = pindex<MODE == MIXED>(c.materials, i);       // parameters by reference run the MIXED kernel
     float kr, kg, kb;
-    ldrgb<STREAMED>(c.KsColor, i, kr, kg, kb);
+    ldrgb<STREAMED>(c.KsColor, k, kr, kg, kb);
     if (MODE == UNIFORM_MATERIAL)
         return ggx_from_material(um, wo, N, T, c.exiting ? (c.exiting[i.full()] != 0) : false, kr, kg, kb);
-    float rough = ldp<STREAMED>(c.specularRoughness, i);
-    float ior = ldp<STREAMED>(c.ior, i);
-    float aniso = ldp<STREAMED>(c.anisotropic, i);
+    float rough = ldp<STREAMED>(c.specularRoughness, k);
+    float ior = ldp<STREAMED>(c.ior, k);
+    float aniso = ldp<STREAMED>(c.anisotropic, k);
     bool exiting = c.exiting ? (c.exiting[i.full()] != 0) : false;
     return ggx_make(wo, N, T, exiting, kr, kg, kb, ior, rough, aniso);
 }
@@ -135,6 +136,7 @@ rls_status check_closure(const rls_ggx_closure *c)
     RLS_REQUIRE(c != nullptr, "closure is NULL");
     RLS_REQUIRE(rlsh::has3(c->wo) && rlsh::has3(c->N) && rlsh::has3(c->T), "wo/N/T plane is NULL");
     RLS_REQUIRE(rlsh::ok_rgb(c->KsColor), "KsColor planes must be all set or all NULL");
+    RLS_REQUIRE(rlsh::ok_materials(c->materials), "materials.id is set but materials.count is 0");
     return RLS_OK;
 }
 
@@ -145,9 +147,9 @@ rls_status launch_kernel(rls_context *ctx, const GgxIO &io, const char *name)
 #ifdef RLS_NO_STREAMED   // experiment switch
     const bool streamed = false;
 #else
-    const bool streamed = c.KsColor.r && c.specularRoughness.v && c.ior.v && c.anisotropic.v;
+    const bool streamed = !c.materials.id && c.KsColor.r && c.specularRoughness.v && c.ior.v && c.anisotropic.v;
 #endif
-    const bool uniform = !c.specularRoughness.v && !c.ior.v && !c.anisotropic.v;       // specColor: either
+    const bool uniform = !c.materials.id && !c.specularRoughness.v && !c.ior.v && !c.anisotropic.v;       // specColor: either
     if (streamed)
         hipLaunchKernelGGL((ggx_kernel<OP, RLS_FAST, STREAMED_ALL>), rlsh::grid_for(ctx, io.n, rlsh::kBlock, RLS_CAP_MULT), dim3(rlsh::kBlock), 0, ctx->stream, io);
     else if (uniform)   // a thread that hoists wants many tiles to spread the hoisted work over (grid_for_hoisting)

@@ -491,12 +491,13 @@ __global__ RLS_INT_ATTR void ggx_integrate_kernel(GgxIntIO a)
         const bool live = i < a.n;
         const int64_t ii = live ? i : a.n - 1;
         const rls_ggx_closure &c = a.c;
+        const PIndex<int64_t> pk = pindex(c.materials, ii);      // parameters by reference (rls_material_index)
         V3 wo = ld3(c.wo, ii), N = ld3(c.N, ii), T = ld3(c.T, ii);
         float kr, kg, kb;
-        ldrgb(c.KsColor, ii, kr, kg, kb);
+        ldrgb(c.KsColor, pk, kr, kg, kb);
         bool exiting = c.exiting ? (c.exiting[ii] != 0) : false;
-        Ggx g = ggx_make(wo, N, T, exiting, kr, kg, kb, ldp(c.ior, ii), ldp(c.specularRoughness, ii),
-                         ldp(c.anisotropic, ii));
+        Ggx g = ggx_make(wo, N, T, exiting, kr, kg, kb, ldp(c.ior, pk), ldp(c.specularRoughness, pk),
+                         ldp(c.anisotropic, pk));
         VndfView w = vndf_view(g.view, g.fr, g.ax, g.ay);
         const uint32_t sx = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream);
         const uint32_t sy = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream + 1);
@@ -530,14 +531,15 @@ __global__ RLS_INT_ATTR void disney_integrate_kernel(DisneyIntIO a)
         const bool live = i < a.n;
         const int64_t ii = live ? i : a.n - 1;
         const rls_disney_closure &c = a.c;
+        const PIndex<int64_t> pk = pindex(c.materials, ii);      // parameters by reference (rls_material_index)
         V3 wo = ld3(c.wo, ii), N = ld3(c.N, ii), T = ld3(c.T, ii);
         float br, bg, bb;
-        ldrgb(c.base_color, ii, br, bg, bb);
+        ldrgb(c.base_color, pk, br, bg, bb);
         float sc[10];
-        sc[0] = ldp(c.subsurface, ii); sc[1] = ldp(c.metallic, ii); sc[2] = ldp(c.specular, ii);
-        sc[3] = ldp(c.specular_tint, ii); sc[4] = ldp(c.roughness, ii); sc[5] = ldp(c.anisotropic, ii);
-        sc[6] = ldp(c.sheen, ii); sc[7] = ldp(c.sheen_tint, ii); sc[8] = ldp(c.clearcoat, ii);
-        sc[9] = ldp(c.clearcoat_gloss, ii);
+        sc[0] = ldp(c.subsurface, pk); sc[1] = ldp(c.metallic, pk); sc[2] = ldp(c.specular, pk);
+        sc[3] = ldp(c.specular_tint, pk); sc[4] = ldp(c.roughness, pk); sc[5] = ldp(c.anisotropic, pk);
+        sc[6] = ldp(c.sheen, pk); sc[7] = ldp(c.sheen_tint, pk); sc[8] = ldp(c.clearcoat, pk);
+        sc[9] = ldp(c.clearcoat_gloss, pk);
         Disney d = disney_make(wo, N, T, br, bg, bb, sc);
         disney_prepare(d);        // what evalBrdf / evalPdf / evalSample recompute per call from the closure alone
         VndfView w = vndf_view(d.view, d.fr, d.ax, d.ay);
@@ -610,11 +612,11 @@ __global__ RLS_INT_ATTR void disney_integrate_kernel(DisneyIntIO a)
 using rlsh::ScatterIO;
 
 
-__device__ __forceinline__ NdProfile scatter_profile(const rls_sss_closure &c, int64_t i)
+__device__ __forceinline__ NdProfile scatter_profile(const rls_sss_closure &c, const PIndex<int64_t> &k)
 {
-    float m = ldp(c.sss_dist_multiplier, i);   // src/rlSkin.cpp:235-236
-    return nd_make<true>(ldp(c.sss_scatter_dist[0], i) * m, ldp(c.sss_scatter_dist[1], i) * m,
-                   ldp(c.sss_scatter_dist[2], i) * m);
+    float m = ldp(c.sss_dist_multiplier, k);   // src/rlSkin.cpp:235-236
+    return nd_make<true>(ldp(c.sss_scatter_dist[0], k) * m, ldp(c.sss_scatter_dist[1], k) * m,
+                   ldp(c.sss_scatter_dist[2], k) * m);
 }
 
 // the analytic scene in registers
@@ -726,11 +728,12 @@ __global__ RLS_INT_ATTR void sss_scatter_kernel(ScatterIO a)
         const bool live = i < a.n;
         const int64_t ii = live ? i : a.n - 1;
         const rls_sss_closure &c = a.c;
-        NdProfile p = scatter_profile(c, ii);
+        const PIndex<int64_t> pk = pindex(c.materials, ii);      // parameters by reference (rls_material_index)
+        NdProfile p = scatter_profile(c, pk);
         Frame fr = sss_frame(ld3(c.N, ii), ld3(c.T, ii), c.has_dPdu != 0);
         const V3 Po = ld3(a.P, ii);
         float br, bg, bb;
-        ldrgb(c.sss_color, ii, br, bg, bb);
+        ldrgb(c.sss_color, pk, br, bg, bb);
         const uint32_t sx = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream);
         const uint32_t sy = hash_u32(a.seed, a.first + (uint64_t)ii, kScrambleStream + 1);
 
@@ -771,6 +774,7 @@ __global__ RLS_INT_ATTR void skin_integrate_kernel(SkinIntIO a)
         const bool live = i < a.n;
         const int64_t ii = live ? i : a.n - 1;
         const rls_skin_closure &c = a.c;
+        const PIndex<int64_t> pk = pindex(c.materials, ii);      // parameters by reference (rls_material_index)
         const V3 wo = ld3(c.wo, ii), N = ld3(c.N, ii), T = ld3(c.T, ii);
         uint32_t scr[6];
 #pragma unroll
@@ -782,12 +786,12 @@ __global__ RLS_INT_ATTR void skin_integrate_kernel(SkinIntIO a)
 
         float sheenFresnel = 0.0f, specularFresnel = 0.0f;
         float shR = 0.0f, shG = 0.0f, shB = 0.0f, spR = 0.0f, spG = 0.0f, spB = 0.0f;
-        const float sheenWeight = ldp(c.sheen_weight, ii);
+        const float sheenWeight = ldp(c.sheen_weight, pk);
         // the group takes the branch together: the weights are per point, the G lanes of a group share the point
         if (sheenWeight > kEps) {                                                     // :191
             float cr, cg, cb;
-            ldrgb(c.sheen_color, ii, cr, cg, cb);
-            Ggx g = ggx_make<true>(wo, N, T, false, cr, cg, cb, ldp(c.sheen_ior, ii), ldp(c.sheen_roughness, ii), 0.0f);
+            ldrgb(c.sheen_color, pk, cr, cg, cb);
+            Ggx g = ggx_make<true>(wo, N, T, false, cr, cg, cb, ldp(c.sheen_ior, pk), ldp(c.sheen_roughness, pk), 0.0f);
             VndfView w = vndf_view_from(local, g.ax, g.ay);
             float lit[3], lf, lc, aF;
             ggx_light_loops<G>(g, w, N, P, a, tab, a.spp, sub, inv, a.seed, a.first + (uint64_t)ii, 3,
@@ -803,11 +807,11 @@ __global__ RLS_INT_ATTR void skin_integrate_kernel(SkinIntIO a)
             shR = lit[0] + shR * inv * a.env[0]; shG = lit[1] + shG * inv * a.env[1]; shB = lit[2] + shB * inv * a.env[2];
         }
         shR *= sheenWeight; shG *= sheenWeight; shB *= sheenWeight;                   // :207
-        const float specWeight = ldp(c.specular_weight, ii);
+        const float specWeight = ldp(c.specular_weight, pk);
         if (specWeight > kEps) {                                                      // :214
             float cr, cg, cb;
-            ldrgb(c.specular_color, ii, cr, cg, cb);
-            Ggx g = ggx_make<true>(wo, N, T, false, cr, cg, cb, ldp(c.specular_ior, ii), ldp(c.specular_roughness, ii), 0.0f);
+            ldrgb(c.specular_color, pk, cr, cg, cb);
+            Ggx g = ggx_make<true>(wo, N, T, false, cr, cg, cb, ldp(c.specular_ior, pk), ldp(c.specular_roughness, pk), 0.0f);
             VndfView w = vndf_view_from(local, g.ax, g.ay);
             float lit[3], lf, lc, aF;
             ggx_light_loops<G>(g, w, N, P, a, tab, a.spp, sub, inv, a.seed, a.first + (uint64_t)ii, 5,
@@ -823,16 +827,16 @@ __global__ RLS_INT_ATTR void skin_integrate_kernel(SkinIntIO a)
         const float sw = specWeight * (1.0f - sheenFresnel);                          // :231
         spR *= sw; spG *= sw; spB *= sw;
 
-        const float mult = ldp(c.sss_dist_multiplier, ii);                            // :235-236
-        float sssWeight = ldp(c.sss_weight, ii);
+        const float mult = ldp(c.sss_dist_multiplier, pk);                            // :235-236
+        float sssWeight = ldp(c.sss_weight, pk);
         sssWeight *= 1.0f - specularFresnel * (1.0f - sheenFresnel);                  // :238
         float ssR = 0.0f, ssG = 0.0f, ssB = 0.0f;
         if (!(sssWeight < kEps)) {                                                    // :244
-            NdProfile p = nd_make<true>(ldp(c.sss_scatter_dist[0], ii) * mult, ldp(c.sss_scatter_dist[1], ii) * mult,
-                                  ldp(c.sss_scatter_dist[2], ii) * mult);
+            NdProfile p = nd_make<true>(ldp(c.sss_scatter_dist[0], pk) * mult, ldp(c.sss_scatter_dist[1], pk) * mult,
+                                  ldp(c.sss_scatter_dist[2], pk) * mult);
             Frame fr = sss_frame(N, T, true);
             float br, bg, bb, accD;
-            ldrgb(c.sss_color, ii, br, bg, bb);
+            ldrgb(c.sss_color, pk, br, bg, bb);
             scatter_loop<G>(p, fr, P, sc, tab, a.spp, sub, scr[4], scr[5], ssR, ssG, ssB, accD);
             ssR = br * ssR * inv * sssWeight; ssG = bg * ssG * inv * sssWeight; ssB = bb * ssB * inv * sssWeight;
         }
@@ -913,12 +917,13 @@ __global__ RLS_INT_ATTR void ggx_refract_integrate_kernel(RefractIntIO a)
         const bool live = i < a.n;
         const int64_t ii = live ? i : a.n - 1;
         const rls_ggx_closure &c = a.c;
+        const PIndex<int64_t> pk = pindex(c.materials, ii);      // parameters by reference (rls_material_index)
         V3 wo = ld3(c.wo, ii), N = ld3(c.N, ii), T = ld3(c.T, ii);
         float kr, kg, kb;
-        ldrgb(c.KsColor, ii, kr, kg, kb);
+        ldrgb(c.KsColor, pk, kr, kg, kb);
         bool exiting = c.exiting ? (c.exiting[ii] != 0) : false;
-        Ggx g = ggx_make(wo, N, T, exiting, kr, kg, kb, ldp(c.ior, ii), ldp(c.specularRoughness, ii),
-                         ldp(c.anisotropic, ii));
+        Ggx g = ggx_make(wo, N, T, exiting, kr, kg, kb, ldp(c.ior, pk), ldp(c.specularRoughness, pk),
+                         ldp(c.anisotropic, pk));
         float acc, tir;
         if (a.traced) {
             VndfView w = vndf_view(g.view, g.fr, g.ax, g.ay);
@@ -1067,17 +1072,18 @@ __global__ RLS_INT_ATTR void ggx_direct_kernel(LightIO a)
         const bool live = i < a.n;
         const int64_t ii = live ? i : a.n - 1;
         const rls_ggx_closure &c = a.c;
+        const PIndex<int64_t> pk = pindex(c.materials, ii);      // parameters by reference (rls_material_index)
         V3 wo = ld3(c.wo, ii), N = ld3(c.N, ii), T = ld3(c.T, ii);
         float kr, kg, kb;
-        ldrgb(c.KsColor, ii, kr, kg, kb);
+        ldrgb(c.KsColor, pk, kr, kg, kb);
         bool exiting = c.exiting ? (c.exiting[ii] != 0) : false;
-        Ggx g = ggx_make(wo, N, T, exiting, kr, kg, kb, ldp(c.ior, ii), ldp(c.specularRoughness, ii),
-                         ldp(c.anisotropic, ii));
+        Ggx g = ggx_make(wo, N, T, exiting, kr, kg, kb, ldp(c.ior, pk), ldp(c.specularRoughness, pk),
+                         ldp(c.anisotropic, pk));
         VndfView w = vndf_view(g.view, g.fr, g.ax, g.ay);
-        OrenNayar on = oren_nayar_make(N, ldp(a.sh.diffuseRoughness, ii));
-        const float ks = ldp(a.sh.Ks, ii), kd = ldp(a.sh.Kd, ii);
+        OrenNayar on = oren_nayar_make(N, ldp(a.sh.diffuseRoughness, pk));
+        const float ks = ldp(a.sh.Ks, pk), kd = ldp(a.sh.Kd, pk);
         float dr, dg, db;
-        ldrgb(a.sh.KdColor, ii, dr, dg, db);
+        ldrgb(a.sh.KdColor, pk, dr, dg, db);
         dr *= kd; dg *= kd; db *= kd;                                       // diffuseColor, src/rlGgx.cpp:279
         float oD[3], oS[3];
         ggx_direct_loops<G>(slow, g, w, on, wo, N, ld3(a.P, ii), !color_is_small(dr, dg, db), a, tab, a.spp, sub,
@@ -1100,11 +1106,12 @@ using rlsh::DisneyLightIO;
     Disney d;                                                                                              \
     {                                                                                                      \
         float br_, bg_, bb_, sc_[10];                                                                      \
-        ldrgb((c).base_color, ii, br_, bg_, bb_);                                                          \
-        sc_[0] = ldp((c).subsurface, ii); sc_[1] = ldp((c).metallic, ii); sc_[2] = ldp((c).specular, ii);  \
-        sc_[3] = ldp((c).specular_tint, ii); sc_[4] = ldp((c).roughness, ii); sc_[5] = ldp((c).anisotropic, ii); \
-        sc_[6] = ldp((c).sheen, ii); sc_[7] = ldp((c).sheen_tint, ii); sc_[8] = ldp((c).clearcoat, ii);    \
-        sc_[9] = ldp((c).clearcoat_gloss, ii);                                                             \
+        const PIndex<int64_t> pk = pindex((c).materials, (int64_t)(ii));                                   \
+        ldrgb((c).base_color, pk, br_, bg_, bb_);                                                          \
+        sc_[0] = ldp((c).subsurface, pk); sc_[1] = ldp((c).metallic, pk); sc_[2] = ldp((c).specular, pk);  \
+        sc_[3] = ldp((c).specular_tint, pk); sc_[4] = ldp((c).roughness, pk); sc_[5] = ldp((c).anisotropic, pk); \
+        sc_[6] = ldp((c).sheen, pk); sc_[7] = ldp((c).sheen_tint, pk); sc_[8] = ldp((c).clearcoat, pk);    \
+        sc_[9] = ldp((c).clearcoat_gloss, pk);                                                             \
         d = disney_make(ld3((c).wo, ii), ld3((c).N, ii), ld3((c).T, ii), br_, bg_, bb_, sc_);              \
         disney_prepare(d);                                                                                 \
     }
@@ -1345,18 +1352,19 @@ __global__ RLS_INT_ATTR void ggx_shade_kernel(GgxShadeIO a)
         const int64_t ii = live ? i : a.n - 1;
         const uint64_t idx = a.first + (uint64_t)ii;
         const rls_ggx_closure &c = a.c;
+        const PIndex<int64_t> pk = pindex(c.materials, ii);      // parameters by reference (rls_material_index)
         V3 wo = ld3(c.wo, ii), N = ld3(c.N, ii), T = ld3(c.T, ii);
         float kr, kg, kb;
-        ldrgb(c.KsColor, ii, kr, kg, kb);
+        ldrgb(c.KsColor, pk, kr, kg, kb);
         bool exiting = c.exiting ? (c.exiting[ii] != 0) : false;
-        Ggx g = ggx_make(wo, N, T, exiting, kr, kg, kb, ldp(c.ior, ii), ldp(c.specularRoughness, ii),
-                         ldp(c.anisotropic, ii));
+        Ggx g = ggx_make(wo, N, T, exiting, kr, kg, kb, ldp(c.ior, pk), ldp(c.specularRoughness, pk),
+                         ldp(c.anisotropic, pk));
         VndfView w = vndf_view(g.view, g.fr, g.ax, g.ay);
-        OrenNayar on = oren_nayar_make(N, ldp(a.sh.diffuseRoughness, ii));
-        const float ks = ldp(a.sh.Ks, ii), kd = ldp(a.sh.Kd, ii), kt = ldp(a.sh.Kt, ii);
+        OrenNayar on = oren_nayar_make(N, ldp(a.sh.diffuseRoughness, pk));
+        const float ks = ldp(a.sh.Ks, pk), kd = ldp(a.sh.Kd, pk), kt = ldp(a.sh.Kt, pk);
         float dr, dg, db, tr, tg, tb;
-        ldrgb(a.sh.KdColor, ii, dr, dg, db);
-        ldrgb(a.sh.KtColor, ii, tr, tg, tb);
+        ldrgb(a.sh.KdColor, pk, dr, dg, db);
+        ldrgb(a.sh.KtColor, pk, tr, tg, tb);
         dr *= kd; dg *= kd; db *= kd;                                        // diffuseColor, src/rlGgx.cpp:279
         tr *= kt; tg *= kt; tb *= kt;                                        // ktColor, :308
         const bool sampleDiffuse = !color_is_small(dr, dg, db);              // :280 (Rr_diff = 0)
@@ -1608,6 +1616,7 @@ rls_status rls_skin_integrate(rls_context *ctx, int64_t n, const rls_skin_closur
     RLS_REQUIRE(rlsh::has3(c->wo) && rlsh::has3(c->N) && rlsh::has3(c->T) && rlsh::has3(P), "wo/N/T/P plane is NULL");
     RLS_REQUIRE(rlsh::ok_rgb(c->sss_color) && rlsh::ok_rgb(c->specular_color) && rlsh::ok_rgb(c->sheen_color),
                 "colour planes must be all set or all NULL");
+    RLS_REQUIRE(rlsh::ok_materials(c->materials), "materials.id is set but materials.count is 0");
     RLS_REQUIRE(scene->geometry == RLS_SCENE_PLANE || scene->geometry == RLS_SCENE_SPHERE, "unknown scene geometry");
     RLS_REQUIRE(rlsh::has3(out->sheen) && rlsh::has3(out->specular) && rlsh::has3(out->sss), "NULL AOV plane");
     RLS_REQUIRE(rlsh::has3(out->out) || (!out->out.r && !out->out.g && !out->out.b), "out planes must be all set or all NULL");
@@ -1634,6 +1643,7 @@ rls_status rls_ggx_integrate_refract(rls_context *ctx, int64_t n, const rls_ggx_
     RLS_REQUIRE(c != nullptr && env != nullptr, "closure or env is NULL");
     RLS_REQUIRE(rlsh::has3(c->wo) && rlsh::has3(c->N) && rlsh::has3(c->T), "wo/N/T plane is NULL");
     RLS_REQUIRE(rlsh::ok_rgb(c->KsColor), "KsColor planes must be all set or all NULL");
+    RLS_REQUIRE(rlsh::ok_materials(c->materials), "materials.id is set but materials.count is 0");
     RLS_REQUIRE(rlsh::has3(result), "NULL output plane");
     rlsh::RefractIntIO io = {};
     io.c = *c; io.env[0] = env[0]; io.env[1] = env[1]; io.env[2] = env[2]; io.traced = traced ? 1 : 0;
@@ -1656,6 +1666,7 @@ rls_status rls_ggx_integrate(rls_context *ctx, int64_t n, const rls_ggx_closure 
     RLS_REQUIRE(c != nullptr, "closure is NULL");
     RLS_REQUIRE(rlsh::has3(c->wo) && rlsh::has3(c->N) && rlsh::has3(c->T), "wo/N/T plane is NULL");
     RLS_REQUIRE(rlsh::ok_rgb(c->KsColor), "KsColor planes must be all set or all NULL");
+    RLS_REQUIRE(rlsh::ok_materials(c->materials), "materials.id is set but materials.count is 0");
     RLS_REQUIRE(rlsh::has3(sum_f_over_pdf) && avg_reflect_weight, "NULL output plane");
     GgxIntIO io = {};
     io.c = *c; io.sum = sum_f_over_pdf; io.avgF = avg_reflect_weight; io.n = n; io.spp = spp_n * spp_n; io.seed = seed; io.first = first_index;
@@ -1678,6 +1689,7 @@ rls_status rls_disney_integrate(rls_context *ctx, int64_t n, const rls_disney_cl
     RLS_REQUIRE(c != nullptr, "closure is NULL");
     RLS_REQUIRE(rlsh::has3(c->wo) && rlsh::has3(c->N) && rlsh::has3(c->T), "wo/N/T plane is NULL");
     RLS_REQUIRE(rlsh::ok_rgb(c->base_color), "base_color planes must be all set or all NULL");
+    RLS_REQUIRE(rlsh::ok_materials(c->materials), "materials.id is set but materials.count is 0");
     RLS_REQUIRE(rlsh::has3(diffuse_sum) && diffuse_count && rlsh::has3(specular_sum) && specular_count,
                 "NULL output plane");
     DisneyIntIO io = {};
@@ -1751,6 +1763,7 @@ rls_status rls_sss_integrate_scatter(rls_context *ctx, int64_t n, const rls_sss_
     RLS_REQUIRE(c != nullptr && scene != nullptr, "closure or scene is NULL");
     RLS_REQUIRE(rlsh::has3(c->N) && rlsh::has3(c->T) && rlsh::has3(P), "N/T/P plane is NULL");
     RLS_REQUIRE(rlsh::ok_rgb(c->sss_color), "sss_color planes must be all set or all NULL");
+    RLS_REQUIRE(rlsh::ok_materials(c->materials), "materials.id is set but materials.count is 0");
     RLS_REQUIRE(scene->geometry == RLS_SCENE_PLANE || scene->geometry == RLS_SCENE_SPHERE, "unknown scene geometry");
     RLS_REQUIRE(rlsh::has3(result), "NULL output plane");
     ScatterIO io = {};
@@ -1773,6 +1786,7 @@ rls_status rls_ggx_direct_lighting(rls_context *ctx, int64_t n, const rls_ggx_cl
     RLS_REQUIRE(c != nullptr && sh != nullptr, "closure or shader is NULL");
     RLS_REQUIRE(rlsh::has3(c->wo) && rlsh::has3(c->N) && rlsh::has3(c->T) && rlsh::has3(P), "wo/N/T/P plane is NULL");
     RLS_REQUIRE(rlsh::ok_rgb(c->KsColor) && rlsh::ok_rgb(sh->KdColor), "colour planes must be all set or all NULL");
+    RLS_REQUIRE(rlsh::ok_materials(c->materials), "materials.id is set but materials.count is 0");
     RLS_REQUIRE(rlsh::has3(direct_diffuse) && rlsh::has3(direct_specular), "NULL output plane");
     LightIO io = {};
     if (rls_status st = copy_lights(lights, n_lights, 1, io.lights, &io.nl)) return st;
@@ -1796,6 +1810,7 @@ rls_status rls_ggx_shade(rls_context *ctx, int64_t n, const rls_ggx_closure *c, 
     RLS_REQUIRE(rlsh::has3(c->wo) && rlsh::has3(c->N) && rlsh::has3(c->T) && rlsh::has3(P), "wo/N/T/P plane is NULL");
     RLS_REQUIRE(rlsh::ok_rgb(c->KsColor) && rlsh::ok_rgb(sh->KdColor) && rlsh::ok_rgb(sh->KtColor),
                 "colour planes must be all set or all NULL");
+    RLS_REQUIRE(rlsh::ok_materials(c->materials), "materials.id is set but materials.count is 0");
     RLS_REQUIRE(rlsh::has3(out->direct_diffuse) && rlsh::has3(out->direct_specular) && rlsh::has3(out->refraction) &&
                 rlsh::has3(out->indirect_diffuse) && rlsh::has3(out->indirect_specular), "NULL AOV plane");
     RLS_REQUIRE(rlsh::has3(out->out) || (!out->out.r && !out->out.g && !out->out.b), "out planes must be all set or all NULL");
@@ -1822,6 +1837,7 @@ rls_status rls_disney_shade(rls_context *ctx, int64_t n, const rls_disney_closur
     RLS_REQUIRE(c != nullptr && env != nullptr && out != nullptr, "closure, env or out is NULL");
     RLS_REQUIRE(rlsh::has3(c->wo) && rlsh::has3(c->N) && rlsh::has3(c->T) && rlsh::has3(P), "wo/N/T/P plane is NULL");
     RLS_REQUIRE(rlsh::ok_rgb(c->base_color), "base_color planes must be all set or all NULL");
+    RLS_REQUIRE(rlsh::ok_materials(c->materials), "materials.id is set but materials.count is 0");
     RLS_REQUIRE(rlsh::has3(out->direct_diffuse) && rlsh::has3(out->direct_specular) && rlsh::has3(out->indirect_diffuse) &&
                 rlsh::has3(out->indirect_specular), "NULL AOV plane");
     RLS_REQUIRE(rlsh::has3(out->out) || (!out->out.r && !out->out.g && !out->out.b), "out planes must be all set or all NULL");
@@ -1848,6 +1864,7 @@ rls_status rls_disney_direct_lighting(rls_context *ctx, int64_t n, const rls_dis
     RLS_REQUIRE(c != nullptr, "closure is NULL");
     RLS_REQUIRE(rlsh::has3(c->wo) && rlsh::has3(c->N) && rlsh::has3(c->T) && rlsh::has3(P), "wo/N/T/P plane is NULL");
     RLS_REQUIRE(rlsh::ok_rgb(c->base_color), "base_color planes must be all set or all NULL");
+    RLS_REQUIRE(rlsh::ok_materials(c->materials), "materials.id is set but materials.count is 0");
     RLS_REQUIRE(rlsh::has3(direct_diffuse) && rlsh::has3(direct_specular), "NULL output plane");
     DisneyLightIO io = {};
     if (rls_status st = copy_lights(lights, n_lights, 1, io.lights, &io.nl)) return st;

@@ -315,6 +315,7 @@ inline bool has3(rls_vec3 v) { return v.x && v.y && v.z; }
 inline bool has3(rls_rgb v) { return v.r && v.g && v.b; }
 inline bool none3(rls_cvec3 v) { return !v.x && !v.y && !v.z; }
 inline bool ok_rgb(const rls_param_rgb &p) { return (p.r && p.g && p.b) || (!p.r && !p.g && !p.b); }
+inline bool ok_materials(const rls_material_index &m) { return m.id == nullptr || m.count > 0; }
 
 } // namespace rlsh
 
@@ -376,10 +377,43 @@ RLS_DEV IO reload_args(const IO &a)
 #endif
 }
 
+RLS_DEV int64_t idx_full(int64_t i) { return i; }
+RLS_DEV int64_t idx_full(const Idx &i) { return i.full(); }
 // I: int64_t or Idx.  STREAMED: every optional parameter plane is present (checked on the host), so the
 // per-parameter "stream or uniform" test -- a scalar branch per parameter per iteration -- disappears.
 template <bool STREAMED = false, class I>
 RLS_DEV float ldp(const rls_param &p, I i) { return (STREAMED || p.v) ? ldg(p.v, i) : p.u; }
+// Parameters by reference (rls_material_index): the index a PARAMETER load uses -- the point itself (per-point planes) or the
+// point's material id (per-material columns; clamped, so a hostile id reads the last entry instead of past the table).
+// INDEXED = false compiles the lookup away (kernels that are only launched without a table).
+template <class I>
+struct PIndex { I i; bool indexed; uint32_t id; };
+template <bool INDEXED = true, class I>
+RLS_DEV PIndex<I> pindex(const rls_material_index &m, I i)
+{
+    PIndex<I> k = { i, false, 0u };
+    if (INDEXED && m.id != nullptr) {
+        k.indexed = true;
+        const uint32_t id = m.id[idx_full(i)];
+        k.id = id < m.count ? id : m.count - 1u;
+    }
+    return k;
+}
+template <bool STREAMED = false, class I>
+RLS_DEV float ldp(const rls_param &p, const PIndex<I> &k)
+{
+    if (STREAMED) return ldg(p.v, k.i);
+    if (!p.v) return p.u;
+    return k.indexed ? p.v[k.id] : ldg(p.v, k.i);
+}
+template <bool STREAMED = false, class I>
+RLS_DEV void ldrgb(const rls_param_rgb &p, const PIndex<I> &k, float &r, float &g, float &b)
+{
+    if (STREAMED) { r = ldg(p.r, k.i); g = ldg(p.g, k.i); b = ldg(p.b, k.i); }
+    else if (!p.r) { r = p.ur; g = p.ug; b = p.ub; }
+    else if (k.indexed) { r = p.r[k.id]; g = p.g[k.id]; b = p.b[k.id]; }
+    else { r = ldg(p.r, k.i); g = ldg(p.g, k.i); b = ldg(p.b, k.i); }
+}
 template <class I>
 RLS_DEV V3 ld3(const rls_cvec3 &p, I i) { return mk(ldg(p.x, i), ldg(p.y, i), ldg(p.z, i)); }
 template <class I>

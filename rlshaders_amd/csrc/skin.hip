@@ -84,7 +84,8 @@ __global__ __launch_bounds__(rlsh::kBlock) void skin_kernel(SkinIO a0)
         if (i.full() >= a0.n) continue;
         const SkinIO a = reload_args(a0);      // the 35 input planes' pointers, for the loads of this tile only
         const rls_skin_closure &c = a.c;
-#define LDP(param) (UNIFORM ? (param).u : ldp<STREAMED>(param, i))
+        const PIndex<Idx> pk = pindex<MODE == MIXED>(c.materials, i);         // parameters by reference run the MIXED kernel
+#define LDP(param) (UNIFORM ? (param).u : ldp<STREAMED>(param, pk))
         V3 wo = ld3(c.wo, i), N = ld3(c.N, i), T = ld3(c.T, i);
 
         float sheenFresnel = 0.0f, specularFresnel = 0.0f;
@@ -96,13 +97,13 @@ __global__ __launch_bounds__(rlsh::kBlock) void skin_kernel(SkinIO a0)
         float sheenWeight = LDP(c.sheen_weight);
         float shr = 0.0f, shg = 0.0f, shb = 0.0f;
         if (UNIFORM) { shr = c.sheen_color.ur; shg = c.sheen_color.ug; shb = c.sheen_color.ub; }
-        else ldrgb<STREAMED>(c.sheen_color, i, shr, shg, shb);
+        else ldrgb<STREAMED>(c.sheen_color, pk, shr, shg, shb);
         float sheenIor = LDP(c.sheen_ior), sheenRough = LDP(c.sheen_roughness);
         float rx0 = ldg(a.xi[0], i), ry0 = ldg(a.xi[1], i);
         float specWeight = LDP(c.specular_weight);
         float spr = 0.0f, spg = 0.0f, spb = 0.0f;
         if (UNIFORM) { spr = c.specular_color.ur; spg = c.specular_color.ug; spb = c.specular_color.ub; }
-        else ldrgb<STREAMED>(c.specular_color, i, spr, spg, spb);
+        else ldrgb<STREAMED>(c.specular_color, pk, spr, spg, spb);
         float specIor = LDP(c.specular_ior), specRough = LDP(c.specular_roughness);
         float rx1 = ldg(a.xi[2], i), ry1 = ldg(a.xi[3], i);
         const bool sheenOn = sheenWeight > kEps, specOn = specWeight > kEps;          // src/rlSkin.cpp:191, 214
@@ -169,11 +170,12 @@ __global__ __launch_bounds__(rlsh::kBlock) void skin_kernel(SkinIO a0)
 rls_status launch_kernel(rls_context *ctx, const SkinIO &io, const char *name)
 {
     const rls_skin_closure &c = io.c;
-    const bool streamed = c.sss_color.r && c.sss_weight.v && c.sss_dist_multiplier.v && c.sss_scatter_dist[0].v &&
+    const bool by_reference = c.materials.id != nullptr;
+    const bool streamed = !by_reference && c.sss_color.r && c.sss_weight.v && c.sss_dist_multiplier.v && c.sss_scatter_dist[0].v &&
                           c.sss_scatter_dist[1].v && c.sss_scatter_dist[2].v && c.specular_color.r &&
                           c.specular_weight.v && c.specular_roughness.v && c.specular_ior.v && c.sheen_color.r &&
                           c.sheen_weight.v && c.sheen_roughness.v && c.sheen_ior.v;
-    const bool uniform = !c.sss_color.r && !c.sss_weight.v && !c.sss_dist_multiplier.v && !c.sss_scatter_dist[0].v &&
+    const bool uniform = !by_reference && !c.sss_color.r && !c.sss_weight.v && !c.sss_dist_multiplier.v && !c.sss_scatter_dist[0].v &&
                          !c.sss_scatter_dist[1].v && !c.sss_scatter_dist[2].v && !c.specular_color.r &&
                          !c.specular_weight.v && !c.specular_roughness.v && !c.specular_ior.v && !c.sheen_color.r &&
                          !c.sheen_weight.v && !c.sheen_roughness.v && !c.sheen_ior.v;
@@ -209,6 +211,7 @@ rls_status rls_skin_sample_eval_pdf(rls_context *ctx, int64_t n, const rls_skin_
     RLS_REQUIRE(rlsh::has3(c->wo) && rlsh::has3(c->N) && rlsh::has3(c->T), "wo/N/T plane is NULL");
     RLS_REQUIRE(rlsh::ok_rgb(c->sss_color) && rlsh::ok_rgb(c->specular_color) && rlsh::ok_rgb(c->sheen_color),
                 "colour planes must be all set or all NULL");
+    RLS_REQUIRE(rlsh::ok_materials(c->materials), "materials.id is set but materials.count is 0");
     for (int k = 0; k < 6; k++) RLS_REQUIRE(xi[k] != nullptr, "xi plane is NULL");
     RLS_REQUIRE(rlsh::has3(out->sheen_wi) && rlsh::has3(out->sheen_f) && out->sheen_pdf && out->sheen_fresnel &&
                 rlsh::has3(out->spec_wi) && rlsh::has3(out->spec_f) && out->spec_pdf && out->spec_fresnel &&

@@ -23,14 +23,17 @@ enum { OP_ND = rlsh::SOP_ND, OP_ND_PDF = rlsh::SOP_ND_PDF, OP_ND_EVAL = rlsh::SO
 enum { OP_CAVITY = rlsh::MOP_CAVITY, OP_DIFFUSE_DIR = rlsh::MOP_DIFFUSE_DIR, OP_UTIL = rlsh::MOP_UTIL,
        OP_REFLECT_LUM = rlsh::MOP_REFLECT_LUM };
 
-template <class I>
+// INDEXED: the parameters are per-material columns (rls_material_index); a specialisation, so that the kernels launched
+// without a table keep their code
+template <bool INDEXED, class I>
 __device__ __forceinline__ NdProfile load_profile(const rls_sss_closure &c, I i)
 {
     // scatterDist = sss_scatter_dist * sss_dist_multiplier (src/rlSkin.cpp:235-236)
-    float m = ldp(c.sss_dist_multiplier, i);
-    float dx = ldp(c.sss_scatter_dist[0], i) * m;
-    float dy = ldp(c.sss_scatter_dist[1], i) * m;
-    float dz = ldp(c.sss_scatter_dist[2], i) * m;
+    const PIndex<I> k = pindex<INDEXED>(c.materials, i);
+    float m = ldp(c.sss_dist_multiplier, k);
+    float dx = ldp(c.sss_scatter_dist[0], k) * m;
+    float dy = ldp(c.sss_scatter_dist[1], k) * m;
+    float dz = ldp(c.sss_scatter_dist[2], k) * m;
     return nd_make(dx, dy, dz);
 }
 
@@ -49,10 +52,12 @@ __device__ __forceinline__ NdProfile uniform_profile(const rls_sss_closure &c)
     return RLS_SSS_UNIFORM_SGPR ? nd_wave_uniform(p) : p;
 }
 
-template <int OP, bool UNIFORM, int FAST_MATH = RLS_FAST>
+enum { PER_POINT = 0, UNIFORM_DISTANCE = 1, BY_REFERENCE = 2 };
+template <int OP, int MODE, int FAST_MATH = RLS_FAST>
 __global__ __launch_bounds__(rlsh::kBlock) void sss_kernel(SssIO a0)
 {
     stage_libm_tables();   // expf / logf tables -> LDS (EXACT mode)
+    constexpr bool UNIFORM = MODE == UNIFORM_DISTANCE;
     NdProfile pu = {};
     if (UNIFORM) pu = uniform_profile(a0.c);
     const TileRange tiles = tile_range(a0.n);
@@ -60,7 +65,7 @@ __global__ __launch_bounds__(rlsh::kBlock) void sss_kernel(SssIO a0)
         const Idx i = make_idx(base);
         if (i.full() >= a0.n) continue;
         const SssIO a = reload_args(a0);       // plane pointers re-read per tile (rls_internal.hpp, reload_args)
-        NdProfile p = UNIFORM ? pu : load_profile(a.c, i);
+        NdProfile p = UNIFORM ? pu : load_profile<MODE == BY_REFERENCE>(a.c, i);
         if (OP == OP_ND) {
             float r = nd_radius(p, ldg(a.rx, i));
             float pdf, R, G, B;
@@ -130,6 +135,7 @@ rls_status check_closure(const rls_sss_closure *c, bool need_frame)
 {
     RLS_REQUIRE(c != nullptr, "closure is NULL");
     RLS_REQUIRE(rlsh::ok_rgb(c->sss_color), "sss_color planes must be all set or all NULL");
+    RLS_REQUIRE(rlsh::ok_materials(c->materials), "materials.id is set but materials.count is 0");
     if (need_frame) RLS_REQUIRE(rlsh::has3(c->N) && rlsh::has3(c->T), "N/T plane is NULL");
     return RLS_OK;
 }
@@ -138,13 +144,16 @@ template <int OP>
 rls_status launch_kernel(rls_context *ctx, const SssIO &io, const char *name)
 {
     const rls_sss_closure &c = io.c;
-    const bool uniform = !c.sss_dist_multiplier.v && !c.sss_scatter_dist[0].v && !c.sss_scatter_dist[1].v && !c.sss_scatter_dist[2].v;
+    const bool uniform = !c.materials.id && !c.sss_dist_multiplier.v && !c.sss_scatter_dist[0].v && !c.sss_scatter_dist[1].v &&
+                         !c.sss_scatter_dist[2].v;
     // evalProfile alone uses nothing setDistance computes but maxR: no uniform specialisation of it
     constexpr bool kHoists = OP != OP_ND_EVAL;
-    if (uniform && kHoists)
-        hipLaunchKernelGGL((sss_kernel<OP, kHoists>), rlsh::grid_for_hoisting(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
+    if (c.materials.id)
+        hipLaunchKernelGGL((sss_kernel<OP, BY_REFERENCE>), rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
+    else if (uniform && kHoists)
+        hipLaunchKernelGGL((sss_kernel<OP, kHoists ? UNIFORM_DISTANCE : PER_POINT>), rlsh::grid_for_hoisting(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
     else
-        hipLaunchKernelGGL((sss_kernel<OP, false>), rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
+        hipLaunchKernelGGL((sss_kernel<OP, PER_POINT>), rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
     return rlsh::check_launch(name);
 }
 

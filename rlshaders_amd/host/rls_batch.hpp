@@ -392,6 +392,10 @@ public:
                        first_index);
     }
 
+    // Parameters by reference (include/rlshaders_amd.h, rls_material_index): every streamed parameter handed to the
+    // constructor is then a per-MATERIAL column of `count` floats and point i takes entry device_ids[i]
+    void setMaterials(const uint32_t *device_ids, uint32_t count) { c_.materials = rls_material_index{device_ids, count}; }
+
 private:
     const Device &dev_;
     int64_t n_;
@@ -478,6 +482,10 @@ public:
     }
     int64_t size() const { return n_; }
 
+    // Parameters by reference (include/rlshaders_amd.h, rls_material_index): every streamed parameter handed to the
+    // constructor is then a per-MATERIAL column of `count` floats and point i takes entry device_ids[i]
+    void setMaterials(const uint32_t *device_ids, uint32_t count) { c_.materials = rls_material_index{device_ids, count}; }
+
 private:
     const Device &dev_;
     int64_t n_;
@@ -511,6 +519,10 @@ public:
     {
         check(rls_nd_eval(dev_.ctx(), n_, &c_, r.plane(0), profile.rgb()));
     }
+
+    // Parameters by reference (include/rlshaders_amd.h, rls_material_index): every streamed parameter handed to the
+    // constructor is then a per-MATERIAL column of `count` floats and point i takes entry device_ids[i]
+    void setMaterials(const uint32_t *device_ids, uint32_t count) { c_.materials = rls_material_index{device_ids, count}; }
 
 private:
     const Device &dev_;
@@ -552,6 +564,10 @@ public:
         check(rls_sss_integrate_scatter(dev_.ctx(), n_, &c_, P.cvec3(), &scene, spp_n, seed, first_index, result.rgb(),
                                         nullptr));
     }
+
+    // Parameters by reference (include/rlshaders_amd.h, rls_material_index): every streamed parameter handed to the
+    // constructor is then a per-MATERIAL column of `count` floats and point i takes entry device_ids[i]
+    void setMaterials(const uint32_t *device_ids, uint32_t count) { c_.materials = rls_material_index{device_ids, count}; }
 
 private:
     const Device &dev_;
@@ -613,6 +629,10 @@ public:
         if (layers) { o.sheenFresnel = layers->plane(0); o.specularFresnel = layers->plane(1); o.sssWeight = layers->plane(2); }
         check(rls_skin_integrate(dev_.ctx(), n_, &c_, P.cvec3(), &scene, env, lights, n_lights, spp_n, seed, first_index, &o));
     }
+
+    // Parameters by reference (include/rlshaders_amd.h, rls_material_index): every streamed parameter handed to the
+    // constructor is then a per-MATERIAL column of `count` floats and point i takes entry device_ids[i]
+    void setMaterials(const uint32_t *device_ids, uint32_t count) { c_.materials = rls_material_index{device_ids, count}; }
 
 private:
     const Device &dev_;

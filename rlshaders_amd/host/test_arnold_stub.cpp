@@ -139,9 +139,9 @@ int run(const char *in, const char *out)
         if (!f) { std::perror(out); return 1; }
         std::fwrite(a.data(), 4, a.size(), f); std::fwrite(b.data(), 4, b.size(), f); std::fwrite(c.data(), 4, c.size(), f);
         std::fclose(f);
-        std::printf("{\"n\": %lld, \"ggx_planes\": %zu, \"disney_planes\": %zu, \"skin_planes\": %zu, \"uniform_parameters\": %lld}\n",
+        std::printf("{\"n\": %lld, \"ggx_planes\": %zu, \"disney_planes\": %zu, \"skin_planes\": %zu, \"uniform_parameters\": %lld, \"reference_batches\": %lld}\n",
                     (long long)n, a.size() / (size_t)n, b.size() / (size_t)n, c.size() / (size_t)n,
-                    (long long)rlstub::detail::uniform_parameters());
+                    (long long)rlstub::detail::uniform_parameters(), (long long)rlstub::detail::reference_batches());
         return 0;
     } catch (const rlsb::Error &e) {
         std::fprintf(stderr, "rlshaders_amd: %s\n", e.what());
@@ -197,9 +197,9 @@ int shade(const char *in, const char *out)
         if (!f) { std::perror(out); return 1; }
         std::fwrite(a.data(), 4, a.size(), f); std::fwrite(b.data(), 4, b.size(), f); std::fwrite(c.data(), 4, c.size(), f);
         std::fclose(f);
-        std::printf("{\"n\": %lld, \"ggx_planes\": %zu, \"disney_planes\": %zu, \"skin_planes\": %zu, \"uniform_parameters\": %lld}\n",
+        std::printf("{\"n\": %lld, \"ggx_planes\": %zu, \"disney_planes\": %zu, \"skin_planes\": %zu, \"uniform_parameters\": %lld, \"reference_batches\": %lld}\n",
                     (long long)n, a.size() / (size_t)n, b.size() / (size_t)n, c.size() / (size_t)n,
-                    (long long)rlstub::detail::uniform_parameters());
+                    (long long)rlstub::detail::uniform_parameters(), (long long)rlstub::detail::reference_batches());
         return 0;
     } catch (const rlsb::Error &e) {
         std::fprintf(stderr, "rlshaders_amd: %s\n", e.what());

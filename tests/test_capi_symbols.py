@@ -57,7 +57,7 @@ def test_struct_layouts_match_header():
     import subprocess
     import tempfile
     from rlshaders_amd import _capi as capi
-    pairs = [("rls_cvec3", capi.CVec3), ("rls_vec3", capi.Vec3), ("rls_rgb", capi.Rgb), ("rls_param", capi.Param),
+    pairs = [("rls_material_index", capi.MaterialIndex), ("rls_cvec3", capi.CVec3), ("rls_vec3", capi.Vec3), ("rls_rgb", capi.Rgb), ("rls_param", capi.Param),
              ("rls_param_rgb", capi.ParamRgb), ("rls_ggx_closure", capi.GgxClosure),
              ("rls_disney_closure", capi.DisneyClosure), ("rls_disney_stream_out", capi.DisneyStreamOut),
              ("rls_sss_closure", capi.SssClosure), ("rls_skin_closure", capi.SkinClosure),

@@ -34,11 +34,13 @@ def _table(node, n, values):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("parameters", ["textured", "constant"])
+@pytest.mark.parametrize("parameters", ["textured", "constant", "instances"])
 def test_three_nodes_through_the_stub(oracle, tmp_path, parameters):
     """textured: every parameter differs from point to point (planes).  constant: every parameter evaluates to the same value
     at every point, as on a node without linked textures -- the stub notices (detail::Par1 / Par3), uploads nothing for them
-    and the library runs its UNIFORM_ALL kernels; the results must be the oracle's all the same."""
+    and the library runs its UNIFORM_ALL kernels; instances: the batch mixes the hits of 23 node instances, each with its own
+    constant parameters -- the stub finds the distinct parameter rows and sends them by reference (detail::Materials,
+    rls_material_index: one id per point, one table entry per instance).  The results must be the oracle's all the same."""
     from rlshaders_amd import build
     build.build_library()
     build.build_host_examples()
@@ -47,6 +49,15 @@ def test_three_nodes_through_the_stub(oracle, tmp_path, parameters):
     g = cases.ggx_mixed(cases.SEED_PARITY, n)
     d = cases.disney_mixed(cases.SEED_PARITY, n)
     s = cases.skin_mixed(cases.SEED_PARITY, n)
+    if parameters == "instances":
+        inst = np.random.default_rng(4).integers(0, 23, n)
+        inst[:64] = np.repeat(np.arange(23), 3)[:64]                      # runs of equal ids, as consecutive hits on a node are
+        gi, di, si = cases.ggx_mixed(cases.SEED_EDGE, 23), cases.disney_mixed(cases.SEED_EDGE, 23), cases.skin_mixed(cases.SEED_EDGE, 23)
+        for k in ("KsColor", "ior", "roughness", "anisotropic"):
+            g[k] = np.ascontiguousarray(gi[k][..., inst])
+        for k in ("base_color",) + tuple(oracle.DISNEY_SCALARS):
+            d[k] = np.ascontiguousarray(di[k][..., inst])
+        s["params"] = {k: np.ascontiguousarray(v[..., inst]) for k, v in si["params"].items()}
     if parameters == "constant":
         full = lambda v: (np.repeat(np.asarray(v, np.float32)[:, None], n, axis=1) if np.ndim(v) else np.full(n, v, np.float32))
         g.update({k: full(v) for k, v in dict(KsColor=(0.9, 0.8, 0.7), ior=1.5, roughness=0.3, anisotropic=0.6).items()})
@@ -74,7 +85,8 @@ def test_three_nodes_through_the_stub(oracle, tmp_path, parameters):
     info = json.loads(p.stdout.strip().splitlines()[-1])
     # rlGgx: KsColor + 3 scalars, rlDisney: base_color + 10, rlSkin: 3 colours + the scatter distance + 8 scalars
     assert info == {"n": n, "ggx_planes": 8, "disney_planes": 14, "skin_planes": 24,
-                    "uniform_parameters": 4 + 11 + 12 if parameters == "constant" else 0}
+                    "uniform_parameters": 4 + 11 + 12 if parameters == "constant" else 0,
+                    "reference_batches": 3 if parameters == "instances" else 0}
     out = np.fromfile(outp, np.float32).reshape(-1, n)
     og, od, osk = out[:8], out[8:22], out[22:]
     # rlGgx: evalSample -> evalBrdf -> evalPdf (+ the Fresnel side effect)
@@ -102,7 +114,8 @@ def test_three_nodes_through_the_stub(oracle, tmp_path, parameters):
 
 
 @pytest.mark.gpu
-def test_whole_shader_evaluate_through_the_stub(oracle, tmp_path):
+@pytest.mark.parametrize("parameters", ["textured", "instances"])
+def test_whole_shader_evaluate_through_the_stub(oracle, tmp_path, parameters):
     """`addShade(globals, evaluator)` per shading point and one `shade()` per node: the whole shader_evaluate of rlGgx,
     rlDisney and rlSkin (rls_ggx_shade, rls_disney_shade, rls_skin_integrate) through the generated stub, against the
     oracle's shader_evaluate on the same points, lights, environment and sample seeds"""
@@ -121,6 +134,16 @@ def test_whole_shader_evaluate_through_the_stub(oracle, tmp_path):
     u = lambda j: oracle.gen_uniform(cases.SEED_PARITY, 0, n, oracle.S_PARAM0 + j)
     shader = dict(KdColor=np.stack([u(0), u(1), u(2)]), Kd=u(3), diffuseRoughness=u(4), Ks=u(5),
                   KtColor=np.stack([u(6), u(7), u(8)]), Kt=u(9))
+    if parameters == "instances":             # the hits of 19 node instances: every parameter constant per instance
+        inst = np.random.default_rng(8).integers(0, 19, n)
+        pick = lambda v: np.ascontiguousarray(v[..., inst])
+        gi, di, si = cases.ggx_mixed(cases.SEED_EDGE, 19), cases.disney_mixed(cases.SEED_EDGE, 19), cases.skin_mixed(cases.SEED_EDGE, 19)
+        for k in ("KsColor", "ior", "roughness", "anisotropic"):
+            g[k] = pick(gi[k])
+        for k in ("base_color",) + tuple(oracle.DISNEY_SCALARS):
+            d[k] = pick(di[k])
+        s["params"] = {k: pick(v) for k, v in si["params"].items()}
+        shader = {k: pick(v[..., :19]) for k, v in shader.items()}
     tg = _table("rlGgx", n, dict(KsColor=g["KsColor"], ior=g["ior"], specularRoughness=g["roughness"],
                                  anisotropic=g["anisotropic"], **shader))
     td = _table("rlDisney", n, {k: d[k] for k in ("base_color",) + tuple(oracle.DISNEY_SCALARS)})
@@ -136,7 +159,8 @@ def test_whole_shader_evaluate_through_the_stub(oracle, tmp_path):
     p = subprocess.run([str(exe), "shade", str(inp), str(outp)], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stderr
     info = json.loads(p.stdout.strip().splitlines()[-1])
-    assert info == {"n": n, "ggx_planes": 18, "disney_planes": 15, "skin_planes": 15, "uniform_parameters": 0}
+    assert info == {"n": n, "ggx_planes": 18, "disney_planes": 15, "skin_planes": 15, "uniform_parameters": 0,
+                    "reference_batches": 3 if parameters == "instances" else 0}
     out = np.fromfile(outp, np.float32).reshape(-1, n)
     og, od, osk = out[:18], out[18:33], out[33:]
     lights = [oracle.make_light(center=(2.0, 2.0, 3.0), radius=1.25, radiance=(3.0, 2.0, 1.0), mis_mode=0),

@@ -58,7 +58,7 @@ S_XI0 = 11
 S_PARAM0 = 32
 
 
-WORKLOADS = ["ggx_reflect_refract", "ggx_reflect_refract_uniform", "ggx_reflect", "ggx_eval", "ggx_pdf", "ggx_direct",
+WORKLOADS = ["ggx_reflect_refract", "ggx_reflect_refract_uniform", "ggx_reflect_refract_materials", "ggx_reflect", "ggx_eval", "ggx_pdf", "ggx_direct",
              "ggx_shade", "disney_direct", "disney_shade", "disney_integrate", "disney_stream", "disney_triple_diffuse",
              "disney_triple_glossy", "disney_triple_glossy_uniform", "disney_triple_glossy_colour_map", "sss_probe", "sss_probe_uniform", "nd_sample", "sss_scatter", "skin", "skin_uniform", "skin_integrate",
              "ggx_reflect_refract_host", "ggx_reflect_refract_host_materials"]
@@ -163,7 +163,7 @@ class Workload:
 
 
 # planes (n floats each) a workload reads and writes: sizes its arena
-PLANES = {"ggx_reflect_refract": 19 + 12, "ggx_reflect_refract_host": 19, "ggx_reflect_refract_host_materials": 15, "ggx_reflect_refract_uniform": 13 + 12, "ggx_reflect": 17 + 8,
+PLANES = {"ggx_reflect_refract": 19 + 12, "ggx_reflect_refract_host": 19, "ggx_reflect_refract_host_materials": 15, "ggx_reflect_refract_uniform": 13 + 12, "ggx_reflect_refract_materials": 13 + 12, "ggx_reflect": 17 + 8,
           "ggx_eval": 17 + 8 + 3, "ggx_pdf": 17 + 8 + 1, "disney_triple_diffuse": 24 + 7, "disney_triple_glossy": 24 + 7, "disney_triple_glossy_uniform": 11 + 7, "disney_triple_glossy_colour_map": 14 + 7,
           "nd_sample": 9 + 7 + 5, "disney_integrate": 22 + 8, "disney_stream": 22 + 8,
           "sss_probe": 17 + 12, "sss_probe_uniform": 11 + 12,
@@ -310,6 +310,22 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
         wl.pipe, wl.host, wl.settle, wl.up_planes = pipe, (hin, hout), settle, nin
         if by_ref:
             wl.table = (table, ids)
+    elif name == "ggx_reflect_refract_materials":
+        # config 2's batch as the hits of 256 node instances, device-resident: a material id per point, the six parameters as
+        # per-instance columns (rls_material_index) -- the MIXED kernel with the parameters gathered from the table
+        import torch
+        M = 256
+        table = dict(specColor=torch.stack([R.gen_uniform(ctx, SEED, 0, M, S_KS + j) for j in range(3)]),
+                     roughness=R.gen_uniform(ctx, SEED, 0, M, S_ROUGH, 0.05, 1.0), ior=R.gen_uniform(ctx, SEED, 0, M, S_IOR, 1.05, 2.55),
+                     anisotropic=R.gen_aniso(ctx, SEED, 0, M))
+        ids = (R.gen_uniform(ctx, SEED, first, n, S_PARAM0 + 30) * M).to(torch.int32).clamp_(0, M - 1)
+        g = R.GgxSampler(ctx, wo, N, T, materials=(ids, M), **table)
+        xi = [u(S_XI0 + j) for j in range(4)]
+        out = (A.planes(3), A.planes(3), A.plane(), A.plane(), A.planes(3), A.plane())
+        wl = Workload(name, 2, (14 + 12) * 4, lambda: g.reflectRefract(xi[0], xi[1], xi[2], xi[3], out=out),
+                      "ggx_kernel<5, {m}, 0>",
+                      "rlGgx reflect+refract VNDF sampling, parameters by reference (256 node instances: a material id per point, "
+                      "six per-instance columns): wo3 N3 T3 xi4 id in, 12 f out")
     elif name == "ggx_reflect_refract_uniform":
         # config 2's kernel as a stub without linked textures runs it: every node parameter one value for the batch
         # (Arnold parameters are constants unless textured), geometry and random numbers streamed
@@ -542,7 +558,7 @@ def _cpu_leg(workload: str, n: int, threads: int):
         x = cases.xi(SEED, n, 4)
         out = g.reflect_refract(x[0], x[1], x[2], x[3])
         return (lambda: g.reflect_refract(x[0], x[1], x[2], x[3], out=out)), 2, "orc_batch_ggx_reflect_refract"
-    if workload in ("ggx_reflect_refract_host", "ggx_reflect_refract_host_materials"):
+    if workload in ("ggx_reflect_refract_host", "ggx_reflect_refract_host_materials", "ggx_reflect_refract_materials"):
         workload = "ggx_reflect_refract"            # the CPU closures' batch is host-resident by nature
     if workload in ("ggx_reflect_refract", "ggx_reflect", "ggx_eval", "ggx_pdf", "ggx_direct", "ggx_shade"):
         c = cases.ggx_mixed(SEED, n)

@@ -216,3 +216,58 @@ def test_whole_node_shading_in_fast_mode(fast, oracle):
             assert np.isfinite(a).all(), (name, k)
             assert abs(a.mean() / b.mean() - 1) < 5e-3, (name, k, a.mean(), b.mean())
             assert np.quantile(cases.rel_err(q[k], r[k]), 0.9) <= 2e-3, (name, k)
+
+
+def test_fast_mode_specialisations_agree(fast):
+    """FAST mode has the UNIFORM_* and by-reference specialisations too (the same templates compiled with RLS_FAST = 1): each
+    must give what FAST's streamed kernels give on the same values as per-point planes -- same arithmetic, so the same bits."""
+    import torch
+    n, m = 1 << 14, 11
+    wo, Nn, T = (dev(a) for a in cases.frame(cases.SEED_PARITY, n))
+    xi = cases.xi(cases.SEED_PARITY, n, 6)
+    dx = [dev(a) for a in xi]
+    full = lambda v: dev(np.repeat(np.asarray(v, np.float32)[:, None], n, axis=1) if np.ndim(v) else np.full(n, v, np.float32))
+
+    def same(a, b, what):
+        a, b = host(a), host(b)
+        ok = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+        assert ok.all(), (what, int((~ok).sum()))
+
+    # uniform against planes
+    g = dict(specColor=(0.9, 0.8, 0.7), ior=1.5, roughness=0.35, anisotropic=0.25)
+    a = R.GgxSampler(fast, wo, Nn, T, **g).reflectRefract(*dx[:4])
+    b = R.GgxSampler(fast, wo, Nn, T, **{k: full(v) for k, v in g.items()}).reflectRefract(*dx[:4])
+    for k, (p, q) in enumerate(zip(a, b)):
+        same(p, q, ("ggx uniform", k))
+    d = dict(base_color=(0.85, 0.7, 0.2), subsurface=0.2, metallic=0.3, specular=0.5, specular_tint=0.25, roughness=0.4,
+             anisotropic=0.4, sheen=0.5, sheen_tint=0.5, clearcoat=0.6, clearcoat_gloss=0.7)
+    for lobe in (R.RLS_RAY_DIFFUSE, R.RLS_RAY_GLOSSY):
+        du, dp = R.DisneySampler(fast, wo, Nn, T, **d), R.DisneySampler(fast, wo, Nn, T, **{k: full(v) for k, v in d.items()})
+        dc = R.DisneySampler(fast, wo, Nn, T, **dict(d, base_color=full(d["base_color"])))          # the colour-map kernel
+        for s in (du, dp, dc):
+            s.setSampleType(lobe)
+        for k, (p, q, r) in enumerate(zip(du.sampleEvalPdf(dx[0], dx[1]), dp.sampleEvalPdf(dx[0], dx[1]), dc.sampleEvalPdf(dx[0], dx[1]))):
+            same(p, q, ("disney uniform", lobe, k))
+            same(r, q, ("disney colour map", lobe, k))
+    sk = dict(cases.SKIN_DEFAULTS, sheen_weight=0.3, sss_scatter_dist=(1.0, 0.6, 0.35))
+    a = R.SkinShader(fast, wo, Nn, T, **sk).sampleEvalPdf(dev(xi))
+    b = R.SkinShader(fast, wo, Nn, T, **{k: full(v) for k, v in sk.items()}).sampleEvalPdf(dev(xi))
+    for k in a:
+        same(a[k], b[k], ("skin uniform", k))
+    a = R.SssSampler(fast, Nn, T, (0.8, 0.5, 0.4), (1.0, 0.6, 0.35)).getProbeRay(dx[0], dx[1])
+    b = R.SssSampler(fast, Nn, T, (0.8, 0.5, 0.4), full((1.0, 0.6, 0.35))).getProbeRay(dx[0], dx[1])
+    for k in a:
+        same(a[k], b[k], ("sss uniform", k))
+    # by reference against planes
+    ids = np.random.default_rng(2).integers(0, m, n).astype(np.int32)
+    t = cases.ggx_mixed(cases.SEED_EDGE, m)
+    cols = dict(specColor=t["KsColor"], ior=t["ior"], roughness=t["roughness"], anisotropic=t["anisotropic"])
+    a = R.GgxSampler(fast, wo, Nn, T, materials=(dev(ids), m), **{k: dev(v) for k, v in cols.items()}).reflectRefract(*dx[:4])
+    b = R.GgxSampler(fast, wo, Nn, T, **{k: dev(np.ascontiguousarray(v[..., ids])) for k, v in cols.items()}).reflectRefract(*dx[:4])
+    for k, (p, q) in enumerate(zip(a, b)):
+        same(p, q, ("ggx by reference", k))
+    ts = cases.skin_mixed(cases.SEED_EDGE, m)["params"]
+    a = R.SkinShader(fast, wo, Nn, T, materials=(dev(ids), m), **{k: dev(v) for k, v in ts.items()}).sampleEvalPdf(dev(xi))
+    b = R.SkinShader(fast, wo, Nn, T, **{k: dev(np.ascontiguousarray(v[..., ids])) for k, v in ts.items()}).sampleEvalPdf(dev(xi))
+    for k in a:
+        same(a[k], b[k], ("skin by reference", k))

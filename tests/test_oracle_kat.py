@@ -122,7 +122,7 @@ def test_nd_profile_properties():
     rr = np.linspace(1e-4, 60, 600001, dtype=np.float64).astype(np.float32)
     s1 = O.Sss(rr.size, (1.0, 1.0, 1.0))
     R = s1.nd_profile(rr)[0].astype(np.float64)
-    integral = np.trapz(R * 2 * np.pi * rr.astype(np.float64), rr.astype(np.float64))
+    integral = np.trapezoid(R * 2 * np.pi * rr.astype(np.float64), rr.astype(np.float64))
     assert abs(integral - 1.0) < 2e-3
 
 

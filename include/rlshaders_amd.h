@@ -79,7 +79,9 @@ typedef struct { const float *r, *g, *b; float ur, ug, ub; } rls_param_rgb;
  * and point i takes entry min(id[i], count - 1): 4 bytes per point instead of 4 per parameter, which is what a host-resident
  * batch pays for on the bus (rls_pipeline_*).  A NULL parameter pointer is still the uniform value.  The arithmetic is
  * the per-point arithmetic on the looked-up values: the same bits as with the values expanded into planes.
- * `id == NULL` (a zero-initialised closure): parameters are per-point planes or uniform values, as before. */
+ * `id == NULL` (a zero-initialised closure): parameters are per-point planes or uniform values, as before.
+ * No counterpart in the reference, which evaluates the parameters per hit (AiShaderEvalParam* at src/rlGgx.cpp:256-259,
+ * src/rlDisney.cpp:155-172, src/rlSkin.cpp:184-236): this is how a batching stub avoids expanding them per point. */
 typedef struct { const uint32_t *id; uint32_t count; } rls_material_index;
 
 /* Arnold ray-type tags selecting the rlDisney lobe (DisneySampler::mSampleType,

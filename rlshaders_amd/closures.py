@@ -191,6 +191,11 @@ class ChunkPlanes:
         directly and do not want a tensor object per plane and chunk"""
         return int(self._ptrs[k]) if self._live[k] else None
 
+    def device_ptr(self, k: int) -> int:
+        """device address of the slot's plane k whether or not a host plane is streamed to / from it (an output the kernel
+        must write but the host does not want stays in the slot)"""
+        return int(self._ptrs[k])
+
     def __getitem__(self, k: int):
         if not self._live[k]:
             return None

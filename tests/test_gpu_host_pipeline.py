@@ -131,3 +131,55 @@ def test_cpp_host_pipeline_example():
     assert got["bit_identical_to_device_resident"] is True and got["points"] == (1 << 21) - 37
     assert got["gsamples_per_s"] > 0 and got["box_h2d"] > 1.0
     print(got)
+
+
+def test_whole_node_by_reference_through_the_pipeline(gpu, oracle):
+    """The whole shader_evaluate of rlGgx on a host-resident batch whose parameters go by reference (a material id per point, the
+    node instances' sixteen parameters as device-resident columns): per shading point only the geometry and the id go up and
+    sg->out.RGB comes down -- the AOV planes exist in the slot, the kernel writes them, nobody downloads them.  Chunked with
+    first_index = the chunk's first point, so every point draws the batch's sample numbers: the result equals ONE
+    device-resident call with the parameters expanded into planes, and the oracle's shader_evaluate."""
+    n, chunk, m = 30_011, 4096, 13
+    c = cases.ggx_mixed(cases.SEED_PARITY, n)
+    t = cases.ggx_mixed(cases.SEED_EDGE, m)
+    u = lambda j, k=m: oracle.gen_uniform(17, 0, k, oracle.S_PARAM0 + j)
+    sh = dict(KdColor=np.stack([u(0), u(1), u(2)]), Kd=u(3), diffuseRoughness=u(4), Ks=u(5), KtColor=np.stack([u(6), u(7), u(8)]), Kt=u(9))
+    ids = np.random.default_rng(3).integers(0, m, n).astype(np.int32)
+    P = np.stack([oracle.gen_uniform(17, 0, n, 40 + j, 0.0, 4.0 if j < 2 else 1.0) for j in range(3)])
+    planes = [c["wo"][k] for k in range(3)] + [c["N"][k] for k in range(3)] + [c["T"][k] for k in range(3)] + [P[k] for k in range(3)] + \
+             [ids.view(np.float32)]
+    hin_all = torch.empty(13, n, dtype=torch.float32, pin_memory=True)
+    hin_all.copy_(torch.from_numpy(np.stack(planes)))
+    hout_all = torch.full((3, n), float("nan"), dtype=torch.float32).pin_memory()
+    hin, hout = [hin_all[k] for k in range(13)], [None] * 15 + [hout_all[k] for k in range(3)]
+    lights = [R.make_light(center=(2.0, 2.0, 3.0), radius=1.25, radiance=(3.0, 2.0, 1.0)),
+              R.make_light(center=(-3.0, 1.0, 2.5), radius=0.5, radiance=(0.5, 4.0, 2.0), mis_mode=2)]
+    tab = {k: dev(v) for k, v in dict(specColor=t["KsColor"], ior=t["ior"], roughness=t["roughness"], anisotropic=t["anisotropic"]).items()}
+    shd = {k: dev(v) for k, v in sh.items()}
+
+    def launch(slot, first, count, i, o):
+        ids_chunk = torch.as_tensor(R.closures._DevicePlane(i.device_ptr(12), count), device="cuda").view(torch.int32)
+        g = R.GgxSampler(slot, i.rows(0), i.rows(3), i.rows(6), materials=(ids_chunk, m), **tab)
+        aov = lambda j: torch.as_tensor(R.closures._DevicePlane(o.device_ptr(3 * j), count, 3, o.device_ptr(3 * j + 1) - o.device_ptr(3 * j)),
+                                        device="cuda")
+        out = {k: aov(j) for j, k in enumerate(R.GgxSampler.SHADE_AOVS + ("out",))}
+        g.shade(i.rows(9), lights, 2, 99, env=(1.0, 0.9, 0.8), out=out, first_index=first, **shd)
+
+    pipe = R.Pipeline(gpu, chunk, 13, 18, 3)
+    try:
+        pipe.run(n, hin, hout, launch)
+    finally:
+        pipe.close()
+    expanded = dict(KsColor=t["KsColor"][:, ids], ior=t["ior"][ids], roughness=t["roughness"][ids], anisotropic=t["anisotropic"][ids])
+    shx = {k: np.ascontiguousarray(v[..., ids]) for k, v in sh.items()}
+    g = R.GgxSampler(gpu, dev(c["wo"]), dev(c["N"]), dev(c["T"]), specColor=dev(np.ascontiguousarray(expanded["KsColor"])),
+                     ior=dev(expanded["ior"]), roughness=dev(expanded["roughness"]), anisotropic=dev(expanded["anisotropic"]))
+    ref = host(g.shade(dev(P), lights, 2, 99, env=(1.0, 0.9, 0.8), **{k: dev(v) for k, v in shx.items()})["out"])
+    got = hout_all.numpy()
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    og = ggx_oracle(oracle, dict(wo=c["wo"], N=c["N"], T=c["T"], **{k: np.ascontiguousarray(v) for k, v in expanded.items()}))
+    olts = [oracle.make_light(center=(2.0, 2.0, 3.0), radius=1.25, radiance=(3.0, 2.0, 1.0)),
+            oracle.make_light(center=(-3.0, 1.0, 2.5), radius=0.5, radiance=(0.5, 4.0, 2.0), mis_mode=2)]
+    orc = og.shade(P, olts, 2, 99, Kd_color=shx["KdColor"], Kd=shx["Kd"], Kd_roughness=shx["diffuseRoughness"], Ks=shx["Ks"],
+                   Kt_color=shx["KtColor"], Kt=shx["Kt"], env=(1.0, 0.9, 0.8))["out"]
+    cases.assert_tight(cases.summarize(cases.rel_err(got, orc)), "whole node through the pipeline vs oracle")

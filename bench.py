@@ -61,7 +61,8 @@ S_PARAM0 = 32
 WORKLOADS = ["ggx_reflect_refract", "ggx_reflect_refract_uniform", "ggx_reflect_refract_materials", "ggx_reflect", "ggx_eval", "ggx_pdf", "ggx_direct",
              "ggx_shade", "disney_direct", "disney_shade", "disney_integrate", "disney_stream", "disney_triple_diffuse",
              "disney_triple_glossy", "disney_triple_glossy_uniform", "disney_triple_glossy_colour_map", "sss_probe", "sss_probe_uniform", "nd_sample", "sss_scatter", "skin", "skin_uniform", "skin_integrate",
-             "ggx_reflect_refract_host", "ggx_reflect_refract_host_materials", "ggx_shade_host_materials"]
+             "ggx_reflect_refract_host", "ggx_reflect_refract_host_materials", "ggx_shade_host_materials",
+             "disney_shade_host_materials", "skin_integrate_host_materials"]
 
 # every lobe of rlDisney switched on: the parameters of disney_triple_glossy_uniform, one value each for the whole batch
 DISNEY_UNIFORM = dict(base_color=(0.850000024, 0.704699695, 0.205699995), subsurface=0.2, metallic=0.3, specular=0.5, specular_tint=0.25,
@@ -84,7 +85,7 @@ BLOCK_ALL = [("ggx_reflect_refract_uniform", 26, 40), ("ggx_reflect", 26, 40), (
              ("sss_probe", 25, 40), ("sss_probe", 26, 40), ("sss_probe_uniform", 26, 40), ("nd_sample", 26, 40),
              ("skin", 26, 30), ("skin", 27, 20), ("skin_uniform", 26, 30),
              ("ggx_reflect_refract_host", 24, 4), ("ggx_reflect_refract_host_materials", 24, 4),
-             ("ggx_shade_host_materials", 24, 4)]
+             ("ggx_shade_host_materials", 24, 4), ("disney_shade_host_materials", 24, 4), ("skin_integrate_host_materials", 24, 4)]
 BLOCK_CONFIGS = [("disney_integrate", 26, 12), ("sss_probe", 25, 40), ("skin", 27, 20)]
 
 
@@ -164,7 +165,7 @@ class Workload:
 
 
 # planes (n floats each) a workload reads and writes: sizes its arena
-PLANES = {"ggx_reflect_refract": 19 + 12, "ggx_reflect_refract_host": 19, "ggx_reflect_refract_host_materials": 15, "ggx_shade_host_materials": 13, "ggx_reflect_refract_uniform": 13 + 12, "ggx_reflect_refract_materials": 13 + 12, "ggx_reflect": 17 + 8,
+PLANES = {"ggx_reflect_refract": 19 + 12, "ggx_reflect_refract_host": 19, "ggx_reflect_refract_host_materials": 15, "ggx_shade_host_materials": 13, "disney_shade_host_materials": 13, "skin_integrate_host_materials": 13, "ggx_reflect_refract_uniform": 13 + 12, "ggx_reflect_refract_materials": 13 + 12, "ggx_reflect": 17 + 8,
           "ggx_eval": 17 + 8 + 3, "ggx_pdf": 17 + 8 + 1, "disney_triple_diffuse": 24 + 7, "disney_triple_glossy": 24 + 7, "disney_triple_glossy_uniform": 11 + 7, "disney_triple_glossy_colour_map": 14 + 7,
           "nd_sample": 9 + 7 + 5, "disney_integrate": 22 + 8, "disney_stream": 22 + 8,
           "sss_probe": 17 + 12, "sss_probe_uniform": 11 + 12,
@@ -311,30 +312,91 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
         wl.pipe, wl.host, wl.settle, wl.up_planes = pipe, (hin, hout), settle, nin
         if by_ref:
             wl.table = (table, ids)
-    elif name == "ggx_shade_host_materials":
-        # the whole shader_evaluate of rlGgx on a batch in page-locked HOST memory: what crosses the bus per shading point is
-        # its geometry (wo3 N3 T3 P3) and a material id up, sg->out.RGB down -- 52 B + 12 B for 144 samples, instead of
-        # 104 B for the 2 samples of config 2's verbs.  256 node instances' sixteen parameters go by reference; the AOVs stay
-        # on the device (an AOV nobody enabled is not downloaded).
+    elif name in ("ggx_shade_host_materials", "disney_shade_host_materials", "skin_integrate_host_materials"):
+        # the whole shader_evaluate of a node on a batch in page-locked HOST memory: what crosses the bus per shading point is
+        # its geometry (wo3 N3 T3 P3) and a material id up, sg->out.RGB down -- 52 B + 12 B for the node's 128-144 (rlSkin: 48)
+        # samples, instead of 104 B for the 2 samples of config 2's verbs.  256 node instances' parameters go by reference
+        # (rls_material_index); the AOVs stay on the device (an AOV nobody enabled is not downloaded).
         import torch
+        node = name.split("_")[0]
         M = 256
+        K, Cc = R._capi, R.closures.C
         gu = lambda stream, lo=0.0, hi=1.0: R.gen_uniform(ctx, SEED, 0, M, stream, lo, hi)
-        tab = dict(Ks=[gu(S_KS + j) for j in range(3)], rough=gu(S_ROUGH, 0.05, 1.0), ior=gu(S_IOR, 1.05, 2.55),
-                   aniso=R.gen_aniso(ctx, SEED, 0, M), KdColor=[gu(S_PARAM0 + j) for j in range(3)], Kd=gu(S_PARAM0 + 3),
-                   KdRough=gu(S_PARAM0 + 4), KsW=gu(S_PARAM0 + 5), KtColor=[gu(S_PARAM0 + 11 + j) for j in range(3)], Kt=gu(S_PARAM0 + 14))
+        gu3 = lambda stream, lo=0.0, hi=1.0: [gu(stream + j, lo, hi) for j in range(3)]
+        col = lambda t: K.Param(t.data_ptr(), 0.0)
+        col3 = lambda t: K.ParamRgb(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), 0.0, 0.0, 0.0)
         ids = (R.gen_uniform(ctx, SEED, first, n, S_PARAM0 + 30) * M).to(torch.int32).clamp_(0, M - 1)
-        P = u3(S_PARAM0 + 8, 0.0, 4.0)
+        P = N if node == "skin" else u3(S_PARAM0 + 8 if node == "ggx" else S_PARAM0 + 16, 0.0, 4.0)      # rlSkin: points on the unit sphere
         dev_in = [wo[0], wo[1], wo[2], N[0], N[1], N[2], T[0], T[1], T[2], P[0], P[1], P[2], ids.view(torch.float32)]
         nin = len(dev_in)
+        lights = [R.make_light(center=(2.0, 2.0, 6.0), radius=1.25, radiance=(3.0, 2.0, 1.0)),
+                  R.make_light(center=(-1.0, 5.0, 7.0), radius=0.6, radiance=(0.5, 0.5, 4.0))]
+        la, nl = R.closures.light_array(lights)
+        env = (Cc.c_float * 3)(1.0, 0.9, 0.8)
+        geometry = lambda c, i: (setattr(c, "wo", K.CVec3(i.ptr(0), i.ptr(1), i.ptr(2))), setattr(c, "N", K.CVec3(i.ptr(3), i.ptr(4), i.ptr(5))),
+                                 setattr(c, "T", K.CVec3(i.ptr(6), i.ptr(7), i.ptr(8))), setattr(c, "materials", K.MaterialIndex(i.ptr(12), M)))
+        rgbs = lambda o, count: [K.Rgb(o.device_ptr(3 * j), o.device_ptr(3 * j + 1), o.device_ptr(3 * j + 2)) for j in range(count)]
+        if node == "ggx":
+            tab = dict(Ks=gu3(S_KS), rough=gu(S_ROUGH, 0.05, 1.0), ior=gu(S_IOR, 1.05, 2.55), aniso=R.gen_aniso(ctx, SEED, 0, M),
+                       KdColor=gu3(S_PARAM0), Kd=gu(S_PARAM0 + 3), KdRough=gu(S_PARAM0 + 4), KsW=gu(S_PARAM0 + 5),
+                       KtColor=gu3(S_PARAM0 + 11), Kt=gu(S_PARAM0 + 14))
+            nout, spp, kernel, samples = 18, 4, "ggx_shade_kernel<1, {m}>", 144
+
+            def chunk_node(slot, cfirst, count, i, o):
+                c = K.GgxClosure()
+                geometry(c, i)
+                c.KsColor, c.specularRoughness, c.ior, c.anisotropic = col3(tab["Ks"]), col(tab["rough"]), col(tab["ior"]), col(tab["aniso"])
+                sh = K.GgxShader(col3(tab["KdColor"]), col(tab["Kd"]), col(tab["KdRough"]), col(tab["KsW"]), col3(tab["KtColor"]), col(tab["Kt"]))
+                out = K.GgxShadeOut(*rgbs(o, 6))
+                K.check(slot.lib.rls_ggx_shade(slot.handle, count, Cc.byref(c), Cc.byref(sh), K.CVec3(i.ptr(9), i.ptr(10), i.ptr(11)), la, nl,
+                                               env, 1, spp, SEED, first + cfirst, Cc.byref(out)))
+        elif node == "disney":
+            tab = dict(base=gu3(S_KS), **{k: gu(S_PARAM0 + j) for j, k in enumerate(K.DISNEY_SCALARS)})
+            nout, spp, kernel, samples = 15, 4, "disney_shade_kernel<1, {m}>", 128
+
+            def chunk_node(slot, cfirst, count, i, o):
+                c = K.DisneyClosure()
+                geometry(c, i)
+                c.base_color = col3(tab["base"])
+                for k in K.DISNEY_SCALARS:
+                    setattr(c, k, col(tab[k]))
+                out = K.DisneyShadeOut(*rgbs(o, 5))
+                K.check(slot.lib.rls_disney_shade(slot.handle, count, Cc.byref(c), K.CVec3(i.ptr(9), i.ptr(10), i.ptr(11)), la, nl, env, spp,
+                                                  SEED, first + cfirst, Cc.byref(out)))
+        else:
+            tab = dict(sss_color=gu3(S_PARAM0), sss_weight=gu(S_PARAM0 + 3), sss_dist_multiplier=gu(S_PARAM0 + 4, 0.5, 1.5),
+                       sss_scatter_dist=gu3(S_PARAM0 + 5, 0.1, 2.1), specular_color=gu3(S_PARAM0 + 8), specular_weight=gu(S_PARAM0 + 11),
+                       specular_roughness=gu(S_PARAM0 + 12, 0.05, 1.0), specular_ior=gu(S_PARAM0 + 13, 1.05, 2.55),
+                       sheen_color=gu3(S_PARAM0 + 14), sheen_weight=gu(S_PARAM0 + 17), sheen_roughness=gu(S_PARAM0 + 18, 0.05, 1.0),
+                       sheen_ior=gu(S_PARAM0 + 19, 1.05, 2.55))
+            scene = R.make_scene("sphere", sphere_radius=1.0, light_dir=(0.0, 0.6, 0.8), use_cavity_fade=True)
+            nout, spp, kernel, samples = 15, 4, "skin_integrate_kernel<1, {m}>", 48
+
+            def chunk_node(slot, cfirst, count, i, o):
+                c = K.SkinClosure()
+                geometry(c, i)
+                for k in ("sss_color", "specular_color", "sheen_color"):
+                    setattr(c, k, col3(tab[k]))
+                for k in ("sss_weight", "sss_dist_multiplier", "specular_weight", "specular_roughness", "specular_ior", "sheen_weight",
+                          "sheen_roughness", "sheen_ior"):
+                    setattr(c, k, col(tab[k]))
+                for k in range(3):
+                    c.sss_scatter_dist[k] = col(tab["sss_scatter_dist"][k])
+                # device planes 0..8 the three layer AOVs, 9..11 their scalars, 12..14 sg->out.RGB (the one that is downloaded)
+                a = rgbs(o, 3)
+                out = K.SkinIntegrateOut(a[0], a[1], a[2], K.Rgb(o.device_ptr(12), o.device_ptr(13), o.device_ptr(14)),
+                                         o.device_ptr(9), o.device_ptr(10), o.device_ptr(11))
+                K.check(slot.lib.rls_skin_integrate(slot.handle, count, Cc.byref(c), K.CVec3(i.ptr(9), i.ptr(10), i.ptr(11)), Cc.byref(scene),
+                                                    env, None, 0, spp, SEED, first + cfirst, Cc.byref(out)))
         hin_all = torch.empty(nin, n, dtype=torch.float32, pin_memory=True)
         hout_all = torch.empty(3, n, dtype=torch.float32, pin_memory=True)
         hin = [hin_all[k] for k in range(nin)]
-        hout = [None] * 15 + [hout_all[k] for k in range(3)]          # 5 AOVs x 3 not downloaded, sg->out.RGB downloaded
+        hout = [None] * (nout - 3) + [hout_all[k] for k in range(3)]          # the AOVs are not downloaded, sg->out.RGB is
         torch.cuda.synchronize()
         for h, d in zip(hin, dev_in):
             h.copy_(d)
         cp = min(n, 1 << chunk_log2)
-        pipe = R.Pipeline(ctx, cp, nin, 18, depth)
+        pipe = R.Pipeline(ctx, cp, nin, nout, depth)
         settle = []
         for _ in range(40):                                              # see ggx_reflect_refract_host
             r = pipe.copy_rates(1 << 27)
@@ -342,32 +404,16 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
             if r["both"] >= 1.4 * max(r["h2d"], r["d2h"]):
                 break
             time.sleep(0.25)
-        lights = [R.make_light(center=(2.0, 2.0, 6.0), radius=1.25, radiance=(3.0, 2.0, 1.0)),
-                  R.make_light(center=(-1.0, 5.0, 7.0), radius=0.6, radiance=(0.5, 0.5, 4.0))]
-        la, nl = R.closures.light_array(lights)
-        env = (R.closures.C.c_float * 3)(1.0, 0.9, 0.8)
-        K = R._capi
-        col = lambda t: K.Param(t.data_ptr(), 0.0)
-        col3 = lambda t: K.ParamRgb(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), 0.0, 0.0, 0.0)
-
-        def chunk_shade(slot, cfirst, count, i, o):
-            c = K.GgxClosure()
-            c.wo, c.N, c.T = K.CVec3(i.ptr(0), i.ptr(1), i.ptr(2)), K.CVec3(i.ptr(3), i.ptr(4), i.ptr(5)), K.CVec3(i.ptr(6), i.ptr(7), i.ptr(8))
-            c.KsColor, c.specularRoughness, c.ior, c.anisotropic = col3(tab["Ks"]), col(tab["rough"]), col(tab["ior"]), col(tab["aniso"])
-            c.materials = K.MaterialIndex(i.ptr(12), M)
-            sh = K.GgxShader(col3(tab["KdColor"]), col(tab["Kd"]), col(tab["KdRough"]), col(tab["KsW"]), col3(tab["KtColor"]), col(tab["Kt"]))
-            out = K.GgxShadeOut(*[K.Rgb(o.device_ptr(3 * j), o.device_ptr(3 * j + 1), o.device_ptr(3 * j + 2)) for j in range(6)])
-            K.check(slot.lib.rls_ggx_shade(slot.handle, count, R.closures.C.byref(c), R.closures.C.byref(sh),
-                                           K.CVec3(i.ptr(9), i.ptr(10), i.ptr(11)), la, nl, env, 1, 4, SEED, first + cfirst,
-                                           R.closures.C.byref(out)))
-
-        wl = Workload(name, 144, (nin + 3) * 4, lambda: pipe.run(n, hin, hout, chunk_shade), "ggx_shade_kernel<1, {m}>",
-                      f"rlGgx shader_evaluate, whole (two lights x 48 + 3 x 16 samples per point), batch resident in page-locked HOST "
-                      f"memory: chunks of {cp} points on {depth} streams, parameters by reference (256 node instances); per shading "
-                      "point 52 B up (wo3 N3 T3 P3 + material id) and 12 B down (sg->out.RGB; the AOVs stay on the device)",
+        what = {"ggx": "rlGgx shader_evaluate, whole (two lights x 48 + 3 x 16 samples per point)",
+                "disney": "rlDisney shader_evaluate, whole (two lights x 48 + 2 x 16 samples per point)",
+                "skin": "rlSkin shader_evaluate (16 samples per layer, probe rays on an analytic sphere)"}[node]
+        wl = Workload(name, samples, (nin + 3) * 4, lambda: pipe.run(n, hin, hout, chunk_node), kernel,
+                      f"{what}, batch resident in page-locked HOST memory: chunks of {cp} points on {depth} streams, parameters by "
+                      "reference (256 node instances); per shading point 52 B up (wo3 N3 T3 P3 + material id) and 12 B down "
+                      "(sg->out.RGB; the AOVs stay on the device)",
                       bound="pcie", launches_per_step=(n + cp - 1) // cp)
         wl.pipe, wl.host, wl.settle, wl.up_planes, wl.down_planes = pipe, (hin, hout), settle, nin, 3
-        wl.table = (tab, ids)
+        wl.table = (tab, ids, P)
     elif name == "ggx_reflect_refract_materials":
         # config 2's batch as the hits of 256 node instances, device-resident: a material id per point, the six parameters as
         # per-instance columns (rls_material_index) -- the MIXED kernel with the parameters gathered from the table
@@ -618,8 +664,8 @@ def _cpu_leg(workload: str, n: int, threads: int):
         return (lambda: g.reflect_refract(x[0], x[1], x[2], x[3], out=out)), 2, "orc_batch_ggx_reflect_refract"
     if workload in ("ggx_reflect_refract_host", "ggx_reflect_refract_host_materials", "ggx_reflect_refract_materials"):
         workload = "ggx_reflect_refract"            # the CPU closures' batch is host-resident by nature
-    if workload == "ggx_shade_host_materials":
-        workload = "ggx_shade"
+    if workload.endswith("_host_materials") and not workload.startswith("ggx_reflect"):
+        workload = workload[:-len("_host_materials")]            # ggx_shade, disney_shade, skin_integrate
     if workload in ("ggx_reflect_refract", "ggx_reflect", "ggx_eval", "ggx_pdf", "ggx_direct", "ggx_shade"):
         c = cases.ggx_mixed(SEED, n)
         g = O.Ggx(c["wo"], c["N"], c["T"], KsColor=c["KsColor"], ior=c["ior"], roughness=c["roughness"],
@@ -822,7 +868,8 @@ def roofline_record(wl, n: int, kernel_ms: float, math: str) -> dict:
                 "kernel_ms": round(launch_ms, 5), "launches_per_step": launches,
                 "algorithmic_bytes_per_point": wl.bytes_per_point, "algorithmic_bytes_per_launch": int(bytes_per_launch),
                 "device_resident_note": "the same kernel on a device-resident batch is the workload " +
-                                        ("ggx_shade" if wl.name.startswith("ggx_shade") else "ggx_reflect_refract")}
+                                        (wl.name[:-len("_host_materials")] if wl.name.endswith("_host_materials") and
+                                         not wl.name.startswith("ggx_reflect") else "ggx_reflect_refract")}
     if wl.bound == "hbm":
         roof = {"bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": int(traffic) if traffic else None}

@@ -131,6 +131,12 @@ def test_cpp_host_pipeline_example():
     assert got["bit_identical_to_device_resident"] is True and got["points"] == (1 << 21) - 37
     assert got["gsamples_per_s"] > 0 and got["box_h2d"] > 1.0
     print(got)
+    # the whole-node mode: rls_ggx_shade per chunk, parameters by reference, only sg->out.RGB downloaded
+    p = subprocess.run([str(exe), "20", "16", "3", "2", "shade"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout, p.stderr)
+    got = json.loads(p.stdout.strip().splitlines()[-1])
+    assert got["mode"] == "shade" and got["bit_identical_to_device_resident"] is True and got["points"] == (1 << 20) - 37
+    print(got)
 
 
 def test_whole_node_by_reference_through_the_pipeline(gpu, oracle):

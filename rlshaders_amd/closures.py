@@ -196,6 +196,15 @@ class ChunkPlanes:
         must write but the host does not want stays in the slot)"""
         return int(self._ptrs[k])
 
+    def device_rows(self, k: int, rows: int = 1, dtype=None):
+        """tensor view of the slot's planes k .. k + rows - 1 whether or not host planes are streamed to / from them: [count]
+        for one plane, [rows, count] for equally spaced ones; ``dtype=torch.int32`` reinterprets the bits (a material-id plane)"""
+        step = self._ptrs[k + 1] - self._ptrs[k] if rows > 1 else 0
+        if any(self._ptrs[k + j] - self._ptrs[k] != j * step for j in range(rows)):
+            raise ValueError("ChunkPlanes.device_rows: planes are not equally spaced")
+        t = torch.as_tensor(_DevicePlane(self._ptrs[k], self._count, rows if rows > 1 else 0, step), device=self._device)
+        return t if dtype is None else t.view(dtype)
+
     def __getitem__(self, k: int):
         if not self._live[k]:
             return None

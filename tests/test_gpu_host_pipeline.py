@@ -164,11 +164,9 @@ def test_whole_node_by_reference_through_the_pipeline(gpu, oracle):
     shd = {k: dev(v) for k, v in sh.items()}
 
     def launch(slot, first, count, i, o):
-        ids_chunk = torch.as_tensor(R.closures._DevicePlane(i.device_ptr(12), count), device="cuda").view(torch.int32)
-        g = R.GgxSampler(slot, i.rows(0), i.rows(3), i.rows(6), materials=(ids_chunk, m), **tab)
-        aov = lambda j: torch.as_tensor(R.closures._DevicePlane(o.device_ptr(3 * j), count, 3, o.device_ptr(3 * j + 1) - o.device_ptr(3 * j)),
-                                        device="cuda")
-        out = {k: aov(j) for j, k in enumerate(R.GgxSampler.SHADE_AOVS + ("out",))}
+        g = R.GgxSampler(slot, i.rows(0), i.rows(3), i.rows(6), materials=(i.device_rows(12, dtype=torch.int32), m), **tab)
+        # the AOV planes are not streamed to the host: device_rows() hands out the slot's planes all the same
+        out = {k: o.device_rows(3 * j, 3) for j, k in enumerate(R.GgxSampler.SHADE_AOVS + ("out",))}
         g.shade(i.rows(9), lights, 2, 99, env=(1.0, 0.9, 0.8), out=out, first_index=first, **shd)
 
     pipe = R.Pipeline(gpu, chunk, 13, 18, 3)

@@ -56,6 +56,9 @@ __device__ __forceinline__ LobeOut ggx_lobe(V3 wo, V3 N, V3 T, V3 local, const G
 // hoisted roughness / ior / distance terms -- the colour-map case -- gains 1 % over STREAMED there and costs the all-uniform case
 // 6 %: 3.47 -> 3.73 ms.)
 enum { MIXED = 0, STREAMED_ALL = 1, UNIFORM_ALL = 2 };
+#ifndef RLS_ND_ONE_SAMPLE_RECIP     // experiment switch: see sss.hip
+#define RLS_ND_ONE_SAMPLE_RECIP 0
+#endif
 #ifndef RLS_SKIN_SGPR          // experiment switch: which hoisted values move to scalar registers (1 the lobes', 2 NDProfile)
 #define RLS_SKIN_SGPR 3
 #endif
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(rlsh::kBlock) void skin_kernel(SkinIO a0)
 
         float r = 0.0f, rpdf = 0.0f, R = 0.0f, G = 0.0f, B = 0.0f;
         if (!(sssWeight < kEps)) {                                          // :244
-            const NdProfile p = UNIFORM ? up : nd_make(dx, dy, dz);
+            const NdProfile p = UNIFORM ? up : nd_make<RLS_ND_ONE_SAMPLE_RECIP != 0>(dx, dy, dz);
             Frame fr = sss_frame(N, T, true);                               // src/rlSss.h:151-154
             V3 off, dir;
             float maxdist;

@@ -23,6 +23,9 @@ enum { OP_ND = rlsh::SOP_ND, OP_ND_PDF = rlsh::SOP_ND_PDF, OP_ND_EVAL = rlsh::SO
 enum { OP_CAVITY = rlsh::MOP_CAVITY, OP_DIFFUSE_DIR = rlsh::MOP_DIFFUSE_DIR, OP_UTIL = rlsh::MOP_UTIL,
        OP_REFLECT_LUM = rlsh::MOP_REFLECT_LUM };
 
+#ifndef RLS_ND_ONE_SAMPLE_RECIP     // experiment switch: the one-sample kernels keep the reciprocals of c1 + 3 c2 as well
+#define RLS_ND_ONE_SAMPLE_RECIP 0
+#endif
 // INDEXED: the parameters are per-material columns (rls_material_index); a specialisation, so that the kernels launched
 // without a table keep their code
 template <bool INDEXED, class I>
@@ -34,7 +37,7 @@ __device__ __forceinline__ NdProfile load_profile(const rls_sss_closure &c, I i)
     float dx = ldp(c.sss_scatter_dist[0], k) * m;
     float dy = ldp(c.sss_scatter_dist[1], k) * m;
     float dz = ldp(c.sss_scatter_dist[2], k) * m;
-    return nd_make(dx, dy, dz);
+    return nd_make<RLS_ND_ONE_SAMPLE_RECIP != 0>(dx, dy, dz);
 }
 
 // UNIFORM: the scatter distance and its multiplier are one value for the batch (an Arnold parameter is a constant unless a

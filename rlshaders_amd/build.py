@@ -31,7 +31,9 @@ HIPCC_FLAGS = [
     f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
     "-ffp-contract=off", "-fno-fast-math",
     # gfx950 issues v_pk_{mul,add}_f32 at half the rate of the scalar forms, and pairing operands costs
-    # moves and registers: with SLP packing off config 2 runs 4 % (EXACT) / 6 % (FAST) faster
+    # moves and registers: with SLP packing off config 2 runs 4 % (EXACT) / 6 % (FAST) faster; measured again in round 3 on the
+    # n^2-spp loops (tools/ab.sh, packing ON against this default): rlDisney 64 spp +16 %, rlSkin shader_evaluate +25 %,
+    # rlGgx shader_evaluate +7 %, its light loop +8 %, integrateScatter +2.5 % slower
     "-fno-slp-vectorize",
     "-fno-gpu-rdc",
     "-Wall", "-Wno-unused-function",

@@ -221,3 +221,77 @@ def sweep_uniform(ctx, n: int, seed: int, draws: int = 8, verbose: bool = True) 
             if bad:
                 print("   parameters of this draw:", p, flush=True)
     return report
+
+
+def sweep_by_reference(ctx, n: int, seed: int, m: int, spp_n: int = 2, verbose: bool = True) -> dict:
+    """Parameters by reference (rls_material_index) at scale: m node instances' parameters as columns and a material id per
+    point against the same values expanded into per-point planes -- every one-sample verb, the integrators, the light loops and
+    the three whole-node kernels, GPU against GPU (the planes kernels are what sweep() holds against the oracle), counted in
+    output words that differ at all.  A tenth of the ids lie beyond the table (clamped to its last entry)."""
+    dev = wo_dev = None
+    hostf = lambda t: t.contiguous().cpu().numpy()
+    report = {}
+
+    def tally(name, got, ref):
+        got = [hostf(t) for t in (got.values() if isinstance(got, dict) else got)]
+        ref = [hostf(t) for t in (ref.values() if isinstance(ref, dict) else ref)]
+        r = _words(got, ref)
+        t = report.setdefault(name, dict(words_differing=0, words=0, max_rel_err=0.0, beyond_1e5=0))
+        for k in ("words_differing", "words", "beyond_1e5"):
+            t[k] += r[k]
+        t["max_rel_err"] = max(t["max_rel_err"], r["max_rel_err"])
+        if verbose:
+            print(f"by reference seed {seed} m {m} {name}: {r['words_differing']} of {r['words']} words differ", flush=True)
+
+    wo, N, T = R.gen_frame(ctx, seed, 0, n)
+    u = lambda stream, lo=0.0, hi=1.0: R.gen_uniform(ctx, seed, 0, n, stream, lo, hi)
+    c = lambda stream, lo=0.0, hi=1.0: R.gen_uniform(ctx, seed + 1, 0, m, stream, lo, hi)          # a column: one entry per instance
+    c3 = lambda stream, lo=0.0, hi=1.0: torch.stack([c(stream + j, lo, hi) for j in range(3)])
+    xi = [u(11 + j) for j in range(6)]
+    raw = (u(70) * (m * 1.1)).to(torch.int32)                       # ~9 % of the ids beyond the table
+    ids = raw.clamp(0, m - 1)                                       # what the library makes of them
+    ex = lambda col: col[..., ids.long()].contiguous()              # the same values as per-point planes
+    mat = (raw, m)
+    P = torch.stack([u(40, 0, 4), u(41, 0, 4), u(42, 0, 1)])
+    lights = [R.make_light(center=(2.0, 2.0, 3.0), radius=1.25, radiance=(3.0, 2.0, 1.0)),
+              R.make_light(center=(-3.0, 1.0, 2.5), radius=0.5, radiance=(0.5, 4.0, 2.0), mis_mode=2)]
+    os.environ["RLS_INTEGRATE_GROUP"] = "1"
+    try:
+        # rlGgx
+        g = dict(specColor=c3(8), ior=c(6, 0.4, 2.55), roughness=c(5, 0.0, 1.0), anisotropic=c(7, 0.0, 1.0))
+        sh = dict(KdColor=c3(20), Kd=c(23), diffuseRoughness=c(24), Ks=c(25), KtColor=c3(26), Kt=c(29))
+        a = R.GgxSampler(ctx, wo, N, T, materials=mat, **g)
+        b = R.GgxSampler(ctx, wo, N, T, **{k: ex(v) for k, v in g.items()})
+        tally("ggx reflect+refract", a.reflectRefract(*xi[:4]), b.reflectRefract(*xi[:4]))
+        wi = b.sampleEvalPdf(xi[0], xi[1])[0]
+        tally("ggx evalBrdf / evalPdf", [a.evalBrdf(wi), a.evalPdf(wi)], [b.evalBrdf(wi), b.evalPdf(wi)])
+        tally("ggx integrate / integrateRefract", list(a.integrate(spp_n, seed)) + list(a.integrateRefract(spp_n, seed)),
+              list(b.integrate(spp_n, seed)) + list(b.integrateRefract(spp_n, seed)))
+        tally("ggx shader_evaluate", a.shade(P, lights, spp_n, seed, env=(1.0, 0.9, 0.8), **sh),
+              b.shade(P, lights, spp_n, seed, env=(1.0, 0.9, 0.8), **{k: ex(v) for k, v in sh.items()}))
+        # rlDisney
+        d = dict(base_color=c3(8), **{k: c(32 + j) for j, k in enumerate(R._capi.DISNEY_SCALARS)})
+        a = R.DisneySampler(ctx, wo, N, T, materials=mat, **d)
+        b = R.DisneySampler(ctx, wo, N, T, **{k: ex(v) for k, v in d.items()})
+        for lobe in (R.RLS_RAY_DIFFUSE, R.RLS_RAY_GLOSSY):
+            a.setSampleType(lobe); b.setSampleType(lobe)
+            tally("disney triple", a.sampleEvalPdf(xi[0], xi[1]), b.sampleEvalPdf(xi[0], xi[1]))
+        tally("disney integrate", a.integrate(spp_n, seed), b.integrate(spp_n, seed))
+        tally("disney shader_evaluate", a.shade(P, lights, spp_n, seed, env=(1.0, 0.9, 0.8)), b.shade(P, lights, spp_n, seed, env=(1.0, 0.9, 0.8)))
+        # rlSss / rlSkin
+        k = dict(sss_color=c3(8), sss_weight=c(35), sss_dist_multiplier=c(36, 0.5, 1.5), sss_scatter_dist=c3(50, 0.02, 2.1),
+                 specular_color=c3(46), specular_weight=c(49), specular_roughness=c(53, 0.05, 1.0), specular_ior=c(54, 1.05, 2.55),
+                 sheen_color=c3(55), sheen_weight=c(58), sheen_roughness=c(59, 0.05, 1.0), sheen_ior=c(60, 1.05, 2.55))
+        a = R.SssSampler(ctx, N, T, k["sss_color"], k["sss_scatter_dist"], multiplier=k["sss_dist_multiplier"], materials=mat)
+        b = R.SssSampler(ctx, N, T, ex(k["sss_color"]), ex(k["sss_scatter_dist"]), multiplier=ex(k["sss_dist_multiplier"]))
+        tally("sss probe", a.getProbeRay(xi[0], xi[1]), b.getProbeRay(xi[0], xi[1]))
+        scene = R.make_scene("sphere", sphere_radius=1.0, light_dir=(0.0, 0.6, 0.8), use_cavity_fade=True)
+        tally("sss integrateScatter", [a.integrateScatter(N, scene, spp_n, seed)], [b.integrateScatter(N, scene, spp_n, seed)])
+        a = R.SkinShader(ctx, wo, N, T, materials=mat, **k)
+        b = R.SkinShader(ctx, wo, N, T, **{q: ex(v) for q, v in k.items()})
+        tally("skin", a.sampleEvalPdf(torch.stack(xi)), b.sampleEvalPdf(torch.stack(xi)))
+        tally("skin shader_evaluate", a.integrate(N, scene, spp_n, seed, env=(1.0, 0.9, 0.8), lights=lights[:1]),
+              b.integrate(N, scene, spp_n, seed, env=(1.0, 0.9, 0.8), lights=lights[:1]))
+    finally:
+        del os.environ["RLS_INTEGRATE_GROUP"]
+    return report

@@ -81,6 +81,7 @@ struct Frame { V3 U, V, N; };
 #define R_TWO_OVER(den) (2.0f * __builtin_amdgcn_rcpf(den))
 #define R_SQRT(x) __builtin_amdgcn_sqrtf(x)
 #define R_EXP(x) __expf(x)
+#define R_EXP_IN_RANGE(x) __expf(x)
 #define R_LOG(x) __logf(x)
 #define R_POW(x, y) __powf(x, y)
 #define R_POW5(x) __powf(x, 5.0f)
@@ -140,6 +141,8 @@ RLS_DEV void stage_libm_tables()
     __syncthreads();
 }
 #define R_EXP(x) rlm::exp32(x, s_libm_tables)
+// expf whose range tests the caller has done for several arguments at once (rls_libm.hpp, exp32_in_range_3)
+#define R_EXP_IN_RANGE(x) rlm::exp32_in_range(x, s_libm_tables)
 #define R_LOG(x) rlm::log32(x, s_libm_tables)
 #define R_POW(x, y) rlm::pow32(x, y, s_libm_tables)
 #ifdef RLS_POW5_GENERAL   // experiment switch
@@ -1131,6 +1134,18 @@ struct NdProfile {
 // getPdf's per-point denominators.  One-sample kernels keep the three of d_i only: each serves three divisions there
 // (setDistance's -maxR / d_i, getPdf's -r / d_i and (e1 + e2) / d_i) -- three reciprocals (4 instructions each) and nine
 // five-instruction quotients instead of nine IEEE divisions; the three of c1 + 3 c2 would serve one division each.
+// expf's range tests ONCE for the several calls NDProfile makes on related arguments (rls_libm.hpp, exp32_in_range_3) instead
+// of a compare and a branch per call.  Measured per kernel, each against the same sources without it (tools/ab.sh, one box,
+// profiles/r03_exp_range_once.txt): in getPdf as the probe-ray loops call it (nd_pdf) integrateScatter -10 %, rlSkin's
+// shader_evaluate -2 %; in setDistance (nd_make) the rlSss probe -2 %, NDProfile alone -2 %, but rlSkin's one-sample kernel
+// +5 % (it sits on a register-allocation edge: skin.hip switches it off); in getPdf + evalProfile of the one-sample kernels
+// (nd_pdf_profile_t) nothing on the probe and +3.7 % with a uniform scatter distance: off.
+#ifndef RLS_ND_PP_RANGE_ONCE
+#define RLS_ND_PP_RANGE_ONCE 0
+#endif
+#ifndef RLS_ND_MAKE_RANGE_ONCE
+#define RLS_ND_MAKE_RANGE_ONCE 1
+#endif
 #ifndef RLS_ND_RECIP_D
 #define RLS_ND_RECIP_D 1        // experiment switch: 0 = the one-sample kernels divide by d_i the IEEE way (round 2)
 #endif
@@ -1149,13 +1164,18 @@ RLS_DEV NdProfile nd_make(float dx, float dy, float dz)
         p.ydm[i] = R_RCPW(p.dm[i]);                  // windowed below; outside it the reciprocals are not used
         if (!(p.d[i] >= 0x1p-13f && p.d[i] <= 0x1p14f)) p.window = 0;      // 2^-13 > AI_EPSILON: d_i == max(d_i, AI_EPSILON)
     }
-    // -maxR / d_i: maxR = 3 max(d) is in [3 x 2^-13, 3 x 2^14] whenever the window holds (or NaN, which fails it)
-    if (__builtin_expect(p.window != 0, 1)) {
+    // -maxR / d_i: maxR = 3 max(d) is in [3 x 2^-13, 3 x 2^14] whenever the window holds (or NaN, which fails it).  expf's
+    // range tests once for the six calls: |q / 3| <= |q|, so the three quotients bound all six arguments
+    float q[3] = { 0.0f, 0.0f, 0.0f };
+    if (p.window != 0) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) q[i] = rlm::div32_y(-p.maxR, p.d[i], p.ydm[i]);
+    }
+    if (__builtin_expect(p.window != 0 && (!RLS_ND_MAKE_RANGE_ONCE || rlm::exp32_in_range_3(q[0], q[1], q[2])), 1)) {
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-            const float q = rlm::div32_y(-p.maxR, p.d[i], p.ydm[i]);
-            p.c1[i] = 1.0f - R_EXP(q);
-            p.c2[i] = 1.0f - R_EXP(R_DIVC(q, 3.0f));
+            p.c1[i] = 1.0f - (RLS_ND_MAKE_RANGE_ONCE ? R_EXP_IN_RANGE(q[i]) : R_EXP(q[i]));
+            p.c2[i] = 1.0f - (RLS_ND_MAKE_RANGE_ONCE ? R_EXP_IN_RANGE(R_DIVC(q[i], 3.0f)) : R_EXP(R_DIVC(q[i], 3.0f)));
         }
     } else
 #endif
@@ -1262,12 +1282,12 @@ RLS_DEV float nd_pdf(const NdProfile &p, float r)
     // each) when every operand is inside that routine's window -- the point's denominators (p.window), r, and the sums
     // e^(-r/d) + e^(-r/3d), which fall below 2^-60 only for r > 41 d; the quotients (p1 + p2) / d are then >= 2^-74
     if (__builtin_expect(!(p.window == 2 && r >= 0x1p-40f && r <= 0x1p40f), 0)) return nd_pdf_ieee(p, r);
-    float s[3];
+    float s[3], q[3];
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const float q = rlm::div32_y(-r, p.dm[i], p.ydm[i]);
-        s[i] = R_EXP(q) + R_EXP(R_DIVC(q, 3.0f));
-    }
+    for (int i = 0; i < 3; i++) q[i] = rlm::div32_y(-r, p.dm[i], p.ydm[i]);
+    if (__builtin_expect(!rlm::exp32_in_range_3(q[0], q[1], q[2]), 0)) return nd_pdf_ieee(p, r);     // expf's range tests, once
+#pragma unroll
+    for (int i = 0; i < 3; i++) s[i] = R_EXP_IN_RANGE(q[i]) + R_EXP_IN_RANGE(R_DIVC(q[i], 3.0f));
     if (__builtin_expect(!(minf(s[0], minf(s[1], s[2])) >= 0x1p-60f), 0)) return nd_pdf_ieee(p, r);
     float pdf = 0.0f;
 #pragma unroll
@@ -1302,16 +1322,29 @@ RLS_DEV void nd_pdf_profile_t(const NdProfile &p, float r, float &pdf, float &R,
     float acc = 0.0f;
     float out[3];
     bool tiny = false;                                // WINDOWED: a sum e^(-r/d) + e^(-r/3d) below div32_y's window
+#if !RLS_FAST
+    // ONCE: expf's range tests once for the nine calls -- |q / 3| <= |q| and, d_i being its own max(d_i, AI_EPSILON) inside
+    // the window, |-r / (3 d_i)| <= |q| as well: the three quotients bound all nine arguments.  Outside the range: the general form
+    constexpr bool ONCE = WINDOWED != 0 && RLS_ND_PP_RANGE_ONCE != 0;
+    float qw[3] = { 0.0f, 0.0f, 0.0f };
+    if (ONCE) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) qw[i] = rlm::div32_y(-r, p.dm[i], p.ydm[i]);
+        if (__builtin_expect(!rlm::exp32_in_range_3(qw[0], qw[1], qw[2]), 0)) { nd_pdf_profile_t<0>(p, r, pdf, R, G, B); return; }
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         const float d = maxf(p.d[i], kEps);
 #if !RLS_FAST
-        const float q = WINDOWED ? rlm::div32_y(-r, p.dm[i], p.ydm[i]) : R_DIV(-r, d);
+        const float q = ONCE ? qw[i] : WINDOWED ? rlm::div32_y(-r, p.dm[i], p.ydm[i]) : R_DIV(-r, d);
+        const float p1 = ONCE ? R_EXP_IN_RANGE(q) : R_EXP(q);
+        const float p2 = ONCE ? R_EXP_IN_RANGE(R_DIVC(q, 3.0f)) : R_EXP(R_DIVC(q, 3.0f));
 #else
         const float q = R_DIV(-r, d);
-#endif
         const float p1 = R_EXP(q);
         const float p2 = R_EXP(R_DIVC(q, 3.0f));
+#endif
 #if !RLS_FAST
         if (WINDOWED == 2) {
             tiny = tiny || !(p1 + p2 >= 0x1p-60f);
@@ -1322,6 +1355,10 @@ RLS_DEV void nd_pdf_profile_t(const NdProfile &p, float r, float &pdf, float &R,
         } else
 #endif
         acc += R_DIV(R_DIV(p1 + p2, d), p.c1[i] + p.c2[i] * 3.0f);
+#if !RLS_FAST
+        if (ONCE) out[i] = R_DIV(p1 + R_EXP_IN_RANGE(R_DIV(-r, 3.0f * p.d[i])), denom * p.d[i]);     // (d_i >= 2^-13 > AI_EPSILON)
+        else
+#endif
         out[i] = p.d[i] < kEps ? 1.0f : R_DIV(p1 + R_EXP(R_DIV(-r, 3.0f * p.d[i])), denom * p.d[i]);
     }
     if (WINDOWED && __builtin_expect(tiny, 0)) { nd_pdf_profile_t<0>(p, r, pdf, R, G, B); return; }

@@ -538,6 +538,21 @@ RLM_FN float exp2_tail(double r, uint64_t ki, double c0, double c1, double c2, c
     return (float)y;
 }
 
+// expf behind its range tests: for |x| < 88 this is all of expf; a NaN comes out as a NaN (the fma chain carries it; the
+// libm returns x + x).  Callers that know a bound for several arguments at once test it once (exp32_in_range_3) instead of once
+// per call -- the test is a compare and a branch per expf, and the NDProfile kernels call expf fifteen times per point.
+RLM_FN float exp32_in_range(float x, const Tables &t);
+// true when |a|, |b| and |c| are all below 88 -- NaNs are ignored by the maximum and may pass: see above
+RLM_FN bool exp32_in_range_3(float a, float b, float c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)), __builtin_fabsf(c)) < 88.0f;
+#else
+    const float m = fmaxf(fmaxf(fabsf(a), fabsf(b)), fabsf(c));
+    return m < 88.0f;
+#endif
+}
+
 RLM_FN float exp32(float x, const Tables &t)
 {
     const uint32_t abstop = (f2u(x) >> 20) & 0x7ffu;
@@ -547,6 +562,11 @@ RLM_FN float exp32(float x, const Tables &t)
         if (x > 0x1.62e42ep6f) return u2f(0x7f800000u);                 // overflow
         if (x < -0x1.9fe368p6f) return 0.0f;                            // underflow
     }
+    return exp32_in_range(x, t);
+}
+
+RLM_FN float exp32_in_range(float x, const Tables &t)
+{
     const double N = 32.0;
     const double InvLn2N = 0x1.71547652b82fep+0 * N, Shift = 0x1.8p+52;
     const double xd = (double)x;

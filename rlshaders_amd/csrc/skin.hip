@@ -13,6 +13,9 @@
 #ifndef RLS_LOAD_RENEW
 #define RLS_LOAD_RENEW 1
 #endif
+#ifndef RLS_ND_MAKE_RANGE_ONCE       // rls_device.hpp, nd_make: measured +5 % on this kernel
+#define RLS_ND_MAKE_RANGE_ONCE 0
+#endif
 #include "rls_internal.hpp"
 
 using namespace rlsd;

@@ -158,3 +158,21 @@ def test_argument_checks(gpu):
     sc.geometry = 5
     with pytest.raises(R.RlsError):
         s.integrateScatter(z, sc, 2, 1)
+
+
+def test_scatter_distances_far_apart(gpu, oracle):
+    """getPdf inside the probe-ray loop tests expf's range once for its six calls (rls_device.hpp, nd_pdf / exp32_in_range_3) and
+    takes the general form when a quotient -r / d_i leaves it -- channels whose scatter distances differ by more than a factor
+    of 29 (r reaches 3 max(d)), mixed with ordinary points within the wavefronts: the sums equal the oracle's on both sides."""
+    c = _sphere_case(oracle, N, 0.35, (0.3, -0.2, 0.1))
+    k = np.arange(N)
+    c["dist"][1, k % 3 == 0] = np.float32(0.002)           # 150 x below channel 0's up to 0.3: -r / d down to -450
+    c["dist"][2, k % 5 == 0] = np.float32(0.0002)          # outside div32_y's window as well
+    c["dist"][0, k % 7 == 0] = np.float32(3.0)
+    so, sg = _scene_pair(oracle, geometry="sphere", sphere_center=(0.3, -0.2, 0.1), sphere_radius=0.35,
+                         light_dir=(0.0, 0.6, 0.8), light_color=(1.5, 1.0, 0.25), use_cavity_fade=True)
+    s, ref, dref, got, dgot = _run_both(gpu, oracle, c, so, sg, 4, 99)
+    st = cases.summarize(cases.rel_err(got, ref))
+    print("scatter, distances far apart", st)
+    cases.assert_tight(st, "scatter, distances far apart")
+    assert np.array_equal(dgot, dref)

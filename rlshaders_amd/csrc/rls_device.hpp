@@ -1221,11 +1221,27 @@ RLS_DEV NdProfile nd_wave_uniform(NdProfile p)
 #ifndef RLS_ND_MERGE_RADIUS
 #define RLS_ND_MERGE_RADIUS 0
 #endif
+#ifndef RLS_ND_RADIUS_SELECTS     // experiment switch: getRadius's channel lottery by selects (measured: the rlSss probe +27 %)
+#define RLS_ND_RADIUS_SELECTS 0
+#endif
 // selectDistLobe + getRadius, src/rlSss.h:30-42, src/rlSss.cpp:36-66
 RLS_DEV float nd_radius(const NdProfile &p, float rx)
 {
     if (p.maxR < kEps) return 0.0f;
     float d, w1, w2;
+#if RLS_ND_RADIUS_SELECTS
+    // the channel lottery without branches: the three arms differ in their constants and in the channel they read
+    {
+        const bool c0 = rx < 0.3333f, c2 = rx > 0.6666f;
+        const float lo = c0 ? 0.0f : c2 ? 0.6666f : 0.3333f;
+        const float C = c0 ? (0.3333f - 0.0f) : c2 ? (1.0f - 0.6666f) : (0.6666f - 0.3333f);
+        const float rC = c0 ? 1.0f / (0.3333f - 0.0f) : c2 ? 1.0f / (1.0f - 0.6666f) : 1.0f / (0.6666f - 0.3333f);
+        rx = clampf(rlm::div32_const(rx - lo, C, rC), 0.0f, 1.0f);
+        d = c0 ? p.d[0] : c2 ? p.d[2] : p.d[1];
+        w1 = c0 ? p.c1[0] : c2 ? p.c1[2] : p.c1[1];
+        w2 = c0 ? p.c2[0] : c2 ? p.c2[2] : p.c2[1];
+    }
+#else
     // LINEARSTEP(lo, hi, t) = CLAMP((t - lo) / (hi - lo), 0, 1) with constant bounds: division by a constant
     if (rx < 0.3333f) {
         rx = clampf(R_DIVC(rx - 0.0f, 0.3333f - 0.0f), 0.0f, 1.0f);
@@ -1237,6 +1253,7 @@ RLS_DEV float nd_radius(const NdProfile &p, float rx)
         rx = clampf(R_DIVC(rx - 0.3333f, 0.6666f - 0.3333f), 0.0f, 1.0f);
         d = p.d[1]; w1 = p.c1[1]; w2 = p.c2[1];
     }
+#endif
     if (d < kEps) return 0.0f;
     float w = R_DIV(w1, w1 + w2 * 3.0f);
     float r;
@@ -1397,9 +1414,21 @@ RLS_DEV Frame sss_frame(V3 Ns, V3 t, bool has_dPdu)
 }
 
 // getProbeRay, src/rlSss.h:487-533
+// RLS_PROBE_SELECTS: the axis lottery without branches.  The three linearstep() calls divide by 0.5 - 0, 0.75 - 0.5 and
+// 1 - 0.75 -- powers of two, so the quotient IS the product with 2 or 4, exactly -- and the three to_frame() calls differ in
+// which axes they read, so one call on selected axes (the middle one's sign moved into o.y: a (-u) = -(a u) exactly) gives
+// the same bits (the parity tests pass with it).  Measured (profiles/r03_exp_range_once.txt): nothing, +-0.3 % on every kernel
+// that draws probe rays -- an experiment switch, off.
+#ifndef RLS_PROBE_SELECTS
+#define RLS_PROBE_SELECTS 0
+#endif
 RLS_DEV float sss_probe_ray(const NdProfile &p, const Frame &fr, float rx, float ry,
                             V3 &offset, V3 &dir, float &maxdist)
 {
+#if RLS_PROBE_SELECTS
+    const bool a0 = rx < 0.5f, a1 = rx < 0.75f;               // idx 0 | 2 | 3 of the reference
+    rx = clampf((rx - (a0 ? 0.0f : a1 ? 0.5f : 0.75f)) * (a0 ? 2.0f : 4.0f), 0.0f, 1.0f);
+#else
     int idx;
     if (rx < 0.5f) {
         idx = 0;
@@ -1411,6 +1440,7 @@ RLS_DEV float sss_probe_ray(const NdProfile &p, const Frame &fr, float rx, float
         idx = 3;
         rx = linearstep(0.75f, 1.0f, rx);
     }
+#endif
     float r = nd_radius(p, rx);
     float rmax = p.maxR;
     float phi = kTwoPi * ry;
@@ -1421,6 +1451,14 @@ RLS_DEV float sss_probe_ray(const NdProfile &p, const Frame &fr, float rx, float
     o.z = s * r;
     o.y = R_SQRT(rmax * rmax - r * r);
     maxdist = o.y * 2.0f;
+#if RLS_PROBE_SELECTS
+    // idx < 2: dir = -N, to_frame(o, U, N, V); idx 2: dir = U, to_frame(o, V, -U, N); idx 3: dir = V, to_frame(o, N, -V, U)
+    const V3 u = a0 ? fr.U : a1 ? fr.V : fr.N;
+    const V3 v = a0 ? fr.N : a1 ? fr.U : fr.V;                 // |middle axis|; its sign goes into o.y
+    const V3 w = a0 ? fr.V : a1 ? fr.N : fr.U;
+    dir = a0 ? -v : v;
+    offset = to_frame(mk(o.x, a0 ? o.y : -o.y, o.z), u, v, w);
+#else
     if (idx < 2) {
         dir = -fr.N;
         offset = to_frame(o, fr.U, -dir, fr.V);
@@ -1431,6 +1469,7 @@ RLS_DEV float sss_probe_ray(const NdProfile &p, const Frame &fr, float rx, float
         dir = fr.V;
         offset = to_frame(o, fr.N, -dir, fr.U);
     }
+#endif
     return r;
 }
 

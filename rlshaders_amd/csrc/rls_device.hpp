@@ -1139,9 +1139,14 @@ struct NdProfile {
 // profiles/r03_exp_range_once.txt): in getPdf as the probe-ray loops call it (nd_pdf) integrateScatter -10 %, rlSkin's
 // shader_evaluate -2 %; in setDistance (nd_make) the rlSss probe -2 %, NDProfile alone -2 %, but rlSkin's one-sample kernel
 // +5 % (it sits on a register-allocation edge: skin.hip switches it off); in getPdf + evalProfile of the one-sample kernels
-// (nd_pdf_profile_t) nothing on the probe and +3.7 % with a uniform scatter distance: off.
+// (nd_pdf_profile_t) nothing on the probe and +3.7 % with a uniform scatter distance: off.  evalProfile alone, which the
+// probe-ray loops call per shaded hit (nd_profile: the reciprocals' quotients + one range test): integrateScatter -6 % more,
+// rlSkin's shader_evaluate -8 % more.
 #ifndef RLS_ND_PP_RANGE_ONCE
 #define RLS_ND_PP_RANGE_ONCE 0
+#endif
+#ifndef RLS_ND_PROFILE_WINDOWED     // evalProfile alone (the probe-ray loops call it per hit): reciprocals + one range test
+#define RLS_ND_PROFILE_WINDOWED 1
 #endif
 #ifndef RLS_ND_MAKE_RANGE_ONCE
 #define RLS_ND_MAKE_RANGE_ONCE 1
@@ -1320,6 +1325,22 @@ RLS_DEV void nd_profile(const NdProfile &p, float r, float &R, float &G, float &
     if (r < kEps) { R = 1.0f; G = 1.0f; B = 1.0f; return; }
     float denom = 8.0f * kPi * r;
     float out[3];
+#if !RLS_FAST && RLS_ND_PROFILE_WINDOWED
+    // inside the window of the per-point reciprocals (d_i >= 2^-13 > AI_EPSILON: the d_i < AI_EPSILON arm cannot occur) the three
+    // quotients -r / d_i through them, and expf's range tests once for the six calls (|-r / (3 d_i)| <= |-r / d_i|)
+    if (__builtin_expect(p.window != 0 && r <= 0x1p40f, 1)) {
+        float q[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) q[i] = rlm::div32_y(-r, p.dm[i], p.ydm[i]);
+        if (__builtin_expect(rlm::exp32_in_range_3(q[0], q[1], q[2]), 1)) {
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+                out[i] = R_DIV(R_EXP_IN_RANGE(q[i]) + R_EXP_IN_RANGE(R_DIV(-r, 3.0f * p.d[i])), denom * p.d[i]);
+            R = out[0]; G = out[1]; B = out[2];
+            return;
+        }
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         float d = p.d[i];

@@ -99,6 +99,7 @@ RLS_DEV float refined_div(float a, float b)
 #define R_RCPG(b) refined_div(1.0f, b)
 #define R_RCPHI(b) __builtin_amdgcn_rcpf(b)
 #define R_DIVC(x, C) ((x) * (1.0f / (C)))
+#define R_DIVCW(x, C) ((x) * (1.0f / (C)))
 #define R_SQRTH(x) rlm::sqrt32(x)
 #define R_SQRT1P(y) __builtin_amdgcn_sqrtf(1.0f + (y))
 #define R_SQRT1M(t) __builtin_amdgcn_sqrtf(1.0f - (t))
@@ -119,6 +120,11 @@ RLS_DEV void stage_libm_tables() {}
 #define R_RCPH(b) rlm::rcp32_w(b)            // of a square root (normalize_h)
 // x / C, C one of the compile-time constants checked in tools/micro/exact1.hip (3, 0.3333, 1 - 0.6666, 0.6666 - 0.3333)
 #define R_DIVC(x, C) rlm::div32_const((x), (C), 1.0f / (C))
+// ... for an x that is inside 2^-100 .. 2^100 and not zero by construction: no range test (say why at the call)
+#define R_DIVCW(x, C) (RLS_ND_DIVC_UNGUARDED ? rlm::div32_const_w((x), (C), 1.0f / (C)) : rlm::div32_const((x), (C), 1.0f / (C)))
+#ifndef RLS_ND_DIVC_UNGUARDED    // experiment switch
+#define RLS_ND_DIVC_UNGUARDED 1
+#endif
 #define R_RCPHI(b) rlm::rcp32_hi(b)          // 1 / x for x that is 0, NaN or >= 2^-126 in magnitude by construction
 #define R_RCPG(b) rlm::rcp32_hi(b)           // of A^2 - 1: 0 or >= 2^-24 in magnitude (A^2 is near 1 or far from it), unbounded above
 #define R_SQRTH(x) rlm::sqrt32(x)
@@ -1180,7 +1186,8 @@ RLS_DEV NdProfile nd_make(float dx, float dy, float dz)
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             p.c1[i] = 1.0f - (RLS_ND_MAKE_RANGE_ONCE ? R_EXP_IN_RANGE(q[i]) : R_EXP(q[i]));
-            p.c2[i] = 1.0f - (RLS_ND_MAKE_RANGE_ONCE ? R_EXP_IN_RANGE(R_DIVC(q[i], 3.0f)) : R_EXP(R_DIVC(q[i], 3.0f)));
+            // (|q| is between 3 x 2^-13 / 2^14 and 3 x 2^14 / 2^-13 inside the window: the division by 3 needs no range test)
+            p.c2[i] = 1.0f - (RLS_ND_MAKE_RANGE_ONCE ? R_EXP_IN_RANGE(R_DIVCW(q[i], 3.0f)) : R_EXP(R_DIVCW(q[i], 3.0f)));
         }
     } else
 #endif
@@ -1309,13 +1316,56 @@ RLS_DEV float nd_pdf(const NdProfile &p, float r)
     for (int i = 0; i < 3; i++) q[i] = rlm::div32_y(-r, p.dm[i], p.ydm[i]);
     if (__builtin_expect(!rlm::exp32_in_range_3(q[0], q[1], q[2]), 0)) return nd_pdf_ieee(p, r);     // expf's range tests, once
 #pragma unroll
-    for (int i = 0; i < 3; i++) s[i] = R_EXP_IN_RANGE(q[i]) + R_EXP_IN_RANGE(R_DIVC(q[i], 3.0f));
+    for (int i = 0; i < 3; i++) s[i] = R_EXP_IN_RANGE(q[i]) + R_EXP_IN_RANGE(R_DIVCW(q[i], 3.0f));      // 2^-54 <= |q| < 88
     if (__builtin_expect(!(minf(s[0], minf(s[1], s[2])) >= 0x1p-60f), 0)) return nd_pdf_ieee(p, r);
     float pdf = 0.0f;
 #pragma unroll
     for (int i = 0; i < 3; i++) pdf += rlm::div32_y(rlm::div32_y(s[i], p.dm[i], p.ydm[i]), p.cw[i], p.ycw[i]);
     return R_DIV(pdf, kTwoPi * r * 3.0f);
 #endif
+}
+
+// getPdf at three radii (the 3-axis MIS pdf of a probe hit asks for them together): nd_pdf()'s tests -- the window, the radii's
+// range, expf's range, the sums' floor -- once for the three calls instead of once each; the same operations per radius and
+// channel, so the same bits, and any failing test sends all three through nd_pdf()
+#ifndef RLS_ND_PDF3_MERGED     // experiment switch
+#define RLS_ND_PDF3_MERGED 0
+#endif
+RLS_DEV void nd_pdf3(const NdProfile &p, float r0, float r1, float r2, float (&out)[3])
+{
+#if !RLS_FAST && RLS_ND_PDF3_MERGED
+    const float r[3] = { r0, r1, r2 };
+    if (__builtin_expect(!(p.maxR < kEps) && p.window == 2 && minf(r0, minf(r1, r2)) >= 0x1p-40f && maxf(r0, maxf(r1, r2)) <= 0x1p40f &&
+                         r0 == r0 && r1 == r1 && r2 == r2, 1)) {
+        float q[3][3];
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) q[j][i] = rlm::div32_y(-r[j], p.dm[i], p.ydm[i]);
+        if (__builtin_expect(rlm::exp32_in_range_3(q[0][0], q[0][1], q[0][2]) && rlm::exp32_in_range_3(q[1][0], q[1][1], q[1][2]) &&
+                             rlm::exp32_in_range_3(q[2][0], q[2][1], q[2][2]), 1)) {
+            float s[3][3], lo = 1.0f;
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    s[j][i] = R_EXP_IN_RANGE(q[j][i]) + R_EXP_IN_RANGE(R_DIVCW(q[j][i], 3.0f));
+                    lo = minf(lo, s[j][i]);
+                }
+            if (__builtin_expect(lo >= 0x1p-60f, 1)) {
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    float pdf = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 3; i++) pdf += rlm::div32_y(rlm::div32_y(s[j][i], p.dm[i], p.ydm[i]), p.cw[i], p.ycw[i]);
+                    out[j] = R_DIV(pdf, kTwoPi * r[j] * 3.0f);
+                }
+                return;
+            }
+        }
+    }
+#endif
+    out[0] = nd_pdf(p, r0); out[1] = nd_pdf(p, r1); out[2] = nd_pdf(p, r2);
 }
 
 // evalProfile, src/rlSss.cpp:86-106
@@ -1377,7 +1427,8 @@ RLS_DEV void nd_pdf_profile_t(const NdProfile &p, float r, float &pdf, float &R,
 #if !RLS_FAST
         const float q = ONCE ? qw[i] : WINDOWED ? rlm::div32_y(-r, p.dm[i], p.ydm[i]) : R_DIV(-r, d);
         const float p1 = ONCE ? R_EXP_IN_RANGE(q) : R_EXP(q);
-        const float p2 = ONCE ? R_EXP_IN_RANGE(R_DIVC(q, 3.0f)) : R_EXP(R_DIVC(q, 3.0f));
+        // (WINDOWED: r >= 2^-40 and d_i <= 2^14, so |q| >= 2^-54, and |q| <= 2^53: the division by 3 needs no range test)
+        const float p2 = ONCE ? R_EXP_IN_RANGE(R_DIVCW(q, 3.0f)) : WINDOWED ? R_EXP(R_DIVCW(q, 3.0f)) : R_EXP(R_DIVC(q, 3.0f));
 #else
         const float q = R_DIV(-r, d);
         const float p1 = R_EXP(q);
@@ -1503,9 +1554,11 @@ RLS_DEV float sss_mis_pdf(const NdProfile &p, const Frame &fr, V3 disp, V3 sN, b
     float rr0 = R_SQRT(o.y + o.z);
     float rr1 = R_SQRT(o.x + o.z);
     float rr2 = R_SQRT(o.x + o.y);
-    return nd_pdf(p, rr0) * absf(dot(fr.U, sN)) * 0.25f
-         + nd_pdf(p, rr1) * absf(dot(fr.V, sN)) * 0.25f
-         + nd_pdf(p, rr2) * absf(dot(fr.N, sN)) * 0.5f;
+    float pd[3];
+    nd_pdf3(p, rr0, rr1, rr2, pd);
+    return pd[0] * absf(dot(fr.U, sN)) * 0.25f
+         + pd[1] * absf(dot(fr.V, sN)) * 0.25f
+         + pd[2] * absf(dot(fr.N, sN)) * 0.5f;
 }
 
 // cavity fade, src/rlSss.h:401-413

@@ -169,6 +169,18 @@ RLM_FN float div32_m(float a, float b)
 // for 2^-100 <= |x| <= 2^100 (the residual x - C q0 is then exact), IEEE division outside (zeros included: the
 // sign of -0 / C would be lost).  Used for the constants
 // tools/micro/exact1.hip has run over all 2^32 numerators: 3, 0.3333, 1 - 0.6666, 0.6666 - 0.3333.
+// the same without the range test, for callers whose x is inside 2^-100 .. 2^100 by construction (and not zero)
+RLM_FN float div32_const_w(float x, float c, float rc)
+{
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RLS_NO_FAST_RCP)
+    const float q0 = x * rc;
+    const float r = __builtin_fmaf(-c, q0, x);
+    return __builtin_fmaf(r, rc, q0);
+#else
+    (void)rc;
+    return x / c;
+#endif
+}
 RLM_FN float div32_const(float x, float c, float rc)
 {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(RLS_NO_FAST_RCP)

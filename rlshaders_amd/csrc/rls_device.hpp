@@ -1144,9 +1144,10 @@ struct NdProfile {
 // of a compare and a branch per call.  Measured per kernel, each against the same sources without it (tools/ab.sh, one box,
 // profiles/r03_exp_range_once.txt): in getPdf as the probe-ray loops call it (nd_pdf) integrateScatter -10 %, rlSkin's
 // shader_evaluate -2 %; in setDistance (nd_make) the rlSss probe -2 %, NDProfile alone -2 %, but rlSkin's one-sample kernel
-// +5 % (it sits on a register-allocation edge: skin.hip switches it off); in getPdf + evalProfile of the one-sample kernels
+// +5 % at the occupancy the compiler picks (it sits on a register-allocation edge: skin.hip pins the occupancy instead and
+// keeps the tests, -2 %); in getPdf + evalProfile of the one-sample kernels
 // (nd_pdf_profile_t), once the divisions by 3 had lost their own tests (R_DIVCW), the rlSss probe -2 %, with a uniform scatter
-// distance -3.5 %, NDProfile alone -4 %, rlSkin's one-sample kernel +4.5 % (off there as well).  evalProfile alone, which the
+// distance -3.5 %, NDProfile alone -4 %, rlSkin's one-sample kernel +4.5 % unless its occupancy is pinned (skin.hip).  evalProfile alone, which the
 // probe-ray loops call per shaded hit (nd_profile: the reciprocals' quotients + one range test): integrateScatter -6 % more,
 // rlSkin's shader_evaluate -8 % more.
 #ifndef RLS_ND_PP_RANGE_ONCE

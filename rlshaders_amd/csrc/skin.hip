@@ -13,12 +13,6 @@
 #ifndef RLS_LOAD_RENEW
 #define RLS_LOAD_RENEW 1
 #endif
-#ifndef RLS_ND_MAKE_RANGE_ONCE       // rls_device.hpp, nd_make: measured +5 % on this kernel
-#define RLS_ND_MAKE_RANGE_ONCE 0
-#endif
-#ifndef RLS_ND_PP_RANGE_ONCE         // rls_device.hpp, nd_pdf_profile_t: measured +4.5 % on this kernel
-#define RLS_ND_PP_RANGE_ONCE 0
-#endif
 #include "rls_internal.hpp"
 
 using namespace rlsd;
@@ -71,8 +65,17 @@ enum { MIXED = 0, STREAMED_ALL = 1, UNIFORM_ALL = 2 };
 #ifndef RLS_SKIN_ND_RECIP      // experiment switch: all of getPdf's reciprocals hoisted as well
 #define RLS_SKIN_ND_RECIP 1
 #endif
+// Occupancy of the rlSkin kernel (waves per SIMD the register allocator must allow).  Left alone it takes 95 vector registers --
+// five waves, one register pair short of four: NDProfile's single range tests (rls_device.hpp, RLS_ND_MAKE_RANGE_ONCE /
+// RLS_ND_PP_RANGE_ONCE), which gain 2-7 % in the rlSss kernels, pushed it to 98-101 registers and four waves, +4.5 ... +5.6 %.
+// Pinned at six waves (80 registers, 4 of them spilled: 20 B of scratch per lane) with those tests: 4.086 -> 3.997 ms (-2.2 %),
+// uniform parameters -0.8 %; at five -1.1 %, at seven +3.7 % (profiles/r03_exp_range_once.txt).
+#ifndef RLS_SKIN_WAVES
+#define RLS_SKIN_WAVES 6
+#endif
+#define RLS_SKIN_ATTR __launch_bounds__(rlsh::kBlock) __attribute__((amdgpu_waves_per_eu(RLS_SKIN_WAVES, RLS_SKIN_WAVES)))
 template <int FAST_MATH, int MODE>
-__global__ __launch_bounds__(rlsh::kBlock) void skin_kernel(SkinIO a0)
+__global__ RLS_SKIN_ATTR void skin_kernel(SkinIO a0)
 {
     constexpr bool STREAMED = MODE == STREAMED_ALL, UNIFORM = MODE == UNIFORM_ALL;
     stage_libm_tables();   // expf / logf tables -> LDS (EXACT mode)

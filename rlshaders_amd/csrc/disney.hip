@@ -64,8 +64,15 @@ __device__ __forceinline__ Disney load_closure(const rls_disney_closure &c, Idx 
     return disney_make(wo, N, T, br, bg, bb, s);
 }
 
+// occupancy of the rlDisney kernels (waves per SIMD the register allocator must allow).  Left alone the glossy triple takes 86
+// vector registers (five waves); pinned at six (80 registers, nothing spilled) it runs 1.7 % faster, the colour-map form 2.1 %
+// (2.080 -> 2.045 ms, 1.794 -> 1.756 ms; tools/ab.sh, two interleaved repetitions); at seven it spills (-0.6 %), at four +3 %
+#ifndef RLS_DISNEY_WAVES
+#define RLS_DISNEY_WAVES 6
+#endif
+#define RLS_DISNEY_ATTR __launch_bounds__(rlsh::kBlock) __attribute__((amdgpu_waves_per_eu(RLS_DISNEY_WAVES, RLS_DISNEY_WAVES)))
 template <int OP, bool DIFFUSE, int FAST_MATH, int MODE>
-__global__ __launch_bounds__(rlsh::kBlock) void disney_kernel(DisneyIO a0)
+__global__ RLS_DISNEY_ATTR void disney_kernel(DisneyIO a0)
 {
     stage_libm_tables();   // powf / logf tables -> LDS (EXACT mode)
     Disney ud = {};

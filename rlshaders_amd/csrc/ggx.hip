@@ -47,8 +47,17 @@ __device__ __forceinline__ Ggx load_closure(const rls_ggx_closure &c, Idx i, con
 }
 
 // FAST_MATH only tags the kernel name (profiles tell the two builds apart)
+// occupancy per verb (waves per SIMD the register allocator must allow; rls_internal.hpp has the first measurement, at six).
+// Re-measured at the end of round 3 (tools/ab.sh, two interleaved repetitions, 5 / 6 / 7 / 8 waves): reflect + refract
+// 2.071 / 2.026 / 2.008 / 2.022 ... 2.054 / - / 2.032 / 2.023 ms on two boxes, the reflect triple 1.690 / 1.642 / 1.628, evalPdf alone
+// 0.701 (6) / 0.674 (7) / 0.652 (8), evalBrdf alone 0.938 (6) / 0.953 (7) / 0.958 (8): eight waves (64 registers, 26 scalar
+// registers spilled to lanes, no scratch) for everything but evalBrdf.
+#ifndef RLS_GGX_WAVES
+#define RLS_GGX_WAVES(OP) ((OP) == OP_EVAL ? 6 : 8)
+#endif
 template <int OP, int FAST_MATH, int MODE>
-__global__ RLS_KERNEL_ATTR void ggx_kernel(GgxIO a0)
+__global__ __launch_bounds__(rlsh::kBlock) __attribute__((amdgpu_waves_per_eu(RLS_GGX_WAVES(OP), RLS_GGX_WAVES(OP))))
+void ggx_kernel(GgxIO a0)
 {
     if (OP == OP_SAMPLE || OP == OP_FUSED || OP == OP_REFLECT_REFRACT || OP == OP_REFRACT || OP == OP_MICROFACET)
         stage_libm_tables();   // the range table of atanf -> LDS (visible-normal sampling calls atan2f twice)

@@ -229,6 +229,7 @@ constexpr int kBlock = RLS_BLOCK;   // 4 wavefronts of 64
 // occupancy of the rlGgx kernels (waves per SIMD the register allocator must allow).  Left alone the reflect+refract
 // kernel takes 72 VGPRs (7 waves) and keeps its 31 plane pointers alive by spilling scalar registers into vector
 // lanes; at 6 waves (up to 80 VGPRs) it runs 1.8 % faster, at 4 or 8 slower (2.285 / 2.244 / 2.38 / 2.36 ms, one box)
+// (round 3: re-measured per verb with the kernels as they are now -- ggx.hip, RLS_GGX_WAVES: eight for all but evalBrdf)
 #ifndef RLS_WAVES_PER_EU
 #define RLS_WAVES_PER_EU 6
 #endif

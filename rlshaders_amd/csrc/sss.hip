@@ -56,8 +56,16 @@ __device__ __forceinline__ NdProfile uniform_profile(const rls_sss_closure &c)
 }
 
 enum { PER_POINT = 0, UNIFORM_DISTANCE = 1, BY_REFERENCE = 2 };
+// occupancy (waves per SIMD the register allocator must allow).  Left alone the kernels take 62 vector and 106 scalar registers:
+// seven waves.  Pinned at eight (78 scalar registers, nothing spilled) the probe runs 3.2 % faster (1.479 -> 1.432 ms) and NDProfile
+// alone 1.9 %; with a uniform scatter distance eight LOSES 2.7 % and seven is what the compiler picks; five +3 %, six 0
+// (tools/ab.sh, two interleaved repetitions).
+#ifndef RLS_SSS_WAVES
+#define RLS_SSS_WAVES(MODE) ((MODE) == UNIFORM_DISTANCE ? 7 : 8)
+#endif
 template <int OP, int MODE, int FAST_MATH = RLS_FAST>
-__global__ __launch_bounds__(rlsh::kBlock) void sss_kernel(SssIO a0)
+__global__ __launch_bounds__(rlsh::kBlock) __attribute__((amdgpu_waves_per_eu(RLS_SSS_WAVES(MODE), RLS_SSS_WAVES(MODE))))
+void sss_kernel(SssIO a0)
 {
     stage_libm_tables();   // expf / logf tables -> LDS (EXACT mode)
     constexpr bool UNIFORM = MODE == UNIFORM_DISTANCE;

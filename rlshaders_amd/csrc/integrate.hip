@@ -36,6 +36,17 @@ namespace {
 // changing with unrelated edits); these loops are chains of dependent arithmetic with LDS table reads in between, and
 // four waves hide that better than the extra registers help: measured 3 -> 4 waves: rlDisney 64 spp 102.7 -> 93.3 ms,
 // rlSkin shader_evaluate 107.3 -> 95.9 ms, the rlGgx light loop 25.6 -> 25.2 ms; 5, 6 and 8 are slower (spills).
+// plane pointers re-read per point (reload_args) in the rlDisney n^2-spp kernel: 126 -> 24 spilled scalar registers, and no
+// time (73.06 / 72.90 ms with, 73.10 / 73.13 without): the spills sat outside the sample loop already.  Kept for the registers;
+// the other loop kernels were left alone.
+#ifndef RLS_INT_RELOAD
+#define RLS_INT_RELOAD 1
+#endif
+#if RLS_INT_RELOAD
+#define RLS_INT_ARGS(a) reload_args(a)
+#else
+#define RLS_INT_ARGS(a) (a)
+#endif
 #ifndef RLS_INT_WAVES
 #define RLS_INT_WAVES 4
 #endif
@@ -530,7 +541,10 @@ __global__ RLS_INT_ATTR void disney_integrate_kernel(DisneyIntIO a)
     for (int64_t it = 0; it < rounds; it++, i += stride) {
         const bool live = i < a.n;
         const int64_t ii = live ? i : a.n - 1;
-        const rls_disney_closure &c = a.c;
+        // the closure's 22 plane pointers re-read from the kernarg segment here, the 8 output pointers at the stores
+        // (rls_internal.hpp, reload_args): none of them stays in a scalar register across the sample loop
+        const DisneyIntIO al = RLS_INT_ARGS(a);
+        const rls_disney_closure &c = al.c;
         const PIndex<int64_t> pk = pindex(c.materials, ii);      // parameters by reference (rls_material_index)
         V3 wo = ld3(c.wo, ii), N = ld3(c.N, ii), T = ld3(c.T, ii);
         float br, bg, bb;
@@ -597,8 +611,9 @@ __global__ RLS_INT_ATTR void disney_integrate_kernel(DisneyIntIO a)
         }
         if (G > 1) { dC = group_sum<G>(dC); sC = group_sum<G>(sC); }      // counts: integers, any order
         if (live && sub == 0) {
-            strgb(a.dsum, i, dR, dG, dB); stg(a.dcount, i, dC);
-            strgb(a.ssum, i, sR, sG, sB); stg(a.scount, i, sC);
+            const DisneyIntIO ao = RLS_INT_ARGS(a);
+            strgb(ao.dsum, i, dR, dG, dB); stg(ao.dcount, i, dC);
+            strgb(ao.ssum, i, sR, sG, sB); stg(ao.scount, i, sC);
         }
     }
 }

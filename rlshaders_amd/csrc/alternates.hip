@@ -15,13 +15,14 @@ using namespace rlsh;   // AOP_*
 __device__ __forceinline__ Disney load_closure(const rls_disney_closure &c, Idx i)
 {
     V3 wo = ld3(c.wo, i), N = ld3(c.N, i), T = ld3(c.T, i);
+    const PIndex<Idx> k = pindex(c.materials, i);            // parameters by reference (rls_material_index)
     float br, bg, bb;
-    ldrgb(c.base_color, i, br, bg, bb);
+    ldrgb(c.base_color, k, br, bg, bb);
     float s[10];
-    s[0] = ldp(c.subsurface, i); s[1] = ldp(c.metallic, i); s[2] = ldp(c.specular, i);
-    s[3] = ldp(c.specular_tint, i); s[4] = ldp(c.roughness, i); s[5] = ldp(c.anisotropic, i);
-    s[6] = ldp(c.sheen, i); s[7] = ldp(c.sheen_tint, i); s[8] = ldp(c.clearcoat, i);
-    s[9] = ldp(c.clearcoat_gloss, i);
+    s[0] = ldp(c.subsurface, k); s[1] = ldp(c.metallic, k); s[2] = ldp(c.specular, k);
+    s[3] = ldp(c.specular_tint, k); s[4] = ldp(c.roughness, k); s[5] = ldp(c.anisotropic, k);
+    s[6] = ldp(c.sheen, k); s[7] = ldp(c.sheen_tint, k); s[8] = ldp(c.clearcoat, k);
+    s[9] = ldp(c.clearcoat_gloss, k);
     return disney_make(wo, N, T, br, bg, bb, s);
 }
 
@@ -115,6 +116,7 @@ rls_status check_closure(const rls_disney_closure *c)
     RLS_REQUIRE(c != nullptr, "closure is NULL");
     RLS_REQUIRE(rlsh::has3(c->wo) && rlsh::has3(c->N) && rlsh::has3(c->T), "wo/N/T plane is NULL");
     RLS_REQUIRE(rlsh::ok_rgb(c->base_color), "base_color planes must be all set or all NULL");
+    RLS_REQUIRE(rlsh::ok_materials(c->materials), "materials.id is set but materials.count is 0");
     return RLS_OK;
 }
 } // namespace

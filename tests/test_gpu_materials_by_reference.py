@@ -110,6 +110,9 @@ def test_disney_every_verb(gpu, oracle):
         _same(dr.evalSample(*dx), dp.evalSample(*dx), (lobe, "evalSample"))
         _same(dr.evalBrdf(ga[0]), dp.evalBrdf(ga[0]), (lobe, "evalBrdf"))
         _same(dr.evalPdf(ga[0]), dp.evalPdf(ga[0]), (lobe, "evalPdf"))
+    # the alternates the reference compiles but never selects read the closure through the same index
+    for kind in (0, 1):
+        _same(dr.altSample(kind, *dx), dp.altSample(kind, *dx), ("altSample", kind))
     ia, ib = dr.integrate(2, 77), dp.integrate(2, 77)
     for k in ia:
         _same(ia[k], ib[k], ("integrate", k))

@@ -48,6 +48,31 @@ struct ResolveRec {
     const char *type(const char *s) const { return s; }
 };
 
+std::vector<float> read_file(const char *path);
+
+// host-only: detail::Materials::find_rows on K columns of n floats (file: n, K, then the columns) -> n ids and, behind them, the
+// table; prints {"by_reference": ..., "count": ...}.  No device is touched.
+int rows(const char *in, const char *out)
+{
+    std::vector<float> d = read_file(in);
+    const size_t n = (size_t)d[0], K = (size_t)d[1];
+    std::vector<rlstub::detail::Col> cols(K);
+    for (size_t k = 0; k < K; k++) cols[k].v[0].assign(d.begin() + 2 + (std::ptrdiff_t)(k * n), d.begin() + 2 + (std::ptrdiff_t)((k + 1) * n));
+    rlstub::detail::Materials mt;
+    for (size_t k = 0; k < K; k++) mt.add1(cols[k]);
+    std::vector<uint32_t> id;
+    const bool by_ref = mt.find_rows(id);
+    std::FILE *f = std::fopen(out, "wb");
+    if (!f) { std::perror(out); return 1; }
+    if (by_ref) {
+        std::fwrite(id.data(), 4, id.size(), f);
+        for (size_t k = 0; k < K; k++) std::fwrite(mt.table[k].data(), 4, mt.table[k].size(), f);
+    }
+    std::fclose(f);
+    std::printf("{\"by_reference\": %s, \"count\": %u}\n", by_ref ? "true" : "false", mt.count);
+    return 0;
+}
+
 int decl()
 {
     std::printf("{\"nodes\": {");
@@ -212,6 +237,7 @@ int shade(const char *in, const char *out)
 int main(int argc, char **argv)
 {
     if (argc >= 2 && !std::strcmp(argv[1], "decl")) return decl();
+    if (argc >= 4 && !std::strcmp(argv[1], "rows")) return rows(argv[2], argv[3]);
     if (argc >= 4 && !std::strcmp(argv[1], "run")) return run(argv[2], argv[3]);
     if (argc >= 4 && !std::strcmp(argv[1], "shade")) return shade(argv[2], argv[3]);
     std::fprintf(stderr, "usage: test_arnold_stub decl | run <in> <out> | shade <in> <out>\n");

@@ -57,3 +57,49 @@ def test_arnold_glue_is_well_formed():
            str(ROOT / "tests" / "native" / "arnold_glue_check.cpp")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def _rows(tmp_path, cols):
+    cols = np.ascontiguousarray(cols, np.float32)
+    K, n = cols.shape
+    inp, outp = tmp_path / "cols.bin", tmp_path / "rows.bin"
+    with open(inp, "wb") as f:
+        np.array([n, K], np.float32).tofile(f)
+        cols.tofile(f)
+    p = subprocess.run([str(_driver()), "rows", str(inp), str(outp)], capture_output=True, text=True, check=True)
+    info = json.loads(p.stdout.strip().splitlines()[-1])
+    raw = np.fromfile(outp, np.uint32)
+    if not info["by_reference"]:
+        return info, None, None
+    ids = raw[:n]
+    table = raw[n:].view(np.float32).reshape(K, info["count"])
+    return info, ids, table
+
+
+def test_stub_finds_the_distinct_parameter_rows(tmp_path):
+    """detail::Materials::find_rows (host only, no device): a batch of the hits of a few node instances goes by reference -- the
+    table holds each distinct row of parameter BITS once, in order of first appearance, and table[:, id] rebuilds every point's
+    row; one row (the uniform case), many rows (textures) and tiny batches do not."""
+    rng = np.random.default_rng(0)
+    n, K, m = 5000, 6, 23
+    inst = rng.normal(size=(K, m)).astype(np.float32)
+    inst[0, 3] = np.float32(-0.0); inst[0, 4] = np.float32(0.0)            # +-0 are different bits: different rows
+    inst[1:, 4] = inst[1:, 3]
+    inst[2, 7] = np.float32("nan"); inst[2, 8] = np.float32("nan")          # NaNs with equal bits: one row if the rest agrees
+    inst[:2, 8] = inst[:2, 7]; inst[3:, 8] = inst[3:, 7]
+    which = np.repeat(rng.integers(0, m, n // 10), 10)                      # runs of consecutive hits on one instance
+    cols = inst[:, which]
+    info, ids, table = _rows(tmp_path, cols)
+    assert info["by_reference"] is True
+    rows_bits = {cols[:, i].view(np.uint32).tobytes() for i in range(n)}
+    assert info["count"] == len(rows_bits) <= m
+    assert np.array_equal(table[:, ids].view(np.uint32), cols.view(np.uint32))
+    first = [np.flatnonzero(ids == k)[0] for k in range(info["count"])]
+    assert first == sorted(first)                                           # ids in order of first appearance
+    # one row: uniform; every point different: textures; too few points: nothing to gain
+    assert _rows(tmp_path, np.repeat(inst[:, :1], n, axis=1))[0] == {"by_reference": False, "count": 1}
+    assert _rows(tmp_path, rng.normal(size=(K, n)).astype(np.float32))[0]["by_reference"] is False
+    assert _rows(tmp_path, cols[:, :12])[0]["by_reference"] is False
+    # more than one row per eight points: planes
+    many = inst[:, rng.integers(0, m, 100)]
+    assert _rows(tmp_path, many)[0]["by_reference"] is False

@@ -9,7 +9,11 @@ the device before the timed region; nothing crosses PCIe inside it.  All planes 
 in one arena, the fastest of `--arena-candidates` equally sized HBM blocks (DESIGN.md, "Placement");
 the JSON line records the probe results under config.placement.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.  For N > 1
+Contract: `python bench.py --gpus N --steps K --warmup W` ends with ONE compact JSON line on rank 0 (the headline: < 1800
+bytes, the LAST line of stdout -- `headline()` below; a reader that keeps only a tail of stdout still gets all of it).
+Everything longer -- the headline's full record (placement probe, device identities, counter sources) and one record per
+workload of the `workloads` block -- is printed as its own JSON line BEFORE the headline, each tagged `"record": ...`, and
+the same records are written to `gpurun_out/bench_workloads.json` (`--records-file`).  For N > 1
 it runs under `python -m torch.distributed.run --nproc-per-node N ...` (one rank per GPU); the
 batch shards by index range with no collective on the data path (weak scaling: every GPU gets its
 own 2^26 points), the only communication being the barrier and the max-over-ranks of the time.
@@ -18,12 +22,12 @@ own 2^26 points), the only communication being the barrier and the max-over-rank
 stream) against the 8 TB/s HBM3E peak.  `cpu_baseline`: the CPU oracle (a port of the reference's
 scalar closure code) timed on this host's cores on a bounded sample of the same workload.
 
-`workloads` (default run only): the other BASELINE configurations (3: rlDisney 64 spp reduced and streamed, 4: the
-rlSss probe at 2^25 and 2^26 points, 5: rlSkin at 2^26 and 2^27) and the verbs an Arnold-side stub calls one by one
-(rlGgx evalBrdf / evalPdf alone, the rlDisney one-sample triple of either lobe, the NDProfile sample, config 2 with
-uniform parameters), each measured in this same process with >= 10 warm-up launches of its own, its own
-`roofline` and a short `cpu_baseline`.  With N > 1 ranks the block holds configs 3, 4 and 5 at their per-GPU sizes.
-`--config {2,3,4,5}` makes one of them the headline (workload + points per GPU of that BASELINE configuration).
+`workloads` block (default run: `configs`): BASELINE configurations 3 (rlDisney 64 spp, reduced), 4 (the rlSss probe, 2^25
+points per GPU) and 5 (rlSkin, 2^27 per GPU), each measured in this same process with >= 10 warm-up launches of its own, its
+own `roofline` and -- on one GPU -- a short `cpu_baseline`; the default run finishes in about a minute.  `--workloads all`
+adds the verbs an Arnold-side stub calls one by one and the host-resident pipelines (minutes; the builder's profiling
+sessions use it).  `--config {2,3,4,5}` makes one configuration the headline (workload + points per GPU of that BASELINE
+configuration) and switches the block off.
 
 Roofline accounting, per record: `frac` is on the bytes the verb's arithmetic needs (`algorithmic_bytes_per_point`;
 where SURVEY.md 8(d) counts planes the reference reads and never uses -- the albedo of NDProfile::setDistance --
@@ -102,8 +106,10 @@ def parse_args():
                     help="BASELINE.json configuration as the headline: 2 ggx_reflect_refract 2^26/GPU, 3 disney_integrate "
                          "2^26/GPU, 4 sss_probe 2^25/GPU (2^28 over 8), 5 skin 2^27/GPU (2^30 over 8)")
     ap.add_argument("--workloads", default="auto", choices=["auto", "all", "configs", "none"],
-                    help="the `workloads` block: all = every other config and verb, configs = BASELINE configs 3-5 only; "
-                         "auto = all on one GPU / configs on several when the headline is the default, none otherwise")
+                    help="the `workloads` block: all = every other config and verb (minutes), configs = BASELINE configs 3-5 "
+                         "only; auto = configs when the headline is the default, none otherwise")
+    ap.add_argument("--records-file", default=None,
+                    help="where the long records go besides stdout (default gpurun_out/bench_workloads.json; '-' = nowhere)")
     ap.add_argument("--chunk-log2", type=int, default=20,
                     help="disney_stream, ggx_reflect_refract_host: points per chunk = 2^this")
     ap.add_argument("--host-resident", action="store_true",
@@ -120,8 +126,12 @@ def parse_args():
                          "vector-issue-bound EXACT kernels by < 1 % (profiles/r02_placement.txt): two candidates are a check, "
                          "not a search; --math fast gains up to 15 % from 16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target seconds of CPU-baseline work (headline)")
-    ap.add_argument("--block-cpu-seconds", type=float, default=3.5, help="the same for each record of the workloads block")
+    ap.add_argument("--checksum", action="store_true",
+                    help="after the timed region: the order-independent 64-bit checksum (rls_checksum) of every output plane "
+                         "of this rank's shard, gathered over the ranks; the shard sums of a G-rank run add up (mod 2^64) "
+                         "to the sum of one process over the same G * n points (validation, BASELINE configs 2-5 only)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target seconds of CPU-baseline work (headline)")
+    ap.add_argument("--block-cpu-seconds", type=float, default=2.5, help="the same for each record of the workloads block")
     ap.add_argument("--block-log2-points", type=int, default=None,
                     help="every record of the workloads block at 2^this points per GPU instead of its configuration's size (tests)")
     a = ap.parse_args()
@@ -142,7 +152,7 @@ def parse_args():
     if a.log2_points is None:
         a.log2_points = 26
     if a.workloads == "auto":
-        a.workloads = "none" if explicit else ("all" if a.gpus == 1 else "configs")
+        a.workloads = "none" if explicit else "configs"
     return a
 
 
@@ -208,6 +218,7 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
             wl = Workload(name, 2, (19 + 12) * 4, lambda: g.reflectRefract(xi[0], xi[1], xi[2], xi[3], out=out),
                           "ggx_kernel<5, {m}, 1>",
                           "rlGgx reflect+refract VNDF sampling, mixed params (SURVEY 8d config 2)", config=2)
+            wl.outputs = out
         else:
             out = (A.planes(3), A.planes(3), A.plane(), A.plane())
             if name == "ggx_reflect":
@@ -545,6 +556,7 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
                           "disney_integrate_kernel<1, {m}>",
                           "rlDisney both lobes x 64 spp, reduced mode (SURVEY 8d config 3, mode R; VALU-bound)", bound="valu",
                           config=3)
+            wl.outputs = out
         else:
             # mode S: every sample's (wi, f, pdf) = 28 B per triple goes to HBM; the 241 GB of a whole 2^26-point batch
             # are produced chunk by chunk into one chunk-sized set of sample-major planes (what a consumer would read
@@ -580,6 +592,7 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
             wl = Workload(name, 1, (11 + 12) * 4, lambda: s.getProbeRay(xi[0], xi[1], out=out),
                           "sss_kernel<3, 0, {m}>", "rlSss ND probe ray + pdf + profile (SURVEY 8d config 4)",
                           survey_bytes=(14 + 12) * 4, config=4)
+            wl.outputs = out
     elif name == "nd_sample":
         # NDProfile alone: setDistance + getRadius + getPdf + evalProfile (src/rlSss.cpp:20-106); SURVEY 8(d) "profile-only":
         # 8 f in (dist3 albedo3 multiplier xi) + 5 f out = 52 B, of which the arithmetic needs dist3 xi: 4 f in
@@ -642,6 +655,7 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
         wl = Workload(name, 3, (32 + 24) * 4, lambda: sk.sampleEvalPdf(xi, out=out),
                       "skin_kernel<{m}, 1>", "rlSkin sheen GGX + specular GGX + SSS (SURVEY 8d config 5)",
                       survey_bytes=(35 + 24) * 4, config=5)
+        wl.outputs = out
     else:
         raise ValueError(name)
     wl.arena = A
@@ -782,8 +796,9 @@ def cpu_baseline(workload: str, target_seconds: float) -> dict | None:
 
     n0 = 1 << 12
     t = min(run(n0, 0.0)[0])
-    # one pass of about a second (bounded by 2^24 points), repeated for target_seconds
-    n = int(min(1 << 24, max(n0, n0 * 1.0 / max(t, 1e-6))))
+    # one pass of about a second -- a third of the target if that is shorter -- (bounded by 2^24 points), repeated for
+    # target_seconds
+    n = int(min(1 << 24, max(n0, n0 * min(1.0, target_seconds / 3.0) / max(t, 1e-6))))
     n = 1 << (n.bit_length() - 1)
     times, spp, what = run(n, target_seconds)
     best, mean = min(times), sum(times) / len(times)
@@ -798,6 +813,9 @@ def cpu_baseline(workload: str, target_seconds: float) -> dict | None:
     return {"value": round(spp * n / best / 1e9, 6), "unit": "Gsamples/s", "cores": threads, "kind": "port",
             "per_core_msamples": round(spp * n / best / 1e6 / threads, 3), "cpu_model": model,
             "mean_value": round(spp * n / mean / 1e9, 6),
+            "note": "port of the reference's scalar closure code without its per-point heap allocation "
+                    "(src/rlGgx.h:152 make_shared): a conservative (fast) CPU baseline",
+            "sample_short": f"{n} points x {spp} samples, best of {len(times)} passes ({sum(times):.0f} s CPU), {what}, {threads} thr",
             "sample": f"{n} points ({spp} samples each) of the same seeded workload, best of {len(times)} passes "
                       f"({sum(times):.1f} s of CPU work), oracle/rls_oracle.c {what} on {threads} threads"}
 
@@ -946,6 +964,66 @@ def measure(R, ctx, ranks, torch, name: str, log2n: int, steps: int, warmup: int
     return wl, n, elapsed, kernel_ms, my_kernel_ms, other_ms
 
 
+# what tests/test_gpu_fast_mode.py holds RLS_MATH_FAST to (the measurement: profiles/r04_fast_conditioning.json)
+FAST_PARITY = "opt-in; see tests/test_gpu_fast_mode.py"
+
+HEADLINE_MAX_BYTES = 1800          # the driver keeps a 2000-character tail of stdout: the last line must fit inside it
+
+
+def _short(text: str, limit: int) -> str:
+    return text if len(text) <= limit else text[:limit - 3] + "..."
+
+
+def headline(detail: dict) -> dict:
+    """The compact last line: the contract's keys, `roofline`, `cpu_baseline`, a `ranks` summary and the other arithmetic
+    mode -- nothing whose size grows with the rank count or with the number of workloads."""
+    pick = lambda d, keys: {k: d[k] for k in keys if k in d}
+    line = pick(detail, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                         "vs_baseline", "dtype", "data"))
+    cfg = detail["config"]
+    line["config"] = pick(cfg, ("workload", "name", "baseline_config", "math", "points_per_gpu", "points_total",
+                                "samples_per_point", "sharding"))
+    line["config"]["workload"] = _short(cfg["workload"], 120)
+    line["roofline"] = pick(detail["roofline"], ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms",
+                                                 "algorithmic_bytes_per_launch", "issue_slot_frac"))
+    if "cpu_baseline" in detail:
+        cb = detail["cpu_baseline"]
+        line["cpu_baseline"] = pick(cb, ("value", "unit", "cores", "kind"))
+        line["cpu_baseline"]["cpu_model"] = _short(cb.get("cpu_model", ""), 48)
+        line["cpu_baseline"]["sample"] = _short(cb.get("sample_short", cb.get("sample", "")), 160)
+    line["ranks"] = pick(detail["ranks"], ("ranks_seen", "world_size", "backend", "distinct_devices", "min_kernel_ms",
+                                           "max_kernel_ms"))
+    if "validation" in detail:
+        line["validation"] = pick(detail["validation"], ("checksum",))
+    if "other_math_mode" in detail:
+        line["other_math_mode"] = pick(detail["other_math_mode"], ("math", "value", "hbm_frac"))
+        line["other_math_mode"]["parity"] = _short(detail["other_math_mode"].get("parity", ""), 120)
+    text = json.dumps(line)
+    for drop in (("other_math_mode", "parity"), ("cpu_baseline", "sample"), ("config", "workload")):
+        if len(text) < HEADLINE_MAX_BYTES:
+            break
+        line[drop[0]][drop[1]] = _short(str(line[drop[0]][drop[1]]), 24)      # never reached with today's strings: a guard
+        text = json.dumps(line)
+    assert len(text) < HEADLINE_MAX_BYTES, len(text)
+    return line
+
+
+def emit(detail: dict, records: list, records_file) -> None:
+    """stdout: one JSON line per long record (`record`: headline_detail / workload), then the compact headline LAST."""
+    long_records = [dict(detail, record="headline_detail")] + list(records)
+    if records_file != "-":
+        path = Path(records_file) if records_file else ROOT / "gpurun_out" / "bench_workloads.json"
+        try:
+            path.parent.mkdir(parents=True, exist_ok=True)
+            path.write_text(json.dumps(long_records, indent=1) + "\n")
+        except OSError as e:                          # a read-only checkout must not cost the run its line
+            print(f"bench.py: records file not written: {e}", file=sys.stderr)
+    for r in long_records:
+        print(json.dumps(r), flush=True)
+    sys.stderr.flush()
+    print(json.dumps(headline(detail)), flush=True)
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -987,17 +1065,27 @@ def main():
         raise SystemExit(f"bench.py: two ranks share a GPU: {identities}")
 
     wl, n, elapsed, kernel_ms, my_ms, other_ms = measure(R, ctx, ranks, torch, args.workload, args.log2_points, args.steps,
-                                                         args.warmup, args.math, args.arena_candidates, args.chunk_log2, True,
+                                                         args.warmup, args.math, args.arena_candidates, args.chunk_log2,
+                                                         not args.checksum,       # (the other mode would overwrite the outputs)
                                                          args.pipeline_depth)
     per_rank_ms = ranks.gather_objects(round(my_ms, 5))
+    shard_sums = None
+    if args.checksum:
+        outs = getattr(wl, "outputs", None)
+        if outs is None:
+            raise SystemExit(f"bench.py: --checksum covers the BASELINE configurations, not {wl.name}")
+        planes = list(outs.values()) if isinstance(outs, dict) else list(outs)
+        mine = sum(R.checksum(ctx, t) for t in planes) & 0xFFFFFFFFFFFFFFFF
+        from rlshaders_amd.sharding import shard_range
+        shard_sums = (ranks.gather_u64(mine), ranks.gather_objects(list(shard_range(world * n, rank, world))))
 
-    line = None
+    detail = None
     if rank == 0:
         samples = world * n * wl.samples_per_point * args.steps
         value = samples / elapsed / 1e9
         roof = roofline_record(wl, n, kernel_ms, args.math)
         bytes_per_step = n * wl.bytes_per_point
-        line = {
+        detail = {
             "metric": "BSDF Gsamples/sec (eval+sample+pdf)",
             "value": round(value, 4),
             "unit": "Gsamples/s",
@@ -1016,7 +1104,7 @@ def main():
                        "control_plane": (f"torch.distributed {backend}" if ranks.dist is not None else "single process"),
                        "placement": wl.arena.info(),
                        # the EXACT kernels are vector-ALU-bound: the first ~10 launches after idle run up to 40 % slower
-                       # while the clocks ramp (DESIGN.md section 5, "Warm-up"); fewer warm-up steps under-report
+                       # while the clocks ramp (DESIGN.md, "Warm-up"); fewer warm-up steps under-report
                        "warmup_note": None if args.warmup >= 10 else
                        f"warmup {args.warmup} < 10: the clock ramp of the first launches is inside the timed region "
                        "(under-reports by ~4 % at 5, ~15 % at 1)"},
@@ -1026,15 +1114,20 @@ def main():
                       "devices": identities, "distinct_devices": len(set(keys)),
                       "per_rank_kernel_ms": per_rank_ms, "min_kernel_ms": min(per_rank_ms), "max_kernel_ms": max(per_rank_ms)},
         }
+        if shard_sums is not None:
+            detail["validation"] = {"shards": shard_sums[1], "shard_checksums": [f"{v:016x}" for v in shard_sums[0]],
+                                    "checksum": f"{sum(shard_sums[0]) & 0xFFFFFFFFFFFFFFFF:016x}",
+                                    "what": "sum of rls_checksum over every output plane of the last timed pass"}
         other = "exact" if args.math == "fast" else "fast"
         if other_ms is not None:
-            line["other_math_mode"] = {"math": other, "kernel_ms": round(other_ms, 5),
-                                       "value": round(world * n * wl.samples_per_point / (other_ms * 1e-3) / 1e9, 4),
-                                       "hbm_frac": round(bytes_per_step / (other_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            detail["other_math_mode"] = {"math": other, "kernel_ms": round(other_ms, 5),
+                                         "value": round(world * n * wl.samples_per_point / (other_ms * 1e-3) / 1e9, 4),
+                                         "hbm_frac": round(bytes_per_step / (other_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                         "parity": FAST_PARITY if other == "fast" else "bit-exact against the CPU oracle"}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(args.workload, args.cpu_seconds)
             if cb:
-                line["cpu_baseline"] = cb
+                detail["cpu_baseline"] = cb
     del wl
     torch.cuda.empty_cache()
 
@@ -1055,12 +1148,12 @@ def main():
             # an extra record must not cost the headline its line (one process: no other rank is waiting at a barrier)
             if world > 1:
                 raise
-            records.append({"name": name, "points_per_gpu": 1 << log2n, "error": f"{type(e).__name__}: {e}"})
+            records.append({"record": "workload", "name": name, "points_per_gpu": 1 << log2n, "error": f"{type(e).__name__}: {e}"})
             torch.cuda.empty_cache()
             continue
         prm = ranks.gather_objects(round(my, 5))
         if rank == 0:
-            rec = {"name": w.name, "baseline_config": w.config, "workload": w.desc, "points_per_gpu": bn,
+            rec = {"record": "workload", "name": w.name, "baseline_config": w.config, "workload": w.desc, "points_per_gpu": bn,
                    "points_total": world * bn, "samples_per_point": w.samples_per_point,
                    "value": round(world * bn * w.samples_per_point * steps / el / 1e9, 4), "unit": "Gsamples/s",
                    "steps": steps, "warmup": warm, "ms_per_step": round(el / steps * 1e3, 5),
@@ -1071,12 +1164,9 @@ def main():
         del w
         torch.cuda.empty_cache()
 
-    if rank == 0:
-        if block:
-            line["workloads"] = records
-        print(json.dumps(line), flush=True)
-
     ranks.close()
+    if rank == 0:
+        emit(detail, records, args.records_file)
 
 
 if __name__ == "__main__":

@@ -24,9 +24,24 @@ def _bench(world, extra=()):
                "--master-addr", "127.0.0.1", "--master-port", str(port), *base]
     p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=str(ROOT))
     assert p.returncode == 0, p.stderr[-3000:]
-    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, p.stdout          # exactly one JSON line, from rank 0
-    return json.loads(lines[0])
+    return _parse(p.stdout)
+
+
+def _parse(stdout):
+    """the compact headline is the LAST line of stdout, parses on its own and fits a 2000-character tail; the long records
+    come before it, one JSON line each, and are attached here under `_records` for the assertions below"""
+    lines = stdout.splitlines()
+    last = lines[-1]
+    assert last.startswith("{") and len(last) < 1800, (len(last), last[:200])
+    assert len(stdout[-2000:].splitlines()[-1]) == len(last)          # what a 2000-character tail keeps is the whole line
+    head = json.loads(last)
+    assert "record" not in head and "roofline" in head and "config" in head and "ranks" in head
+    recs = [json.loads(l) for l in lines[:-1] if l.startswith("{")]
+    assert all("record" in r for r in recs) and [r["record"] for r in recs].count("headline_detail") == 1
+    head["_records"] = recs
+    head["_detail"] = [r for r in recs if r["record"] == "headline_detail"][0]
+    head["workloads"] = [r for r in recs if r["record"] == "workload"]
+    return head
 
 
 @pytest.mark.gpu
@@ -46,7 +61,9 @@ def test_two_ranks_one_json_line():
     assert abs(two["value"] - 2 * (1 << 20) * 2 * 3 / (two["ms_per_step"] * 3e-3) / 1e9) / two["value"] < 0.02
     assert "x2" in two["config"]["sharding"]
     # the line says who took part: both ranks seen (gathered over the process group), each with its own kernel time
-    rk = two["ranks"]
+    assert two["ranks"]["ranks_seen"] == 2 and two["ranks"]["distinct_devices"] == 1 and "devices" not in two["ranks"]
+    rk = two["_detail"]["ranks"]
+    assert two["_detail"]["value"] == two["value"] and two["_detail"]["roofline"]["kernel_ms"] == two["roofline"]["kernel_ms"]
     assert rk["ranks_seen"] == 2 and rk["world_size"] == 2 and [d["rank"] for d in rk["devices"]] == [0, 1]
     assert len({d["pid"] for d in rk["devices"]}) == 2 and len(rk["per_rank_kernel_ms"]) == 2
     assert rk["min_kernel_ms"] <= rk["max_kernel_ms"] and rk["max_kernel_ms"] == max(rk["per_rank_kernel_ms"])
@@ -74,8 +91,8 @@ def test_workloads_block_and_config_presets():
     p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--config", "5", "--log2-points", "18", "--steps", "3",
                         "--warmup", "2", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900, cwd=str(ROOT))
     assert p.returncode == 0, p.stderr[-3000:]
-    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["config"]["name"] == "skin" and line["config"]["baseline_config"] == 5 and "workloads" not in line
+    line = _parse(p.stdout)
+    assert line["config"]["name"] == "skin" and line["config"]["baseline_config"] == 5 and line["workloads"] == []
 
 
 @pytest.mark.gpu
@@ -90,17 +107,57 @@ def test_rccl_control_path_on_one_gpu():
     def run(cmd):
         p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=str(ROOT))
         assert p.returncode == 0, p.stderr[-3000:]
-        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-        assert len(lines) == 1, p.stdout
-        return json.loads(lines[0])
+        return _parse(p.stdout)
 
     port = 29900 + os.getpid() % 90
     rccl = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
                 "127.0.0.1", "--master-port", str(port), *base])
     plain = run([sys.executable, *base])
-    assert rccl["config"]["control_plane"] == "torch.distributed nccl" and plain["config"]["control_plane"] == "single process"
+    assert rccl["_detail"]["config"]["control_plane"] == "torch.distributed nccl"
+    assert plain["_detail"]["config"]["control_plane"] == "single process"
     assert rccl["n_gpus"] == 1
     print("RCCL-launched", rccl["value"], "plain", plain["value"])
     # two separate 2^26-point runs on a shared box: kernel time, not wall time, and a wide gate
     assert abs(rccl["roofline"]["kernel_ms"] / plain["roofline"]["kernel_ms"] - 1) < 0.08
     assert rccl["ranks"]["ranks_seen"] == 1 and rccl["ranks"]["backend"] == "nccl"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", [4, 5])
+def test_eight_rank_dress_rehearsal(config):
+    """BASELINE configs 4 and 5 are 8-GPU jobs.  Eight ranks (gloo, sharing this box's one GPU) at 2^20 points each: the
+    shards tile [0, 8 * 2^20), their output checksums add up (mod 2^64) to one process's checksum over the same 2^23 points,
+    and the last line is the compact headline with ranks_seen == 8 -- so the driver's 8-GPU run yields a parsed record."""
+    eight = _bench(8, ("--config", str(config), "--checksum"))          # _bench passes --log2-points 20
+    n = 1 << 20
+    assert eight["n_gpus"] == 8 and eight["ranks"]["ranks_seen"] == 8 and eight["ranks"]["world_size"] == 8
+    assert eight["config"]["baseline_config"] == config and eight["config"]["points_total"] == 8 * n
+    v = eight["_detail"]["validation"]
+    assert v["shards"] == [[g * n, n] for g in range(8)]
+    assert len(set(v["shard_checksums"])) == 8                           # eight different shards, not one shard eight times
+    assert int(v["checksum"], 16) == sum(int(c, 16) for c in v["shard_checksums"]) % (1 << 64)
+    env = dict(os.environ)
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--config", str(config), "--log2-points", "23", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline", "--checksum"], capture_output=True, text=True, env=env,
+                       timeout=900, cwd=str(ROOT))
+    assert p.returncode == 0, p.stderr[-3000:]
+    one = _parse(p.stdout)
+    assert one["_detail"]["validation"]["shards"] == [[0, 8 * n]]
+    assert one["validation"]["checksum"] == eight["validation"]["checksum"]
+
+
+@pytest.mark.gpu
+def test_default_shape_with_cpu_baseline():
+    """the default command's shape at small sizes: configs block (3 records, each with its own cpu_baseline) printed before
+    a headline that carries roofline and cpu_baseline"""
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--log2-points", "18", "--workloads", "configs",
+                        "--block-log2-points", "14", "--cpu-seconds", "0.3", "--block-cpu-seconds", "0.2", "--steps", "3",
+                        "--warmup", "2"], capture_output=True, text=True, timeout=900, cwd=str(ROOT))
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = _parse(p.stdout)
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "Gsamples/s" and cb["sample"]
+    assert [r["name"] for r in line["workloads"]] == ["disney_integrate", "sss_probe", "skin"]
+    assert all(r["cpu_baseline"]["value"] > 0 for r in line["workloads"])
+    saved = json.loads((ROOT / "gpurun_out" / "bench_workloads.json").read_text())
+    assert [r["record"] for r in saved] == ["headline_detail", "workload", "workload", "workload"]

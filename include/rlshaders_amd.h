@@ -185,7 +185,10 @@ void        rls_graph_destroy(rls_graph *graph);
  * and the output planes are downloaded to host_out[k] + first_point.  With depth >= 2 the upload of chunk k + 1, the
  * kernels of chunk k and the download of chunk k - 1 overlap.  A NULL host plane is skipped (a uniform parameter, an
  * unwanted output).  Host planes that are equally spaced inside ONE allocation (a [planes, n] array: rlsb::HostPlanes)
- * travel as one strided copy per chunk and direction -- a third faster than one copy per plane.  rls_pipeline_run returns when every chunk has arrived in host memory; the slots compute in the
+ * travel as one strided copy per chunk and direction -- a third faster than one copy per plane.  The host planes SHOULD be
+ * page-locked (rls_host_alloc / rls_host_register): pageable memory is accepted, but the runtime then stages every copy
+ * through its own pinned buffer and blocks the calling thread meanwhile -- the results are the same, the overlap is gone
+ * (the Python wrapper refuses pageable tensors for that reason).  rls_pipeline_run returns when every chunk has arrived in host memory; the slots compute in the
  * arithmetic mode of the context the pipeline was created on.  Results are those of the device-resident call on the
  * same points, bit for bit.  PCIe-bound by construction: rls_measure_copy_rates gives the box's pinned-memory rates
  * (host -> device, device -> host, both at once; GB/s) to hold a pipeline's throughput against. */

@@ -1723,8 +1723,9 @@ rls_status rls_disney_integrate(rls_context *ctx, int64_t n, const rls_disney_cl
 }
 
 // Streamed mode in chunks of the point range (2^26 points x 128 triples x 28 B = 241 GB does not fit beside the
-// inputs): each chunk is one launch over [p0, p0 + count) with every plane pointer advanced by p0 and the sampler's
-// first_index by p0, so the samples are those of the unchunked call.
+// inputs): each chunk is one launch over [p0, p0 + count) with every per-point plane pointer (by reference: the material
+// ids instead of the parameter columns) advanced by p0 and the sampler's first_index by p0, so the samples are those of
+// the unchunked call.
 rls_status rls_disney_integrate_chunked(rls_context *ctx, int64_t n, const rls_disney_closure *c,
                                         int spp_n, uint32_t seed, uint64_t first_index,
                                         rls_rgb diffuse_sum, float *diffuse_count,
@@ -1747,11 +1748,17 @@ rls_status rls_disney_integrate_chunked(rls_context *ctx, int64_t n, const rls_d
         const int64_t count = n - p0 < chunk_points ? n - p0 : chunk_points;
         rls_disney_closure cc = *c;
         cc.wo = adv(c->wo, p0); cc.N = adv(c->N, p0); cc.T = adv(c->T, p0);
-        cc.base_color = adv(c->base_color, p0);
-        cc.subsurface = adv(c->subsurface, p0); cc.metallic = adv(c->metallic, p0); cc.specular = adv(c->specular, p0);
-        cc.specular_tint = adv(c->specular_tint, p0); cc.roughness = adv(c->roughness, p0);
-        cc.anisotropic = adv(c->anisotropic, p0); cc.sheen = adv(c->sheen, p0); cc.sheen_tint = adv(c->sheen_tint, p0);
-        cc.clearcoat = adv(c->clearcoat, p0); cc.clearcoat_gloss = adv(c->clearcoat_gloss, p0);
+        if (c->materials.id) {
+            // parameters by reference: the parameter pointers are per-MATERIAL columns of materials.count floats and stay
+            // where they are; what belongs to the chunk's points is their material ids
+            cc.materials.id = c->materials.id + p0;
+        } else {
+            cc.base_color = adv(c->base_color, p0);
+            cc.subsurface = adv(c->subsurface, p0); cc.metallic = adv(c->metallic, p0); cc.specular = adv(c->specular, p0);
+            cc.specular_tint = adv(c->specular_tint, p0); cc.roughness = adv(c->roughness, p0);
+            cc.anisotropic = adv(c->anisotropic, p0); cc.sheen = adv(c->sheen, p0); cc.sheen_tint = adv(c->sheen_tint, p0);
+            cc.clearcoat = adv(c->clearcoat, p0); cc.clearcoat_gloss = adv(c->clearcoat_gloss, p0);
+        }
         rls_status st = rls_disney_integrate(ctx, count, &cc, spp_n, seed, first_index + (uint64_t)p0,
                                              adv(diffuse_sum, p0), diffuse_count ? diffuse_count + p0 : nullptr,
                                              adv(specular_sum, p0), specular_count ? specular_count + p0 : nullptr, chunk);

@@ -26,11 +26,13 @@ struct Slot {
 
 // host planes [k0, k1) <-> device planes of one slot, rows [p0, p0 + count): one hipMemcpyAsync per plane, or -- where
 // consecutive host planes are a constant positive distance apart -- one hipMemcpy2DAsync per run of planes
-// (a run may be equally spaced by accident -- separate allocations next to each other -- and then the runtime refuses the
-// strided copy, whose source must lie in one allocation: the run goes plane by plane and the pipeline stops trying)
+// whose spacing is at least the batch's n points, i.e. planes that do not overlap.  (A run may be equally spaced by accident
+// -- separate allocations next to each other -- and then the runtime refuses the strided copy, whose source must lie in one
+// allocation: the run goes plane by plane, and so does the rest of THIS rls_pipeline_run call; `strided` is the caller's
+// per-run flag, the next run looks at its own planes afresh.)
 template <class HostPtr>
 hipError_t copy_planes(bool up, int planes, HostPtr const *host, float *const *dev, int64_t dev_stride, int64_t p0,
-                       int64_t count, hipStream_t stream, bool &strided)
+                       int64_t count, int64_t n, hipStream_t stream, bool &strided)
 {
     hipError_t e = hipSuccess;
     const size_t row = (size_t)count * sizeof(float);
@@ -39,6 +41,7 @@ hipError_t copy_planes(bool up, int planes, HostPtr const *host, float *const *d
         int m = k + 1;                                                // the run [k, m) of equally spaced host planes
         if (strided && m < planes && host[m] && host[m] > host[k]) {
             const ptrdiff_t d = host[m] - host[k];
+            if (d < n) { m = k + 1; goto single; }                        // closer than n floats: not the planes of one [planes, n] array
             while (m + 1 < planes && host[m + 1] && host[m + 1] - host[m] == d) m++;
             m++;
             if (m - k >= 2) {
@@ -53,6 +56,7 @@ hipError_t copy_planes(bool up, int planes, HostPtr const *host, float *const *d
             }
             m = k + 1;
         }
+    single:
         if (up) e = hipMemcpyAsync(dev[k], host[k] + p0, row, hipMemcpyHostToDevice, stream);
         else e = hipMemcpyAsync((void *)(host[k] + p0), dev[k], row, hipMemcpyDeviceToHost, stream);
         k = m;
@@ -66,7 +70,7 @@ struct rls_pipeline {
     rls_context *parent;
     int64_t chunk_points, stride;
     int in_planes, out_planes, depth;
-    bool strided;              // RLS_PIPELINE_STRIDED=0 turns the strided copies off (one copy per plane)
+    bool strided;              // RLS_PIPELINE_STRIDED=0 turns the strided copies off (one copy per plane); fixed at creation
     Slot *slots;
 };
 
@@ -183,6 +187,7 @@ rls_status rls_pipeline_run(rls_pipeline *p, int64_t n, const float *const *host
     RLS_REQUIRE(!p->parent->capturing, "not allowed while a launch graph is being recorded");
     rls_status st = RLS_OK;
     int64_t c = 0;
+    bool strided = p->strided;             // this run's: a refused strided copy sends the rest of THIS run plane by plane
     for (int64_t p0 = 0; p0 < n && st == RLS_OK; p0 += p->chunk_points, c++) {
         const int64_t count = n - p0 < p->chunk_points ? n - p0 : p->chunk_points;
         Slot &sl = p->slots[c % p->depth];
@@ -192,11 +197,11 @@ rls_status rls_pipeline_run(rls_pipeline *p, int64_t n, const float *const *host
         if (e != hipSuccess) { st = rlsh::hip_fail(e, "rls_pipeline_run: hipSetDevice"); break; }
         // a NULL host plane is a plane the caller does not stream (a uniform parameter, an unwanted output).  Runs of host
         // planes that are equally spaced in memory (rlsb::HostPlanes, a [planes, n] array) travel as ONE strided copy
-        e = copy_planes(true, p->in_planes, host_in, sl.in, p->stride, p0, count, stream, p->strided);
+        e = copy_planes(true, p->in_planes, host_in, sl.in, p->stride, p0, count, n, stream, strided);
         if (e != hipSuccess) { st = rlsh::hip_fail(e, "rls_pipeline_run: upload"); break; }
         st = launch(user, sl.ctx, p0, count, sl.in, sl.out);
         if (st != RLS_OK) break;
-        e = copy_planes(false, p->out_planes, host_out, sl.out, p->stride, p0, count, stream, p->strided);
+        e = copy_planes(false, p->out_planes, host_out, sl.out, p->stride, p0, count, n, stream, strided);
         if (e != hipSuccess) { st = rlsh::hip_fail(e, "rls_pipeline_run: download"); break; }
     }
     // drain every slot, also after a failure: the caller's host buffers must not be written behind its back

@@ -166,7 +166,7 @@ int run(const char *in, const char *out)
         std::fclose(f);
         std::printf("{\"n\": %lld, \"ggx_planes\": %zu, \"disney_planes\": %zu, \"skin_planes\": %zu, \"uniform_parameters\": %lld, \"reference_batches\": %lld}\n",
                     (long long)n, a.size() / (size_t)n, b.size() / (size_t)n, c.size() / (size_t)n,
-                    (long long)rlstub::detail::uniform_parameters(), (long long)rlstub::detail::reference_batches());
+                    (long long)rlstub::detail::uniform_parameters().load(), (long long)rlstub::detail::reference_batches().load());
         return 0;
     } catch (const rlsb::Error &e) {
         std::fprintf(stderr, "rlshaders_amd: %s\n", e.what());
@@ -224,7 +224,7 @@ int shade(const char *in, const char *out)
         std::fclose(f);
         std::printf("{\"n\": %lld, \"ggx_planes\": %zu, \"disney_planes\": %zu, \"skin_planes\": %zu, \"uniform_parameters\": %lld, \"reference_batches\": %lld}\n",
                     (long long)n, a.size() / (size_t)n, b.size() / (size_t)n, c.size() / (size_t)n,
-                    (long long)rlstub::detail::uniform_parameters(), (long long)rlstub::detail::reference_batches());
+                    (long long)rlstub::detail::uniform_parameters().load(), (long long)rlstub::detail::reference_batches().load());
         return 0;
     } catch (const rlsb::Error &e) {
         std::fprintf(stderr, "rlshaders_amd: %s\n", e.what());

@@ -116,6 +116,21 @@ def test_disney_every_verb(gpu, oracle):
     ia, ib = dr.integrate(2, 77), dp.integrate(2, 77)
     for k in ia:
         _same(ia[k], ib[k], ("integrate", k))
+    # streamed mode in chunks (rls_disney_integrate_chunked): by reference a chunk advances the material IDS, not the
+    # per-material columns (M = 37 floats: a column advanced by a chunk's first point would be read far out of bounds).  Sums =
+    # the unchunked call's, every chunk's samples = the planes form's, on ragged chunks (N is not a multiple of 3000)
+    seen = {"ref": [], "planes": []}
+    grab = lambda key: (lambda first, count, ch: seen[key].append((first, count, [host(ch[k]).copy() for k in ("wi", "f", "pdf")])))
+    ca, _ = dr.integrateChunked(2, 77, 3000, consume=grab("ref"))
+    cb, _ = dp.integrateChunked(2, 77, 3000, consume=grab("planes"))
+    for k in ia:
+        _same(ca[k], ia[k], ("integrateChunked by reference vs integrate", k))
+        _same(cb[k], ia[k], ("integrateChunked planes vs integrate", k))
+    assert [c[:2] for c in seen["ref"]] == [(p0, min(3000, N - p0)) for p0 in range(0, N, 3000)] == [c[:2] for c in seen["planes"]]
+    for (p0, count, a), (_, _, b) in zip(seen["ref"], seen["planes"]):
+        m = 2 * 4 * count
+        for k, (u, v) in enumerate(zip(a, b)):
+            assert np.array_equal(u[..., :m].view(np.uint32), v[..., :m].view(np.uint32)), ("chunk samples", p0, k)
     P = dev(np.stack([oracle.gen_uniform(9, 0, N, 40 + j, 0.0, 4.0 if j < 2 else 1.0) for j in range(3)]))
     lights = [R.make_light(center=(2.0, 2.0, 3.0), radius=1.25, radiance=(3.0, 2.0, 1.0))]
     sa, sb = dr.shade(P, lights, 2, 77, env=(1.0, 0.9, 0.8)), dp.shade(P, lights, 2, 77, env=(1.0, 0.9, 0.8))

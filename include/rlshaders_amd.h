@@ -130,6 +130,19 @@ int         rls_context_device(const rls_context *ctx);
 const char *rls_last_error(void);
 const char *rls_status_string(rls_status s);
 int         rls_version(void);                 /* major*1000 + minor */
+/* Which host libm the EXACT kernels reproduce bit for bit.  The reference's closures call sinf / cosf / expf / logf / powf /
+ * atan2f / acosf / tanf of the C library the renderer runs on (src/rlGgx.cpp:27-58, src/rlDisney.cpp:177,399,549,576,
+ * src/rlSss.cpp:31-32,59,62,78-79,102); this library restates glibc's (>= 2.28) algorithms, and of glibc's two x86-64 builds
+ * the one chosen when the library was compiled: rls_libm_flavour() returns "glibc-fma" (the build glibc's ifunc selects on
+ * every CPU with AVX2 + FMA) or "glibc-sse2".
+ * rls_host_libm_matches() asks the CALLER's libm (the one this process resolves): the 42 fp32 arguments on which the two
+ * glibc builds differ -- every such argument of sinf / cosf / expf / powf(x, 5), found by sweeping all 2^32 -- must give the
+ * followed build's result, and this library's routines compiled for the host must agree with the host's on 4096 arguments
+ * per function (a libm that is neither build).  *mismatches = the number of disagreements.  "Bit for bit like the CPU
+ * closures" holds on THIS host only when it is 0; otherwise results stay within the 1e-5 contract and differ in the last
+ * bit on a ~1e-8 ... 1e-6 share of arguments (glibc's other build) or more (another C library).  Needs no device. */
+const char *rls_libm_flavour(void);
+rls_status  rls_host_libm_matches(int *mismatches);
 /* Device properties the host side sizes shards with. */
 rls_status  rls_device_info(rls_context *ctx, int *compute_units, size_t *hbm_bytes_total,
                             size_t *hbm_bytes_free, char *arch_name, size_t arch_name_len);

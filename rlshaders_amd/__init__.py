@@ -7,11 +7,11 @@ classes; it fails loudly when the HIP library is missing -- there is no CPU path
 """
 from ._capi import (RLS_KERNEL_NDF, RLS_KERNEL_VNDF, RLS_RAY_DIFFUSE, RLS_RAY_GLOSSY, RlsError, load)
 from .closures import (Arena, Context, DisneySampler, GaussianProfile, GgxSampler, NDProfile, Pipeline, SkinShader, SssSampler,
-                       checksum,
+                       checksum, host_libm_mismatches, libm_flavour,
                        gen_aniso, gen_frame, gen_uniform, make_light, make_scene, util_directions, util_reflect_luminance)
 
 __all__ = [
     "Context", "Arena", "Pipeline", "GgxSampler", "DisneySampler", "NDProfile", "GaussianProfile", "SssSampler", "SkinShader",
     "RLS_RAY_DIFFUSE", "RLS_RAY_GLOSSY", "RLS_KERNEL_VNDF", "RLS_KERNEL_NDF",
-    "RlsError", "load", "gen_frame", "gen_uniform", "gen_aniso", "checksum", "util_directions", "util_reflect_luminance", "make_scene", "make_light",
+    "RlsError", "load", "gen_frame", "gen_uniform", "gen_aniso", "checksum", "libm_flavour", "host_libm_mismatches", "util_directions", "util_reflect_luminance", "make_scene", "make_light",
 ]

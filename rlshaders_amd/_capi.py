@@ -177,6 +177,8 @@ PROTOTYPES = {
     "rls_last_error": (C.c_char_p, []),
     "rls_status_string": (C.c_char_p, [C.c_int]),
     "rls_version": (C.c_int, []),
+    "rls_libm_flavour": (C.c_char_p, []),
+    "rls_host_libm_matches": (C.c_int, [C.POINTER(C.c_int)]),
     "rls_device_info": (C.c_int, [_ctx, C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
                                   C.c_char_p, C.c_size_t]),
     "rls_device_alloc": (C.c_int, [_ctx, C.c_size_t, C.POINTER(_vp)]),

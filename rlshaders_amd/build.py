@@ -22,9 +22,9 @@ OBJDIR = PKG / "build"
 LIB = LIBDIR / "librlshaders_amd.so"
 ARCH = "gfx950"
 
-SOURCES = ["context.hip", "pipeline.hip", "ggx.hip", "disney.hip", "sss.hip", "skin.hip", "integrate.hip", "alternates.hip"]
+SOURCES = ["context.hip", "pipeline.hip", "libm_check.hip", "ggx.hip", "disney.hip", "sss.hip", "skin.hip", "integrate.hip", "alternates.hip"]
 FAST_UNITS = {"ggx.hip", "disney.hip", "sss.hip", "skin.hip", "integrate.hip", "alternates.hip"}
-HEADERS = [CSRC / "rls_device.hpp", CSRC / "rls_libm.hpp", CSRC / "rls_libm_tables.inc", CSRC / "rls_internal.hpp",
+HEADERS = [CSRC / "rls_device.hpp", CSRC / "rls_libm.hpp", CSRC / "rls_libm_tables.inc", CSRC / "rls_libm_flavour_args.inc", CSRC / "rls_internal.hpp",
            PKG.parent / "include" / "rlshaders_amd.h"]
 
 HIPCC_FLAGS = [

@@ -1038,6 +1038,18 @@ def gen_aniso(ctx: Context, seed: int, first: int, n: int, out: Optional[torch.T
     return out
 
 
+def libm_flavour() -> str:
+    """which host libm the EXACT kernels reproduce bit for bit: "glibc-fma" or "glibc-sse2" (rls_libm_flavour)"""
+    return capi.load().rls_libm_flavour().decode()
+
+
+def host_libm_mismatches() -> int:
+    """0 when THIS process's libm is the one the library follows (rls_host_libm_matches); needs no device"""
+    v = C.c_int(-1)
+    check(capi.load().rls_host_libm_matches(C.byref(v)))
+    return int(v.value)
+
+
 def checksum(ctx: Context, t: torch.Tensor) -> int:
     flat = t.reshape(-1)
     v = C.c_uint64()

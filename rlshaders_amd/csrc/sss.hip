@@ -23,6 +23,9 @@ enum { OP_ND = rlsh::SOP_ND, OP_ND_PDF = rlsh::SOP_ND_PDF, OP_ND_EVAL = rlsh::SO
 enum { OP_CAVITY = rlsh::MOP_CAVITY, OP_DIFFUSE_DIR = rlsh::MOP_DIFFUSE_DIR, OP_UTIL = rlsh::MOP_UTIL,
        OP_REFLECT_LUM = rlsh::MOP_REFLECT_LUM };
 
+#ifndef RLS_SSS_TWO_TILES           // experiment switch, see sss_kernel
+#define RLS_SSS_TWO_TILES 0
+#endif
 #ifndef RLS_ND_ONE_SAMPLE_RECIP     // experiment switch: the one-sample kernels keep the reciprocals of c1 + 3 c2 as well
 #define RLS_ND_ONE_SAMPLE_RECIP 0
 #endif
@@ -72,6 +75,72 @@ void sss_kernel(SssIO a0)
     NdProfile pu = {};
     if (UNIFORM) pu = uniform_profile(a0.c);
     const TileRange tiles = tile_range(a0.n);
+#if RLS_SSS_TWO_TILES
+    // Experiment (round 4): two tiles per loop iteration and lane -- the loads of both issued ahead of the
+    // arithmetic of either, the stores of both after it: twice the memory-level parallelism per wave and two independent
+    // instruction streams for the scheduler.  Measured: profiles/r04_sss_two_points.txt.  Off.
+    if ((OP == OP_PROBE || OP == OP_ND) && MODE == PER_POINT) {
+        for (int64_t base = tiles.first; base < tiles.end; base += 2 * tiles.step) {
+            const Idx i0 = make_idx(base), i1 = make_idx(base + tiles.step);
+            const bool ok0 = i0.full() < a0.n, ok1 = base + tiles.step < tiles.end && i1.full() < a0.n;
+            const SssIO a = reload_args(a0);
+            float in[2][12];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const Idx i = t ? i1 : i0;
+#pragma unroll
+                for (int k = 0; k < 12; k++) in[t][k] = 1.0f;
+                if (t ? ok1 : ok0) {
+                    in[t][0] = ldp(a.c.sss_dist_multiplier, i);
+#pragma unroll
+                    for (int k = 0; k < 3; k++) in[t][1 + k] = ldp(a.c.sss_scatter_dist[k], i);
+                    in[t][4] = ldg(a.rx, i);
+                    if (OP == OP_PROBE) {
+                        in[t][5] = ldg(a.ry, i);
+                        V3 N = ld3(a.c.N, i), T = ld3(a.c.T, i);
+                        in[t][6] = N.x; in[t][7] = N.y; in[t][8] = N.z; in[t][9] = T.x; in[t][10] = T.y; in[t][11] = T.z;
+                    }
+                }
+            }
+            float out[2][12];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const float m = in[t][0];
+                NdProfile p = nd_make<RLS_ND_ONE_SAMPLE_RECIP != 0>(in[t][1] * m, in[t][2] * m, in[t][3] * m);
+                float r, pdf, R, G, B;
+                if (OP == OP_ND) {
+                    r = nd_radius(p, in[t][4]);
+                } else {
+                    Frame fr = sss_frame(mk(in[t][6], in[t][7], in[t][8]), mk(in[t][9], in[t][10], in[t][11]), a.c.has_dPdu != 0);
+                    V3 off, dir;
+                    float maxdist;
+                    r = sss_probe_ray(p, fr, in[t][4], in[t][5], off, dir, maxdist);
+                    out[t][5] = off.x; out[t][6] = off.y; out[t][7] = off.z; out[t][8] = dir.x; out[t][9] = dir.y; out[t][10] = dir.z;
+                    out[t][11] = maxdist;
+                }
+                nd_pdf_profile(p, r, pdf, R, G, B);
+                out[t][0] = r; out[t][1] = pdf; out[t][2] = R; out[t][3] = G; out[t][4] = B;
+            }
+            const SssIO b = reload_args(a0);
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const Idx i = t ? i1 : i0;
+                if (!(t ? ok1 : ok0)) continue;
+                stg(b.r, i, out[t][0]);
+                stg(b.pdf, i, out[t][1]);
+                strgb(b.profile, i, out[t][2], out[t][3], out[t][4]);
+                if (OP == OP_PROBE) {
+                    V3 off = mk(out[t][5], out[t][6], out[t][7]);
+                    if (b.P.x) off = ld3(b.P, i) + off;
+                    st3(b.origin, i, off);
+                    st3(b.dir, i, mk(out[t][8], out[t][9], out[t][10]));
+                    stg(b.maxdist, i, out[t][11]);
+                }
+            }
+        }
+        return;
+    }
+#endif
     for (int64_t base = tiles.first; base < tiles.end; base += tiles.step) {
         const Idx i = make_idx(base);
         if (i.full() >= a0.n) continue;

@@ -15,6 +15,9 @@
 // pdf 0, floors); failures of the device layer throw rlsb::Error carrying the rls_status.
 #pragma once
 
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
 #include <cstddef>
 #include <cstdint>
 #include <exception>
@@ -53,10 +56,38 @@ inline Shard shardRange(int64_t total, int rank, int world)
 }
 inline int deviceCount() { return rls_device_count(); }
 
+// Which host libm the EXACT kernels reproduce, and whether THIS process's libm is that one (rls_host_libm_matches): the
+// first Device of a process asks once and says so on stderr when it is not -- results then stay within the 1e-5 contract
+// of the CPU closures on this host, but are not bit-identical to them.  RLS_QUIET_LIBM_CHECK=1 silences it.
+inline const char *libmFlavour() { return rls_libm_flavour(); }
+inline int hostLibmMismatches()
+{
+    int bad = -1;
+    check(rls_host_libm_matches(&bad));
+    return bad;
+}
+inline void warnOnceIfHostLibmDiffers()
+{
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *quiet = std::getenv("RLS_QUIET_LIBM_CHECK");
+        if (quiet && quiet[0] == '1') return;
+        int bad = 0;
+        if (rls_host_libm_matches(&bad) == RLS_OK && bad != 0)
+            std::fprintf(stderr, "rlshaders_amd: this host's libm is not the one the library follows (%s): %d of its probe "
+                                 "arguments differ -- results are within 1e-5 of this host's CPU closures, not bit-identical\n",
+                         rls_libm_flavour(), bad);
+    });
+}
+
 // One GPU + the stream the closures launch on.
 class Device {
 public:
-    explicit Device(int ordinal = 0) { check(rls_context_create(ordinal, &ctx_)); }
+    explicit Device(int ordinal = 0)
+    {
+        check(rls_context_create(ordinal, &ctx_));
+        warnOnceIfHostLibmDiffers();
+    }
     ~Device() { rls_context_destroy(ctx_); }
     Device(const Device &) = delete;
     Device &operator=(const Device &) = delete;

@@ -48,7 +48,7 @@ def test_sample_and_fused(gpu, oracle, mixed, lobe, name):
     # invalid samples (zero vector, src/rlDisney.cpp:385-387) must be flagged identically
     z_ref = (ref[0] == 0).all(axis=0)
     z_got = (got[0] == 0).all(axis=0)
-    assert (z_ref != z_got).mean() <= 1e-4
+    assert (z_ref != z_got).sum() <= cases.flag_slack()          # none under strict parity
     both = ~z_ref & ~z_got
     for k, nm in enumerate(("wi", "f", "pdf")):
         st = cases.summarize(cases.rel_err(got[k][..., both], ref[k][..., both]))
@@ -110,7 +110,7 @@ def test_integrate_reduced_and_streamed(gpu, oracle):
     print("disney integrate streamed wi", st)
     cases.assert_tight(st, "streamed wi")
     for k in ("diffuse_count", "specular_count"):
-        assert (got[k] != ref[k]).sum() <= 1, k
+        assert (got[k] != ref[k]).sum() <= cases.flag_slack(), k
     for k in ("diffuse_sum", "specular_sum"):
         st = cases.summarize(cases.rel_err(got[k], ref[k]))
         print("disney integrate", k, st)

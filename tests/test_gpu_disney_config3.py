@@ -34,7 +34,7 @@ def test_integrate_8x8_against_oracle(gpu, oracle):
     s = disney_sampler(gpu, c)
     base = _with_group(1, lambda: {k: host(v) for k, v in s.integrate(spp_n, seed).items()})
     for k in COUNTS:
-        assert (base[k] != ref[k]).sum() <= 1, k
+        assert (base[k] != ref[k]).sum() <= cases.flag_slack(), k
         assert base[k].min() >= 0 and base[k].max() <= spp_n * spp_n
     for k in SUMS:
         st = cases.summarize(cases.rel_err(base[k], ref[k]))
@@ -166,7 +166,7 @@ def test_full_size_config3(gpu, oracle):
         c = dict(wo=sub(wo), N=sub(N), T=sub(T), base_color=sub(base), **{k: sub(v) for k, v in sc.items()})
         ref = disney_oracle(oracle, c).integrate(spp_n, seed, first_index=p0)
         for k in COUNTS:
-            assert (sub(out[k]) != ref[k]).sum() <= 1, (w, k)
+            assert (sub(out[k]) != ref[k]).sum() <= cases.flag_slack(), (w, k)
         for k in SUMS:
             cases.assert_tight(cases.summarize(cases.rel_err(sub(out[k]), ref[k])), ("window", w, k))
 

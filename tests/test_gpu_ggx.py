@@ -203,7 +203,7 @@ def test_edge_cases(gpu, oracle):
     gfin = (np.isfinite(got[0]).all(axis=0) & np.isfinite(got[1]).all(axis=0) & np.isfinite(got[2])
             & np.isfinite(got[3]))
     assert (~fin).sum() > 0, "the edge set must contain points where the reference itself is not finite"
-    assert (fin != gfin).sum() <= 1
+    assert (fin != gfin).sum() <= cases.flag_slack()          # none under strict parity (a glibc-FMA host)
     both = fin & gfin
     for k, nm in enumerate(("wi", "f", "pdf", "fresnel")):
         a = got[k][..., both]

@@ -360,8 +360,10 @@ RLS_DEV TileRange tile_range(int64_t n)
 // for a few instructions each; the s_load_dwordx4/x8 that fetch them go to the scalar cache and cost no vector issue.
 // The empty asm makes the pointer opaque, so the loads cannot be hoisted back out of the loop.  IO must be the kernel's
 // first (only) parameter.  Measured (profiles/r03_reload_args.txt, two libraries interleaved on one box): rlSkin 246 -> 42
-// spilled SGPRs, 4.44 -> 4.34 ms (-2.2 %); the rlSss probe 30 -> 0, 1.710 -> 1.686 ms (-1.4 %); the rlGgx kernels 52 -> 2
-// but +2.3 % (2.054 -> 2.102 ms: stores that used to leave early now wait for the reload), so ggx.hip does not use it.
+// spilled SGPRs, 4.44 -> 4.34 ms (-2.2 %); the rlSss probe 30 -> 0, 1.710 -> 1.686 ms (-1.4 %); the rlGgx kernels 52 -> 2:
+// +2.3 % when first measured at six waves per SIMD (2.054 -> 2.102 ms), but since those kernels run at eight waves (64
+// vector registers, where every spilled scalar costs a lane write) the reload is worth 7 %: 2.139 ms without it, 2.001 ms with
+// (profiles/r04_ggx_ab.txt, tools/ab.sh, two interleaved repetitions) -- ggx.hip uses it (RLS_GGX_RELOAD 1).
 #ifndef RLS_RELOAD_ARGS
 #define RLS_RELOAD_ARGS 1
 #endif

@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--log2-points", type=int, default=24)
     ap.add_argument("--seed", type=int, default=99)
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--corners", type=int, default=96, help="random corners of the 1-ulp input box per outlier, besides the 38 axis nudges")
     ap.add_argument("--out", default=str(ROOT / "gpurun_out" / "r04_fast_conditioning.json"))
     a = ap.parse_args()
     import torch
@@ -72,19 +73,25 @@ def main():
     og = ggx_oracle(O, c, nthreads=thr)
     ref = og.reflect_refract(x[0], x[1], x[2], x[3])
     ctx = R.Context(0)
-    res = {"workload": "ggx_reflect_refract (BASELINE config 2)", "points": n, "seed": a.seed, "tolerance": TOL,
+    res = {"workload": "ggx_reflect_refract (BASELINE config 2)", "points": n, "seed": a.seed, "tolerance": TOL, "axis_nudges": 38, "random_corners": a.corners,
            "libm_flavour": R.libm_flavour(), "host_libm_mismatches": R.host_libm_mismatches(), "modes": {}}
     for mode in ("exact", "fast"):
         ctx.set_math_mode(mode == "fast")
         s = ggx_sampler(ctx, c)
         got = [host(t) for t in s.reflectRefract(dev(x[0]), dev(x[1]), dev(x[2]), dev(x[3]))]
         err = [cases.rel_err(g, r) for g, r in zip(got, ref)]
+        for k, (g, r) in enumerate(zip(got, ref)):
+            # equal bits (an infinity the reference produces too) or NaN on both sides: no error, whatever inf - inf says
+            same = (g.view(np.uint32) == r.view(np.uint32)) | (np.isnan(g) & np.isnan(r))
+            err[k] = np.where(same.all(axis=0) if same.ndim == 2 else same, 0.0, err[k])
         out_any = np.zeros(n, bool)
         for e in err:
             out_any |= ~(e <= TOL)
         idx = np.nonzero(out_any)[0]
         rec = {"points_with_an_output_beyond_tolerance": int(idx.size), "share": float(idx.size / n), "outputs": {}}
         res["modes"][mode] = rec
+        if 0 < idx.size < 8:                                  # (the oracle's batch entry points want more than one point)
+            idx = np.union1d(idx, np.arange(8))
         if idx.size == 0:
             for k, nm in enumerate(NAMES):
                 rec["outputs"][nm] = cases.summarize(err[k])
@@ -106,6 +113,38 @@ def main():
                     upd = e > sens[k]
                     sens[k] = np.where(upd, e, sens[k])
                     which[k] = np.where(upd, ki, which[k])
+        # ... and under +-1 ulp of SEVERAL inputs at once: `--corners` random corners of the 1-ulp box around the point (each of
+        # the 19 scalars moved by -1, 0 or +1 ulp).  The oracle is a step function of its inputs -- a dot product of three
+        # rounded products need not change at all under one component's ulp -- so axis nudges alone under-sample how far
+        # the reference's own result moves inside that box
+        rng = np.random.default_rng(a.seed + (0 if mode == "exact" else 1))
+        sens_axis = [s_.copy() for s_ in sens]
+        for _ in range(a.corners):
+            c2, x2 = cs, xs
+            for key in keys:
+                step = rng.integers(-1, 2, idx.size)
+                name, j = key
+                def nudge(v):
+                    up = np.nextafter(v, np.float32(np.inf)).astype(np.float32)
+                    dn = np.nextafter(v, np.float32(-np.inf)).astype(np.float32)
+                    return np.where(step > 0, up, np.where(step < 0, dn, v)).astype(np.float32)
+                if name == "xi":
+                    if x2 is xs:
+                        x2 = xs.copy()
+                    one = np.nextafter(np.float32(1), np.float32(0))
+                    x2[j] = np.clip(nudge(xs[j]), 0, one).astype(np.float32)
+                elif j is None:
+                    c2 = dict(c2); c2[name] = nudge(cs[name])
+                else:
+                    c2 = dict(c2)
+                    arr = c2[name].copy() if c2[name] is not cs[name] else cs[name].copy()
+                    arr[j] = nudge(cs[name][j])
+                    c2[name] = arr
+            p = ggx_oracle(O, c2, nthreads=thr).reflect_refract(x2[0], x2[1], x2[2], x2[3])
+            for k in range(len(NAMES)):
+                e = cases.rel_err(p[k], base[k]).astype(np.float64)
+                e = np.where(np.isfinite(e), e, np.inf)
+                sens[k] = np.maximum(sens[k], e)
         for k, nm in enumerate(NAMES):
             e_all = err[k]
             st = cases.summarize(e_all)
@@ -117,6 +156,7 @@ def main():
             if m:
                 sk = sens[k][mine]
                 ratio = e[mine] / np.maximum(sk, 1e-30)
+                o["unexplained_by_axis_nudges_alone"] = int((sens_axis[k][mine] < TOL / 4).sum())
                 o["unexplained_sens_lt_quarter_tol"] = int((sk < TOL / 4).sum())
                 o["unexplained_share_of_outliers"] = float((sk < TOL / 4).mean())
                 o["unexplained_sens_lt_tol"] = int((sk < TOL).sum())

@@ -18,10 +18,6 @@ it runs under `python -m torch.distributed.run --nproc-per-node N ...` (one rank
 batch shards by index range with no collective on the data path (weak scaling: every GPU gets its
 own 2^26 points), the only communication being the barrier and the max-over-ranks of the time.
 
-Before the W warm-up steps the device is kept busy for `--wake-ms` (60) milliseconds with a workload-neutral vector-ALU kernel
-(`device_wake`): a VALU-bound kernel's first launches after idle run up to 40 % slower while the power state reacts, and the
-driver's command warms up with 5 steps only.  The timed region is untouched: exactly K steps of the workload after W of them.
-
 `roofline`: algorithmic bytes per launch / average kernel duration (HIP events on the launch
 stream) against the 8 TB/s HBM3E peak.  `cpu_baseline`: the CPU oracle (a port of the reference's
 scalar closure code) timed on this host's cores on a bounded sample of the same workload.
@@ -129,10 +125,6 @@ def parse_args():
                          "probing; 0 = no arena, every plane group its own allocation (for comparison).  Placement moves the "
                          "vector-issue-bound EXACT kernels by < 1 % (profiles/r02_placement.txt): two candidates are a check, "
                          "not a search; --math fast gains up to 15 % from 16")
-    ap.add_argument("--wake-ms", type=float, default=60.0,
-                    help="before the warm-up steps: this many ms of a workload-NEUTRAL vector-ALU kernel (powf over a scratch "
-                         "plane, rls_libm_eval) so that the device has left its idle power state when the W warm-up steps "
-                         "of the workload begin; 0 = off.  Never inside the timed region; recorded in the detail record")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--checksum", action="store_true",
                     help="after the timed region: the order-independent 64-bit checksum (rls_checksum) of every output plane "
@@ -928,31 +920,8 @@ def roofline_record(wl, n: int, kernel_ms: float, math: str) -> dict:
     return roof
 
 
-def device_wake(R, ctx, torch, ms: float) -> dict:
-    """Keep the vector ALUs busy for `ms` milliseconds with a kernel that is NOT the workload (powf over a scratch plane):
-    the first ~10 launches of a VALU-bound kernel after idle run up to 40 % slower while the power state reacts to the load
-    ("Warm-up"; bandwidth-bound work does not trigger it).  A renderer's GPU is never idle between flushes; a
-    freshly started bench process is.  Untimed, before the W warm-up steps of the workload."""
-    import ctypes as C
-    if ms <= 0:
-        return {"ms": 0.0, "launches": 0}
-    m = 1 << 24
-    x = R.gen_uniform(ctx, SEED, 0, m, 60, 0.05, 1.0)
-    y = R.gen_uniform(ctx, SEED, 0, m, 61, 0.5, 5.0)
-    out = torch.empty_like(x)
-    vp = lambda t: C.c_void_p(t.data_ptr())
-    t0 = time.perf_counter()
-    k = 0
-    while (time.perf_counter() - t0) * 1e3 < ms:
-        for _ in range(4):
-            R._capi.check(ctx.lib.rls_libm_eval(ctx.handle, 9, m, vp(x), vp(y), vp(out)))      # RLS_FN_POW
-            k += 1
-        ctx.synchronize()
-    return {"ms": round((time.perf_counter() - t0) * 1e3, 1), "launches": k, "kernel": "rls_libm_eval(RLS_FN_POW), 2^24 arguments"}
-
-
 def measure(R, ctx, ranks, torch, name: str, log2n: int, steps: int, warmup: int, math: str, candidates: int,
-            chunk_log2: int, other_mode: bool, depth: int = 3, wake_ms: float = 0.0):
+            chunk_log2: int, other_mode: bool, depth: int = 3):
     """Build one workload on this rank's shard, warm it up, time `steps` passes between barriers.
     -> (workload, n, elapsed seconds [max over ranks], kernel ms per step [max over ranks], this rank's kernel ms,
         kernel ms per step in the other arithmetic mode or None)"""
@@ -964,7 +933,6 @@ def measure(R, ctx, ranks, torch, name: str, log2n: int, steps: int, warmup: int
     assert count == n
     wl = make_workload(R, ctx, name, n, first=first, candidates=candidates, chunk_log2=chunk_log2, depth=depth)
     torch.cuda.synchronize()
-    wl.wake = device_wake(R, ctx, torch, wake_ms)
     for _ in range(warmup):
         wl.launch()
     torch.cuda.synchronize()
@@ -998,7 +966,8 @@ def measure(R, ctx, ranks, torch, name: str, log2n: int, steps: int, warmup: int
 
 
 # what tests/test_gpu_fast_mode.py holds RLS_MATH_FAST to (the measurement: profiles/r04_fast_conditioning.json)
-FAST_PARITY = "opt-in; see tests/test_gpu_fast_mode.py"
+FAST_PARITY = ("opt-in; SURVEY 8(c) protocol (3) on 2^24 points: 2.7 % of points have an output beyond 1e-5, 98.8-99.9 % of those "
+               "outliers where the oracle itself moves > 2.5e-6 in its inputs' 1-ulp box, <= 4.2e-5 of points beyond 8 x that")
 
 HEADLINE_MAX_BYTES = 1800          # the driver keeps a 2000-character tail of stdout: the last line must fit inside it
 
@@ -1100,7 +1069,7 @@ def main():
     wl, n, elapsed, kernel_ms, my_ms, other_ms = measure(R, ctx, ranks, torch, args.workload, args.log2_points, args.steps,
                                                          args.warmup, args.math, args.arena_candidates, args.chunk_log2,
                                                          not args.checksum,       # (the other mode would overwrite the outputs)
-                                                         args.pipeline_depth, wake_ms=args.wake_ms)
+                                                         args.pipeline_depth)
     per_rank_ms = ranks.gather_objects(round(my_ms, 5))
     shard_sums = None
     if args.checksum:
@@ -1135,12 +1104,12 @@ def main():
                        "points_per_gpu": n, "points_total": world * n,
                        "samples_per_point": wl.samples_per_point, "sharding": f"index-range x{world}, no collective",
                        "control_plane": (f"torch.distributed {backend}" if ranks.dist is not None else "single process"),
-                       "placement": wl.arena.info(), "device_wake": wl.wake,
+                       "placement": wl.arena.info(),
                        # the EXACT kernels are vector-ALU-bound: the first ~10 launches after idle run up to 40 % slower
                        # while the clocks ramp ("Warm-up"); fewer warm-up steps under-report
-                       "warmup_note": None if args.warmup >= 10 or args.wake_ms >= 30 else
-                       f"warmup {args.warmup} < 10 and no device wake: the clock ramp of the first launches is inside the "
-                       "timed region (under-reports by ~4 % at 5, ~15 % at 1)"},
+                       "warmup_note": None if args.warmup >= 10 else
+                       f"warmup {args.warmup} < 10: the clock ramp of the first launches is inside the timed region "
+                       "(under-reports by 1-4 % at 5, ~15 % at 1)"},
             "roofline": roof,
             # the ranks that took part, as gathered over the process group: a straggler or a doubled-up device shows here
             "ranks": {"ranks_seen": len(identities), "world_size": world, "backend": backend if ranks.dist is not None else None,

@@ -75,25 +75,50 @@ struct Frame { V3 U, V, N; };
 #define RLS_FAST 0
 #endif
 #if RLS_FAST
-#define R_DIV(a, b) ((a) * __builtin_amdgcn_rcpf(b))
-#define R_RCP(b) __builtin_amdgcn_rcpf(b)
-#define R_RCPW(b) __builtin_amdgcn_rcpf(b)
-#define R_TWO_OVER(den) (2.0f * __builtin_amdgcn_rcpf(den))
-#define R_SQRT(x) __builtin_amdgcn_sqrtf(x)
-#define R_EXP(x) __expf(x)
-#define R_EXP_IN_RANGE(x) __expf(x)
-#define R_LOG(x) __logf(x)
-#define R_POW(x, y) __powf(x, y)
-#define R_POW5(x) __powf(x, 5.0f)
-// the visible-normal slope equations amplify every rounding error: there,
-// and only there, FAST spends a Newton step on the reciprocal (~0.5 ulp) and the exact sqrt
+// RLS_FAST_REFINED (round 4 experiment, off): FAST's divisions and square roots at ~0.5 ulp everywhere -- v_rcp_f32 + one
+// Newton step with v_div_fixup_f32, v_sqrt_f32 + the +-1 ulp correction -- instead of the raw 1-ulp instructions.  Measured
+// (profiles/r04_fast_refined.txt): config 2 1.31 -> 1.43 ms (+9 %), rlSkin +8 %, the rlDisney glossy triple +11 % -- and
+// NOT ONE outlier fewer against the CPU closures (381 212 -> 379 013 of 2^24 `f` values beyond 1e-5, the same ~300
+// unexplained): FAST's distance from the reference is the reference's own rounding pattern (the angle round trip, the
+// cancellation in the slope equations' discriminant), not the last bit of FAST's primitives.
+#ifndef RLS_FAST_REFINED
+#define RLS_FAST_REFINED 0
+#endif
+// the visible-normal slope equations amplify every rounding error: there FAST always spent a Newton
+// step on the reciprocal (~0.5 ulp) and the exact sqrt
 RLS_DEV float refined_div(float a, float b)
 {
     float r = __builtin_amdgcn_rcpf(b);
     float q = a * r;
     float e = __builtin_fmaf(-b, q, a);
+#if RLS_FAST_REFINED
+    return __builtin_amdgcn_div_fixupf(__builtin_fmaf(e, r, q), b, a);      // x / 0, 0 / x, inf, NaN as IEEE division has them
+#else
     return __builtin_fmaf(e, r, q);
+#endif
 }
+#if RLS_FAST_REFINED
+#define R_DIV(a, b) refined_div((a), (b))
+#define R_RCP(b) refined_div(1.0f, (b))
+#define R_RCPW(b) refined_div(1.0f, (b))
+#define R_TWO_OVER(den) refined_div(2.0f, (den))
+#define R_SQRT(x) rlm::sqrt32<false>(x)           // (no rescaling branch for radicands below 2^-96: FAST does not need it)
+#define R_SQRT1P(y) rlm::sqrt32_1p(y)
+#define R_SQRT1M(t) rlm::sqrt32<false>(1.0f - (t))
+#else
+#define R_DIV(a, b) ((a) * __builtin_amdgcn_rcpf(b))
+#define R_RCP(b) __builtin_amdgcn_rcpf(b)
+#define R_RCPW(b) __builtin_amdgcn_rcpf(b)
+#define R_TWO_OVER(den) (2.0f * __builtin_amdgcn_rcpf(den))
+#define R_SQRT(x) __builtin_amdgcn_sqrtf(x)
+#define R_SQRT1P(y) __builtin_amdgcn_sqrtf(1.0f + (y))
+#define R_SQRT1M(t) __builtin_amdgcn_sqrtf(1.0f - (t))
+#endif
+#define R_EXP(x) __expf(x)
+#define R_EXP_IN_RANGE(x) __expf(x)
+#define R_LOG(x) __logf(x)
+#define R_POW(x, y) __powf(x, y)
+#define R_POW5(x) __powf(x, 5.0f)
 #define R_DIVH(a, b) refined_div(a, b)
 #define R_RCPH(b) refined_div(1.0f, b)
 #define R_RCPG(b) refined_div(1.0f, b)
@@ -101,8 +126,6 @@ RLS_DEV float refined_div(float a, float b)
 #define R_DIVC(x, C) ((x) * (1.0f / (C)))
 #define R_DIVCW(x, C) ((x) * (1.0f / (C)))
 #define R_SQRTH(x) rlm::sqrt32(x)
-#define R_SQRT1P(y) __builtin_amdgcn_sqrtf(1.0f + (y))
-#define R_SQRT1M(t) __builtin_amdgcn_sqrtf(1.0f - (t))
 #define R_SQRTH1P(y) rlm::sqrt32_1p(y)
 RLS_DEV void t_sincos(float x, float *s, float *c) { *s = __sinf(x); *c = __cosf(x); }
 RLS_DEV void t_sincos_any(float x, float *s, float *c) { t_sincos(x, s, c); }
@@ -258,6 +281,9 @@ struct VndfView {
 // so closures that share (wo, N, T) but differ in alpha (rlSkin's sheen and specular lobes) compute
 // it once.  EXACT: sphericalDirection(clamp(N.V), atan2f(V.V, U.V)) (src/rlGgx.cpp:68-72);
 // FAST: the dot products themselves.
+#ifndef RLS_FAST_VIEW_Z_AS_REFERENCE
+#define RLS_FAST_VIEW_Z_AS_REFERENCE 1
+#endif
 #if RLS_FAST
 RLS_DEV V3 vndf_local(V3 view, const Frame &fr)
 {
@@ -275,7 +301,15 @@ RLS_DEV VndfView vndf_view_from(V3 local, float ax, float ay)
     float sx = local.x * ax;
     float sy = local.y * ay;
     float h2 = sx * sx + sy * sy;
+#if RLS_FAST_VIEW_Z_AS_REFERENCE
+    // cos(theta') of the stretched view decides between the closed-form slopes and the uniform fallback at 1 - 1e-4
+    // (src/rlGgx.cpp:75-79), and the two give DIFFERENT (equally valid) samples: formed by AiV3Normalize's own sequence --
+    // exact sqrt, correctly rounded reciprocal, product -- it rounds as the reference's does whenever the local view agrees
+    // to a few ulp (z' moves by 1e-4 of what they move), so FAST takes the reference's side of the threshold
+    float z = cz * rlm::rcp32_w(rlm::sqrt32(h2 + cz * cz));
+#else
     float z = R_DIVH(cz, R_SQRTH(h2 + cz * cz));          // cos(theta') of the stretched view
+#endif
     float h = R_SQRTH(h2);
     bool flat = !(z < (1.0f - kEps));
     w.cosPhi = (flat || h2 == 0.0f) ? 1.0f : R_DIVH(sx, h);

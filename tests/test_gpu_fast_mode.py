@@ -1,7 +1,7 @@
 """GPU: RLS_MATH_FAST (hardware rcp/sqrt/sin/cos/exp arithmetic, algebraic view analysis) against the
 oracle.  FAST is opt-in; it is held to the north-star tolerance statistically, with the same
 conditioning-aware protocol SURVEY.md 8(c) prescribes: medians at round-off, a bounded fraction beyond
-1e-5, and every outlier on a point where the oracle itself moves under a 1-ulp nudge of xi."""
+1e-5, and the outliers on points where the oracle itself moves inside the 1-ulp box of its inputs (tests/conditioning.py)."""
 import numpy as np
 import pytest
 
@@ -46,38 +46,43 @@ def test_ggx_eval_pdf_decoupled(fast, oracle):
     assert ef["max"] <= 2e-4 and ep["max"] <= 2e-4
 
 
-def _sens(og, x, ref):
-    out = [np.zeros(N) for _ in ref]
-    one = np.nextafter(np.float32(1), np.float32(0))
-    for k, d in ((0, 1), (0, -1), (1, 1), (1, -1)):
-        y = [x[0].copy(), x[1].copy(), x[2], x[3]]
-        y[k] = np.clip(np.nextafter(y[k], np.float32(2.0 if d > 0 else -1.0)), 0, one).astype(np.float32)
-        pert = og.reflect_refract(*y)
-        for j in range(len(ref)):
-            out[j] = np.maximum(out[j], cases.rel_err(pert[j], ref[j]))
-    return out
-
-
 def test_ggx_chain_conditioning(fast, oracle):
+    """SURVEY.md 8(c) protocol (3) on config 2's kernel: a FAST output may be beyond 1e-5 only where the oracle's own output
+    moves inside the 1-ulp box of its 19 inputs (tests/conditioning.py: 38 axis nudges + 64 random corners), and then by no
+    more than 8 x that movement -- the factor the 2^24-point measurement supports (profiles/r04_fast_conditioning.json:
+    beyond 8 x on 1.2e-5 ... 4.2e-5 of the points per output, beyond 1024 x on none since cos(theta') of the stretched view is
+    formed by the reference's own sequence; 98.8 ... 99.9 % of the outliers have the oracle moving by > 1e-5 / 4 itself)."""
+    import conditioning as Q
     c = cases.ggx_mixed(cases.SEED_PARITY, N)
     x = cases.xi(cases.SEED_PARITY, N, 4)
-    og = ggx_oracle(oracle, c)
-    ref = og.reflect_refract(x[0], x[1], x[2], x[3])
+    mk = lambda cc: ggx_oracle(oracle, cc)
+    ref = mk(c).reflect_refract(x[0], x[1], x[2], x[3])
     s = ggx_sampler(fast, c)
     got = [host(t) for t in s.reflectRefract(dev(x[0]), dev(x[1]), dev(x[2]), dev(x[3]))]
-    sens = _sens(og, x, ref)
-    for k, nm in enumerate(("wi", "f", "pdf", "fresnel", "wt", "weight")):
-        e = cases.rel_err(got[k], ref[k])
-        st = cases.summarize(e)
+    err = Q.chain_errors(got, ref)
+    out = np.zeros(N, bool)
+    for e in err:
+        out |= ~(e <= TOL)
+    idx = np.union1d(np.nonzero(out)[0], np.arange(8))
+    assert idx.size <= 0.05 * N                                   # ~2.7 % of the points have some output beyond 1e-5
+    cs, xs = Q.subset(c, x, idx)
+    sens, _ = Q.ggx_chain_sensitivity(mk, cs, xs, [np.ascontiguousarray(r[..., idx]) for r in ref], corners=64, seed=1)
+    for k, nm in enumerate(Q.NAMES):
+        st = cases.summarize(err[k])
         print("fast ggx chain", nm, st)
         assert st["nonfinite"] == 0
         assert st["median"] <= 2e-6, (nm, st)
         assert st["frac_gt_1e5"] <= 5e-2 and st["p99"] <= 1e-4 and st["p999"] <= 1e-3, (nm, st)
-        if k < 4:   # sensitivity was probed on the reflect sample's xi: large errors only where
-            # the oracle itself is ill conditioned
-            bad = e > np.maximum(1e-4, 1024.0 * sens[k])
-            assert bad.mean() <= 2e-3, (nm, float(bad.mean()), st)
-    # EXACT and FAST agree with each other to the same statistics, and EXACT stays the default
+        e = err[k][idx]
+        beyond8 = int((e > np.maximum(TOL, 8.0 * sens[k])).sum())
+        beyond1024 = int((e > np.maximum(TOL, 1024.0 * sens[k])).sum())
+        unexplained = int((~(e <= TOL) & (sens[k] < TOL / 4)).sum())
+        print("   outliers", int((~(e <= TOL)).sum()), "beyond 8 x sens", beyond8, "beyond 1024 x", beyond1024, "unexplained", unexplained)
+        # 2^24 points: <= 4.2e-5 of the points beyond 8 x; here 2^16 points, so a handful at most
+        assert beyond8 <= 2e-4 * N, (nm, beyond8)
+        assert beyond1024 == 0, (nm, beyond1024)
+        assert unexplained <= 2e-4 * N, (nm, unexplained)
+    # EXACT stays the default
     ex = R.Context(0)
     assert ex.lib.rls_context_get_math_mode(ex.handle) == 0
     ex.close()

@@ -3,12 +3,12 @@
 src/rlGgx.cpp:63-99): "outliers must coincide with points whose oracle output moves > 1e-5 under a 1-ulp input perturbation".
 
 For every point where a FAST output is more than 1e-5 (relative) from the CPU oracle's, the oracle's OWN movement of that
-output under +-1 ulp of each of the 19 input scalars (wo3 N3 T3 KsColor3 roughness ior anisotropic xi4 -- 38 oracle passes
-over the outliers) is measured: `sens`.  Reported per output:
-  * how many outliers there are and the share of them with sens < 1e-5 / 4 ("unexplained": FAST is off by more than the
-    tolerance where the reference itself does not move by a quarter of it);
-  * the factor k = err / sens over the outliers (quantiles), and the share of ALL points with err > max(1e-5, k * sens) for
-    k = 1, 2, 4, 8, 16, 64, 1024 -- the gate tests/test_gpu_fast_mode.py should hold FAST to.
+output inside the 1-ulp box of its 19 input scalars is measured (tests/conditioning.py: 38 axis nudges + `--corners` random
+corners; points still unexplained get `--more-corners` further corners): `sens`.  Reported per output:
+  * outliers, and how many of them have sens < 1e-5 / 4 ("unexplained": FAST is off by more than the tolerance where the
+    reference itself does not move by a quarter of it anywhere in the sampled box);
+  * the factor err / sens over the outliers, and how many points have err > max(1e-5, k * sens) for k = 1 ... 1024 -- the gate
+    tests/test_gpu_fast_mode.py holds FAST to.
 usage: python tools/fast_conditioning.py [--log2-points 24] [--seed 99] [--out gpurun_out/r04_fast_conditioning.json]"""
 import argparse
 import json
@@ -21,35 +21,7 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
-
-NAMES = ("wi", "f", "pdf", "fresnel", "wt", "weight")
 TOL = 1e-5
-
-
-def inputs_of(c, x):
-    """the 19 input scalars as a flat list of (name, get, set) on copies"""
-    keys = [("wo", j) for j in range(3)] + [("N", j) for j in range(3)] + [("T", j) for j in range(3)] + \
-           [("KsColor", j) for j in range(3)] + [("roughness", None), ("ior", None), ("anisotropic", None)] + \
-           [("xi", j) for j in range(4)]
-    return keys
-
-
-def perturbed(c, x, key, direction):
-    name, j = key
-    c2 = {k: v for k, v in c.items()}
-    x2 = x
-    toward = np.float32(np.inf if direction > 0 else -np.inf)
-    if name == "xi":
-        x2 = x.copy()
-        one = np.nextafter(np.float32(1), np.float32(0))
-        x2[j] = np.clip(np.nextafter(x[j], toward), 0, one).astype(np.float32)
-    elif j is None:
-        c2[name] = np.nextafter(c[name], toward).astype(np.float32)
-    else:
-        a = c[name].copy()
-        a[j] = np.nextafter(a[j], toward).astype(np.float32)
-        c2[name] = a
-    return c2, x2
 
 
 def main():
@@ -58,122 +30,89 @@ def main():
     ap.add_argument("--seed", type=int, default=99)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--corners", type=int, default=96, help="random corners of the 1-ulp input box per outlier, besides the 38 axis nudges")
+    ap.add_argument("--more-corners", type=int, default=4000, help="further corners for the points the first pass leaves unexplained")
     ap.add_argument("--out", default=str(ROOT / "gpurun_out" / "r04_fast_conditioning.json"))
     a = ap.parse_args()
-    import torch
     import cases
+    import conditioning as Q
     import oracle_lib as O
     import rlshaders_amd as R
     from gpu_util import dev, ggx_oracle, ggx_sampler, host
     n = 1 << a.log2_points
     thr = a.threads or O.hardware_threads()
+    mk = lambda cc: ggx_oracle(O, cc, nthreads=thr)
     t0 = time.time()
     c = cases.ggx_mixed(a.seed, n)
     x = cases.xi(a.seed, n, 4)
-    og = ggx_oracle(O, c, nthreads=thr)
-    ref = og.reflect_refract(x[0], x[1], x[2], x[3])
+    ref = mk(c).reflect_refract(x[0], x[1], x[2], x[3])
     ctx = R.Context(0)
-    res = {"workload": "ggx_reflect_refract (BASELINE config 2)", "points": n, "seed": a.seed, "tolerance": TOL, "axis_nudges": 38, "random_corners": a.corners,
+    res = {"workload": "ggx_reflect_refract (BASELINE config 2)", "points": n, "seed": a.seed, "tolerance": TOL,
+           "axis_nudges": 2 * len(Q.KEYS), "random_corners": a.corners, "more_corners_for_the_unexplained": a.more_corners,
            "libm_flavour": R.libm_flavour(), "host_libm_mismatches": R.host_libm_mismatches(), "modes": {}}
     for mode in ("exact", "fast"):
         ctx.set_math_mode(mode == "fast")
-        s = ggx_sampler(ctx, c)
-        got = [host(t) for t in s.reflectRefract(dev(x[0]), dev(x[1]), dev(x[2]), dev(x[3]))]
-        err = [cases.rel_err(g, r) for g, r in zip(got, ref)]
-        for k, (g, r) in enumerate(zip(got, ref)):
-            # equal bits (an infinity the reference produces too) or NaN on both sides: no error, whatever inf - inf says
-            same = (g.view(np.uint32) == r.view(np.uint32)) | (np.isnan(g) & np.isnan(r))
-            err[k] = np.where(same.all(axis=0) if same.ndim == 2 else same, 0.0, err[k])
+        got = [host(t) for t in ggx_sampler(ctx, c).reflectRefract(dev(x[0]), dev(x[1]), dev(x[2]), dev(x[3]))]
+        err = Q.chain_errors(got, ref)
         out_any = np.zeros(n, bool)
         for e in err:
             out_any |= ~(e <= TOL)
         idx = np.nonzero(out_any)[0]
         rec = {"points_with_an_output_beyond_tolerance": int(idx.size), "share": float(idx.size / n), "outputs": {}}
         res["modes"][mode] = rec
-        if 0 < idx.size < 8:                                  # (the oracle's batch entry points want more than one point)
-            idx = np.union1d(idx, np.arange(8))
         if idx.size == 0:
-            for k, nm in enumerate(NAMES):
-                rec["outputs"][nm] = cases.summarize(err[k])
+            for k, nm in enumerate(Q.NAMES):
+                rec["outputs"][nm] = {"stats": cases.summarize(err[k]), "outliers": 0}
             continue
-        # the oracle's own movement under +-1 ulp of every input scalar, on the outliers only
-        cs = {k: (np.ascontiguousarray(v[..., idx]) if isinstance(v, np.ndarray) else v) for k, v in c.items()}
-        xs = np.ascontiguousarray(x[:, idx])
+        if idx.size < 8:                                  # (the oracle's batch entry points want more than one point)
+            idx = np.union1d(idx, np.arange(8))
+        cs, xs = Q.subset(c, x, idx)
         base = [np.ascontiguousarray(r[..., idx]) for r in ref]
-        sens = [np.zeros(idx.size, np.float64) for _ in NAMES]
-        which = [np.full(idx.size, -1, np.int32) for _ in NAMES]
-        keys = inputs_of(c, x)
-        for ki, key in enumerate(keys):
-            for d in (1, -1):
-                c2, x2 = perturbed(cs, xs, key, d)
-                p = ggx_oracle(O, c2, nthreads=thr).reflect_refract(x2[0], x2[1], x2[2], x2[3])
-                for k in range(len(NAMES)):
-                    e = cases.rel_err(p[k], base[k]).astype(np.float64)
-                    e = np.where(np.isfinite(e), e, np.inf)
-                    upd = e > sens[k]
-                    sens[k] = np.where(upd, e, sens[k])
-                    which[k] = np.where(upd, ki, which[k])
-        # ... and under +-1 ulp of SEVERAL inputs at once: `--corners` random corners of the 1-ulp box around the point (each of
-        # the 19 scalars moved by -1, 0 or +1 ulp).  The oracle is a step function of its inputs -- a dot product of three
-        # rounded products need not change at all under one component's ulp -- so axis nudges alone under-sample how far
-        # the reference's own result moves inside that box
-        rng = np.random.default_rng(a.seed + (0 if mode == "exact" else 1))
-        sens_axis = [s_.copy() for s_ in sens]
-        for _ in range(a.corners):
-            c2, x2 = cs, xs
-            for key in keys:
-                step = rng.integers(-1, 2, idx.size)
-                name, j = key
-                def nudge(v):
-                    up = np.nextafter(v, np.float32(np.inf)).astype(np.float32)
-                    dn = np.nextafter(v, np.float32(-np.inf)).astype(np.float32)
-                    return np.where(step > 0, up, np.where(step < 0, dn, v)).astype(np.float32)
-                if name == "xi":
-                    if x2 is xs:
-                        x2 = xs.copy()
-                    one = np.nextafter(np.float32(1), np.float32(0))
-                    x2[j] = np.clip(nudge(xs[j]), 0, one).astype(np.float32)
-                elif j is None:
-                    c2 = dict(c2); c2[name] = nudge(cs[name])
-                else:
-                    c2 = dict(c2)
-                    arr = c2[name].copy() if c2[name] is not cs[name] else cs[name].copy()
-                    arr[j] = nudge(cs[name][j])
-                    c2[name] = arr
-            p = ggx_oracle(O, c2, nthreads=thr).reflect_refract(x2[0], x2[1], x2[2], x2[3])
-            for k in range(len(NAMES)):
-                e = cases.rel_err(p[k], base[k]).astype(np.float64)
-                e = np.where(np.isfinite(e), e, np.inf)
-                sens[k] = np.maximum(sens[k], e)
-        for k, nm in enumerate(NAMES):
-            e_all = err[k]
-            st = cases.summarize(e_all)
-            e = e_all[idx].astype(np.float64)
-            e = np.where(np.isfinite(e), e, np.inf)
+        sens, which = Q.ggx_chain_sensitivity(mk, cs, xs, base, corners=a.corners, seed=a.seed)
+        sens1 = [s.copy() for s in sens]
+        # second pass: the points some output of which is an outlier the first pass does not explain
+        un = np.zeros(idx.size, bool)
+        for k in range(len(Q.NAMES)):
+            un |= ~(err[k][idx] <= TOL) & (sens[k] < TOL / 4)
+        j = np.nonzero(un)[0]
+        rec["unexplained_points_after_first_pass"] = int(j.size)
+        if j.size and a.more_corners:
+            jj = j if j.size >= 8 else np.union1d(j, np.arange(min(8, idx.size)))
+            c2, x2 = Q.subset(cs, xs, jj)
+            b2 = [np.ascontiguousarray(b[..., jj]) for b in base]
+            s2, _ = Q.ggx_chain_sensitivity(mk, c2, x2, b2, corners=a.more_corners, seed=a.seed + 1, axis=False,
+                                            sens=[s[jj].copy() for s in sens], which=[w[jj].copy() for w in which])
+            for k in range(len(Q.NAMES)):
+                sens[k][jj] = s2[k]
+        for k, nm in enumerate(Q.NAMES):
+            e = err[k][idx].astype(np.float64)
             mine = ~(e <= TOL)                              # outliers of THIS output
             m = int(mine.sum())
-            o = {"stats": st, "outliers": m, "share_of_points": m / n}
+            o = {"stats": cases.summarize(err[k]), "outliers": m, "share_of_points": m / n}
             if m:
                 sk = sens[k][mine]
                 ratio = e[mine] / np.maximum(sk, 1e-30)
-                o["unexplained_by_axis_nudges_alone"] = int((sens_axis[k][mine] < TOL / 4).sum())
+                fin = np.isfinite(ratio)
+                o["unexplained_after_first_pass"] = int((sens1[k][mine] < TOL / 4).sum())
                 o["unexplained_sens_lt_quarter_tol"] = int((sk < TOL / 4).sum())
-                o["unexplained_share_of_outliers"] = float((sk < TOL / 4).mean())
-                o["unexplained_sens_lt_tol"] = int((sk < TOL).sum())
-                o["err_over_sens_quantiles"] = {q: float(np.quantile(ratio, float(q))) for q in ("0.5", "0.9", "0.99", "0.999", "1.0")}
+                o["explained_share_of_outliers"] = float(1.0 - (sk < TOL / 4).mean())
+                o["unexplained_share_of_points"] = float((sk < TOL / 4).sum() / n)
+                o["err_over_sens_quantiles"] = {q: float(np.quantile(ratio[fin], float(q))) for q in ("0.5", "0.9", "0.99", "0.999")} if fin.any() else {}
                 o["beyond_k_times_sens"] = {str(kf): int((e[mine] > np.maximum(TOL, kf * sk)).sum()) for kf in (1, 2, 4, 8, 16, 64, 1024)}
                 o["beyond_k_times_sens_share_of_points"] = {kk: v / n for kk, v in o["beyond_k_times_sens"].items()}
                 wk = which[k][mine]
-                names = [f"{a_}{'' if j is None else j}" for a_, j in keys]
-                top = np.bincount(wk[wk >= 0], minlength=len(keys))
-                o["most_sensitive_input_histogram"] = {names[i]: int(top[i]) for i in np.argsort(-top)[:6] if top[i]}
-                worst = np.argsort(-(e[mine] / np.maximum(TOL, 8 * sk)))[:5]
-                o["worst_counter_examples"] = [{"point": int(idx[mine][w]), "err": float(e[mine][w]), "sens": float(sk[w]),
-                                                "roughness": float(c["roughness"][idx[mine][w]]), "ior": float(c["ior"][idx[mine][w]]),
-                                                "anisotropic": float(c["anisotropic"][idx[mine][w]])} for w in worst]
+                top = np.bincount(wk[wk >= 0], minlength=len(Q.KEYS))
+                o["most_sensitive_axis_histogram"] = {Q.KEY_NAMES[i]: int(top[i]) for i in np.argsort(-top)[:6] if top[i]}
+                worst = np.argsort(-np.where(np.isfinite(e[mine]), e[mine], 1e300) / np.maximum(TOL, 8 * sk))[:8]
+                pts = idx[mine]
+                o["worst_counter_examples"] = [
+                    {"point": int(pts[w]), "err": float(e[mine][w]), "sens": float(sk[w]), "roughness": float(c["roughness"][pts[w]]),
+                     "ior": float(c["ior"][pts[w]]), "anisotropic": float(c["anisotropic"][pts[w]]),
+                     "cos_view": float(np.sum(c["wo"][:, pts[w]] * c["N"][:, pts[w]])), "xi": [float(v) for v in x[:, pts[w]]]}
+                    for w in worst]
             rec["outputs"][nm] = o
-        print(mode, json.dumps({nm: {kk: vv for kk, vv in o.items() if kk not in ("stats", "worst_counter_examples")}
-                                for nm, o in rec["outputs"].items()}, indent=1), flush=True)
+        for nm, o in rec["outputs"].items():
+            print(mode, nm, json.dumps({kk: vv for kk, vv in o.items() if kk not in ("stats", "worst_counter_examples",
+                                                                                      "beyond_k_times_sens_share_of_points")}), flush=True)
     res["seconds"] = round(time.time() - t0, 1)
     Path(a.out).parent.mkdir(parents=True, exist_ok=True)
     Path(a.out).write_text(json.dumps(res, indent=1) + "\n")

@@ -42,10 +42,14 @@ def main():
     for name in ("bench.json", "bench_trace.json"):
         p = os.path.join(src, name)
         lines = [l for l in open(p).read().splitlines() if l.startswith("{")] if os.path.exists(p) else []
-        if lines and name == "bench.json":
-            line = json.loads(lines[-1])
-        if lines:
-            json.dump(json.loads(lines[-1]), open(os.path.join(dst, f"{tag}_{workload}_{name}"), "w"), indent=1)
+        # bench.py prints the long records first and the compact headline last: keep the headline's FULL record
+        recs = [json.loads(l) for l in lines]
+        full = [r for r in recs if r.get("record") == "headline_detail"]
+        pick = full[-1] if full else (recs[-1] if recs else None)
+        if pick is not None and name == "bench.json":
+            line = pick
+        if pick is not None:
+            json.dump(pick, open(os.path.join(dst, f"{tag}_{workload}_{name}"), "w"), indent=1)
     if line is None:
         raise SystemExit(f"no bench line under {src}")
     ksub = line["roofline"]["kernel"]

@@ -966,8 +966,7 @@ def measure(R, ctx, ranks, torch, name: str, log2n: int, steps: int, warmup: int
 
 
 # what tests/test_gpu_fast_mode.py holds RLS_MATH_FAST to (the measurement: profiles/r04_fast_conditioning.json)
-FAST_PARITY = ("opt-in; SURVEY 8(c) protocol (3) on 2^24 points: 2.7 % of points have an output beyond 1e-5, 98.8-99.9 % of those "
-               "outliers where the oracle itself moves > 2.5e-6 in its inputs' 1-ulp box, <= 4.2e-5 of points beyond 8 x that")
+FAST_PARITY = "opt-in, uncredited; protocol (3): 98.8-99.9 % of outliers where the oracle moves in its 1-ulp box, 4e-5 of points > 8x"
 
 HEADLINE_MAX_BYTES = 1800          # the driver keeps a 2000-character tail of stdout: the last line must fit inside it
 

@@ -24,7 +24,7 @@ scalar closure code) timed on this host's cores on a bounded sample of the same 
 
 `workloads` block (default run: `configs`): BASELINE configurations 3 (rlDisney 64 spp, reduced), 4 (the rlSss probe, 2^25
 points per GPU) and 5 (rlSkin, 2^27 per GPU), each measured in this same process with >= 10 warm-up launches of its own, its
-own `roofline` and -- on one GPU -- a short `cpu_baseline`; the default run finishes in about a minute.  `--workloads all`
+own `roofline` and -- on one GPU -- a short `cpu_baseline`; the default run finishes in about half a minute.  `--workloads all`
 adds the verbs an Arnold-side stub calls one by one and the host-resident pipelines (minutes; the builder's profiling
 sessions use it).  `--config {2,3,4,5}` makes one configuration the headline (workload + points per GPU of that BASELINE
 configuration) and switches the block off.

@@ -16,7 +16,8 @@ workload of the `workloads` block -- is printed as its own JSON line BEFORE the 
 the same records are written to `gpurun_out/bench_workloads.json` (`--records-file`).  For N > 1
 it runs under `python -m torch.distributed.run --nproc-per-node N ...` (one rank per GPU); the
 batch shards by index range with no collective on the data path (weak scaling: every GPU gets its
-own 2^26 points), the only communication being the barrier and the max-over-ranks of the time.
+own 2^26 points), the only communication being a barrier + device synchronise either side of the K timed steps and the
+max over ranks of each rank's own elapsed time (taken after its synchronise, before the closing barrier).
 
 `roofline`: algorithmic bytes per launch / average kernel duration (HIP events on the launch
 stream) against the 8 TB/s HBM3E peak.  `cpu_baseline`: the CPU oracle (a port of the reference's
@@ -944,8 +945,8 @@ def measure(R, ctx, ranks, torch, name: str, log2n: int, steps: int, warmup: int
         wl.launch()
     ctx.timer_stop()
     torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0     # THIS rank's K steps (its device is idle again); the slowest rank's is the job's
     ranks.barrier()
-    elapsed = time.perf_counter() - t0
     my_kernel_ms = ctx.timer_elapsed_ms() / max(steps, 1)
     if wl.bound == "pcie":                 # the pipeline runs on its own streams and returns when the batch is back in host
         my_kernel_ms = elapsed / max(steps, 1) * 1e3      # memory: the pass is timed on the host clock

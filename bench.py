@@ -569,8 +569,9 @@ def make_workload(R, ctx, name: str, n: int, first: int, candidates: int = 1, ch
                           lambda: d.integrateChunked(8, SEED, cp, out=out, chunk=chunk, first_index=first),
                           "disney_integrate_kernel<1, {m}>",
                           f"rlDisney both lobes x 64 spp, streamed mode in chunks of {cp} points (SURVEY 8d config 3, "
-                          "mode S: 88 B in + 32 B sums + 128 x 28 B samples per point; runs at the speed of its arithmetic)",
-                          launches_per_step=(n + cp - 1) // cp, config=3)
+                          "mode S: 88 B in + 32 B sums + 128 x 28 B samples per point; VALU-bound: it runs at the speed of "
+                          "mode R's arithmetic, 0.35 of the HBM peak)",
+                          bound="valu", launches_per_step=(n + cp - 1) // cp, config=3)
     elif name in ("sss_probe", "sss_probe_uniform"):
         uniform = name.endswith("uniform")
         # _uniform: scatter distance and albedo one value for the batch, as a node without linked textures has them

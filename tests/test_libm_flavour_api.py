@@ -40,3 +40,15 @@ def test_c_program_can_ask_without_a_device(tmp_path):
                     "-lrlshaders_amd", f"-Wl,-rpath,{lib}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lm"], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
     assert out[0] == R.libm_flavour() and int(out[1]) == R.host_libm_mismatches()
+    # the other way round: glibc told (GLIBC_TUNABLES) to behave as on a CPU without AVX2 / FMA resolves sinf / cosf / expf /
+    # powf to its SSE2 build -- the check must then report exactly the discriminating arguments, and nothing else
+    if cases.host_libm_flavour()["flavour"] == "fma":
+        import os
+        env = dict(os.environ, GLIBC_TUNABLES="glibc.cpu.hwcaps=-AVX2,-FMA")
+        out = subprocess.run([str(exe)], capture_output=True, text=True, check=True, env=env).stdout.split()
+        golden = cases.host_libm_flavour()["discriminating"]
+        assert int(out[1]) in (0, golden), out          # 0: a glibc that ignores the tunable (< 2.33 spelling); else all of them
+        if int(out[1]) == 0:
+            import pytest
+            pytest.skip("this glibc does not honour GLIBC_TUNABLES=glibc.cpu.hwcaps=-AVX2,-FMA")
+        assert int(out[1]) == golden == 42

@@ -140,7 +140,9 @@ int         rls_version(void);                 /* major*1000 + minor */
  * followed build's result, and this library's routines compiled for the host must agree with the host's on 4096 arguments
  * per function (a libm that is neither build).  *mismatches = the number of disagreements.  "Bit for bit like the CPU
  * closures" holds on THIS host only when it is 0; otherwise results stay within the 1e-5 contract and differ in the last
- * bit on a ~1e-8 ... 1e-6 share of arguments (glibc's other build) or more (another C library).  Needs no device. */
+ * bit on a ~1e-8 ... 1e-6 share of arguments (glibc's other build) or more (another C library).  Needs no device.
+ * (The library builds in either flavour -- `python -m rlshaders_amd.build --variant sse2 -DRLM_GLIBC_FMA=0` -- and the SSE2
+ * flavour is checked against glibc's SSE2 build the same way: 0 differences on all 2^32 arguments per function.) */
 const char *rls_libm_flavour(void);
 rls_status  rls_host_libm_matches(int *mismatches);
 /* Device properties the host side sizes shards with. */

@@ -50,8 +50,8 @@ def test_ggx_chain_conditioning(fast, oracle):
     """SURVEY.md 8(c) protocol (3) on config 2's kernel: a FAST output may be beyond 1e-5 only where the oracle's own output
     moves inside the 1-ulp box of its 19 inputs (tests/conditioning.py: 38 axis nudges + 64 random corners), and then by no
     more than 8 x that movement -- the factor the 2^24-point measurement supports (profiles/r04_fast_conditioning.json:
-    beyond 8 x on 1.2e-5 ... 4.2e-5 of the points per output, beyond 1024 x on none since cos(theta') of the stretched view is
-    formed by the reference's own sequence; 98.8 ... 99.9 % of the outliers have the oracle moving by > 1e-5 / 4 itself)."""
+    beyond 8 x on 1.2e-5 ... 4.2e-5 of the points per output, beyond 1024 x on 0 ... 4 points of 2^24 over three seeds -- no
+    branch flips since cos(theta') of the stretched view is formed by the reference's own sequence; 98.8 ... 99.9 % of the outliers have the oracle moving by > 1e-5 / 4 itself)."""
     import conditioning as Q
     c = cases.ggx_mixed(cases.SEED_PARITY, N)
     x = cases.xi(cases.SEED_PARITY, N, 4)

@@ -1005,7 +1005,8 @@ def headline(detail: dict) -> dict:
     for drop in (("other_math_mode", "parity"), ("cpu_baseline", "sample"), ("config", "workload")):
         if len(text) < HEADLINE_MAX_BYTES:
             break
-        line[drop[0]][drop[1]] = _short(str(line[drop[0]][drop[1]]), 24)      # never reached with today's strings: a guard
+        if drop[0] in line and drop[1] in line[drop[0]]:
+            line[drop[0]][drop[1]] = _short(str(line[drop[0]][drop[1]]), 24)      # never reached with today's strings: a guard
         text = json.dumps(line)
     assert len(text) < HEADLINE_MAX_BYTES, len(text)
     return line

@@ -60,6 +60,19 @@ def test_headline_fits_a_2000_character_tail():
         assert "devices" not in line["ranks"] and line["ranks"]["ranks_seen"] == world
 
 
+def test_headline_without_the_optional_objects():
+    """N > 1 (no cpu_baseline), --checksum (no other_math_mode), a VALU-bound headline without a committed instruction mix"""
+    b = _bench()
+    d = _worst_case_detail(8)
+    for k in ("cpu_baseline", "other_math_mode"):
+        d.pop(k)
+    d["roofline"].update(bound="valu", achieved=None, frac=None, traffic=None, issue_slot_frac=None)
+    text = json.dumps(b.headline(d))
+    line = json.loads(text)
+    assert len(text) < 1800 and "cpu_baseline" not in line and line["validation"]["checksum"] == "f" * 16
+    assert line["roofline"]["bound"] == "valu" and line["roofline"]["frac"] is None
+
+
 def test_emit_prints_the_headline_last(tmp_path, capsys):
     b = _bench()
     detail = _worst_case_detail(8)

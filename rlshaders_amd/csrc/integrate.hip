@@ -1147,6 +1147,9 @@ __device__ __forceinline__ Disney disney_fetch(const Disney &d, int src)
     h.vn = lane_fetch(d.vn, src); h.FV = lane_fetch(d.FV, src); h.gsV = lane_fetch(d.gsV, src); h.grV = lane_fetch(d.grV, src);
     h.ccA2m1 = lane_fetch(d.ccA2m1, src); h.ccLogA2 = lane_fetch(d.ccLogA2, src);
     h.ccw = lane_fetch(d.ccw, src); h.vnc = lane_fetch(d.vnc, src); h.om = lane_fetch(d.om, src);
+#if !RLS_FAST
+    h.yax = 0.0f; h.yay = 0.0f;      // the reciprocals of alpha_x, alpha_y stay at home: a fetched closure divides the IEEE way
+#endif
     return h;
 }
 // the light-sampling strategy of rlDisney's light loop for the queued light samples: both lobes (evalDiffuseLightSample,

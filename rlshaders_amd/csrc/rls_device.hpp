@@ -750,6 +750,9 @@ struct Disney {
     float ccw, vnc;               // evalSpecularPdf: clearcoat / (clearcoat + 1), max(1e-4, vn), src/rlDisney.cpp:529,533
     float gtr2Weight;             // sampleSpecularDirection: 1 / (clearcoat + 1), src/rlDisney.cpp:371
     float om;                     // 1 - metallic
+#if !RLS_FAST
+    float yax, yay;               // RN(1 / ax), RN(1 / ay) for D_GTR2Aniso's two quotients (RLS_DISNEY_D_RECIP); 0: outside div32_y's window
+#endif
 };
 
 // The constructor (src/rlDisney.cpp:155-192) in two halves: what the ten scalars alone decide, and what needs base_color.
@@ -775,6 +778,9 @@ RLS_DEV DisneyTints disney_make_scalars(Disney &d, const float (&s)[10])
     d.ax = maxf(1e-2f, R_DIV(sqr(d.roughness), aspect));
     d.ay = maxf(1e-2f, sqr(d.roughness) * aspect);
     d.specRough = sqr(d.roughness);
+#if !RLS_FAST
+    d.yax = 0.0f; d.yay = 0.0f;      // "no reciprocals": D_GTR2Aniso divides the IEEE way until disney_prepare_material() has run
+#endif
     return t;
 }
 RLS_DEV void disney_make_base(Disney &d, const DisneyTints &t, float bR, float bG, float bB)
@@ -821,11 +827,33 @@ RLS_DEV float D_GTR1(const Disney &d, float mn2)
     return R_DIV((a2 - 1.0f) * kInvPi, den);
 }
 // src/rlDisney.cpp:561-568
+// RLS_DISNEY_D_RECIP (round 4): the two quotients by alpha_x, alpha_y -- per-point denominators that every sample of the n^2-spp
+// loops divides by -- through their correctly rounded reciprocals (rlm::div32_y: five instructions each instead of the IEEE
+// sequence's fifteen fma-equivalents).  div32_y wants 2^-14 <= alpha <= 2^14 (d.yax != 0 says so) and a numerator that is
+// zero or in [2^-75, 2^40]: h.u, h.v of a unit half vector are; below 2^-75 the quotient's square is below 2^-122 beside
+// the other two terms' >= 1e-2, so its last bit cannot reach the sum; above 2^40, infinite or NaN (hostile inputs) the whole
+// wavefront takes the IEEE form -- one test for both quotients.
+#ifndef RLS_DISNEY_D_RECIP
+#define RLS_DISNEY_D_RECIP 1
+#endif
 RLS_DEV float D_GTR2Aniso(const Disney &d, V3 m, float mn2)
 {
     float hu = dot(m, d.fr.U);
     float hv = dot(m, d.fr.V);
+#if !RLS_FAST
+    float qu, qv;
+    const bool plain = !(absf(hu) <= 0x1p40f && absf(hv) <= 0x1p40f) || d.yax == 0.0f;
+    if (__builtin_expect(!RLS_DISNEY_D_RECIP || __builtin_amdgcn_ballot_w64(plain) != 0ull, 0)) {
+        qu = R_DIV(hu, d.ax);
+        qv = R_DIV(hv, d.ay);
+    } else {
+        qu = rlm::div32_y(hu, d.ax, d.yax);
+        qv = rlm::div32_y(hv, d.ay, d.yay);
+    }
+    float den = d.ax * d.ay * sqr(sqr(qu) + sqr(qv) + mn2);
+#else
     float den = d.ax * d.ay * sqr(sqr(R_DIV(hu, d.ax)) + sqr(R_DIV(hv, d.ay)) + mn2);
+#endif
     return R_DIV(kInvPi, den);
 }
 
@@ -849,6 +877,12 @@ RLS_DEV void disney_prepare_material(Disney &d)
     d.ccw = R_DIV(d.clearcoat, d.clearcoat + 1.0f);
     d.gtr2Weight = R_RCP(d.clearcoat + 1.0f);
     d.om = 1.0f - d.metallic;
+#if !RLS_FAST
+    // ax, ay = max(1e-2, r^2 / aspect), max(1e-2, r^2 aspect): inside div32_y's window [2^-14, 2^14] unless the roughness is absurd
+    const bool win = RLS_DISNEY_D_RECIP && d.ax <= 0x1p14f && d.ay <= 0x1p14f && d.ax >= 0x1p-14f && d.ay >= 0x1p-14f;
+    d.yax = win ? rlm::rcp32_w(d.ax) : 0.0f;
+    d.yay = win ? rlm::rcp32_w(d.ay) : 0.0f;
+#endif
 }
 RLS_DEV void disney_prepare_view(Disney &d)
 {
@@ -874,6 +908,9 @@ RLS_DEV void disney_wave_uniform(Disney &d)
     d.specRough = wave_uniform(d.specRough); d.ax = wave_uniform(d.ax); d.ay = wave_uniform(d.ay);
     d.ccA2m1 = wave_uniform(d.ccA2m1); d.ccLogA2 = wave_uniform(d.ccLogA2); d.ccw = wave_uniform(d.ccw);
     d.gtr2Weight = wave_uniform(d.gtr2Weight); d.om = wave_uniform(d.om);
+#if !RLS_FAST
+    d.yax = wave_uniform(d.yax); d.yay = wave_uniform(d.yay);
+#endif
 }
 RLS_DEV DisneyTints disney_wave_uniform(DisneyTints t)
 {

@@ -204,9 +204,23 @@ __device__ __forceinline__ void disney_spec_push(SlowLds<K> &L, int k, int &cnt,
                                                  float rx, float ry)
 {
     const bool gtr2 = rx < d.gtr2Weight;
-    const float rxp = R_DIV(gtr2 ? rx : rx - d.gtr2Weight, gtr2 ? d.gtr2Weight : 1.0f - d.gtr2Weight);
+    const float num = gtr2 ? rx : rx - d.gtr2Weight, den = gtr2 ? d.gtr2Weight : 1.0f - d.gtr2Weight;
     V2 slope;
-    const bool needU = vndf_slope_closed(w, rxp, ry, slope);                 // every lane; used where gtr2
+    float rxp;
+    bool needU;
+#if !RLS_FAST
+    // rx comes from the in-kernel sampler (a multiple of 2^-24 below 1) and the two denominators are per-point values: the
+    // rescaled rx and A = 2 rx' / G1 - 1 through their reciprocals (rlm::div32_y) unless some lane has none (RLS_LOOP_RECIP)
+    const float y = gtr2 ? d.yW : d.y1mW;
+    if (__builtin_expect(RLS_LOOP_RECIP && __builtin_amdgcn_ballot_w64(y == 0.0f || w.yG1 == 0.0f) == 0ull, 1)) {
+        rxp = rlm::div32_y(num, den, y);
+        needU = vndf_slope_closed<true>(w, rxp, ry, slope);
+    } else
+#endif
+    {
+        rxp = R_DIV(num, den);
+        needU = vndf_slope_closed(w, rxp, ry, slope);                        // every lane; used where gtr2
+    }
     slow_push<K>(L, k, cnt, ok && (!gtr2 || needU), gtr2 ? ry : rxp, gtr2 ? rxp : ry, gtr2 ? -1.0f : sqr(d.roughness),
                  slope.x, slope.y, gtr2 ? 1 : 0);
 }
@@ -239,7 +253,13 @@ template <int K>
 __device__ __forceinline__ void ggx_vndf_push(SlowLds<K> &L, int k, int &cnt, bool ok, const VndfView &w, float rx, float ry)
 {
     V2 slope;
-    const bool needU = vndf_slope_closed(w, rx, ry, slope);
+    bool needU;
+#if !RLS_FAST
+    if (__builtin_expect(RLS_LOOP_RECIP && __builtin_amdgcn_ballot_w64(w.yG1 == 0.0f) == 0ull, 1))
+        needU = vndf_slope_closed<true>(w, rx, ry, slope);       // rx from the in-kernel sampler: G1's reciprocal serves
+    else
+#endif
+        needU = vndf_slope_closed(w, rx, ry, slope);
     slow_push<K>(L, k, cnt, ok && needU, ry, rx, -1.0f, slope.x, slope.y, 1);
 }
 template <int K>
@@ -1149,6 +1169,7 @@ __device__ __forceinline__ Disney disney_fetch(const Disney &d, int src)
     h.ccw = lane_fetch(d.ccw, src); h.vnc = lane_fetch(d.vnc, src); h.om = lane_fetch(d.om, src);
 #if !RLS_FAST
     h.yax = 0.0f; h.yay = 0.0f;      // the reciprocals of alpha_x, alpha_y stay at home: a fetched closure divides the IEEE way
+    h.yW = 0.0f; h.y1mW = 0.0f;
 #endif
     return h;
 }

@@ -275,6 +275,9 @@ struct VndfView {
     float cosPhi, sinPhi;   // of the stretched view azimuth
     float B, B2, G1, invB;  // tanf(theta) terms (valid when !nearNormal)
     bool nearNormal;        // theta < AI_EPSILON -> uniform slope sample
+#if !RLS_FAST
+    float yG1;              // RN(1 / G1) for the n^2-spp loops' A = 2 rx / G1 - 1 (RLS_LOOP_RECIP); 0: G1 outside div32_y's window
+#endif
 };
 
 // The view direction in the local frame as the reference obtains it -- independent of the roughness,
@@ -353,6 +356,9 @@ RLS_DEV VndfView vndf_view_from(V3 local, float ax, float ay)
     // B = tanf(theta) with theta = 0 or in [acos(1 - 1e-4), pi] (or NaN): 0 or 8.7e-8 <= |B| <= 2.3e7 -- an fp32
     // angle cannot come closer to pi/2 or pi than that
     w.invB = R_RCPW(B);
+    // G1 = 2 / (1 + sqrt(1 + B^2)) is in (0, 1]; below 2^-14 (a stretched view within 1e-4 of the horizon) no reciprocal is kept.
+    // Only the n^2-spp loops read it (kernels that do not never compute it)
+    w.yG1 = (w.G1 >= 0x1p-14f) ? rlm::rcp32_w(w.G1) : 0.0f;
     return w;
 }
 
@@ -407,9 +413,20 @@ RLS_DEV float slope_y_ratio(float u)
 // Per-sample part of sampleSlope + evalSample: src/rlGgx.cpp:36-60, 89-98.
 // vndf_slope_closed: the closed-form slopes (36-60); returns true where the reference takes the uniform fallback
 // instead (27: theta < eps, 38: |A^2 - 1| < eps) -- the slopes it writes are then unused.
+// LOOP_RECIP (the n^2-spp loops, whose rx comes from the in-kernel sampler: zero or a multiple of 2^-24 below 1, possibly
+// divided by the lobe weight -- never in (0, 2^-75)): the caller has checked that w.yG1 != 0 in every active lane and the
+// quotient by the per-point G1 goes through its reciprocal (rlm::div32_y), the same correctly rounded value.
+#ifndef RLS_LOOP_RECIP
+#define RLS_LOOP_RECIP 1
+#endif
+template <bool LOOP_RECIP = false>
 RLS_DEV bool vndf_slope_closed(const VndfView &w, float rx, float ry, V2 &slope)
 {
+#if !RLS_FAST
+    float A = (LOOP_RECIP ? rlm::div32_y(2.0f * rx, w.G1, w.yG1) : R_DIVH(2.0f * rx, w.G1)) - 1.0f;
+#else
     float A = R_DIVH(2.0f * rx, w.G1) - 1.0f;
+#endif
     float A2 = sqr(A);
     float tmp = R_RCPG(A2 - 1.0f);
     float D = R_SQRTH(maxf(0.0f, w.B2 * sqr(tmp) - (A2 - w.B2) * tmp));
@@ -752,6 +769,7 @@ struct Disney {
     float om;                     // 1 - metallic
 #if !RLS_FAST
     float yax, yay;               // RN(1 / ax), RN(1 / ay) for D_GTR2Aniso's two quotients (RLS_DISNEY_D_RECIP); 0: outside div32_y's window
+    float yW, y1mW;               // RN(1 / gtr2Weight), RN(1 / (1 - gtr2Weight)) for the lobe pick's rescaled rx (RLS_LOOP_RECIP); 0: no reciprocal
 #endif
 };
 
@@ -780,6 +798,7 @@ RLS_DEV DisneyTints disney_make_scalars(Disney &d, const float (&s)[10])
     d.specRough = sqr(d.roughness);
 #if !RLS_FAST
     d.yax = 0.0f; d.yay = 0.0f;      // "no reciprocals": D_GTR2Aniso divides the IEEE way until disney_prepare_material() has run
+    d.yW = 0.0f; d.y1mW = 0.0f;
 #endif
     return t;
 }
@@ -882,6 +901,10 @@ RLS_DEV void disney_prepare_material(Disney &d)
     const bool win = RLS_DISNEY_D_RECIP && d.ax <= 0x1p14f && d.ay <= 0x1p14f && d.ax >= 0x1p-14f && d.ay >= 0x1p-14f;
     d.yax = win ? rlm::rcp32_w(d.ax) : 0.0f;
     d.yay = win ? rlm::rcp32_w(d.ay) : 0.0f;
+    // gtr2Weight = 1 / (clearcoat + 1) and its complement: in the window for every clearcoat in [2.5e-4, 4 x 16383] or so
+    const float w1 = d.gtr2Weight, w2 = 1.0f - d.gtr2Weight;
+    d.yW = (RLS_LOOP_RECIP && w1 >= 0x1p-14f && w1 <= 0x1p14f) ? rlm::rcp32_w(w1) : 0.0f;
+    d.y1mW = (RLS_LOOP_RECIP && w2 >= 0x1p-14f && w2 <= 0x1p14f) ? rlm::rcp32_w(w2) : 0.0f;
 #endif
 }
 RLS_DEV void disney_prepare_view(Disney &d)
@@ -910,6 +933,7 @@ RLS_DEV void disney_wave_uniform(Disney &d)
     d.gtr2Weight = wave_uniform(d.gtr2Weight); d.om = wave_uniform(d.om);
 #if !RLS_FAST
     d.yax = wave_uniform(d.yax); d.yay = wave_uniform(d.yay);
+    d.yW = wave_uniform(d.yW); d.y1mW = wave_uniform(d.y1mW);
 #endif
 }
 RLS_DEV DisneyTints disney_wave_uniform(DisneyTints t)

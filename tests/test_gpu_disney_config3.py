@@ -256,3 +256,43 @@ def test_packed_rare_branches_with_every_lane_asking(gpu, oracle):
     got = _with_group(1, lambda: [host(t) for t in ggx_sampler(gpu, g).integrate(3, seed)])
     for nm, a, b in zip(("sum", "avg"), got, ref):
         cases.assert_tight(cases.summarize(cases.rel_err(a, b)), ("ggx every lane asks", nm))
+
+
+def test_loop_reciprocals_at_their_window_borders(gpu, oracle):
+    """The sample loops divide by alpha_x, alpha_y, the lobe weight 1 / (clearcoat + 1), its complement and G1 through
+    per-point reciprocals when those lie inside rlm::div32_y's window, and the IEEE way for the whole wavefront when a lane's
+    do not (RLS_DISNEY_D_RECIP, RLS_LOOP_RECIP).  Parameter sets on either side of every border, in one batch (so that
+    wavefronts mix both kinds) and as uniform values: bit for bit the oracle's sums and counts."""
+    n, spp_n, seed = 1 << 12, 4, 31
+    base = cases.disney_mixed(cases.SEED_PARITY, n)
+    k = np.arange(n) % 8
+    c = dict(base)
+    # clearcoat: 0 (complement of the weight is 0), 1e-6 and 2e-4 (complement below / near 2^-14), ordinary
+    c["clearcoat"] = np.choose(k % 4, [np.zeros(n, np.float32), np.full(n, 1e-6, np.float32), np.full(n, 2.4e-4, np.float32),
+                                       base["clearcoat"]]).astype(np.float32)
+    # roughness: 0 and 1e-3 (alpha floored at 1e-2), ordinary, 130 (alpha = 16900 > 2^14: no reciprocal), 1e20 (alpha infinite)
+    c["roughness"] = np.choose(k, [np.zeros(n, np.float32), np.full(n, 1e-3, np.float32), base["roughness"], base["roughness"],
+                                   np.full(n, 130.0, np.float32), base["roughness"], np.full(n, 1e20, np.float32),
+                                   base["roughness"]]).astype(np.float32)
+    # grazing views: the stretched view's G1 falls below 2^-14 for alpha tan(theta) > 2^15
+    wo = base["wo"].copy()
+    graze = (k == 5)
+    t = (base["T"] + 1e-6 * base["N"]).astype(np.float32)
+    wo[:, graze] = (t / np.linalg.norm(t, axis=0, keepdims=True))[:, graze].astype(np.float32)
+    c["wo"] = wo
+    ref = disney_oracle(oracle, c).integrate(spp_n, seed)
+    got = _with_group(1, lambda: {kk: host(v) for kk, v in disney_sampler(gpu, c).integrate(spp_n, seed).items()})
+    for kk in SUMS + COUNTS:
+        a, b = got[kk], ref[kk]
+        same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+        assert same.all() or not cases.strict_parity(), (kk, int((~same).sum()))
+    # the same borders as UNIFORM values (the hoisted path keeps the reciprocals in scalar registers)
+    for cc, rr in ((0.0, 0.4), (1e-6, 0.4), (2.4e-4, 0.0), (0.7, 130.0), (0.3, 1e-3)):
+        cu = dict(base, clearcoat=np.float32(cc), roughness=np.float32(rr))
+        cu_o = dict(base, clearcoat=np.full(n, cc, np.float32), roughness=np.full(n, rr, np.float32))
+        ref = disney_oracle(oracle, cu_o).integrate(spp_n, seed)
+        got = _with_group(1, lambda: {kk: host(v) for kk, v in disney_sampler(gpu, cu).integrate(spp_n, seed).items()})
+        for kk in SUMS + COUNTS:
+            a, b = got[kk], ref[kk]
+            same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+            assert same.all() or not cases.strict_parity(), (cc, rr, kk, int((~same).sum()))

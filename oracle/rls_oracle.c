@@ -120,6 +120,16 @@ orc_v2 orc_concentric_disk_sample(float rx, float ry)
 
 /* ====================================== rlGgx ========================================== */
 
+/* src/rlGgx.h:152: the reference's constructor heap-allocates its normal-distribution sampler
+ * (std::make_shared<NDSampler>: ONE allocation of the control block, 16 B, and the VNDFKernel object -- a reference, a
+ * vector and two floats, 32 B), released when the closure leaves shader_evaluate's stack.  This restatement keeps the
+ * sampler's fields inside orc_ggx and allocates nothing.  orc_set_closure_alloc(1) makes orc_ggx_init pay that
+ * allocation and its release (the fields written through, so the pair is not optimised away): bench.py's "port+alloc"
+ * CPU leg, which brackets the real closure path's cost.  It changes no value. */
+static int g_closure_alloc = 0;
+void orc_set_closure_alloc(int on) { g_closure_alloc = on; }
+int orc_get_closure_alloc(void) { return g_closure_alloc; }
+
 /* src/rlGgx.h:130-156.  Boundary: wo = -sg->Rd, Nf = sg->Nf, T = tangent returned by the
  * closed AiBuildLocalFramePolar (input), exiting = !(dot(sg->N, sg->Rd) < AI_EPSILON). */
 void orc_ggx_init(orc_ggx *g, orc_v3 wo, orc_v3 Nf, orc_v3 T, int exiting,
@@ -141,6 +151,14 @@ void orc_ggx_init(orc_ggx *g, orc_v3 wo, orc_v3 Nf, orc_v3 T, int exiting,
     float aspect = sqrtf(1.0f - anisotropic * 0.9f);
     g->alphaX = MAXf(1e-4f, SQRf(roughness) / aspect);
     g->alphaY = MAXf(1e-4f, SQRf(roughness) * aspect);
+    if (g_closure_alloc) {                                               /* line 152, see above */
+        volatile float *nd = (volatile float *)malloc(48);
+        if (nd) {
+            nd[4] = (float)(uintptr_t)g;                                 /* mBasis (a reference) */
+            nd[6] = wo.x; nd[7] = wo.y; nd[8] = wo.z; nd[9] = g->alphaX; nd[10] = g->alphaY;
+            free((void *)nd);
+        }
+    }
     g->roughness = MAXf(1e-5f, SQRf(roughness));
 }
 
@@ -2288,9 +2306,16 @@ static inline orc_v3 v3normalize_div(orc_v3 a)
     return v3(a.x / l, a.y / l, a.z / l);
 }
 
-void orc_gen_frame(uint32_t seed, uint64_t first, int64_t n, orc_v3p wo, orc_v3p N, orc_v3p T)
+/* the generators fill index ranges independently (every value is a hash of its own index): large batches on all threads */
+typedef struct { uint32_t seed, stream; uint64_t first; orc_v3p wo, N, T; float lo, hi; float *out; } gen_job;
+
+static void gen_frame_range(int64_t k0, int64_t k1, void *ctx)
 {
-    for (int64_t k = 0; k < n; k++) {
+    const gen_job *j = (const gen_job *)ctx;
+    const uint32_t seed = j->seed;
+    const uint64_t first = j->first;
+    const orc_v3p wo = j->wo, N = j->N, T = j->T;
+    for (int64_t k = k0; k < k1; k++) {
         uint64_t i = first + (uint64_t)k;
         float u0 = orc_hash_u01(seed, i, ORC_S_N0);
         float z = 1.0f - 2.0f * u0;
@@ -2318,18 +2343,40 @@ void orc_gen_frame(uint32_t seed, uint64_t first, int64_t n, orc_v3p wo, orc_v3p
     }
 }
 
+static int gen_threads(int64_t n) { return n >= (1 << 18) ? orc_hardware_threads() : 1; }
+
+void orc_gen_frame(uint32_t seed, uint64_t first, int64_t n, orc_v3p wo, orc_v3p N, orc_v3p T)
+{
+    gen_job j = { .seed = seed, .first = first, .wo = wo, .N = N, .T = T };
+    parallel_for(n, gen_threads(n), gen_frame_range, &j);
+}
+
+static void gen_uniform_range(int64_t k0, int64_t k1, void *ctx)
+{
+    const gen_job *j = (const gen_job *)ctx;
+    float span = j->hi - j->lo;
+    for (int64_t k = k0; k < k1; k++) {
+        j->out[k] = j->lo + span * orc_hash_u01(j->seed, j->first + (uint64_t)k, j->stream);
+    }
+}
+
 void orc_gen_uniform(uint32_t seed, uint64_t first, int64_t n, uint32_t stream, float lo, float hi, float *out)
 {
-    float span = hi - lo;
-    for (int64_t k = 0; k < n; k++) {
-        out[k] = lo + span * orc_hash_u01(seed, first + (uint64_t)k, stream);
+    gen_job j = { .seed = seed, .stream = stream, .first = first, .lo = lo, .hi = hi, .out = out };
+    parallel_for(n, gen_threads(n), gen_uniform_range, &j);
+}
+
+static void gen_aniso_range(int64_t k0, int64_t k1, void *ctx)
+{
+    const gen_job *j = (const gen_job *)ctx;
+    for (int64_t k = k0; k < k1; k++) {
+        uint64_t i = j->first + (uint64_t)k;
+        j->out[k] = (i & 1ULL) ? orc_hash_u01(j->seed, i, ORC_S_ANISO) : 0.0f;
     }
 }
 
 void orc_gen_aniso(uint32_t seed, uint64_t first, int64_t n, float *out)
 {
-    for (int64_t k = 0; k < n; k++) {
-        uint64_t i = first + (uint64_t)k;
-        out[k] = (i & 1ULL) ? orc_hash_u01(seed, i, ORC_S_ANISO) : 0.0f;
-    }
+    gen_job j = { .seed = seed, .first = first, .out = out };
+    parallel_for(n, gen_threads(n), gen_aniso_range, &j);
 }

@@ -441,6 +441,10 @@ void orc_gen_uniform(uint32_t seed, uint64_t first, int64_t n, uint32_t stream, 
 void orc_gen_aniso(uint32_t seed, uint64_t first, int64_t n, float *out);
 
 int orc_hardware_threads(void);
+/* src/rlGgx.h:152 (std::make_shared per closure): 1 = orc_ggx_init pays one 48-byte heap allocation + release, as the
+ * reference's constructor does; values unchanged (bench.py's "port+alloc" CPU baseline leg).  Default 0. */
+void orc_set_closure_alloc(int on);
+int orc_get_closure_alloc(void);
 
 #ifdef __cplusplus
 }

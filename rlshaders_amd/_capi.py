@@ -188,6 +188,9 @@ PROTOTYPES = {
     "rls_timer_start": (C.c_int, [_ctx]),
     "rls_timer_stop": (C.c_int, [_ctx]),
     "rls_timer_elapsed_ms": (C.c_int, [_ctx, C.POINTER(C.c_float)]),
+    "rls_diag_clock_stamps_begin": (C.c_int, [_ctx]),
+    "rls_diag_clock_stamps_read": (C.c_int, [_ctx, _i64, _vp, C.POINTER(_i64)]),
+    "rls_diag_clock_stamps_end": (C.c_int, [_ctx]),
     "rls_arena_create": (C.c_int, [_ctx, _i64, C.c_int, C.c_int, C.POINTER(_vp)]),
     "rls_arena_plane": (_vp, [_vp, C.c_int]),
     "rls_arena_info": (C.c_int, [_vp, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_float),

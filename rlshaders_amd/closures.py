@@ -80,6 +80,45 @@ class Context:
         check(self.lib.rls_timer_elapsed_ms(self.handle, C.byref(ms)))
         return float(ms.value)
 
+    # ---- in-kernel clock stamps (rls_diag_clock_stamps_*; a measurement aid, not part of the closure surface) ----------
+    def clock_stamps_begin(self) -> None:
+        """From here to clock_stamps_end() the kernels of BASELINE configs 2-5 run as their stamped instantiation."""
+        check(self.lib.rls_diag_clock_stamps_begin(self.handle))
+
+    def clock_stamps_end(self) -> None:
+        check(self.lib.rls_diag_clock_stamps_end(self.handle))
+
+    def clock_stamps_read(self):
+        """uint64 [workgroups, 4]: {memtime at entry, at exit, memrealtime at entry, at exit} of the workgroups of the last
+        stamped launch (synchronises; slots of workgroups that did not run are dropped)."""
+        import numpy as np
+        count = C.c_int64()
+        check(self.lib.rls_diag_clock_stamps_read(self.handle, 0, None, C.byref(count)))
+        raw = np.zeros((count.value, 4), dtype=np.uint64)
+        check(self.lib.rls_diag_clock_stamps_read(self.handle, count.value, raw.ctypes.data_as(C.c_void_p), C.byref(count)))
+        return raw[raw[:, 3] != 0]
+
+    @staticmethod
+    def clock_from_stamps(stamps, realtime_hz: float = 100e6) -> dict:
+        """Effective shader clock of the stamped launch: per workgroup d(memtime) / d(memrealtime) x 100 MHz
+        (MI355X_MICROARCH.md, DVFS item 6); the median over the workgroups is the figure, p05 / p95 its spread.
+        `span_ms` = last exit - first entry on the 100 MHz counter: the launch's duration as the stamps see it (compare
+        with the HIP-event time of the same launch to check the counter's rate)."""
+        import numpy as np
+        if len(stamps) == 0:
+            raise RuntimeError("no stamps: no stamped kernel ran since clock_stamps_begin()")
+        dt = (stamps[:, 1] - stamps[:, 0]).astype(np.float64)
+        dr = (stamps[:, 3] - stamps[:, 2]).astype(np.float64)
+        ok = dr > 0
+        ghz = dt[ok] / dr[ok] * realtime_hz / 1e9
+        # the realtime counter ticks every 10 ns: a workgroup that lives 15 us is resolved to 0.07 %
+        return {"effective_clock_ghz": round(float(np.median(ghz)), 4),
+                "p05_ghz": round(float(np.percentile(ghz, 5)), 4), "p95_ghz": round(float(np.percentile(ghz, 95)), 4),
+                "workgroups": int(ok.sum()),
+                "median_workgroup_us": round(float(np.median(dr[ok])) / realtime_hz * 1e6, 3),
+                "median_workgroup_cycles": int(np.median(dt[ok])),
+                "span_ms": round(float(stamps[:, 3].max() - stamps[:, 2].min()) / realtime_hz * 1e3, 5)}
+
     def device_info(self) -> dict:
         cus = C.c_int()
         total = C.c_size_t()

@@ -110,6 +110,7 @@ void rls_context_destroy(rls_context *ctx)
     }
     if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
     if (ctx->scratch_u64) (void)hipFree(ctx->scratch_u64);
+    if (ctx->stamp_buf) (void)hipFree(ctx->stamp_buf);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->ev_probe_start) (void)hipEventDestroy(ctx->ev_probe_start);
@@ -260,6 +261,53 @@ rls_status rls_timer_elapsed_ms(rls_context *ctx, float *ms)
     RLS_REQUIRE(!ctx->capturing, "not allowed while a launch graph is being recorded");
     RLS_HIP_TRY(hipEventSynchronize(ctx->ev_stop));
     RLS_HIP_TRY(hipEventElapsedTime(ms, ctx->ev_start, ctx->ev_stop));
+    return RLS_OK;
+}
+
+// ---- in-kernel clock stamps (diagnostic) -----------------------------------------------------
+// rls_internal.hpp, ClockStamp: while in force, rls_ggx_reflect_refract (all planes streamed), rls_sss_probe_ray
+// (per-point distances), rls_skin_sample_eval_pdf (all planes streamed) and rls_disney_integrate (one lane per point)
+// launch the stamped instantiation of their kernel; every other entry point launches what it always launches.
+rls_status rls_diag_clock_stamps_begin(rls_context *ctx)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    RLS_REQUIRE(!ctx->capturing, "not allowed while a launch graph is being recorded");
+    RLS_HIP_TRY(hipSetDevice(ctx->device));
+    if (!ctx->stamp_buf) {
+        // one slot per workgroup of the largest grid any pointwise launch uses (grid_for: the cap x RLS_CAP_MULT, rounded
+        // up to a multiple of 8)
+        ctx->stamp_slots = (int64_t)ctx->compute_units * ctx->blocks_per_cu * RLS_CAP_MULT + 8;
+        RLS_HIP_TRY(hipMalloc((void **)&ctx->stamp_buf, sizeof(unsigned long long) * (size_t)(4 + 4 * ctx->stamp_slots)));
+    }
+    RLS_HIP_TRY(hipMemsetAsync(ctx->stamp_buf, 0, sizeof(unsigned long long) * (size_t)(4 + 4 * ctx->stamp_slots), ctx->stream));
+    const unsigned long long slots = (unsigned long long)ctx->stamp_slots;
+    RLS_HIP_TRY(hipMemcpyAsync(ctx->stamp_buf, &slots, sizeof(slots), hipMemcpyHostToDevice, ctx->stream));
+    RLS_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->stamps = ctx->stamp_buf;
+    return RLS_OK;
+}
+
+rls_status rls_diag_clock_stamps_read(rls_context *ctx, int64_t capacity, uint64_t *stamps_host, int64_t *count)
+{
+    RLS_REQUIRE(ctx != nullptr && count != nullptr, "NULL argument");
+    RLS_REQUIRE(ctx->stamps != nullptr, "rls_diag_clock_stamps_begin is not in force");
+    RLS_REQUIRE(capacity >= 0 && (capacity == 0 || stamps_host != nullptr), "capacity < 0 or stamps_host is NULL");
+    RLS_HIP_TRY(hipSetDevice(ctx->device));
+    static_assert(sizeof(uint64_t) == sizeof(unsigned long long), "stamp words are 64 bits");
+    const int64_t take = capacity < ctx->stamp_slots ? capacity : ctx->stamp_slots;
+    *count = ctx->stamp_slots;       // slots there are; workgroups that never ran leave theirs zero
+    if (take > 0) {
+        RLS_HIP_TRY(hipMemcpyAsync(stamps_host, ctx->stamp_buf + 4, sizeof(uint64_t) * 4 * (size_t)take, hipMemcpyDeviceToHost,
+                                   ctx->stream));
+        RLS_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return RLS_OK;
+}
+
+rls_status rls_diag_clock_stamps_end(rls_context *ctx)
+{
+    RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
+    ctx->stamps = nullptr;
     return RLS_OK;
 }
 

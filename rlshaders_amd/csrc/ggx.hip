@@ -55,9 +55,11 @@ __device__ __forceinline__ Ggx load_closure(const rls_ggx_closure &c, Idx i, con
 #ifndef RLS_GGX_WAVES
 #define RLS_GGX_WAVES(OP) ((OP) == OP_EVAL ? 6 : 8)
 #endif
+#define RLS_GGX_ATTR(OP) __launch_bounds__(rlsh::kBlock) __attribute__((amdgpu_waves_per_eu(RLS_GGX_WAVES(OP), RLS_GGX_WAVES(OP))))
+// the kernel body: inlined into ggx_kernel (the product) and into ggx_kernel_stamped (the diagnostic instantiation that
+// brackets it with clock stamps, rls_internal.hpp ClockStamp).  a0 is the kernel's first parameter (reload_args).
 template <int OP, int FAST_MATH, int MODE>
-__global__ __launch_bounds__(rlsh::kBlock) __attribute__((amdgpu_waves_per_eu(RLS_GGX_WAVES(OP), RLS_GGX_WAVES(OP))))
-void ggx_kernel(GgxIO a0)
+__device__ __forceinline__ void ggx_body(const GgxIO &a0)
 {
     if (OP == OP_SAMPLE || OP == OP_FUSED || OP == OP_REFLECT_REFRACT || OP == OP_REFRACT || OP == OP_MICROFACET)
         stage_libm_tables();   // the range table of atanf -> LDS (visible-normal sampling calls atan2f twice)
@@ -140,6 +142,21 @@ void ggx_kernel(GgxIO a0)
     }
 }
 
+template <int OP, int FAST_MATH, int MODE>
+__global__ RLS_GGX_ATTR(OP) void ggx_kernel(GgxIO a0)
+{
+    ggx_body<OP, FAST_MATH, MODE>(a0);
+}
+
+template <int OP, int FAST_MATH, int MODE>
+__global__ RLS_GGX_ATTR(OP) void ggx_kernel_stamped(GgxIO a0, unsigned long long *stamps)
+{
+    ClockStamp<1> cs;
+    cs.begin();
+    ggx_body<OP, FAST_MATH, MODE>(a0);
+    cs.end(stamps);
+}
+
 rls_status check_closure(const rls_ggx_closure *c)
 {
     RLS_REQUIRE(c != nullptr, "closure is NULL");
@@ -159,6 +176,13 @@ rls_status launch_kernel(rls_context *ctx, const GgxIO &io, const char *name)
     const bool streamed = !c.materials.id && c.KsColor.r && c.specularRoughness.v && c.ior.v && c.anisotropic.v;
 #endif
     const bool uniform = !c.materials.id && !c.specularRoughness.v && !c.ior.v && !c.anisotropic.v;       // specColor: either
+    if constexpr (OP == OP_REFLECT_REFRACT) {      // BASELINE config 2 under rls_diag_clock_stamps_begin: the stamped instantiation
+        if (streamed && ctx->stamps) {
+            hipLaunchKernelGGL((ggx_kernel_stamped<OP, RLS_FAST, STREAMED_ALL>), rlsh::grid_for(ctx, io.n, rlsh::kBlock, RLS_CAP_MULT),
+                               dim3(rlsh::kBlock), 0, ctx->stream, io, ctx->stamps);
+            return rlsh::check_launch(name);
+        }
+    }
     if (streamed)
         hipLaunchKernelGGL((ggx_kernel<OP, RLS_FAST, STREAMED_ALL>), rlsh::grid_for(ctx, io.n, rlsh::kBlock, RLS_CAP_MULT), dim3(rlsh::kBlock), 0, ctx->stream, io);
     else if (uniform)   // a thread that hoists wants many tiles to spread the hoisted work over (grid_for_hoisting)

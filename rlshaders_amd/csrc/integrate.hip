@@ -545,8 +545,10 @@ __global__ RLS_INT_ATTR void ggx_integrate_kernel(GgxIntIO a)
 
 // ---------------------------------------------------------------------------------------------
 
-template <int G, int FAST_MATH = RLS_FAST>
-__global__ RLS_INT_ATTR void disney_integrate_kernel(DisneyIntIO a)
+// the kernel body: inlined into disney_integrate_kernel (the product) and disney_integrate_kernel_stamped (diagnostic: the
+// same body between clock stamps, rls_internal.hpp ClockStamp).  `a` is the kernel's first parameter (reload_args).
+template <int G, int FAST_MATH>
+__device__ __forceinline__ void disney_integrate_body(const DisneyIntIO a)
 {
     constexpr int K = RLS_SPEC_BLOCK;
     __shared__ uint32_t tab[2][kMaxSpp];
@@ -636,6 +638,21 @@ __global__ RLS_INT_ATTR void disney_integrate_kernel(DisneyIntIO a)
             strgb(ao.ssum, i, sR, sG, sB); stg(ao.scount, i, sC);
         }
     }
+}
+
+template <int G, int FAST_MATH = RLS_FAST>
+__global__ RLS_INT_ATTR void disney_integrate_kernel(DisneyIntIO a)
+{
+    disney_integrate_body<G, FAST_MATH>(a);
+}
+
+template <int G, int FAST_MATH = RLS_FAST>
+__global__ RLS_INT_ATTR void disney_integrate_kernel_stamped(DisneyIntIO a, unsigned long long *stamps)
+{
+    ClockStamp<1> cs;
+    cs.begin();
+    disney_integrate_body<G, FAST_MATH>(a);
+    cs.end(stamps);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1561,6 +1578,14 @@ rls_status launch_g(rls_context *ctx, K k1, K k4, K k16, K k64, int g, const IO 
     return rlsh::check_launch(name);
 }
 
+// BASELINE config 3 (one lane per point) under rls_diag_clock_stamps_begin: the stamped instantiation
+inline rls_status launch_disney_stamped(rls_context *ctx, const rlsh::DisneyIntIO &io, const char *name)
+{
+    hipLaunchKernelGGL(disney_integrate_kernel_stamped<1>, rlsh::grid_for(ctx, io.n, rlsh::kBlock), dim3(rlsh::kBlock), 0, ctx->stream,
+                       io, ctx->stamps);
+    return rlsh::check_launch(name);
+}
+
 // the lights of a light loop, validated and copied into a kernel's argument struct
 inline rls_status copy_lights(const rls_sphere_light *lights, int n_lights, int at_least, rls_sphere_light *dst, int *count)
 {
@@ -1591,6 +1616,7 @@ RLS_HIDDEN rls_status rls_fast_ggx_integrate(rls_context *ctx, int g, const rlsh
 }
 RLS_HIDDEN rls_status rls_fast_disney_integrate(rls_context *ctx, int g, const rlsh::DisneyIntIO *io)
 {
+    if (ctx->stamps && g == 1) return launch_disney_stamped(ctx, *io, "rls_disney_integrate[fast, stamped]");
     return launch_g(ctx, disney_integrate_kernel<1>, disney_integrate_kernel<4>, disney_integrate_kernel<16>,
                     disney_integrate_kernel<64>, g, *io, "rls_disney_integrate[fast]");
 }
@@ -1742,6 +1768,7 @@ rls_status rls_disney_integrate(rls_context *ctx, int64_t n, const rls_disney_cl
     // streamed planes are sample-major: one lane per point keeps every store coalesced
     int g = io.streamed ? 1 : pick_group(ctx, n, io.spp);
     if (ctx->fast) return rls_fast_disney_integrate(ctx, g, &io);
+    if (ctx->stamps && g == 1) return launch_disney_stamped(ctx, io, "rls_disney_integrate[stamped]");
     return launch_g(ctx, disney_integrate_kernel<1>, disney_integrate_kernel<4>, disney_integrate_kernel<16>,
                     disney_integrate_kernel<64>, g, io, "rls_disney_integrate");
 }

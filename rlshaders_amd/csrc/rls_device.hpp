@@ -31,6 +31,9 @@ struct V3 { float x, y, z; };
 struct V2 { float x, y; };
 
 #define RLS_DEV __device__ __forceinline__
+#ifndef RLS_BLOCK
+#define RLS_BLOCK 256     // threads per workgroup of every kernel (rls_internal.hpp, kBlock)
+#endif
 
 RLS_DEV float sqr(float a) { return a * a; }
 RLS_DEV float absf(float a) { return a < 0.0f ? -a : a; }
@@ -75,15 +78,9 @@ struct Frame { V3 U, V, N; };
 #define RLS_FAST 0
 #endif
 #if RLS_FAST
-// RLS_FAST_REFINED (round 4 experiment, off): FAST's divisions and square roots at ~0.5 ulp everywhere -- v_rcp_f32 + one
-// Newton step with v_div_fixup_f32, v_sqrt_f32 + the +-1 ulp correction -- instead of the raw 1-ulp instructions.  Measured
-// (profiles/r04_fast_refined.txt): config 2 1.31 -> 1.43 ms (+9 %), rlSkin +8 %, the rlDisney glossy triple +11 % -- and
-// NOT ONE outlier fewer against the CPU closures (381 212 -> 379 013 of 2^24 `f` values beyond 1e-5, the same ~300
-// unexplained): FAST's distance from the reference is the reference's own rounding pattern (the angle round trip, the
-// cancellation in the slope equations' discriminant), not the last bit of FAST's primitives.
-#ifndef RLS_FAST_REFINED
-#define RLS_FAST_REFINED 0
-#endif
+// (round 4 tried FAST's divisions and square roots at ~0.5 ulp everywhere -- v_rcp_f32 + a Newton step with v_div_fixup_f32,
+// v_sqrt_f32 + the +-1 ulp correction: config 2 +9 %, rlSkin +8 %, and not one outlier fewer against the CPU closures,
+// profiles/r04_fast_refined_timing.txt; the switch was removed in round 5, the code is in history at 1c59d76)
 // the visible-normal slope equations amplify every rounding error: there FAST always spent a Newton
 // step on the reciprocal (~0.5 ulp) and the exact sqrt
 RLS_DEV float refined_div(float a, float b)
@@ -91,21 +88,8 @@ RLS_DEV float refined_div(float a, float b)
     float r = __builtin_amdgcn_rcpf(b);
     float q = a * r;
     float e = __builtin_fmaf(-b, q, a);
-#if RLS_FAST_REFINED
-    return __builtin_amdgcn_div_fixupf(__builtin_fmaf(e, r, q), b, a);      // x / 0, 0 / x, inf, NaN as IEEE division has them
-#else
     return __builtin_fmaf(e, r, q);
-#endif
 }
-#if RLS_FAST_REFINED
-#define R_DIV(a, b) refined_div((a), (b))
-#define R_RCP(b) refined_div(1.0f, (b))
-#define R_RCPW(b) refined_div(1.0f, (b))
-#define R_TWO_OVER(den) refined_div(2.0f, (den))
-#define R_SQRT(x) rlm::sqrt32<false>(x)           // (no rescaling branch for radicands below 2^-96: FAST does not need it)
-#define R_SQRT1P(y) rlm::sqrt32_1p(y)
-#define R_SQRT1M(t) rlm::sqrt32<false>(1.0f - (t))
-#else
 #define R_DIV(a, b) ((a) * __builtin_amdgcn_rcpf(b))
 #define R_RCP(b) __builtin_amdgcn_rcpf(b)
 #define R_RCPW(b) __builtin_amdgcn_rcpf(b)
@@ -113,7 +97,6 @@ RLS_DEV float refined_div(float a, float b)
 #define R_SQRT(x) __builtin_amdgcn_sqrtf(x)
 #define R_SQRT1P(y) __builtin_amdgcn_sqrtf(1.0f + (y))
 #define R_SQRT1M(t) __builtin_amdgcn_sqrtf(1.0f - (t))
-#endif
 #define R_EXP(x) __expf(x)
 #define R_EXP_IN_RANGE(x) __expf(x)
 #define R_LOG(x) __logf(x)
@@ -166,7 +149,7 @@ RLS_DEV void stage_libm_tables()
 {
     const uint64_t *src = reinterpret_cast<const uint64_t *>(&c_libm_tables);
     uint64_t *dst = reinterpret_cast<uint64_t *>(&s_libm_tables);
-    for (unsigned t = threadIdx.x; t < sizeof(rlm::Tables) / 8; t += blockDim.x) dst[t] = src[t];
+    for (unsigned t = threadIdx.x; t < sizeof(rlm::Tables) / 8; t += RLS_BLOCK) dst[t] = src[t];      // every launch is RLS_BLOCK threads wide
     __syncthreads();
 }
 #define R_EXP(x) rlm::exp32(x, s_libm_tables)

@@ -19,6 +19,11 @@ struct rls_context {
     unsigned long long *scratch_u64;   // device, 8 bytes (checksum accumulator)
     int fast;                 // RLS_MATH_FAST selected (rls_context_set_math_mode)
     int capturing;            // between rls_graph_begin_capture and rls_graph_end_capture
+    // rls_diag_clock_stamps_*: while `stamps` is set the four BASELINE kernels launch their stamped instantiation
+    // (ClockStamp below); word 0 of the buffer holds the slot count, workgroup b writes words 4 + 4 b .. 7 + 4 b
+    unsigned long long *stamps;       // = stamp_buf between rls_diag_clock_stamps_begin and _end, else NULL
+    unsigned long long *stamp_buf;    // device, 8 * (4 + 4 * stamp_slots) bytes, allocated by the first _begin
+    int64_t stamp_slots;
 };
 
 // Every kernel translation unit is compiled twice: with RLS_FAST=0 it carries the C ABI and the
@@ -379,6 +384,34 @@ RLS_DEV IO reload_args(const IO &a)
     return a;
 #endif
 }
+
+// In-kernel clock stamps, for the DIAGNOSTIC instantiations of the four BASELINE kernels only (`*_kernel_stamped`, launched
+// while rls_diag_clock_stamps_begin is in force; the product kernels instantiate ClockStamp<0>, which is empty: no stamp
+// executes in them and their code is unchanged -- checked on the disassembly, profiles/r05_stamped_isa.txt).  Wave 0 of
+// every workgroup reads the shader-clock counter (s_memtime: one tick per shader cycle) and the constant 100 MHz counter
+// (s_memrealtime) on entry and on exit; effective clock of that workgroup's lifetime = d(memtime) / d(memrealtime) x 100 MHz
+// (MI355X_MICROARCH.md, "DVFS give-back" item 6).  The stamps go to a buffer of their own; no output depends on them.
+template <int STAMP> struct ClockStamp {
+    RLS_DEV void begin() {}
+    RLS_DEV void end(unsigned long long *) {}
+};
+template <> struct ClockStamp<1> {
+    unsigned long long t0, r0;
+    RLS_DEV void begin()
+    {
+        t0 = __builtin_amdgcn_s_memtime();
+        r0 = __builtin_amdgcn_s_memrealtime();
+    }
+    RLS_DEV void end(unsigned long long *buf)
+    {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0 && buf != nullptr && (unsigned long long)blockIdx.x < buf[0]) {
+            unsigned long long *w = buf + 4 + 4 * (size_t)blockIdx.x;
+            w[0] = t0; w[1] = t1; w[2] = r0; w[3] = r1;
+        }
+    }
+};
 
 RLS_DEV int64_t idx_full(int64_t i) { return i; }
 RLS_DEV int64_t idx_full(const Idx &i) { return i.full(); }

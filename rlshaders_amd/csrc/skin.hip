@@ -74,8 +74,10 @@ enum { MIXED = 0, STREAMED_ALL = 1, UNIFORM_ALL = 2 };
 #define RLS_SKIN_WAVES 6
 #endif
 #define RLS_SKIN_ATTR __launch_bounds__(rlsh::kBlock) __attribute__((amdgpu_waves_per_eu(RLS_SKIN_WAVES, RLS_SKIN_WAVES)))
+// the kernel body: inlined into skin_kernel (the product) and skin_kernel_stamped (diagnostic: the same body between clock
+// stamps, rls_internal.hpp ClockStamp).  a0 is the kernel's first parameter (reload_args).
 template <int FAST_MATH, int MODE>
-__global__ RLS_SKIN_ATTR void skin_kernel(SkinIO a0)
+__device__ __forceinline__ void skin_body(const SkinIO &a0)
 {
     constexpr bool STREAMED = MODE == STREAMED_ALL, UNIFORM = MODE == UNIFORM_ALL;
     stage_libm_tables();   // expf / logf tables -> LDS (EXACT mode)
@@ -179,6 +181,21 @@ __global__ RLS_SKIN_ATTR void skin_kernel(SkinIO a0)
     }
 }
 
+template <int FAST_MATH, int MODE>
+__global__ RLS_SKIN_ATTR void skin_kernel(SkinIO a0)
+{
+    skin_body<FAST_MATH, MODE>(a0);
+}
+
+template <int FAST_MATH, int MODE>
+__global__ RLS_SKIN_ATTR void skin_kernel_stamped(SkinIO a0, unsigned long long *stamps)
+{
+    ClockStamp<1> cs;
+    cs.begin();
+    skin_body<FAST_MATH, MODE>(a0);
+    cs.end(stamps);
+}
+
 rls_status launch_kernel(rls_context *ctx, const SkinIO &io, const char *name)
 {
     const rls_skin_closure &c = io.c;
@@ -192,7 +209,9 @@ rls_status launch_kernel(rls_context *ctx, const SkinIO &io, const char *name)
                          !c.specular_weight.v && !c.specular_roughness.v && !c.specular_ior.v && !c.sheen_color.r &&
                          !c.sheen_weight.v && !c.sheen_roughness.v && !c.sheen_ior.v;
     const dim3 grid = rlsh::grid_for(ctx, io.n, rlsh::kBlock, RLS_CAP_MULT);
-    if (streamed)
+    if (streamed && ctx->stamps)      // BASELINE config 5 under rls_diag_clock_stamps_begin: the stamped instantiation
+        hipLaunchKernelGGL((skin_kernel_stamped<RLS_FAST, STREAMED_ALL>), grid, dim3(rlsh::kBlock), 0, ctx->stream, io, ctx->stamps);
+    else if (streamed)
         hipLaunchKernelGGL((skin_kernel<RLS_FAST, STREAMED_ALL>), grid, dim3(rlsh::kBlock), 0, ctx->stream, io);
     else if (uniform)   // a thread that hoists wants many tiles to spread the hoisted work over (grid_for_hoisting)
         hipLaunchKernelGGL((skin_kernel<RLS_FAST, UNIFORM_ALL>), rlsh::grid_for_hoisting(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);

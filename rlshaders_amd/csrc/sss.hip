@@ -23,9 +23,6 @@ enum { OP_ND = rlsh::SOP_ND, OP_ND_PDF = rlsh::SOP_ND_PDF, OP_ND_EVAL = rlsh::SO
 enum { OP_CAVITY = rlsh::MOP_CAVITY, OP_DIFFUSE_DIR = rlsh::MOP_DIFFUSE_DIR, OP_UTIL = rlsh::MOP_UTIL,
        OP_REFLECT_LUM = rlsh::MOP_REFLECT_LUM };
 
-#ifndef RLS_SSS_TWO_TILES           // experiment switch, see sss_kernel
-#define RLS_SSS_TWO_TILES 0
-#endif
 #ifndef RLS_ND_ONE_SAMPLE_RECIP     // experiment switch: the one-sample kernels keep the reciprocals of c1 + 3 c2 as well
 #define RLS_ND_ONE_SAMPLE_RECIP 0
 #endif
@@ -66,81 +63,18 @@ enum { PER_POINT = 0, UNIFORM_DISTANCE = 1, BY_REFERENCE = 2 };
 #ifndef RLS_SSS_WAVES
 #define RLS_SSS_WAVES(MODE) ((MODE) == UNIFORM_DISTANCE ? 7 : 8)
 #endif
-template <int OP, int MODE, int FAST_MATH = RLS_FAST>
-__global__ __launch_bounds__(rlsh::kBlock) __attribute__((amdgpu_waves_per_eu(RLS_SSS_WAVES(MODE), RLS_SSS_WAVES(MODE))))
-void sss_kernel(SssIO a0)
+#define RLS_SSS_ATTR(MODE) __launch_bounds__(rlsh::kBlock) __attribute__((amdgpu_waves_per_eu(RLS_SSS_WAVES(MODE), RLS_SSS_WAVES(MODE))))
+// the kernel body: inlined into sss_kernel (the product) and sss_kernel_stamped (diagnostic: the same body between clock
+// stamps, rls_internal.hpp ClockStamp).  a0 is the kernel's first parameter (reload_args).
+template <int OP, int MODE, int FAST_MATH>
+__device__ __forceinline__ void sss_body(const SssIO &a0)
 {
     stage_libm_tables();   // expf / logf tables -> LDS (EXACT mode)
     constexpr bool UNIFORM = MODE == UNIFORM_DISTANCE;
     NdProfile pu = {};
     if (UNIFORM) pu = uniform_profile(a0.c);
     const TileRange tiles = tile_range(a0.n);
-#if RLS_SSS_TWO_TILES
-    // Experiment (round 4): two tiles per loop iteration and lane -- the loads of both issued ahead of the
-    // arithmetic of either, the stores of both after it: twice the memory-level parallelism per wave and two independent
-    // instruction streams for the scheduler.  Measured: profiles/r04_sss_two_points.txt.  Off.
-    if ((OP == OP_PROBE || OP == OP_ND) && MODE == PER_POINT) {
-        for (int64_t base = tiles.first; base < tiles.end; base += 2 * tiles.step) {
-            const Idx i0 = make_idx(base), i1 = make_idx(base + tiles.step);
-            const bool ok0 = i0.full() < a0.n, ok1 = base + tiles.step < tiles.end && i1.full() < a0.n;
-            const SssIO a = reload_args(a0);
-            float in[2][12];
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                const Idx i = t ? i1 : i0;
-#pragma unroll
-                for (int k = 0; k < 12; k++) in[t][k] = 1.0f;
-                if (t ? ok1 : ok0) {
-                    in[t][0] = ldp(a.c.sss_dist_multiplier, i);
-#pragma unroll
-                    for (int k = 0; k < 3; k++) in[t][1 + k] = ldp(a.c.sss_scatter_dist[k], i);
-                    in[t][4] = ldg(a.rx, i);
-                    if (OP == OP_PROBE) {
-                        in[t][5] = ldg(a.ry, i);
-                        V3 N = ld3(a.c.N, i), T = ld3(a.c.T, i);
-                        in[t][6] = N.x; in[t][7] = N.y; in[t][8] = N.z; in[t][9] = T.x; in[t][10] = T.y; in[t][11] = T.z;
-                    }
-                }
-            }
-            float out[2][12];
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                const float m = in[t][0];
-                NdProfile p = nd_make<RLS_ND_ONE_SAMPLE_RECIP != 0>(in[t][1] * m, in[t][2] * m, in[t][3] * m);
-                float r, pdf, R, G, B;
-                if (OP == OP_ND) {
-                    r = nd_radius(p, in[t][4]);
-                } else {
-                    Frame fr = sss_frame(mk(in[t][6], in[t][7], in[t][8]), mk(in[t][9], in[t][10], in[t][11]), a.c.has_dPdu != 0);
-                    V3 off, dir;
-                    float maxdist;
-                    r = sss_probe_ray(p, fr, in[t][4], in[t][5], off, dir, maxdist);
-                    out[t][5] = off.x; out[t][6] = off.y; out[t][7] = off.z; out[t][8] = dir.x; out[t][9] = dir.y; out[t][10] = dir.z;
-                    out[t][11] = maxdist;
-                }
-                nd_pdf_profile(p, r, pdf, R, G, B);
-                out[t][0] = r; out[t][1] = pdf; out[t][2] = R; out[t][3] = G; out[t][4] = B;
-            }
-            const SssIO b = reload_args(a0);
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                const Idx i = t ? i1 : i0;
-                if (!(t ? ok1 : ok0)) continue;
-                stg(b.r, i, out[t][0]);
-                stg(b.pdf, i, out[t][1]);
-                strgb(b.profile, i, out[t][2], out[t][3], out[t][4]);
-                if (OP == OP_PROBE) {
-                    V3 off = mk(out[t][5], out[t][6], out[t][7]);
-                    if (b.P.x) off = ld3(b.P, i) + off;
-                    st3(b.origin, i, off);
-                    st3(b.dir, i, mk(out[t][8], out[t][9], out[t][10]));
-                    stg(b.maxdist, i, out[t][11]);
-                }
-            }
-        }
-        return;
-    }
-#endif
+    // (two tiles per loop iteration and lane were tried in round 4 and lose: profiles/r04_sss_two_points.txt)
     for (int64_t base = tiles.first; base < tiles.end; base += tiles.step) {
         const Idx i = make_idx(base);
         if (i.full() >= a0.n) continue;
@@ -179,6 +113,21 @@ void sss_kernel(SssIO a0)
             stg(a.pdf, i, sss_mis_pdf(p, fr, ld3(a.disp, i), ld3(a.sampleN, i), a.literal != 0));
         }
     }
+}
+
+template <int OP, int MODE, int FAST_MATH = RLS_FAST>
+__global__ RLS_SSS_ATTR(MODE) void sss_kernel(SssIO a0)
+{
+    sss_body<OP, MODE, FAST_MATH>(a0);
+}
+
+template <int OP, int MODE, int FAST_MATH = RLS_FAST>
+__global__ RLS_SSS_ATTR(MODE) void sss_kernel_stamped(SssIO a0, unsigned long long *stamps)
+{
+    ClockStamp<1> cs;
+    cs.begin();
+    sss_body<OP, MODE, FAST_MATH>(a0);
+    cs.end(stamps);
 }
 
 
@@ -228,6 +177,12 @@ rls_status launch_kernel(rls_context *ctx, const SssIO &io, const char *name)
                          !c.sss_scatter_dist[2].v;
     // evalProfile alone uses nothing setDistance computes but maxR: no uniform specialisation of it
     constexpr bool kHoists = OP != OP_ND_EVAL;
+    if constexpr (OP == OP_PROBE) {      // BASELINE config 4 under rls_diag_clock_stamps_begin: the stamped instantiation
+        if (ctx->stamps && !c.materials.id && !(uniform && kHoists)) {
+            hipLaunchKernelGGL((sss_kernel_stamped<OP, PER_POINT>), rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io, ctx->stamps);
+            return rlsh::check_launch(name);
+        }
+    }
     if (c.materials.id)
         hipLaunchKernelGGL((sss_kernel<OP, BY_REFERENCE>), rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
     else if (uniform && kHoists)

@@ -137,6 +137,11 @@ def hardware_threads() -> int:
     return int(lib().orc_hardware_threads())
 
 
+def set_closure_alloc(on: bool) -> None:
+    """orc_set_closure_alloc: orc_ggx_init pays the reference's per-closure heap allocation (src/rlGgx.h:152) or not."""
+    lib().orc_set_closure_alloc(1 if on else 0)
+
+
 def f32(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.float32)
 

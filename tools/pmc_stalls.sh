@@ -1,33 +1,24 @@
 #!/bin/bash
-# Where the waves of a workload's dominant kernel spend their cycles: busy / wait counters of the SQ, per launch.
-# usage: tools/pmc_stalls.sh <workload>...   -> gpurun_out/pmc_stalls.txt
-cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-OUT=gpurun_out/pmc_stalls.txt; : > $OUT
-for W in "$@"; do
-  d=gpurun_out/stalls_$W; rm -rf $d; mkdir -p $d
-  SHORT="python3 bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --arena-candidates 1"
-  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $d/a -- $SHORT > /dev/null 2>&1
-  rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM --output-format csv -d $d/b -- $SHORT > /dev/null 2>&1
-  rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT --output-format csv -d $d/c -- $SHORT > /dev/null 2>&1
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $d/e -- $SHORT > /dev/null 2>&1
-  rocprofv3 --pmc SQ_INST_CYCLES_SALU SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT --output-format csv -d $d/f -- $SHORT > /dev/null 2>&1
-  python3 - "$d" "$W" <<'PY' >> $OUT
-import csv, glob, sys
-d, w = sys.argv[1:3]
-acc = {}
-for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
-    per = {}
-    for r in csv.DictReader(open(f)):
-        if not any(k in r["Kernel_Name"] for k in ("skin_kernel", "ggx_kernel", "sss_kernel", "disney_kernel", "integrate_kernel", "shade_kernel", "scatter_kernel", "direct_kernel")): continue
-        per.setdefault((r["Counter_Name"], r["Dispatch_Id"]), 0.0)
-        per[(r["Counter_Name"], r["Dispatch_Id"])] += float(r["Counter_Value"])
-    for (c, _), v in per.items():
-        acc.setdefault(c, []).append(v)
-m = {k: sum(v) / len(v) for k, v in acc.items()}
-wc = m.get("SQ_WAVE_CYCLES", 0) or 1
-print(w)
-for k in sorted(m):
-    print(f"   {k:24s} {m[k]:.4g}   / wave_cycles {m[k] / wc:.4f}" + (f"   per wave {m[k] / m['SQ_WAVES']:.1f}" if m.get("SQ_WAVES") and k.startswith("SQ_INSTS") else ""))
-PY
-done
-cat $OUT
+# Where the waves of a workload's dominant kernel spend their cycles: busy / wait / issue counters of the SQ per launch, BY
+# EXACT KERNEL NAME (the name bench.py prints as roofline.kernel -- `ggx_kernel<5, 0, 1>` is the EXACT kernel, `<5, 1, 1>`
+# the FAST one, `ggx_kernel_stamped<...>` the diagnostic instantiation: neither of the latter two is counted), with the
+# profiled command launching nothing but the measured kernel (--no-other-mode --no-clock).
+# usage: tools/pmc_stalls.sh <tag> <workload> [bench args ...]   -> gpurun_out/stalls_<tag>_<workload>/ ;
+#        tools/summarize_stalls.py <tag> <workload> turns that into profiles/<tag>_<workload>_stalls.json
+set -u
+TAG=$1; W=$2; shift 2
+R=$PWD
+cd /tmp && export TMPDIR=/tmp && cd $R
+d=$R/gpurun_out/stalls_${TAG}_$W; rm -rf $d; mkdir -p $d
+SHORT="python3 bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-other-mode --no-clock --arena-candidates 1 --workloads none $*"
+$SHORT > $d/bench.json 2> $d/bench.err
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $d/a -- $SHORT > /dev/null 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM --output-format csv -d $d/b -- $SHORT > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT --output-format csv -d $d/c -- $SHORT > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $d/e -- $SHORT > /dev/null 2>&1
+rocprofv3 --pmc SQ_INST_CYCLES_SALU SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT --output-format csv -d $d/f -- $SHORT > /dev/null 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $d/g -- $SHORT > /dev/null 2>&1
+rocprofv3 --pmc SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INSTS_VMEM SQ_IFETCH --output-format csv -d $d/h -- $SHORT > /dev/null 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU2 SQ_THREAD_CYCLES_VALU SQ_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d $d/i -- $SHORT > /dev/null 2>&1
+rocprofv3 --pmc SQ_INST_CYCLES_SMEM SQ_LEVEL_WAVES SQ_INST_LEVEL_VMEM SQ_IFETCH_LEVEL --output-format csv -d $d/j -- $SHORT > /dev/null 2>&1
+echo "$W: $(find $d -name '*counter_collection.csv' | wc -l) counter files; $(tail -c 200 $d/bench.err)"

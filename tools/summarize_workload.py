@@ -34,6 +34,48 @@ def pmc(dirname, sub):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
+def clock_record(src, dst, tag, workload, ksub, math):
+    """profiles/<tag>_<workload>_clock.json: the shader clock the kernel holds, two independent ways --
+    (a) GRBM_GUI_ACTIVE / 8 / dispatch duration per dispatch of the exact kernel (rocprofv3 --pmc pass on a batch large enough
+        for dispatches of >= 10 ms, where the quotient is within 3 % of the in-kernel clock: MI355X_MICROARCH.md, DVFS give-back);
+    (b) the in-kernel stamps (s_memtime / s_memrealtime, stamped instantiation) after two seconds of back-to-back launches
+        (bench.py --sustain-seconds 2).  `effective_clock_ghz` = (b) when there is one, else (a)."""
+    rec = {"workload": workload, "math": math, "kernel": ksub}
+    clocks, durs = [], []
+    for f in newest(glob.glob(os.path.join(src, "clock_grbm", "**", "*counter_collection.csv"), recursive=True)):
+        per = {}                                        # rows of one dispatch (one per XCD, if rocprofv3 splits them) add up
+        for r in csv.DictReader(open(f)):
+            if ksub in r["Kernel_Name"] and r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                e = per.setdefault(r["Dispatch_Id"], [0.0, float(r["End_Timestamp"]) - float(r["Start_Timestamp"])])
+                e[0] += float(r["Counter_Value"])
+        for v, d in per.values():
+            if d > 0:
+                clocks.append(v / 8.0 / d)
+                durs.append(d / 1e6)
+    if clocks:
+        clocks.sort(); durs.sort()
+        rec["grbm_clock_ghz"] = round(clocks[len(clocks) // 2], 4)
+        rec["grbm_dispatch_ms"] = round(durs[len(durs) // 2], 4)
+        rec["grbm_dispatches"] = len(clocks)
+    p = os.path.join(src, "clock_sustained.json")
+    if os.path.exists(p):
+        recs = [json.loads(l) for l in open(p).read().splitlines() if l.startswith("{")]
+        full = [r for r in recs if r.get("record") == "headline_detail"]
+        if full and full[-1]["roofline"].get("clock"):
+            c = full[-1]["roofline"]["clock"]
+            rec["sustained_clock_ghz"] = c["effective_clock_ghz"]
+            rec["stamps"] = c
+            rec["sustained_kernel_ms"] = full[-1]["roofline"]["kernel_ms"]
+    ghz = rec.get("sustained_clock_ghz") or rec.get("grbm_clock_ghz")
+    if not ghz:
+        return
+    rec["effective_clock_ghz"] = ghz
+    rec["source"] = ("tools/profile_workload.sh: rocprofv3 --pmc GRBM_GUI_ACTIVE (own pass) and bench.py --sustain-seconds 2 "
+                     "(in-kernel stamps, rls_diag_clock_stamps_*)")
+    json.dump(rec, open(os.path.join(dst, f"{tag}_{workload}_clock.json"), "w"), indent=1)
+    print("clock", {k: rec[k] for k in rec if k.endswith("ghz") or k.endswith("_ms")})
+
+
 def main():
     tag, workload = sys.argv[1], sys.argv[2]
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{workload}")
@@ -79,6 +121,7 @@ def main():
                        "the factor measured on rls_checksum (known byte count) in the same session"}
         json.dump(t, open(os.path.join(dst, f"{tag}_{workload}_traffic.json"), "w"), indent=1)
         print("traffic", t["hbm_bytes_per_launch"], "ratio", t["ratio_to_algorithmic"])
+    clock_record(src, dst, tag, workload, ksub, math)
     mix = {}
     for d in ("mix_a", "mix_b", "mix_c", "mix_d"):
         mix.update(pmc(os.path.join(src, d), ksub))

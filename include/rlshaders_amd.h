@@ -132,15 +132,19 @@ const char *rls_status_string(rls_status s);
 int         rls_version(void);                 /* major*1000 + minor */
 /* Which host libm the EXACT kernels reproduce bit for bit.  The reference's closures call sinf / cosf / expf / logf / powf /
  * atan2f / acosf / tanf of the C library the renderer runs on (src/rlGgx.cpp:27-58, src/rlDisney.cpp:177,399,549,576,
- * src/rlSss.cpp:31-32,59,62,78-79,102); this library restates glibc's (>= 2.28) algorithms, and of glibc's two x86-64 builds
- * the one chosen when the library was compiled: rls_libm_flavour() returns "glibc-fma" (the build glibc's ifunc selects on
- * every CPU with AVX2 + FMA) or "glibc-sse2".
+ * src/rlSss.cpp:31-32,59,62,78-79,102); this library restates glibc's algorithms (verified range 2.28 <= glibc < 2.41: the
+ * code was read from the disassembly of 2.35; glibc 2.41 replaced tanf / acosf / atan2f and others by correctly rounded
+ * CORE-MATH versions, and a host with such a glibc reports mismatches > 0 through the tanf / acosf / atan2f probes below;
+ * provenance and licences: THIRD_PARTY.md), and of glibc's two x86-64 builds the one chosen when the library was compiled:
+ * rls_libm_flavour() returns "glibc-fma" (the build glibc's ifunc selects on every CPU with AVX2 + FMA) or "glibc-sse2".
  * rls_host_libm_matches() asks the CALLER's libm (the one this process resolves): the 42 fp32 arguments on which the two
  * glibc builds differ -- every such argument of sinf / cosf / expf / powf(x, 5), found by sweeping all 2^32 -- must give the
  * followed build's result, and this library's routines compiled for the host must agree with the host's on 4096 arguments
  * per function (a libm that is neither build).  *mismatches = the number of disagreements.  "Bit for bit like the CPU
- * closures" holds on THIS host only when it is 0; otherwise results stay within the 1e-5 contract and differ in the last
- * bit on a ~1e-8 ... 1e-6 share of arguments (glibc's other build) or more (another C library).  Needs no device.
+ * closures" holds on THIS host if and only if it is 0.  Otherwise the elementary functions differ in the last bit on a
+ * ~1e-8 ... 1e-6 share of arguments (glibc's other build) or more (a newer glibc, musl, MSVC's UCRT -- the reference
+ * author's platform, rlShaders.sln), and chained closure outputs show SURVEY.md Appendix D's alternate-libm tail: 0.009-0.14 %
+ * of them beyond 1e-5 relative -- the reference disagreeing with itself across platforms.  Needs no device.
  * (The library builds in either flavour -- `python -m rlshaders_amd.build --variant sse2 -DRLM_GLIBC_FMA=0` -- and the SSE2
  * flavour is checked against glibc's SSE2 build the same way: 0 differences on all 2^32 arguments per function.) */
 const char *rls_libm_flavour(void);

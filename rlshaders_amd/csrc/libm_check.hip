@@ -2,10 +2,12 @@
 //
 // "Bit for bit like the CPU closures" is a statement about one libm: the reference's closures call sinf / cosf / expf /
 // logf / powf / atan2f / acosf / tanf of whatever C library the renderer runs on (src/rlGgx.cpp:27-58, src/rlDisney.cpp:177,
-// 399,549,576, src/rlSss.cpp:31-32,59,62,78-79,102); csrc/rls_libm.hpp restates glibc's (>= 2.28) algorithms, and of the two
-// x86-64 builds glibc ships the one RLM_GLIBC_FMA selects at compile time.  A host with another C library (musl, MSVC's
-// UCRT, glibc on a CPU without FMA when the library follows the FMA build) gets results within the 1e-5 contract but not
-// bit-identical ones; these two entry points let a host ask instead of assume.
+// 399,549,576, src/rlSss.cpp:31-32,59,62,78-79,102); csrc/rls_libm.hpp restates glibc's algorithms (verified range 2.28 <=
+// glibc < 2.41, read from 2.35; 2.41's correctly rounded tanf / acosf / atan2f are a different libm and fail part 2 below), and
+// of the two x86-64 builds glibc ships the one RLM_GLIBC_FMA selects at compile time.  A host with another C library (a newer
+// glibc, musl, MSVC's UCRT, glibc on a CPU without FMA when the library follows the FMA build) gets the alternate-libm tail
+// of SURVEY.md Appendix D (0.009-0.14 % of chained outputs beyond 1e-5), not bit-identical results; these two entry points
+// let a host ask instead of assume.
 #include <math.h>
 
 #include "rls_internal.hpp"

@@ -386,8 +386,8 @@ RLS_DEV IO reload_args(const IO &a)
 }
 
 // In-kernel clock stamps, for the DIAGNOSTIC instantiations of the four BASELINE kernels only (`*_kernel_stamped`, launched
-// while rls_diag_clock_stamps_begin is in force; the product kernels instantiate ClockStamp<0>, which is empty: no stamp
-// executes in them and their code is unchanged -- checked on the disassembly, profiles/r05_stamped_isa.txt).  Wave 0 of
+// while rls_diag_clock_stamps_begin is in force; the product kernels share the body and contain no counter read -- the
+// disassembly before and after the split: profiles/r05_stamped_isa.txt).  Wave 0 of
 // every workgroup reads the shader-clock counter (s_memtime: one tick per shader cycle) and the constant 100 MHz counter
 // (s_memrealtime) on entry and on exit; effective clock of that workgroup's lifetime = d(memtime) / d(memrealtime) x 100 MHz
 // (MI355X_MICROARCH.md, "DVFS give-back" item 6).  The stamps go to a buffer of their own; no output depends on them.

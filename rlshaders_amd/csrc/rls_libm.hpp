@@ -7,9 +7,7 @@
 // functions differently from the libm the reference's CPU build links (glibc on Linux), so the
 // only way to make the GPU closures agree with the CPU closures on every point -- not just on
 // the well-conditioned ones -- is to compute the angles with the same algorithms:
-//   * atanf / atan2f / acosf / tanf: the fdlibm single-precision algorithms (Sun Microsystems,
-//     1993; "Permission to use, copy, modify, and distribute this software is freely granted,
-//     provided that this notice is preserved") that glibc <= 2.40 ships in
+//   * atanf / atan2f / acosf / tanf: the fdlibm single-precision algorithms (notice below) that glibc <= 2.40 ships in
 //     sysdeps/ieee754/flt-32/{s_atanf,e_atan2f,e_acosf,s_tanf,k_tanf,e_rem_pio2f}.c -- pure
 //     fp32 + - * / sqrt sequences, reproducible exactly with FMA contraction off;
 //   * sinf / cosf: the double-precision polynomial scheme of glibc >= 2.28 (s_sincosf.h, from
@@ -22,6 +20,21 @@
 //
 // The header compiles for the host too (tests/test_libm_faithful.py builds it with g++ and
 // compares every routine against the host libm over millions of arguments, bit for bit).
+//
+// Provenance and licences of what is restated here: THIRD_PARTY.md at the repository root.  The fdlibm routines (atan32,
+// atan2_32, acos32, kernel_tan32 / tan32 and their variants below) derive from code that carries this notice:
+/*
+ * ====================================================
+ * Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.
+ *
+ * Developed at SunPro, a Sun Microsystems, Inc. business.
+ * Permission to use, copy, modify, and distribute this
+ * software is freely granted, provided that this notice
+ * is preserved.
+ * ====================================================
+ */
+// The sinf / cosf / expf / logf / powf routines restate Arm Optimized Routines (Copyright (c) 2017-2018, Arm Limited; MIT);
+// glibc contributed observed behaviour only (which steps its FMA build fuses), no code.
 #pragma once
 
 #include <math.h>

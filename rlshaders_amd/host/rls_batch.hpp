@@ -57,8 +57,9 @@ inline Shard shardRange(int64_t total, int rank, int world)
 inline int deviceCount() { return rls_device_count(); }
 
 // Which host libm the EXACT kernels reproduce, and whether THIS process's libm is that one (rls_host_libm_matches): the
-// first Device of a process asks once and says so on stderr when it is not -- results then stay within the 1e-5 contract
-// of the CPU closures on this host, but are not bit-identical to them.  RLS_QUIET_LIBM_CHECK=1 silences it.
+// first Device of a process asks once and says so on stderr when it is not -- results are then not bit-identical to the CPU
+// closures on this host and show the alternate-libm tail of SURVEY.md Appendix D (0.009-0.14 % of chained outputs beyond 1e-5
+// relative: the reference disagreeing with itself across C libraries).  RLS_QUIET_LIBM_CHECK=1 silences it.
 inline const char *libmFlavour() { return rls_libm_flavour(); }
 inline int hostLibmMismatches()
 {

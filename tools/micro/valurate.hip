@@ -1,6 +1,11 @@
 // Issue cost of single VALU opcodes on gfx950: each kernel runs a long unrolled stream of ONE instruction over eight
 // independent register chains (no dependency stalls), W waves per SIMD; cost = SIMD-cycles per wave-instruction.
+// Round 5: every kernel stamps s_memtime / s_memrealtime around its loop (first wave of each workgroup), so the cost is
+// printed in TRUE shader cycles (at the clock the stream actually held) beside the figure at the 2.4 GHz attribute clock
+// that round 2 printed: the chip holds 1.7 GHz under a dense fp32-fma stream and 2.3 GHz under a transcendental one.
 // build: hipcc --offload-arch=gfx950 -O3 -o valurate valurate.hip ; run: ./valurate
+// under `rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VALU2 SQ_INSTS_VALU SQ_CYCLES -- ./valurate 8` (W = 8 only) the
+// per-kernel counters say what one instruction of each class does to the two counters the stall analysis rests on.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -20,8 +25,12 @@ constexpr int kIters = 2048, kChains = 8;
     }                                                                                                    \
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
 
+#define STAMP_BEGIN const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#define STAMP_END                                                                                       \
+    { const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();  \
+      if (threadIdx.x == 0) { st[2 * blockIdx.x] = t1 - t0; st[2 * blockIdx.x + 1] = r1 - r0; } }
 #define KERNEL(NAME, ASM)                                                                                \
-    __global__ void NAME(const float *p, float *out) { const float t = (float)threadIdx.x * 1e-9f; BODY(ASM) }
+    __global__ void NAME(const float *p, float *out, unsigned long long *st) { const float t = (float)threadIdx.x * 1e-9f; STAMP_BEGIN BODY(ASM) STAMP_END }
 
 #define A_FMA(i) "v_fma_f32 %" #i ", %" #i ", %8, %9\n"
 #define A_MUL(i) "v_mul_f32 %" #i ", %" #i ", %8\n"
@@ -69,23 +78,27 @@ KERNEL(k_fract, A_FRACT) KERNEL(k_dscale, A_DSCALE) KERNEL(k_dfmas, A_DFMAS) KER
     }                                                                                                    \
     out[blockIdx.x * blockDim.x + threadIdx.x] = (float)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7);
 #define KERNEL64(NAME, ASM)                                                                              \
-    __global__ void NAME(const float *p, float *out) { const double t = (double)threadIdx.x * 1e-9; BODY64(ASM) }
+    __global__ void NAME(const float *p, float *out, unsigned long long *st) { const double t = (double)threadIdx.x * 1e-9; STAMP_BEGIN BODY64(ASM) STAMP_END }
 #define D_FMA(i) "v_fma_f64 %" #i ", %" #i ", %8, %9\n"
 #define D_MUL(i) "v_mul_f64 %" #i ", %" #i ", %8\n"
 #define D_ADD(i) "v_add_f64 %" #i ", %" #i ", %8\n"
 KERNEL64(k_fma64, D_FMA) KERNEL64(k_mul64, D_MUL) KERNEL64(k_add64, D_ADD) KERNEL64(k_pkfma, A_PKFMA)
 
-typedef void (*kern_t)(const float *, float *);
+typedef void (*kern_t)(const float *, float *, unsigned long long *);
 struct Case { const char *name; kern_t k; int per_chain; };
 
-int main()
+#include <algorithm>
+#include <vector>
+int main(int argc, char **argv)
 {
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
     int khz = 0;
     CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, 0));
+    const int only_w = argc > 1 ? atoi(argv[1]) : 0;          // ./valurate 8: W = 8 only (PMC runs)
     float *p, *out;
+    unsigned long long *st;
     float hp[10] = {1.1f, 1.2f, 1.3f, 1.4f, 1.5f, 1.6f, 1.7f, 1.8f, 0.999f, 0.001f};
     CHECK(hipMalloc(&p, sizeof(hp)));
     CHECK(hipMemcpy(p, hp, sizeof(hp), hipMemcpyHostToDevice));
@@ -102,26 +115,36 @@ int main()
     };
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    printf("%d CUs, clock attribute %d MHz; cycles per wave-instruction per SIMD at W waves per SIMD (at the attribute clock)\n", cus, khz / 1000);
-    printf("%-20s %8s %8s %8s\n", "instruction", "W=1", "W=4", "W=8");
+    printf("%d CUs, clock attribute %d MHz; per wave64 instruction per SIMD at W waves per SIMD: cycles at the attribute clock | "
+           "clock held (GHz, in-kernel stamps) | TRUE cycles\n", cus, khz / 1000);
+    printf("%-20s %26s %26s %26s\n", "instruction", "W=1", "W=4", "W=8");
     for (const Case &c : cases) {
         printf("%-20s", c.name);
         for (int W : {1, 4, 8}) {
+            if (only_w && W != only_w) continue;
             const int blocks = cus * W;
             CHECK(hipMalloc(&out, (size_t)blocks * block * 4));
-            c.k<<<blocks, block>>>(p, out);
+            CHECK(hipMalloc(&st, (size_t)blocks * 16));
+            for (int r = 0; r < 20; r++) c.k<<<blocks, block>>>(p, out, st);       // ~0.1 s of the stream before it is timed
             CHECK(hipDeviceSynchronize());
             CHECK(hipEventRecord(e0));
-            for (int r = 0; r < 5; r++) c.k<<<blocks, block>>>(p, out);
+            for (int r = 0; r < 5; r++) c.k<<<blocks, block>>>(p, out, st);
             CHECK(hipEventRecord(e1));
             CHECK(hipEventSynchronize(e1));
             float ms;
             CHECK(hipEventElapsedTime(&ms, e0, e1));
             ms /= 5;
+            std::vector<unsigned long long> h((size_t)blocks * 2);
+            CHECK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
+            std::vector<double> ghz;
+            for (int b = 0; b < blocks; b++) if (h[2 * b + 1]) ghz.push_back((double)h[2 * b] / (double)h[2 * b + 1] * 0.1);
+            std::sort(ghz.begin(), ghz.end());
+            const double clock = ghz.empty() ? 0.0 : ghz[ghz.size() / 2];
             const double instr_per_simd = (double)W * kIters * kChains * c.per_chain;
             const double cycles = ms * 1e-3 * (double)khz * 1e3;
-            printf(" %8.2f", cycles / instr_per_simd);
+            printf("   %6.2f | %5.3f GHz | %5.2f", cycles / instr_per_simd, clock, cycles / instr_per_simd * clock * 1e6 / khz);
             CHECK(hipFree(out));
+            CHECK(hipFree(st));
         }
         printf("\n");
     }

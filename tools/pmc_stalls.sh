@@ -10,7 +10,8 @@ TAG=$1; W=$2; shift 2
 R=$PWD
 cd /tmp && export TMPDIR=/tmp && cd $R
 d=$R/gpurun_out/stalls_${TAG}_$W; rm -rf $d; mkdir -p $d
-SHORT="python3 bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-other-mode --no-clock --arena-candidates 1 --workloads none $*"
+# STALL_STEPS / STALL_WARMUP: 3 / 1 for a quick look; 20 / 10 gives the counters of warm launches at the clock the kernel settles at
+SHORT="python3 bench.py --workload $W --steps ${STALL_STEPS:-3} --warmup ${STALL_WARMUP:-1} --no-cpu-baseline --no-other-mode --no-clock --arena-candidates 1 --workloads none $*"
 $SHORT > $d/bench.json 2> $d/bench.err
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $d/a -- $SHORT > /dev/null 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM --output-format csv -d $d/b -- $SHORT > /dev/null 2>&1

@@ -52,7 +52,7 @@ def test_flags_are_the_parity_flags(built):
     from rlshaders_amd import build as b
     ninja = (built / "build.ninja")
     text = ninja.read_text() if ninja.exists() else "\n".join(p.read_text() for p in built.rglob("flags.make"))
-    hip_lines = [l for l in text.splitlines() if "--offload-arch=gfx950" in l and "FLAGS" in l]
+    hip_lines = [l for l in text.splitlines() if "--offload-arch=gfx950" in l and l.strip().startswith(("FLAGS =", "HIP_FLAGS ="))]
     assert hip_lines
     for flag in b.HIPCC_FLAGS:
         if flag.startswith("--offload-arch") or flag == "-fPIC":       # (CMake spells these itself)

@@ -12,10 +12,10 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _bench(world, extra=()):
+def _bench(world, extra=(), cpu_baseline=False):
     env = dict(os.environ, RLS_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     base = [str(ROOT / "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--log2-points", "20",
-            "--no-cpu-baseline", *extra]
+            *(("--cpu-seconds", "0.3") if cpu_baseline else ("--no-cpu-baseline",)), *extra]
     if world == 1:
         cmd = [sys.executable, *base]
     else:
@@ -147,6 +147,28 @@ def test_eight_rank_dress_rehearsal(config):
 
 
 @pytest.mark.gpu
+def test_multi_rank_line_is_self_sufficient():
+    """an N > 1 line carries `roofline` AND `cpu_baseline` (rank 0 times the CPU leg after the closing
+    barrier, outside the timed region, while the other ranks wait), `ranks` keeps distinct_devices, and both clocks of the
+    timed region are there: the slowest rank's own K steps (ms_per_step, what `value` is quoted on) and rank 0's
+    barrier-to-barrier wall (ms_per_step_wall).  Eight ranks over gloo on this box's one GPU."""
+    eight = _bench(8, cpu_baseline=True)
+    assert eight["n_gpus"] == 8 and eight["ranks"]["ranks_seen"] == 8
+    assert eight["ranks"]["distinct_devices"] == 1 and eight["ranks"]["world_size"] == 8
+    rf, cb = eight["roofline"], eight["cpu_baseline"]
+    assert rf["bound"] == "hbm" and rf["kernel_ms"] > 0 and 0 < rf["frac"] < 1
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+    assert cb["with_alloc"]["kind"] == "port+alloc" and 0 < cb["with_alloc"]["value"] <= cb["value"] * 1.25
+    assert eight["_detail"]["cpu_baseline"]["ranks_waiting"] == 7
+    # rank 0's wall clock between the barriers contains the slowest rank's own time up to the skew of the barrier exits
+    assert eight["ms_per_step_wall"] > 0 and eight["ms_per_step_wall"] >= 0.5 * eight["ms_per_step"]
+    # rank 0 measured the clock its kernel ran at (eight ranks share the GPU here: no statement about its value)
+    assert 0.5 < rf["effective_clock_ghz"] <= 2.45 and rf.get("issue_slot_frac_at_clock") is not None
+    one = _bench(1, cpu_baseline=True)
+    assert "ranks_waiting" not in one["_detail"]["cpu_baseline"] and one["cpu_baseline"]["with_alloc"]["value"] > 0
+
+
+@pytest.mark.gpu
 def test_default_shape_with_cpu_baseline():
     """the default command's shape at small sizes: configs block (3 records, each with its own cpu_baseline) printed before
     a headline that carries roofline and cpu_baseline"""
@@ -157,6 +179,8 @@ def test_default_shape_with_cpu_baseline():
     line = _parse(p.stdout)
     cb = line["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "Gsamples/s" and cb["sample"]
+    assert cb["with_alloc"]["kind"] == "port+alloc" and cb["with_alloc"]["value"] > 0
+    assert line["ms_per_step_wall"] > 0 and line["roofline"]["effective_clock_ghz"] > 0.5
     assert [r["name"] for r in line["workloads"]] == ["disney_integrate", "sss_probe", "skin"]
     assert all(r["cpu_baseline"]["value"] > 0 for r in line["workloads"])
     saved = json.loads((ROOT / "gpurun_out" / "bench_workloads.json").read_text())

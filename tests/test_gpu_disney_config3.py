@@ -258,6 +258,23 @@ def test_packed_rare_branches_with_every_lane_asking(gpu, oracle):
         cases.assert_tight(cases.summarize(cases.rel_err(a, b)), ("ggx every lane asks", nm))
 
 
+def _border_check(a, b, is_count, what):
+    """bit for bit (NaN where the oracle has NaN) under strict parity; on another libm flavour still: the same non-finite
+    pattern -- a wrong window guard of the loop reciprocals shows as NaN / inf / garbage, not as a last-bit difference --
+    sums within the tight tolerance, counts within flag_slack()"""
+    same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+    if cases.strict_parity():
+        assert same.all(), (what, int((~same).sum()))
+        return
+    assert np.array_equal(np.isfinite(a), np.isfinite(b)) and np.array_equal(np.isnan(a), np.isnan(b)), what
+    fin = np.isfinite(b)
+    if is_count:
+        assert int((a[fin] != b[fin]).sum()) <= cases.flag_slack() * 64, (what, int((a[fin] != b[fin]).sum()))
+    else:
+        cases.assert_tight(cases.summarize(cases.rel_err(a[..., fin] if a.ndim == 1 else a[:, fin.all(axis=0)],
+                                                         b[..., fin] if b.ndim == 1 else b[:, fin.all(axis=0)])), what)
+
+
 def test_loop_reciprocals_at_their_window_borders(gpu, oracle):
     """The sample loops divide by alpha_x, alpha_y, the lobe weight 1 / (clearcoat + 1), its complement and G1 through
     per-point reciprocals when those lie inside rlm::div32_y's window, and the IEEE way for the whole wavefront when a lane's
@@ -283,9 +300,7 @@ def test_loop_reciprocals_at_their_window_borders(gpu, oracle):
     ref = disney_oracle(oracle, c).integrate(spp_n, seed)
     got = _with_group(1, lambda: {kk: host(v) for kk, v in disney_sampler(gpu, c).integrate(spp_n, seed).items()})
     for kk in SUMS + COUNTS:
-        a, b = got[kk], ref[kk]
-        same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
-        assert same.all() or not cases.strict_parity(), (kk, int((~same).sum()))
+        _border_check(got[kk], ref[kk], kk in COUNTS, (kk,))
     # the same borders as UNIFORM values (the hoisted path keeps the reciprocals in scalar registers)
     for cc, rr in ((0.0, 0.4), (1e-6, 0.4), (2.4e-4, 0.0), (0.7, 130.0), (0.3, 1e-3)):
         cu = dict(base, clearcoat=np.float32(cc), roughness=np.float32(rr))
@@ -293,6 +308,4 @@ def test_loop_reciprocals_at_their_window_borders(gpu, oracle):
         ref = disney_oracle(oracle, cu_o).integrate(spp_n, seed)
         got = _with_group(1, lambda: {kk: host(v) for kk, v in disney_sampler(gpu, cu).integrate(spp_n, seed).items()})
         for kk in SUMS + COUNTS:
-            a, b = got[kk], ref[kk]
-            same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
-            assert same.all() or not cases.strict_parity(), (cc, rr, kk, int((~same).sum()))
+            _border_check(got[kk], ref[kk], kk in COUNTS, (cc, rr, kk))

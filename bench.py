@@ -36,6 +36,11 @@ where SURVEY.md 8(d) counts planes the reference reads and never uses -- the alb
 PMC counters saw (profiles/*_traffic.json, separate rocprofv3 --pmc passes of the same command), and
 `issue_slot_frac` prices the VALU wave-instructions the counters saw (profiles/*_flops.json) against one
 wave-instruction per SIMD every two cycles: 256 CUs x 4 SIMDs x 2.4 GHz / 2 = 1.2288e12 per second.
+`effective_clock_ghz` is the shader clock the kernel actually held (in-kernel s_memtime / s_memrealtime stamps of the kernel's
+diagnostic instantiation, launched right behind the timed launches: rls_diag_clock_stamps_*), `issue_slot_frac_at_clock`
+the same pricing at that clock, and `valu_busy_frac` the share of the launch's SIMD cycles in which the vector ALU holds an
+instruction at all (profiles/*_stalls.json: SQ counters by exact kernel name) -- the direct measure of how close to its
+issue ceiling a kernel runs, since only the cheapest instruction class costs two cycles.
 """
 from __future__ import annotations
 
@@ -458,6 +463,14 @@ def roofline_record(wl, n: int, kernel_ms: float, math: str, clock: dict | None 
         if ck:
             roof["clock_profile"] = {k: ck.get(k) for k in ("file", "effective_clock_ghz", "grbm_clock_ghz", "sustained_clock_ghz")
                                      if ck.get(k) is not None}
+    # how busy the issue port is, measured: share of the launch's SIMD quad-cycles in which the vector ALU holds an instruction
+    # (SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2 over SQ_CYCLES, dispatches of this kernel by exact name: tools/pmc_stalls.sh)
+    stl = profile_record(wl.name, math, "stalls", "valu_port")
+    if stl:
+        roof["valu_busy_frac"] = stl["valu_port"]["busy"]
+        roof["valu_port"] = {k: stl["valu_port"][k] for k in ("holding_two", "holding_one", "idle", "instructions_issued_in_pairs")
+                             if k in stl["valu_port"]}
+        roof["valu_port"]["source"] = stl["file"]
     if wl.survey_bytes:
         roof["survey_bytes_per_point"] = wl.survey_bytes
         roof["frac_survey_bytes"] = round(n * wl.survey_bytes / launches / sec / 1e9 / HBM_PEAK_GBS, 4)
@@ -563,7 +576,7 @@ def headline(detail: dict) -> dict:
     line["config"]["workload"] = _short(cfg["workload"], 120)
     line["roofline"] = pick(detail["roofline"], ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms",
                                                  "algorithmic_bytes_per_launch", "issue_slot_frac", "effective_clock_ghz",
-                                                 "issue_slot_frac_at_clock"))
+                                                 "issue_slot_frac_at_clock", "valu_busy_frac"))
     if "cpu_baseline" in detail:
         cb = detail["cpu_baseline"]
         line["cpu_baseline"] = pick(cb, ("value", "unit", "cores", "kind"))

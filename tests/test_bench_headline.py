@@ -73,6 +73,33 @@ def test_headline_without_the_optional_objects():
     assert line["roofline"]["bound"] == "valu" and line["roofline"]["frac"] is None
 
 
+def test_headline_survives_unbounded_strings():
+    """every free-text field grown past any sensible size (kernel name, sharding, metric, unit, cpu model): the
+    line still fits, still carries the contract's keys with roofline and cpu_baseline numbers -- optional objects go first --
+    and nothing on the output path raises."""
+    b = _bench()
+    d = _worst_case_detail(64)
+    d["metric"] = "m" * 3000
+    d["unit"] = "u" * 500
+    d["data"] = "d" * 500
+    d["config"]["sharding"] = "s" * 3000
+    d["config"]["name"] = "ggx_reflect_refract"
+    d["roofline"]["kernel"] = "k" * 3000
+    d["roofline"].update(effective_clock_ghz=1.9, issue_slot_frac_at_clock=0.75, valu_busy_frac=0.97)
+    d["cpu_baseline"]["cpu_model"] = "c" * 3000
+    d["cpu_baseline"]["with_alloc"] = {"value": 0.3, "kind": "port+alloc", "what": "w" * 1000}
+    d["ms_per_step_wall"] = 2.0
+    text = json.dumps(b.headline(d))
+    assert len(text) < b.HEADLINE_MAX_BYTES
+    line = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["value"] == d["value"] and line["roofline"]["frac"] == d["roofline"]["frac"]
+    assert line["roofline"]["effective_clock_ghz"] == 1.9 and line["roofline"]["valu_busy_frac"] == 0.97
+    assert line["cpu_baseline"]["value"] == d["cpu_baseline"]["value"] and line["cpu_baseline"]["with_alloc"]["value"] == 0.3
+
+
 def test_emit_prints_the_headline_last(tmp_path, capsys):
     b = _bench()
     detail = _worst_case_detail(8)

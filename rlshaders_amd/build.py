@@ -22,9 +22,11 @@ OBJDIR = PKG / "build"
 LIB = LIBDIR / "librlshaders_amd.so"
 ARCH = "gfx950"
 
-SOURCES = ["context.hip", "pipeline.hip", "libm_check.hip", "ggx.hip", "disney.hip", "sss.hip", "skin.hip", "integrate.hip", "alternates.hip"]
-FAST_UNITS = {"ggx.hip", "disney.hip", "sss.hip", "skin.hip", "integrate.hip", "alternates.hip"}
-HEADERS = [CSRC / "rls_device.hpp", CSRC / "rls_libm.hpp", CSRC / "rls_libm_tables.inc", CSRC / "rls_libm_flavour_args.inc", CSRC / "rls_internal.hpp",
+# the largest units first (the thread pool starts them first); integrate / lights / scatter / shade share csrc/rls_loops.hpp
+SOURCES = ["shade.hip", "integrate.hip", "lights.hip", "scatter.hip", "skin.hip", "ggx.hip", "disney.hip", "sss.hip", "alternates.hip", "context.hip", "pipeline.hip",
+           "libm_check.hip"]
+FAST_UNITS = {"ggx.hip", "disney.hip", "sss.hip", "skin.hip", "integrate.hip", "lights.hip", "scatter.hip", "shade.hip", "alternates.hip"}
+HEADERS = [CSRC / "rls_device.hpp", CSRC / "rls_libm.hpp", CSRC / "rls_libm_tables.inc", CSRC / "rls_libm_flavour_args.inc", CSRC / "rls_internal.hpp", CSRC / "rls_loops.hpp",
            PKG.parent / "include" / "rlshaders_amd.h"]
 
 HIPCC_FLAGS = [

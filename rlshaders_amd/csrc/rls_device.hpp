@@ -1077,7 +1077,7 @@ RLS_DEV V3 disney_sample_specular(const Disney &d, const VndfView &w, float rx, 
 // rlDisney's clearcoat half vector (sampleGTR1Direction: the lanes whose random number falls beyond gtr2Weight).  Both
 // are "a radius from one random number, an azimuth 2 pi x the other": an exact division, one or two exact square roots,
 // an fp64 sincosf -- and powf for the clearcoat lobe.  slow_eval is that common form; the n^2-spp loops queue the
-// requests of K samples per wavefront in LDS and evaluate them 64 at a time (integrate.hip, SlowLds): the same functions
+// requests of K samples per wavefront in LDS and evaluate them 64 at a time (rls_loops.hpp, SlowLds): the same functions
 // on the same arguments, on another lane.  Measured bound (the branches replaced by nothing,
 // profiles/r02_valu_rates.txt): rlDisney 64 spp -15 % (clearcoat) and -6 % (fallback); rlGgx loops -5 %.
 struct SlowOut { float x, y, z; };

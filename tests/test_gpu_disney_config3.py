@@ -155,7 +155,7 @@ def test_full_size_config3(gpu, oracle):
     alt = _with_group(4, lambda: d.integrate(spp_n, seed))
     for k in COUNTS:
         assert torch.equal(alt[k], out[k]), k
-    # four lanes per point: the sums grow in sample order all the same (fold, integrate.hip) -- every word of 2^26 points
+    # four lanes per point: the sums grow in sample order all the same (fold, rls_loops.hpp) -- every word of 2^26 points
     assert ck == {k: R.checksum(ctx, alt[k]) for k in SUMS + COUNTS}
     del alt
     # oracle on eight windows of 256 points; first_index aligns the oracle's scrambles with the batch's
@@ -229,7 +229,7 @@ def test_sharded_integrators_draw_the_batch_numbers(gpu, oracle):
 
 def test_packed_rare_branches_with_every_lane_asking(gpu, oracle):
     """the n^2-spp loops queue the rare sampler branches of four samples per wavefront in LDS and evaluate them 64 at a
-    time (integrate.hip, SlowLds).  Here every lane asks at every sample -- views along the normal make every visible-
+    time (rls_loops.hpp, SlowLds).  Here every lane asks at every sample -- views along the normal make every visible-
     normal sample take the uniform-slope fallback, and clearcoat = 1 sends a fifth of the samples to the clearcoat lobe
     -- so the queue holds 256 requests per pass of four samples and is worked off in four rounds; also a sample count (9)
     that is not a multiple of four, and G > 1 (the lanes of a group hold different samples)."""

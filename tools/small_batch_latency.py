@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Latency of one small flush through the n^2-spp loops: lanes per point chosen automatically (4 / 16 / 64 for batches too small
-to fill the GPU; the sums still grow in sample order: fold, integrate.hip) against one lane per point (RLS_INTEGRATE_GROUP=1).
+to fill the GPU; the sums still grow in sample order: fold, rls_loops.hpp) against one lane per point (RLS_INTEGRATE_GROUP=1).
 usage: tools/small_batch_latency.py  -> one JSON line"""
 import json
 import os

@@ -16,7 +16,8 @@ def test_design_md_is_short_and_narrow():
 
 
 def test_named_profiles_exist():
-    text = (ROOT / "DESIGN.md").read_text(encoding="utf8") + (ROOT / "docs" / "experiments_r04.md").read_text(encoding="utf8")
+    text = "".join((ROOT / f).read_text(encoding="utf8") for f in ("DESIGN.md", "docs/experiments_r04.md", "docs/experiments_r05.md",
+                                                                 "THIRD_PARTY.md"))
     missing = []
     for m in set(re.findall(r"`(?:profiles/)?(r0\d_[A-Za-z0-9_.*]+)`", text)):
         name = m.rstrip(".")

@@ -296,8 +296,8 @@ def cpu_baseline(workload: str, target_seconds: float, full: bool = True) -> dic
         fn0, spp, what = _cpu_leg(workload, n0, threads)
         fn0()
         t = min(passes(fn0, 0.0, 3))
-        if t >= 0.1 or n0 >= 1 << 20:       # (the oracle runs small batches on one thread: only a pass of 2^20 points or
-            break                           # of 0.1 s says what all threads do)
+        if t >= 0.1 or n0 >= 1 << 20:       # (thread start-up and first-touch page faults dominate shorter passes: only a pass
+            break                           # of 0.1 s, or of 2^20 points, says what all threads do)
         n0 <<= 4
     per_point = t / n0
     del fn0

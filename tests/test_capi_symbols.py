@@ -82,6 +82,20 @@ def test_product_never_touches_oracle():
         assert "oracle_lib" not in t and "librls_oracle" not in t and "rls_oracle.h" not in t, p
     out = subprocess.run(["ldd", str(pkg / "lib" / "librlshaders_amd.so")], capture_output=True, text=True).stdout
     assert "rls_oracle" not in out
+    # bench: the workload table (what the GPU legs launch) never names the oracle; the driver imports it in the two functions
+    # of its cpu_baseline leg and nowhere else
+    import ast
+    t = (ROOT / "bench_workloads.py").read_text()
+    assert "oracle_lib" not in t and "import cases" not in t and "librls_oracle" not in t
+    tree = ast.parse((ROOT / "bench.py").read_text())
+    where = set()
+    for fn in [n for n in ast.walk(tree) if isinstance(n, (ast.FunctionDef, ast.Module))]:
+        for node in (fn.body if isinstance(fn, ast.Module) else ast.walk(fn)):
+            if isinstance(node, (ast.Import, ast.ImportFrom)):
+                names = [a.name for a in node.names] + ([node.module] if isinstance(node, ast.ImportFrom) else [])
+                if any(n in ("oracle_lib", "cases") for n in names):
+                    where.add(fn.name if isinstance(fn, ast.FunctionDef) else "<module>")
+    assert where == {"_cpu_leg", "cpu_baseline"}, where
 
 
 def test_shard_range_matches_the_python_sharding():

@@ -33,8 +33,8 @@ def thousands(x):
     return f"{x:,.0f}".replace(",", " ")
 
 
-print("| workload (`bench.py --workload`) | BASELINE config | time per pass (rocprofv3 average) | throughput | roofline | HBM bytes the counters saw ÷ algorithmic (fraction of 8 TB/s on them) | VALU / SALU instr. per point, issue-slot fraction | CPU baseline (oracle, all host threads) |")
-print("|---|---|---|---|---|---|---|---|")
+print("| workload (`bench.py --workload`) | BASELINE config | time per pass (rocprofv3 average) | throughput | roofline | HBM bytes the counters saw ÷ algorithmic (fraction of 8 TB/s on them) | VALU / SALU instr. per point, issue-slot fraction | clock GHz: stamps after 2 s of load / GRBM; issue-slot fraction at that clock | vector ALU busy (two / one / idle) | CPU baseline (oracle, all host threads) |")
+print("|---|---|---|---|---|---|---|---|---|---|")
 for w, cfg in ROWS:
     b, f, t, tr = load(w, "bench"), load(w, "flops"), load(w, "traffic"), load(w, "bench_trace")
     if b is None:
@@ -62,8 +62,20 @@ for w, cfg in ROWS:
     else:
         valu = "—"
     unit = b["unit"]
+    ck, st = load(w, "clock"), load(w, "stalls")             # round 5: the measured clock and the issue port (tools/pmc_stalls.sh)
+    clock = "—"
+    if ck:
+        ghz = ck["effective_clock_ghz"]
+        clock = f"{ck.get('sustained_clock_ghz', '—')} / {ck.get('grbm_clock_ghz', '—')}"
+        if f:
+            clock += f"; {f['instructions_per_point']['SQ_INSTS_VALU'] * ppl / 64 / sec / (1024 * ghz * 1e9 / 2):.2f}"
+    port = "—"
+    if st and st.get("valu_port"):
+        v = st["valu_port"]
+        port = f"{v['busy']:.3f} ({v['holding_two']:.2f} / {v['holding_one']:.2f} / {v['idle']:.2f})"
+    cb = b.get("cpu_baseline")
     print(f"| `{w}` | {cfg} | {tm}" + (f" ({prof:.3f})" if prof and lp == 1 else "") + f" | {b['value']:.1f} {unit} | {roof} | {ratio} | {valu} | "
-          f"{b['cpu_baseline']['value']:.3f} ({b['cpu_baseline']['cores']} threads) |")
+          f"{clock} | {port} | " + (f"{cb['value']:.3f} ({cb['cores']} threads)" if cb else "—") + " |")
 for name, label in (("ggx_reflect_bench_only", "`ggx_reflect` | — (reflect triple only)"), ("bench_fast", "`ggx_reflect_refract --math fast` | 2, FAST arithmetic")):
     p = ROOT / "profiles" / f"{TAG}_{name}.json"
     if p.exists():

@@ -17,8 +17,14 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
 
-def hwmon_dirs():
-    return sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+def hwmon_dirs(pci=None):
+    """hwmon directories of the amdgpu cards; with `pci` ("0000:75:00.0") only the one of that PCI function (a box shows the
+    hwmon files of every card of its node in sysfs, whichever single GPU HIP is allowed to see)"""
+    dirs = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+    if pci:
+        import os
+        dirs = [d for d in dirs if pci.lower() in os.path.realpath(os.path.dirname(os.path.dirname(d))).lower()]
+    return dirs
 
 
 def read_int(path):
@@ -70,8 +76,11 @@ def main():
     import torch
     import rlshaders_amd as R
     from bench_workloads import make_workload
-    dirs = hwmon_dirs()
-    print(json.dumps({"hwmon": dirs, "files": sorted(p.name for p in Path(dirs[0]).iterdir() if p.is_file()) if dirs else []}))
+    pr = torch.cuda.get_device_properties(0)
+    pci = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
+    dirs = hwmon_dirs(pci)
+    print(json.dumps({"device": pr.name, "pci": pci, "hwmon": dirs,
+                      "files": sorted(p.name for p in Path(dirs[0]).iterdir() if p.is_file()) if dirs else []}))
     if not dirs:
         raise SystemExit("no hwmon directory visible")
     d = dirs[0]

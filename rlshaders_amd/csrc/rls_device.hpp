@@ -1738,8 +1738,17 @@ RLS_DEV float hash_u01(uint32_t seed, uint64_t index, uint32_t stream)
 // ---- streaming loads / stores -------------------------------------------------------------------
 // Every plane is read or written exactly once per launch: non-temporal so the streams do not
 // evict each other from L2 / Infinity Cache.
-RLS_DEV float ldg(const float *p, int64_t i) { return __builtin_nontemporal_load(p + i); }
-RLS_DEV void stg(float *p, int64_t i, float v) { __builtin_nontemporal_store(v, p + i); }
+// Cache policy of the plane accesses.  Every plane is touched exactly once per launch, so both directions are non-temporal
+// (0).  Experiment switch (round 5, after the pointwise kernels turned out to run at the board's power cap -- a policy that
+// spares the caches' energy would come back as clock): 1 plain loads, 2 plain stores, 3 both plain.  Measured:
+// profiles/r05_mem_policy.txt.
+#ifndef RLS_MEM_POLICY
+#define RLS_MEM_POLICY 0
+#endif
+template <class P> RLS_DEV float ld_policy(P p) { return (RLS_MEM_POLICY & 1) ? *p : __builtin_nontemporal_load(p); }
+template <class P> RLS_DEV void st_policy(float v, P p) { if (RLS_MEM_POLICY & 2) *p = v; else __builtin_nontemporal_store(v, p); }
+RLS_DEV float ldg(const float *p, int64_t i) { return ld_policy(p + i); }
+RLS_DEV void stg(float *p, int64_t i, float v) { st_policy(v, p + i); }
 
 // A point index split into a wave-uniform 64-bit part and a 32-bit lane part: `p + base` is scalar
 // arithmetic and the access becomes global_load_dword v, v_lane_offset, s[base] -- no 64-bit vector
@@ -1802,13 +1811,13 @@ RLS_DEV float ldg(const float *p, Idx i)
 #if RLS_LOAD_RENEW
     asm volatile("" : "+v"(i.byte));
 #endif
-    return __builtin_nontemporal_load(at(p, i));
+    return ld_policy(at(p, i));
 }
 RLS_DEV void stg(float *p, Idx i, float v)
 {
     // stores sit in later basic blocks than make_idx(): renew the barrier so the zext is local again
     asm volatile("" : "+v"(i.byte));
-    __builtin_nontemporal_store(v, at(p, i));
+    st_policy(v, at(p, i));
 }
 
 } // namespace rlsd

@@ -16,7 +16,7 @@ GROUP_A = {"RLS_DISNEY_RELOAD": 0, "RLS_GGX_RELOAD": 0, "RLS_INT_RELOAD": 0, "RL
            "RLS_ATAN_SELECTS": 1, "RLS_POW5_GENERAL": 1, "RLS_LOOP_RECIP": 0, "RLS_DISNEY_D_RECIP": 0, "RLS_ND_RECIP_D": 0,
            "RLS_ND_PP_RANGE_ONCE": 0, "RLS_ND_PROFILE_WINDOWED": 0, "RLS_ND_MAKE_RANGE_ONCE": 0, "RLS_SQRT_NO_FALLBACK": 1,
            "RLS_NO_FAST_RCP": 1, "RLS_SKIN_SGPR": 0, "RLS_SSS_UNIFORM_SGPR": 0, "RLS_SPEC_BLOCK": 2, "RLS_INT_WAVES": 3,
-           "RLS_WAVES_PER_EU": 5, "RLS_SKIN_WAVES": 5, "RLS_FAST_VIEW_Z_AS_REFERENCE": 0}
+           "RLS_WAVES_PER_EU": 5, "RLS_SKIN_WAVES": 5, "RLS_FAST_VIEW_Z_AS_REFERENCE": 0, "RLS_MEM_POLICY": 3}
 GROUP_B = {"RLS_ANGLE_SELECTS": 1, "RLS_LOAD_RENEW": 1, "RLS_ND_ONE_SAMPLE_RECIP": 1, "RLS_SKIN_ND_RECIP": 1,
            "RLS_NO_PAIR_COMPACTION": 1, "RLS_ND_DIVC_UNGUARDED": 1, "RLS_ND_MERGE_RADIUS": 1, "RLS_ND_RADIUS_SELECTS": 1,
            "RLS_ND_PDF3_MERGED": 1, "RLS_PROBE_SELECTS": 1, "RLS_DISNEY_LIGHT_WAVES": 4, "RLS_SPEC_BLOCK": 8}

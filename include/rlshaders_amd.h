@@ -186,7 +186,9 @@ rls_status  rls_timer_elapsed_ms(rls_context *ctx, float *ms);   /* synchronises
  * kernels contain no stamp.  _read copies out, per workgroup slot, four words {memtime at entry, at exit, memrealtime at
  * entry, at exit} of the LAST stamped launch (stamps_host holds 4 * capacity words; *count = slots there are; a slot
  * whose workgroup did not run is all zero) and synchronises.  Effective shader clock of a workgroup's lifetime =
- * (w1 - w0) / (w3 - w2) x 100 MHz; bench.py reports the median as roofline.effective_clock_ghz. */
+ * (w1 - w0) / (w3 - w2) x 100 MHz; bench.py reports the median as roofline.effective_clock_ghz.
+ * Not for production use: a stamped launch takes ~2 % longer than the product's, and a context on which _begin is left in
+ * force keeps launching the diagnostic instantiations until _end (or rls_context_destroy).  One context, one host thread. */
 rls_status  rls_diag_clock_stamps_begin(rls_context *ctx);
 rls_status  rls_diag_clock_stamps_read(rls_context *ctx, int64_t capacity, uint64_t *stamps_host, int64_t *count);
 rls_status  rls_diag_clock_stamps_end(rls_context *ctx);

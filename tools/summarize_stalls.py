@@ -36,9 +36,10 @@ def per_dispatch(dirname, kernel):
     return vals, dur
 
 
-def main():
-    tag, w = sys.argv[1], sys.argv[2]
-    d = os.path.join(ROOT, "gpurun_out", f"stalls_{tag}_{w}")
+def main(argv=None, root=ROOT):
+    argv = sys.argv if argv is None else argv
+    tag, w = argv[1], argv[2]
+    d = os.path.join(root, "gpurun_out", f"stalls_{tag}_{w}")
     recs = [json.loads(l) for l in open(os.path.join(d, "bench.json")).read().splitlines() if l.startswith("{")]
     line = [r for r in recs if r.get("record") == "headline_detail"][-1]
     kernel = line["roofline"]["kernel"]
@@ -65,7 +66,7 @@ def main():
         out["grbm_clock_ghz"] = round(clocks[len(clocks) // 2], 4)
         out["grbm_clock_note"] = ("GRBM_GUI_ACTIVE / 8 / dispatch duration; reads high on dispatches shorter than ~0.3 ms, within "
                                   "3 % of the in-kernel clock on dispatches of 10 ms or more (MI355X_MICROARCH.md, DVFS give-back)")
-    clock = float(sys.argv[3]) if len(sys.argv) > 3 else out.get("grbm_clock_ghz")
+    clock = float(argv[3]) if len(argv) > 3 else out.get("grbm_clock_ghz")
     g = lambda c: mean.get(c)
     if g("SQ_WAVE_CYCLES"):
         wc = g("SQ_WAVE_CYCLES")
@@ -106,9 +107,10 @@ def main():
             out["mean_waves_per_simd"] = round(4.0 * g("SQ_WAVE_CYCLES") / simd_cycles, 3)
         if g("SQ_INSTS_VALU"):
             out["valu_issue_frac_at_clock"] = round(g("SQ_INSTS_VALU") * 2.0 / simd_cycles, 4)       # 2 cycles per instruction nominal
-    p = os.path.join(ROOT, "profiles", f"{tag}_{w}_stalls.json")
+    p = os.path.join(root, "profiles", f"{tag}_{w}_stalls.json")
     json.dump(out, open(p, "w"), indent=1)
     print(json.dumps({k: out[k] for k in out if k not in ("counters_per_launch", "source", "dispatches_per_counter")}, indent=1))
+    return out
 
 
 if __name__ == "__main__":

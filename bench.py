@@ -59,8 +59,9 @@ sys.path.insert(0, str(ROOT / "tests"))
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 VALU_PEAK_TFLOPS = 157.3  # fp32 vector peak of the same guide (packed-fp32 FMA rate; the integrators' bound)
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2   # wave64 VALU instructions per second: one per SIMD every two cycles
-from bench_workloads import (DISNEY_UNIFORM, PLANES, SEED, SKIN_UNIFORM, S_IOR, S_KS, S_PARAM0, S_ROUGH, S_XI0, WORKLOADS,
-                             Workload, make_workload)      # the workload table (re-exported: tools import it from here)
+# the workload table; `Workload`, `PLANES` and `make_workload` are re-exported (tools/diag_*.py import them from here)
+from bench_workloads import (DISNEY_UNIFORM, PLANES, SEED, SKIN_UNIFORM, S_KS, S_PARAM0, WORKLOADS, Workload,  # noqa: F401
+                             make_workload)
 
 # BASELINE.json configs -> (workload, log2 of the points ONE GPU holds): config 4 is 2^28 points over 8 GPUs, config 5 2^30
 CONFIG_PRESETS = {2: ("ggx_reflect_refract", 26), 3: ("disney_integrate", 26), 4: ("sss_probe", 25), 5: ("skin", 27)}

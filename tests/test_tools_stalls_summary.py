@@ -58,3 +58,29 @@ def test_by_name_median_and_port_decomposition(tmp_path):
     assert abs(v["instructions_issued_in_pairs"] - 300_000 / 380_000) < 1e-4
     saved = json.loads((tmp_path / "profiles" / "t_ggx_reflect_refract_stalls.json").read_text())
     assert saved["valu_port"] == v and saved["other_kernels_counted"] == 0
+
+
+def test_clock_record_grbm_and_stamps(tmp_path):
+    """tools/summarize_workload.py clock_record: GRBM_GUI_ACTIVE rows of one dispatch add up (rocprofv3 may split them by XCD),
+    / 8 / the dispatch's own duration, by exact kernel name; the sustained stamps of the bench line take precedence"""
+    spec = importlib.util.spec_from_file_location("summarize_workload", ROOT / "tools" / "summarize_workload.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    src, dst = tmp_path / "prof", tmp_path / "profiles"
+    dst.mkdir()
+    rows = []
+    for disp in (1, 2, 3):
+        for x in range(8):                                   # 8 ms dispatch at 1.9 GHz: 1.52e7 cycles per XCD
+            rows.append((disp, EXACT, "GRBM_GUI_ACTIVE", 1.9e9 * 8e-3, 1_000_000, 1_000_000 + 8_000_000))
+    rows.append((4, FAST, "GRBM_GUI_ACTIVE", 8 * 2.4e9 * 8e-3, 0, 8_000_000))
+    rows.append((5, STAMPED, "GRBM_GUI_ACTIVE", 8 * 1.0e9 * 8e-3, 0, 8_000_000))
+    _write(src / "clock_grbm" / "x" / "1_counter_collection.csv", rows)
+    mod.clock_record(str(src), str(dst), "t", "ggx_reflect_refract", "ggx_kernel<5, 0, 1>", "exact")
+    rec = json.loads((dst / "t_ggx_reflect_refract_clock.json").read_text())
+    assert abs(rec["grbm_clock_ghz"] - 1.9) < 1e-3 and rec["grbm_dispatches"] == 3 and abs(rec["grbm_dispatch_ms"] - 8.0) < 1e-6
+    assert rec["effective_clock_ghz"] == rec["grbm_clock_ghz"] and "sustained_clock_ghz" not in rec
+    (src / "clock_sustained.json").write_text(json.dumps({"record": "headline_detail", "roofline": {
+        "kernel_ms": 2.0, "clock": {"effective_clock_ghz": 1.876, "workgroups": 262144}}}) + "\n")
+    mod.clock_record(str(src), str(dst), "t", "ggx_reflect_refract", "ggx_kernel<5, 0, 1>", "exact")
+    rec = json.loads((dst / "t_ggx_reflect_refract_clock.json").read_text())
+    assert rec["sustained_clock_ghz"] == 1.876 and rec["effective_clock_ghz"] == 1.876 and abs(rec["grbm_clock_ghz"] - 1.9) < 1e-3

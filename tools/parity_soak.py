@@ -53,6 +53,11 @@ def main():
                 t["words"] += r["words"]
                 t["beyond_1e5"] += r["beyond_1e5"]
                 t["max_rel_err"] = max(t["max_rel_err"], r["max_rel_err"])
+            if args.out:                  # after every seed: a call that runs into the lease's time limit keeps what it has
+                done = seeds[:seeds.index(seed) + 1]
+                Path(args.out).write_text(json.dumps(dict(partial=True, seeds_done=done, closures=total,
+                                                          words=sum(t["words"] for t in total.values()),
+                                                          words_differing=sum(t["words_differing"] for t in total.values())), indent=1))
     summary = dict(points_per_seed=1 << args.log2_points, seeds=seeds, lane_groups=groups, spp_n=args.spp_n, mode="RLS_MATH_EXACT", uniform_draws_per_seed=args.uniform_draws, by_reference_table_sizes=args.by_reference,
                    seconds=round(time.time() - t0, 1), closures=total,
                    words=sum(t["words"] for t in total.values()),

@@ -178,20 +178,8 @@ rls_status  rls_timer_start(rls_context *ctx);
 rls_status  rls_timer_stop(rls_context *ctx);
 rls_status  rls_timer_elapsed_ms(rls_context *ctx, float *ms);   /* synchronises on the stop event */
 
-/* In-kernel clock stamps (measurement aid, no reference counterpart).  Between _begin and _end the kernels of the four
- * BASELINE configurations -- rls_ggx_reflect_refract with every parameter streamed, rls_sss_probe_ray with per-point
- * scatter distances, rls_skin_sample_eval_pdf with every parameter streamed, rls_disney_integrate at one lane per point --
- * are launched as their DIAGNOSTIC instantiation: the same kernel body bracketed by reads of the shader-clock counter
- * (s_memtime) and of the constant 100 MHz counter (s_memrealtime) by the first wave of every workgroup.  The product
- * kernels contain no stamp.  _read copies out, per workgroup slot, four words {memtime at entry, at exit, memrealtime at
- * entry, at exit} of the LAST stamped launch (stamps_host holds 4 * capacity words; *count = slots there are; a slot
- * whose workgroup did not run is all zero) and synchronises.  Effective shader clock of a workgroup's lifetime =
- * (w1 - w0) / (w3 - w2) x 100 MHz; bench.py reports the median as roofline.effective_clock_ghz.
- * Not for production use: a stamped launch takes ~2 % longer than the product's, and a context on which _begin is left in
- * force keeps launching the diagnostic instantiations until _end (or rls_context_destroy).  One context, one host thread. */
-rls_status  rls_diag_clock_stamps_begin(rls_context *ctx);
-rls_status  rls_diag_clock_stamps_read(rls_context *ctx, int64_t capacity, uint64_t *stamps_host, int64_t *count);
-rls_status  rls_diag_clock_stamps_end(rls_context *ctx);
+/* Measurement aids (the in-kernel clock stamps bench.py reads the shader clock with) are NOT part of the drop-in surface:
+ * they are declared in rlshaders_amd_diag.h; a plugin never needs them. */
 
 /* Launch graphs.  A renderer that flushes small batches (a bucket's worth of shading points) through
  * the same device buffers again and again is launch-bound, not kernel-bound: record the rls_* calls of

@@ -27,7 +27,7 @@ SOURCES = ["shade.hip", "integrate.hip", "lights.hip", "scatter.hip", "skin.hip"
            "libm_check.hip"]
 FAST_UNITS = {"ggx.hip", "disney.hip", "sss.hip", "skin.hip", "integrate.hip", "lights.hip", "scatter.hip", "shade.hip", "alternates.hip"}
 HEADERS = [CSRC / "rls_device.hpp", CSRC / "rls_libm.hpp", CSRC / "rls_libm_tables.inc", CSRC / "rls_libm_flavour_args.inc", CSRC / "rls_internal.hpp", CSRC / "rls_loops.hpp",
-           PKG.parent / "include" / "rlshaders_amd.h"]
+           PKG.parent / "include" / "rlshaders_amd.h", PKG.parent / "include" / "rlshaders_amd_diag.h"]
 
 HIPCC_FLAGS = [
     f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",

@@ -291,6 +291,7 @@ rls_status rls_diag_clock_stamps_read(rls_context *ctx, int64_t capacity, uint64
 {
     RLS_REQUIRE(ctx != nullptr && count != nullptr, "NULL argument");
     RLS_REQUIRE(ctx->stamps != nullptr, "rls_diag_clock_stamps_begin is not in force");
+    RLS_REQUIRE(!ctx->capturing, "not allowed while a launch graph is being recorded");
     RLS_REQUIRE(capacity >= 0 && (capacity == 0 || stamps_host != nullptr), "capacity < 0 or stamps_host is NULL");
     RLS_HIP_TRY(hipSetDevice(ctx->device));
     static_assert(sizeof(uint64_t) == sizeof(unsigned long long), "stamp words are 64 bits");
@@ -323,6 +324,8 @@ rls_status rls_graph_begin_capture(rls_context *ctx)
     RLS_REQUIRE(ctx != nullptr, "ctx is NULL");
     RLS_REQUIRE(ctx->stream != nullptr, "the NULL stream cannot be captured: use the context's own stream");
     RLS_REQUIRE(!ctx->capturing, "a capture is already in progress on this context");
+    // a recorded stamped launch would keep writing stamps on every replay, long after rls_diag_clock_stamps_end
+    RLS_REQUIRE(ctx->stamps == nullptr, "not allowed between rls_diag_clock_stamps_begin and _end");
     RLS_HIP_TRY(hipSetDevice(ctx->device));
     // thread-local: other host threads driving other contexts keep running normally
     RLS_HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));

@@ -177,9 +177,9 @@ rls_status launch_kernel(rls_context *ctx, const GgxIO &io, const char *name)
 #endif
     const bool uniform = !c.materials.id && !c.specularRoughness.v && !c.ior.v && !c.anisotropic.v;       // specColor: either
     if constexpr (OP == OP_REFLECT_REFRACT) {      // BASELINE config 2 under rls_diag_clock_stamps_begin: the stamped instantiation
-        if (streamed && ctx->stamps) {
+        if (unsigned long long *stamps = streamed ? rlsh::stamps_for_launch(ctx) : nullptr) {
             hipLaunchKernelGGL((ggx_kernel_stamped<OP, RLS_FAST, STREAMED_ALL>), rlsh::grid_for(ctx, io.n, rlsh::kBlock, RLS_CAP_MULT),
-                               dim3(rlsh::kBlock), 0, ctx->stream, io, ctx->stamps);
+                               dim3(rlsh::kBlock), 0, ctx->stream, io, stamps);
             return rlsh::check_launch(name);
         }
     }

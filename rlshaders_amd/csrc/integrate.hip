@@ -218,10 +218,10 @@ __global__ RLS_INT_ATTR void ggx_refract_integrate_kernel(RefractIntIO a)
 }
 
 // BASELINE config 3 (one lane per point) under rls_diag_clock_stamps_begin: the stamped instantiation
-inline rls_status launch_disney_stamped(rls_context *ctx, const rlsh::DisneyIntIO &io, const char *name)
+inline rls_status launch_disney_stamped(rls_context *ctx, const rlsh::DisneyIntIO &io, unsigned long long *stamps, const char *name)
 {
     hipLaunchKernelGGL(disney_integrate_kernel_stamped<1>, rlsh::grid_for(ctx, io.n, rlsh::kBlock), dim3(rlsh::kBlock), 0, ctx->stream,
-                       io, ctx->stamps);
+                       io, stamps);
     return rlsh::check_launch(name);
 }
 
@@ -235,7 +235,8 @@ RLS_HIDDEN rls_status rls_fast_ggx_integrate(rls_context *ctx, int g, const rlsh
 }
 RLS_HIDDEN rls_status rls_fast_disney_integrate(rls_context *ctx, int g, const rlsh::DisneyIntIO *io)
 {
-    if (ctx->stamps && g == 1) return launch_disney_stamped(ctx, *io, "rls_disney_integrate[fast, stamped]");
+    if (unsigned long long *stamps = g == 1 ? rlsh::stamps_for_launch(ctx) : nullptr)
+        return launch_disney_stamped(ctx, *io, stamps, "rls_disney_integrate[fast, stamped]");
     return launch_g(ctx, disney_integrate_kernel<1>, disney_integrate_kernel<4>, disney_integrate_kernel<16>,
                     disney_integrate_kernel<64>, g, *io, "rls_disney_integrate[fast]");
 }
@@ -322,7 +323,8 @@ rls_status rls_disney_integrate(rls_context *ctx, int64_t n, const rls_disney_cl
     // streamed planes are sample-major: one lane per point keeps every store coalesced
     int g = io.streamed ? 1 : pick_group(ctx, n, io.spp);
     if (ctx->fast) return rls_fast_disney_integrate(ctx, g, &io);
-    if (ctx->stamps && g == 1) return launch_disney_stamped(ctx, io, "rls_disney_integrate[stamped]");
+    if (unsigned long long *stamps = g == 1 ? rlsh::stamps_for_launch(ctx) : nullptr)
+        return launch_disney_stamped(ctx, io, stamps, "rls_disney_integrate[stamped]");
     return launch_g(ctx, disney_integrate_kernel<1>, disney_integrate_kernel<4>, disney_integrate_kernel<16>,
                     disney_integrate_kernel<64>, g, io, "rls_disney_integrate");
 }

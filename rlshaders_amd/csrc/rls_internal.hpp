@@ -6,6 +6,7 @@
 #include <stdio.h>
 
 #include "../../include/rlshaders_amd.h"
+#include "../../include/rlshaders_amd_diag.h"
 #include "rls_device.hpp"
 
 struct rls_context {
@@ -322,6 +323,20 @@ inline bool has3(rls_rgb v) { return v.r && v.g && v.b; }
 inline bool none3(rls_cvec3 v) { return !v.x && !v.y && !v.z; }
 inline bool ok_rgb(const rls_param_rgb &p) { return (p.r && p.g && p.b) || (!p.r && !p.g && !p.b); }
 inline bool ok_materials(const rls_material_index &m) { return m.id == nullptr || m.count > 0; }
+
+// Host side of the stamps: the buffer a launch hands to a `*_kernel_stamped` instantiation, or NULL when the product kernel is
+// to run (rls_diag_clock_stamps_begin not in force).  The slots are cleared on the launch stream first, so _read returns the
+// stamps of the LAST stamped launch only, whatever grid an earlier stamped launch of the same begin/end bracket used.  A
+// bracket and a graph recording exclude each other (context.hip), so a stamped launch is never baked into a graph.
+inline unsigned long long *stamps_for_launch(rls_context *ctx)
+{
+    if (!ctx->stamps || ctx->capturing) return nullptr;
+    if (hipMemsetAsync(ctx->stamps + 4, 0, sizeof(unsigned long long) * 4 * (size_t)ctx->stamp_slots, ctx->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return ctx->stamps;
+}
 
 } // namespace rlsh
 

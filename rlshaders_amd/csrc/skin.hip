@@ -209,8 +209,9 @@ rls_status launch_kernel(rls_context *ctx, const SkinIO &io, const char *name)
                          !c.specular_weight.v && !c.specular_roughness.v && !c.specular_ior.v && !c.sheen_color.r &&
                          !c.sheen_weight.v && !c.sheen_roughness.v && !c.sheen_ior.v;
     const dim3 grid = rlsh::grid_for(ctx, io.n, rlsh::kBlock, RLS_CAP_MULT);
-    if (streamed && ctx->stamps)      // BASELINE config 5 under rls_diag_clock_stamps_begin: the stamped instantiation
-        hipLaunchKernelGGL((skin_kernel_stamped<RLS_FAST, STREAMED_ALL>), grid, dim3(rlsh::kBlock), 0, ctx->stream, io, ctx->stamps);
+    unsigned long long *stamps = streamed ? rlsh::stamps_for_launch(ctx) : nullptr;
+    if (stamps)                       // BASELINE config 5 under rls_diag_clock_stamps_begin: the stamped instantiation
+        hipLaunchKernelGGL((skin_kernel_stamped<RLS_FAST, STREAMED_ALL>), grid, dim3(rlsh::kBlock), 0, ctx->stream, io, stamps);
     else if (streamed)
         hipLaunchKernelGGL((skin_kernel<RLS_FAST, STREAMED_ALL>), grid, dim3(rlsh::kBlock), 0, ctx->stream, io);
     else if (uniform)   // a thread that hoists wants many tiles to spread the hoisted work over (grid_for_hoisting)

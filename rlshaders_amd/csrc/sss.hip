@@ -178,8 +178,8 @@ rls_status launch_kernel(rls_context *ctx, const SssIO &io, const char *name)
     // evalProfile alone uses nothing setDistance computes but maxR: no uniform specialisation of it
     constexpr bool kHoists = OP != OP_ND_EVAL;
     if constexpr (OP == OP_PROBE) {      // BASELINE config 4 under rls_diag_clock_stamps_begin: the stamped instantiation
-        if (ctx->stamps && !c.materials.id && !(uniform && kHoists)) {
-            hipLaunchKernelGGL((sss_kernel_stamped<OP, PER_POINT>), rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io, ctx->stamps);
+        if (unsigned long long *stamps = (!c.materials.id && !(uniform && kHoists)) ? rlsh::stamps_for_launch(ctx) : nullptr) {
+            hipLaunchKernelGGL((sss_kernel_stamped<OP, PER_POINT>), rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io, stamps);
             return rlsh::check_launch(name);
         }
     }

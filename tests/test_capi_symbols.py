@@ -9,10 +9,25 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def declared_symbols():
-    text = (ROOT / "include" / "rlshaders_amd.h").read_text()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(rls_[a-z0-9_]+)\s*\(", text)))
+HEADERS = ("rlshaders_amd.h", "rlshaders_amd_diag.h")     # the drop-in boundary; the measurement aids (same library)
+
+
+def declared_symbols(headers=HEADERS):
+    names = set()
+    for h in headers:
+        text = (ROOT / "include" / h).read_text()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(rls_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
+
+
+def test_diagnostics_are_not_in_the_drop_in_header():
+    """what a plugin binds (rlshaders_amd.h) declares no measurement aid; rlshaders_amd_diag.h declares
+    nothing else"""
+    drop_in, diag = declared_symbols(HEADERS[:1]), declared_symbols(HEADERS[1:])
+    assert not [s for s in drop_in if s.startswith("rls_diag_")]
+    assert diag and all(s.startswith("rls_diag_") for s in diag), diag
+    assert "rlshaders_amd_diag.h" not in re.sub(r"/\*.*?\*/", "", (ROOT / "include" / HEADERS[0]).read_text(), flags=re.S)
 
 
 def test_header_symbols_exported_and_bound():
@@ -32,10 +47,13 @@ def test_header_compiles_as_c_and_cxx(tmp_path):
     import subprocess
     src = tmp_path / "t.c"
     src.write_text('#include "rlshaders_amd.h"\nint main(void){ rls_ggx_closure c; (void)c; return rls_version() ? 0 : 0; }\n')
-    for cc, std in (("gcc", "-std=c99"), ("g++", "-std=c++14")):
-        p = subprocess.run([cc, std, "-Wall", "-Werror", "-pedantic", "-fsyntax-only", f"-I{ROOT / 'include'}",
-                            "-x", "c" if cc == "gcc" else "c++", str(src)], capture_output=True, text=True)
-        assert p.returncode == 0, p.stderr
+    diag = tmp_path / "d.c"
+    diag.write_text('#include "rlshaders_amd_diag.h"\nint main(void){ return rls_diag_clock_stamps_end(0) ? 0 : 0; }\n')
+    for unit in (src, diag):
+        for cc, std in (("gcc", "-std=c99"), ("g++", "-std=c++14")):
+            p = subprocess.run([cc, std, "-Wall", "-Werror", "-pedantic", "-fsyntax-only", f"-I{ROOT / 'include'}",
+                                "-x", "c" if cc == "gcc" else "c++", str(unit)], capture_output=True, text=True)
+            assert p.returncode == 0, p.stderr
 
 
 def test_no_gpu_fails_loudly():

@@ -48,6 +48,22 @@ def test_same_exported_symbols_as_the_header_and_the_python_build(built):
     assert got == _exported(b.build_library())
 
 
+def test_same_device_code_as_the_python_build(built):
+    """The library a plugin maintainer links is the CMake one; the one the GPU tests, the soaks and bench.py run is
+    rlshaders_amd/build.py's.  CMAKE_BUILD_TYPE=Release adds -DNDEBUG and spells / orders the flags its own way, so equality
+    of the flag lists proves nothing: compare what the GPU executes.  Every gfx950 code object in the two libraries carries the
+    same instructions, kernel descriptors and data (rlshaders_amd/codeid.py: sha-256 per code object over .text / .rodata /
+    .data, then over the sorted set), so the parity evidence gathered on one build holds for the other bit for bit."""
+    from rlshaders_amd import build as b
+    from rlshaders_amd.codeid import DeviceCode
+    cm, py = DeviceCode(built / "librlshaders_amd.so"), DeviceCode(b.build_library())
+    assert len(cm.units) == len(py.units) >= 12
+    assert sorted(u for u, _ in cm.units) == sorted(u for u, _ in py.units)
+    assert cm.library_id == py.library_id
+    for k in ("ggx_kernel<5, 0, 1>", "sss_kernel<3, 0, 0>", "skin_kernel<0, 1>", "disney_integrate_kernel<1, 0>"):
+        assert cm.unit_of_kernel(k) is not None and cm.unit_of_kernel(k) == py.unit_of_kernel(k), k
+
+
 def test_flags_are_the_parity_flags(built):
     from rlshaders_amd import build as b
     ninja = (built / "build.ninja")
@@ -64,7 +80,7 @@ def test_flags_are_the_parity_flags(built):
 
 
 def test_install_tree_and_outside_consumer(built, tmp_path):
-    for rel in ("include/rlshaders_amd.h", "include/rls_batch.hpp", "include/rl_arnold_stub.hpp", "lib/librlshaders_amd.so",
+    for rel in ("include/rlshaders_amd.h", "include/rlshaders_amd_diag.h", "include/rls_batch.hpp", "include/rl_arnold_stub.hpp", "lib/librlshaders_amd.so",
                 "lib/cmake/rlshaders_amd/rlshaders_amdConfig.cmake", "lib/cmake/rlshaders_amd/rlshaders_amdTargets.cmake",
                 "share/doc/rlshaders_amd/THIRD_PARTY.md"):
         assert (PREFIX / rel).exists(), rel

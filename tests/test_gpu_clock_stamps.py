@@ -1,4 +1,4 @@
-"""GPU: the diagnostic clock stamps (rls_diag_clock_stamps_*, include/rlshaders_amd.h).  The stamped instantiation of each
+"""GPU: the diagnostic clock stamps (rls_diag_clock_stamps_*, include/rlshaders_amd_diag.h).  The stamped instantiation of each
 BASELINE kernel must produce the product kernel's bits, stamp every workgroup it ran, and report a clock a gfx950 can hold;
 outside begin/end nothing is stamped."""
 import sys
@@ -79,6 +79,64 @@ def test_nothing_is_stamped_outside_begin_end(gpu):
     with pytest.raises(RuntimeError):
         R.Context.clock_from_stamps(gpu.clock_stamps_read())
     gpu.clock_stamps_end()
+
+
+def test_read_returns_the_last_stamped_launch_only(gpu):
+    """two stamped launches with different grids inside ONE begin/end bracket -- the slots the larger grid wrote
+    must not come back with the smaller launch (they would skew the median clock and span_ms): every stamped launch clears
+    the slots on its stream first"""
+    from bench_workloads import make_workload
+    big = make_workload(R, gpu, "ggx_reflect_refract", 1 << 20, first=0, candidates=1)
+    small = make_workload(R, gpu, "sss_probe", 1 << 16, first=0, candidates=1)
+    gpu.clock_stamps_begin()
+    try:
+        big.launch()
+        assert len(gpu.clock_stamps_read()) == (1 << 20) // 256
+        small.launch()
+        st = gpu.clock_stamps_read()
+        assert len(st) == (1 << 16) // 256, len(st)
+        # ... and they are the small launch's: all entered after the big launch's read-back
+        big.launch()
+        later = gpu.clock_stamps_read()
+        assert len(later) == (1 << 20) // 256 and later[:, 2].min() > st[:, 3].max()
+    finally:
+        gpu.clock_stamps_end()
+
+
+def test_stamps_and_graph_recording_exclude_each_other():
+    """a stamped launch recorded into a graph would keep writing stamps on every replay after _end, and _read
+    inside a recording would synchronise a capturing stream"""
+    from bench_workloads import make_workload
+    ctx = R.Context(0, use_torch_stream=False)          # the context's own stream: the NULL stream cannot be captured
+    try:
+        wl = make_workload(R, ctx, "ggx_reflect_refract", 1 << 16, first=0, candidates=1)
+        outs = list(wl.outputs.values()) if isinstance(wl.outputs, dict) else list(wl.outputs)
+        ctx.clock_stamps_begin()
+        with pytest.raises(R.RlsError, match="clock_stamps"):
+            ctx.capture().__enter__()
+        wl.launch()                                     # the refused recording left the context usable
+        assert len(ctx.clock_stamps_read()) == (1 << 16) // 256
+        ctx.clock_stamps_end()
+        want = [R.checksum(ctx, t) for t in outs]
+        with ctx.capture() as graph:
+            with pytest.raises(R.RlsError):
+                ctx.clock_stamps_begin()                # not while recording
+            wl.launch()
+        ctx.synchronize()
+        for t in outs:
+            t.zero_()
+        torch.cuda.synchronize()                        # (zero_ ran on torch's stream, the graph runs on the context's own)
+        graph.launch()
+        ctx.synchronize()
+        assert [R.checksum(ctx, t) for t in outs] == want
+        # the recorded launch is the product kernel: replaying it inside a later bracket stamps nothing
+        ctx.clock_stamps_begin()
+        graph.launch()
+        ctx.synchronize()
+        assert len(ctx.clock_stamps_read()) == 0
+        ctx.clock_stamps_end()
+    finally:
+        ctx.close()
 
 
 def test_bad_arguments(gpu):

@@ -353,11 +353,28 @@ def cpu_baseline(workload: str, target_seconds: float, full: bool = True) -> dic
     return rec
 
 
-def profile_record(workload: str, math: str, suffix: str, key: str):
+def loaded_code(kernel: str | None = None) -> dict:
+    """Which device code is being timed: the ids of the library this process has loaded (rlshaders_amd/codeid.py: sha-256 over
+    the gfx950 code objects inside the .so) and of the code object that holds `kernel`."""
+    from rlshaders_amd import _capi
+    from rlshaders_amd.codeid import device_code
+    try:
+        return device_code(_capi.loaded_path()).record(kernel)
+    except Exception as e:                                # noqa: BLE001   (an unreadable library must not cost the line)
+        return {"library_id": None, "unit_id": None, "error": f"{type(e).__name__}: {e}"}
+
+
+def profile_record(workload: str, math: str, suffix: str, key: str, code: dict | None = None):
     """The newest committed PMC record for this workload and arithmetic mode (profiles/*_<suffix>.json), or None.
-    Counters come from separate `rocprofv3 --pmc` passes of this very command (tools/profile_round.sh); they cannot
-    be collected inside an un-profiled run, so the line says which file each one comes from."""
-    best = None
+    Counters come from separate `rocprofv3 --pmc` passes of this very command (tools/profile_workload.sh); they cannot
+    be collected inside an un-profiled run, so the line says which file each one comes from -- and the file says which
+    BINARY it was taken on (`code`: library_id / unit_id, written by the summarisers from the bench line of the profiled
+    session).  With `code` (the ids of the library loaded now, loaded_code()) a record is usable only if it describes the same
+    machine code: same kernel_id (the kernel's instructions, descriptor and constants), else same unit_id (the code object that
+    holds it), else -- for records that name neither -- same library_id.  The
+    newest usable record wins; if there is none the newest record comes back marked `stale` and the caller drops every
+    counter-derived key."""
+    best, newest = None, None
     for p in sorted((ROOT / "profiles").glob(f"*_{suffix}.json")):
         try:
             d = json.loads(p.read_text())
@@ -365,8 +382,23 @@ def profile_record(workload: str, math: str, suffix: str, key: str):
             continue
         if d.get("workload") == workload and d.get("math", "exact") == math and d.get(key):
             d["file"] = f"profiles/{p.name}"
-            best = d
+            newest = d
+            if code is None or code_matches(d.get("code"), code):
+                best = d
+    if best is None and newest is not None:
+        newest["stale"] = True
+        return newest
     return best
+
+
+def code_matches(recorded: dict | None, live: dict) -> bool:
+    """does a profile's `code` stamp describe the device code loaded now?"""
+    if not recorded:
+        return False                                      # an unstamped profile proves nothing about this binary
+    for key in ("kernel_id", "unit_id"):                  # the kernel's own bytes; else the code object that holds it
+        if recorded.get(key) and live.get(key):
+            return recorded[key] == live[key]
+    return bool(recorded.get("library_id")) and recorded.get("library_id") == live.get("library_id")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -388,8 +420,21 @@ def roofline_record(wl, n: int, kernel_ms: float, math: str, clock: dict | None 
     launch_ms = kernel_ms / launches                                   # average duration of one kernel launch
     sec = launch_ms * 1e-3
     achieved_gbs = bytes_per_launch / sec / 1e9
-    tr = profile_record(wl.name, math, "traffic", "hbm_bytes_per_launch")
-    fl = profile_record(wl.name, math, "flops", "flops_per_point")
+    # which machine code this is, and which committed counter records describe it: a record taken on other device code is
+    # STALE -- its numbers are dropped from the line (counter_source.stale says so), never quoted beside a live `frac`
+    kernel = wl.kernel.format(m=1 if math == "fast" else 0)          # as rocprofv3 --kernel-trace names it
+    code = loaded_code(kernel)
+    stale = []
+
+    def counters(suffix, key):
+        d = profile_record(wl.name, math, suffix, key, code)
+        if d is not None and d.get("stale"):
+            stale.append({"file": d["file"], "taken_on": d.get("code") or "unstamped"})
+            return None
+        return d
+
+    tr = counters("traffic", "hbm_bytes_per_launch")
+    fl = counters("flops", "flops_per_point")
     # the PMC passes ran at their own batch size: scale the counters to this launch by the points it covers
     traffic = None
     if tr:
@@ -441,15 +486,18 @@ def roofline_record(wl, n: int, kernel_ms: float, math: str, clock: dict | None 
         "valu_per_point": valu, "salu_per_point": salu,
         "issue_slot_peak": "256 CUs x 4 SIMDs x 2.4 GHz / 2 = 1.2288e12 wave64 VALU instructions per second",
         "counter_source": {"traffic": tr["file"] if tr else None, "instruction_mix": fl["file"] if fl else None,
-                           "note": "rocprofv3 --pmc passes of this command (tools/profile_workload.sh), not this run"},
-        "kernel": wl.kernel.format(m=1 if math == "fast" else 0),      # as rocprofv3 --kernel-trace names it
+                           "note": "rocprofv3 --pmc passes of this command (tools/profile_workload.sh), not this run; used "
+                                   "only when taken on the device code loaded now (`code`, rlshaders_amd/codeid.py)",
+                           "stale": False},
+        "code": code,
+        "kernel": kernel,
         "kernel_ms": round(launch_ms, 5), "launches_per_step": launches,
         "algorithmic_bytes_per_point": wl.bytes_per_point,
         "algorithmic_bytes_per_launch": int(bytes_per_launch)})
     # the shader clock the kernel held.  Live: in-kernel stamps of the stamped instantiation, launched right behind the timed
     # launches (measure()); cross-check: profiles/*_clock.json (GRBM_GUI_ACTIVE / 8 / kernel time, a rocprofv3 --pmc pass, and
     # the stamps after seconds of sustained load -- tools/profile_workload.sh)
-    ck = profile_record(wl.name, math, "clock", "effective_clock_ghz")
+    ck = counters("clock", "effective_clock_ghz")
     ghz = clock["effective_clock_ghz"] if clock else (ck["effective_clock_ghz"] if ck else None)
     if ghz:
         roof["effective_clock_ghz"] = ghz
@@ -466,12 +514,17 @@ def roofline_record(wl, n: int, kernel_ms: float, math: str, clock: dict | None 
                                      if ck.get(k) is not None}
     # how busy the issue port is, measured: share of the launch's SIMD quad-cycles in which the vector ALU holds an instruction
     # (SQ_ACTIVE_INST_VALU - SQ_ACTIVE_INST_VALU2 over SQ_CYCLES, dispatches of this kernel by exact name: tools/pmc_stalls.sh)
-    stl = profile_record(wl.name, math, "stalls", "valu_port")
+    stl = counters("stalls", "valu_port")
     if stl:
         roof["valu_busy_frac"] = stl["valu_port"]["busy"]
         roof["valu_port"] = {k: stl["valu_port"][k] for k in ("holding_two", "holding_one", "idle", "instructions_issued_in_pairs")
                              if k in stl["valu_port"]}
         roof["valu_port"]["source"] = stl["file"]
+    if stale:
+        roof["counter_source"]["stale"] = True
+        roof["counter_source"]["stale_files"] = stale
+        roof["counter_source"]["stale_note"] = ("these records were taken on other device code than the library loaded now: "
+                                                "every counter-derived key they would have filled is null or absent")
     if wl.survey_bytes:
         roof["survey_bytes_per_point"] = wl.survey_bytes
         roof["frac_survey_bytes"] = round(n * wl.survey_bytes / launches / sec / 1e9 / HBM_PEAK_GBS, 4)
@@ -578,6 +631,9 @@ def headline(detail: dict) -> dict:
     line["roofline"] = pick(detail["roofline"], ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms",
                                                  "algorithmic_bytes_per_launch", "issue_slot_frac", "effective_clock_ghz",
                                                  "issue_slot_frac_at_clock", "valu_busy_frac"))
+    if detail["roofline"].get("code"):
+        line["roofline"]["library_id"] = detail["roofline"]["code"].get("library_id")
+        line["roofline"]["counters_stale"] = bool(detail["roofline"].get("counter_source", {}).get("stale"))
     if "cpu_baseline" in detail:
         cb = detail["cpu_baseline"]
         line["cpu_baseline"] = pick(cb, ("value", "unit", "cores", "kind"))
@@ -632,29 +688,130 @@ def emit(detail: dict, records: list, records_file) -> None:
     print(json.dumps(headline(detail)), flush=True)
 
 
+RANK_FAILED, BAD_LAUNCH = 1, 2          # exit codes: a rank raised / the launch itself cannot work (too few GPUs, no GPU)
+
+
+def error_line(message: str, rank, world: int, **more) -> None:
+    """One JSON line that says what went wrong and where -- on stdout, where the driver looks for the result line (a reader
+    that parses the last line finds `error` instead of `value`), and on stderr."""
+    line = json.dumps(dict({"error": message, "rank": rank, "world_size": world, "bench": "bench.py"}, **more))
+    print(line, file=sys.stderr, flush=True)
+    print(line, flush=True)
+
+
+def visible_gpus() -> int:
+    """GPUs this process could use.  torch.cuda.device_count() does not initialise the HIP runtime on this image, so the
+    parent may call it and still start children."""
+    try:
+        import torch
+        return int(torch.cuda.device_count())
+    except Exception:                                    # noqa: BLE001
+        return 0
+
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` launched bare: check that N ranks CAN run before anything is spawned, then start one rank
+    per GPU as CHILD processes (never a re-exec of this process) and return their exit code."""
+    backend = os.environ.get("RLS_DIST_BACKEND", "nccl")
+    have = visible_gpus()
+    if have == 0:
+        error_line("no GPU visible; the closures only run on the HIP path", None, args.gpus)
+        return BAD_LAUNCH
+    if backend == "nccl" and args.gpus > have:
+        error_line(f"--gpus {args.gpus} but only {have} GPU(s) visible: one rank per GPU over RCCL needs {args.gpus} devices "
+                   "(nothing was launched)", None, args.gpus, gpus_visible=have)
+        return BAD_LAUNCH
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()),
+           *sys.argv[1:]]
+    return subprocess.call(cmd)
+
+
 def main():
     args = parse_args()
+    # the host driver only does dmabuf IPC: RCCL between processes needs this set before HIP initialises (harmless otherwise)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world == 1:
-        # launched bare: start one rank per GPU as child processes and return their exit code
-        port = 29500 + (os.getpid() % 2000)
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()),
-               *sys.argv[1:]]
-        sys.exit(subprocess.call(cmd))
+        sys.exit(spawn_ranks(args))
+    rank = int(os.environ.get("RANK", "0"))
+    try:
+        run_rank(args, world)
+    except SystemExit as e:
+        if e.code in (None, 0):
+            raise
+        # a refusal with a message (two ranks on one GPU, no GPU, ...): the same one-line shape as any other failure
+        error_line(str(e.code), rank, world)
+        sys.stdout.flush()
+        os._exit(e.code if isinstance(e.code, int) else BAD_LAUNCH)
+    except BaseException as e:                            # noqa: BLE001
+        # A rank that dies must take the job down NOW and say why: print the line, then leave without running the process
+        # group's destructors (they can wait on peers that sit in a barrier).  torchrun sees the non-zero child, stops the
+        # other ranks and exits non-zero itself.
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        error_line(f"{type(e).__name__}: {e}", rank, world)
+        sys.stdout.flush()
+        os._exit(RANK_FAILED)
 
+
+def run_rank(args, world: int):
     import torch
     import rlshaders_amd as R
     from rlshaders_amd.sharding import Ranks
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py: no GPU visible; the closures only run on the HIP path")
+    rank_env = int(os.environ.get("RANK", "0"))
     # one rank per GPU.  RLS_DIST_BACKEND=gloo (tests only) lets several ranks share one GPU so that the
     # multi-rank control path can be exercised on a single-GPU box, where RCCL refuses duplicate devices.
     backend = os.environ.get("RLS_DIST_BACKEND", "nccl")
-    device_index = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    have = torch.cuda.device_count()                      # (does not initialise HIP)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+    if have == 0 or (backend == "nccl" and local_world > have):
+        # no GPU, or launched under torchrun with more ranks than devices: every rank leaves at once, before the rendezvous
+        # (no peer waits for anyone); local rank 0 says why, in one line
+        if local_rank == 0:
+            error_line("no GPU visible; the closures only run on the HIP path" if have == 0 else
+                       f"{local_world} ranks on this node but only {have} GPU(s) visible: one rank per GPU over RCCL needs "
+                       f"{local_world} devices", rank_env, world, gpus_visible=have)
+        sys.stdout.flush()
+        os._exit(BAD_LAUNCH)
+    device_index = local_rank % have if backend != "nccl" else local_rank
     torch.cuda.set_device(device_index)
+
+    block = {"all": BLOCK_ALL, "configs": BLOCK_CONFIGS, "none": []}[args.workloads]
+    if args.block_log2_points is not None:
+        block = [(w, args.block_log2_points, min(st, 5)) for w, _, st in block]
+        block = sorted(set(block), key=block.index)
+    block = [b for b in block if not (b[0] == args.workload and b[1] == args.log2_points)]
+
+    # ---- the CPU legs: rank 0's host cores, BEFORE the process group is formed and before any GPU work -----------------
+    # With N > 1 the other ranks are then asleep in the store rendezvous of init_process_group (a socket wait), not spinning
+    # in a device barrier on the cores the oracle's threads want.  Bounded so that the ranks never wait long: <= ~15 s in all.
+    cpu_records = {}
+    if rank_env == 0 and not args.no_cpu_baseline:
+        head_s, block_s = args.cpu_seconds, args.block_cpu_seconds
+        if world > 1:
+            head_s, block_s = min(head_s, 8.0), min(block_s, 2.0)
+        t_cpu = time.perf_counter()
+        for key, name, seconds, full in [("headline", args.workload, head_s, True)] + \
+                [(f"{n_}@{l2}", n_, block_s, False) for n_, l2, _ in block]:
+            try:
+                cb = cpu_baseline(name, seconds, full=full)
+            except Exception as e:                        # noqa: BLE001   (the GPU number must not be lost to the CPU leg)
+                cb = {"error": f"{type(e).__name__}: {e}"}
+            if cb is not None:
+                cb["when"] = ("before the process group is formed and before any GPU work" +
+                              (f": the other {world - 1} ranks sleep in the store rendezvous meanwhile" if world > 1 else ""))
+                if world > 1:
+                    cb["ranks_waiting"] = world - 1
+            cpu_records[key] = cb
+        cpu_seconds_total = time.perf_counter() - t_cpu
+        for cb in cpu_records.values():
+            if cb is not None:
+                cb["all_cpu_legs_seconds"] = round(cpu_seconds_total, 2)
+
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ        # under torchrun, also with one rank
     ranks = Ranks(backend=backend if (world > 1 or launched) else None,
                   device=torch.device("cuda", device_index) if backend == "nccl" else torch.device("cpu"),
@@ -671,6 +828,8 @@ def main():
     keys = [(d["host"], d.get("uuid") or d.get("pci_bus_id") or d["index"]) for d in identities]
     if backend == "nccl" and len(set(keys)) != len(keys):
         raise SystemExit(f"bench.py: two ranks share a GPU: {identities}")
+    if os.environ.get("RLS_BENCH_FAIL_RANK") == str(rank):          # tests: a rank that dies while the others wait for it
+        raise RuntimeError(f"RLS_BENCH_FAIL_RANK={rank}: this rank was told to fail")
 
     m = measure(R, ctx, ranks, torch, args.workload, args.log2_points, args.steps, args.warmup, args.math, args.arena_candidates,
                 args.chunk_log2, not (args.checksum or args.no_other_mode),       # (the other mode would overwrite the outputs)
@@ -735,23 +894,12 @@ def main():
                                          "value": round(world * n * wl.samples_per_point / (other_ms * 1e-3) / 1e9, 4),
                                          "hbm_frac": round(bytes_per_step / (other_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                          "parity": FAST_PARITY if other == "fast" else "bit-exact against the CPU oracle"}
-        if not args.no_cpu_baseline:
-            # rank 0's host cores, after the closing barrier and outside every timed region; with world > 1 the other ranks
-            # wait at their next barrier meanwhile (their host threads sleep in it)
-            cb = cpu_baseline(args.workload, args.cpu_seconds)
-            if cb:
-                if world > 1:
-                    cb["ranks_waiting"] = world - 1
-                detail["cpu_baseline"] = cb
+        if cpu_records.get("headline"):
+            detail["cpu_baseline"] = cpu_records["headline"]
     del wl, m
     torch.cuda.empty_cache()
 
     # ---- the other configurations and verbs, same process, each with its own warm-up --------------------------------
-    block = {"all": BLOCK_ALL, "configs": BLOCK_CONFIGS, "none": []}[args.workloads]
-    if args.block_log2_points is not None:
-        block = [(w, args.block_log2_points, min(st, 5)) for w, _, st in block]
-        block = sorted(set(block), key=block.index)
-    block = [b for b in block if not (b[0] == args.workload and b[1] == args.log2_points)]
     records = []
     for name, log2n, steps in block:
         warm = max(10, args.warmup)
@@ -775,8 +923,8 @@ def main():
                    "steps": steps, "warmup": warm, "ms_per_step": round(el / steps * 1e3, 5),
                    "ms_per_step_wall": round(bm["wall"] / steps * 1e3, 5),
                    "roofline": roofline_record(w, bn, kms, args.math, bm["clock"]), "per_rank_kernel_ms": prm}
-            if not args.no_cpu_baseline:
-                rec["cpu_baseline"] = cpu_baseline(name, args.block_cpu_seconds, full=False)
+            if cpu_records.get(f"{name}@{log2n}"):
+                rec["cpu_baseline"] = cpu_records[f"{name}@{log2n}"]
             records.append(rec)
         del w, bm
         torch.cuda.empty_cache()

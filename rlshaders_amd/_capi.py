@@ -311,7 +311,18 @@ def load() -> C.CDLL:
     if missing:
         raise RuntimeError(f"rlshaders_amd: {path} lacks C-ABI symbols: {missing}")
     _lib = lib
+    global _lib_path
+    _lib_path = path.resolve()
     return lib
+
+
+_lib_path = None
+
+
+def loaded_path() -> Path:
+    """the file the C ABI was loaded from (RLSHADERS_AMD_LIB or the in-tree build) -- what rlshaders_amd.codeid identifies"""
+    load()
+    return _lib_path
 
 
 def check(status: int) -> None:

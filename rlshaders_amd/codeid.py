@@ -5,17 +5,26 @@ binary.  This module says which: it reads the gfx950 code objects straight out o
 section (one clang offload bundle per translation unit) and hashes what the GPU executes --
 
 * ``unit_id``: sha-256 (16 hex digits) over the loadable contents of ONE code object: ``.text`` (instructions),
-  ``.rodata`` (kernel descriptors: register counts, LDS size, scratch) and ``.data``;
+  ``.rodata`` (kernel descriptors: register counts, LDS size, scratch; constants) and ``.data``;
 * ``library_id``: sha-256 over the sorted unit ids -- independent of link order, so the library built by
   rlshaders_amd/build.py and the one built by CMakeLists.txt carry the same id exactly when every kernel in them is the
   same machine code;
 * ``unit_of_kernel(name)``: the unit that holds a kernel, found by its Itanium-mangled name fragment (``ggx_kernel<5, 0, 1>``
   -> ``10ggx_kernelILi5ELi0ELi1EE``), so a profile taken by exact kernel name is tied to that kernel's unit and is not
-  invalidated by a change to some other unit or to host code.
+  invalidated by a change to some other unit or to host code;
+* ``kernel_id(name)``: sha-256 over ONE kernel -- its instructions (the function's bytes in ``.text``; every device function
+  is inlined, the code objects hold no other FUNC symbol), its 64-byte kernel descriptor, and the unit's constant data
+  (``.rodata`` outside the descriptors, ``.data``).  Moving a kernel into another translation unit beside other kernels
+  keeps its kernel_id when the compiler emits the same bytes for it; any change to its instructions, registers, LDS or
+  constants changes it.
 
 Host code, comments and link order do not enter; compiler flags and every header a kernel includes do, through the
-instructions they produce.  Pure Python (struct + hashlib), no tool of the ROCm installation is run: bench.py calls it on
-the GPU box for the library it has just loaded.
+instructions they produce.  One field of every kernel descriptor is left out: KERNEL_CODE_ENTRY_BYTE_OFFSET, the distance
+from the descriptor to the kernel's first instruction.  It is layout, not code, and it moves by a cache line with the
+length of the ``__hip_cuid_<hash>`` symbol clang derives from the PATHS on its command line (a 15-digit hash instead of a
+16-digit one shortens ``.dynstr`` by a byte): the same sources compiled into another object directory would otherwise read
+as other device code one time in a few.  Pure Python (struct + hashlib), no tool of the ROCm installation is run: bench.py
+calls it on the GPU box for the library it has just loaded.
 """
 from __future__ import annotations
 
@@ -49,19 +58,83 @@ def _sections(elf: bytes) -> Dict[str, Tuple[int, int, int]]:
     return out
 
 
-def _symbols(elf: bytes, secs) -> List[str]:
-    """names of the FUNC symbols (the kernels and whatever device functions were not inlined)"""
+def _symtab(elf: bytes, secs) -> List[Tuple[str, int, int, int, int]]:
+    """(name, type, section index, value, size) of every symbol"""
     if ".symtab" not in secs or ".strtab" not in secs:
         return []
     off, size, _ = secs[".symtab"]
     soff, ssize, _ = secs[".strtab"]
     strtab = elf[soff:soff + ssize]
-    names = []
+    out = []
     for k in range(size // 24):
-        name, info = struct.unpack_from("<IB", elf, off + 24 * k)
-        if info & 0xF == 2:                                   # STT_FUNC
-            names.append(strtab[name:strtab.index(b"\0", name)].decode())
-    return names
+        name, info, _other, shndx, value, sz = struct.unpack_from("<IBBHQQ", elf, off + 24 * k)
+        out.append((strtab[name:strtab.index(b"\0", name)].decode(), info & 0xF, shndx, value, sz))
+    return out
+
+
+def _symbols(elf: bytes, secs) -> List[str]:
+    """names of the FUNC symbols (the kernels and whatever device functions were not inlined)"""
+    return [s[0] for s in _symtab(elf, secs) if s[1] == 2]             # STT_FUNC
+
+
+def _section_table(elf: bytes) -> List[Tuple[str, int, int, int, int]]:
+    """(name, type, address, file offset, size) by section index"""
+    shoff, = struct.unpack_from("<Q", elf, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", elf, 0x3A)
+    raw = [struct.unpack_from("<IIQQQQ", elf, shoff + k * shentsize) for k in range(shnum)]
+    stroff, strsize = raw[shstrndx][4], raw[shstrndx][5]
+    strtab = elf[stroff:stroff + strsize]
+    return [(strtab[n:strtab.index(b"\0", n)].decode(), typ, addr, off, size) for n, typ, _f, addr, off, size in raw]
+
+
+KD_SIZE = 64
+KD_ENTRY_OFFSET = slice(16, 24)         # amd_kernel_descriptor_t.kernel_code_entry_byte_offset (int64): layout, not code
+
+
+def _normalised_kd(kd: bytes) -> bytes:
+    b = bytearray(kd)
+    if len(b) == KD_SIZE:
+        b[KD_ENTRY_OFFSET] = b"\0" * 8
+    return bytes(b)
+
+
+def kernel_digests(elf: bytes) -> Dict[str, str]:
+    """mangled kernel name -> kernel id (module docstring) for every kernel of one code object"""
+    table = _section_table(elf)
+    secs = {name: (off, size, typ) for name, typ, _a, off, size in table}
+    syms = _symtab(elf, secs)
+
+    def body(sym):
+        _n, _t, shndx, value, size = sym
+        if not (0 < shndx < len(table)):
+            return None
+        _sn, typ, addr, off, _ss = table[shndx]
+        return None if typ == 8 else elf[off + value - addr:off + value - addr + size]
+
+    kds = {s[0][:-3]: s for s in syms if s[0].endswith(".kd")}
+    # the unit's constant data: .rodata with the kernel descriptors cut out, .data
+    const = hashlib.sha256()
+    for name in (".rodata", ".data"):
+        idx = [k for k, s in enumerate(table) if s[0] == name]
+        if not idx or table[idx[0]][1] == 8:
+            continue
+        _sn, _typ, addr, off, size = table[idx[0]]
+        blob = bytearray(elf[off:off + size])
+        for s in kds.values():
+            if s[2] == idx[0]:
+                lo = s[3] - addr
+                blob[lo:lo + s[4]] = b"\0" * s[4]
+        const.update(name.encode() + b"\0" + bytes(blob))
+    const = const.digest()
+    out = {}
+    for s in syms:
+        if s[1] != 2 or s[0] not in kds:
+            continue
+        code, kd = body(s), body(kds[s[0]])
+        if code is None or kd is None:
+            continue
+        out[s[0]] = hashlib.sha256(struct.pack("<QQ", len(code), len(kd)) + code + _normalised_kd(kd) + const).hexdigest()[:16]
+    return out
 
 
 def fatbin(path) -> bytes:
@@ -96,14 +169,23 @@ def code_objects(fb: bytes) -> List[bytes]:
 
 def unit_digest(elf: bytes) -> Tuple[str, List[str]]:
     """(unit id, FUNC symbol names) of one code object"""
-    secs = _sections(elf)
+    table = _section_table(elf)
+    secs = {name: (off, size, typ) for name, typ, _a, off, size in table}
+    syms = _symtab(elf, secs)
     h = hashlib.sha256()
     for name in HASHED_SECTIONS:
-        if name in secs:
-            off, size, typ = secs[name]
-            body = b"" if typ == 8 else elf[off:off + size]         # SHT_NOBITS occupies no file bytes
-            h.update(name.encode() + b"\0" + struct.pack("<Q", size) + body)
-    return h.hexdigest()[:16], _symbols(elf, secs)
+        idx = [k for k, s in enumerate(table) if s[0] == name]
+        if not idx:
+            continue
+        _n, typ, addr, off, size = table[idx[0]]
+        body = bytearray(b"" if typ == 8 else elf[off:off + size])         # SHT_NOBITS occupies no file bytes
+        if body:
+            for s in syms:                                                  # the descriptors' entry offsets are layout
+                if s[0].endswith(".kd") and s[2] == idx[0] and s[4] == KD_SIZE:
+                    lo = s[3] - addr
+                    body[lo:lo + KD_SIZE] = _normalised_kd(bytes(body[lo:lo + KD_SIZE]))
+        h.update(name.encode() + b"\0" + struct.pack("<Q", size) + bytes(body))
+    return h.hexdigest()[:16], [s[0] for s in syms if s[1] == 2]
 
 
 def mangled_fragment(kernel: str) -> Optional[str]:
@@ -128,7 +210,11 @@ class DeviceCode:
 
     def __init__(self, path):
         self.path = str(path)
-        self.units = [unit_digest(e) for e in code_objects(fatbin(path))]          # [(unit id, [symbols])]
+        objs = code_objects(fatbin(path))
+        self.units = [unit_digest(e) for e in objs]                                # [(unit id, [symbols])]
+        self.kernels: Dict[str, str] = {}                                          # mangled name -> kernel id
+        for e in objs:
+            self.kernels.update(kernel_digests(e))
         self.library_id = hashlib.sha256("\n".join(sorted(u for u, _ in self.units)).encode()).hexdigest()[:16]
 
     def unit_of_kernel(self, kernel: str) -> Optional[str]:
@@ -138,11 +224,19 @@ class DeviceCode:
         hits = sorted({u for u, syms in self.units if any(frag in s for s in syms)})
         return hits[0] if len(hits) == 1 else None
 
+    def kernel_id(self, kernel: str) -> Optional[str]:
+        frag = mangled_fragment(kernel)
+        if not frag:
+            return None
+        hits = sorted({k for name, k in self.kernels.items() if frag in name})
+        return hits[0] if len(hits) == 1 else None
+
     def record(self, kernel: Optional[str] = None) -> dict:
         rec = {"library_id": self.library_id}
         if kernel:
             rec["kernel"] = kernel
             rec["unit_id"] = self.unit_of_kernel(kernel)
+            rec["kernel_id"] = self.kernel_id(kernel)
         return rec
 
 
@@ -171,7 +265,7 @@ if __name__ == "__main__":
     dc = DeviceCode(lib)
     out = {"library": str(lib), "library_id": dc.library_id, "units": len(dc.units)}
     if names:
-        out["kernels"] = {k: dc.unit_of_kernel(k) for k in names}
+        out["kernels"] = {k: {"unit_id": dc.unit_of_kernel(k), "kernel_id": dc.kernel_id(k)} for k in names}
     else:
         out["unit_ids"] = sorted(u for u, _ in dc.units)
     print(json.dumps(out, indent=1))

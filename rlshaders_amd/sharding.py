@@ -10,6 +10,7 @@ torch.distributed supplies it -- backend "nccl" (= RCCL over xGMI) on GPUs, "glo
 """
 from __future__ import annotations
 
+import datetime
 import os
 from typing import List, Optional, Tuple
 
@@ -28,7 +29,10 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
 class Ranks:
     """Thin wrapper over torch.distributed that degrades to a no-op for a single process."""
 
-    def __init__(self, backend: Optional[str] = None, device: Optional[torch.device] = None, launched: bool = False):
+    DEFAULT_TIMEOUT_S = 120.0        # rendezvous + every collective (RLS_DIST_TIMEOUT_S overrides)
+
+    def __init__(self, backend: Optional[str] = None, device: Optional[torch.device] = None, launched: bool = False,
+                 timeout_s: Optional[float] = None):
         """``launched``: opt in to initialising the process group for a ONE-rank run as well (bench.py and the tests pass it
         when a launcher started them: the control path of an N-rank run -- init_process_group("nccl", device_id), barrier,
         device all_reduce -- is then the one a single-GPU box exercises too).  Without it a single process never touches
@@ -40,6 +44,7 @@ class Ranks:
         self.device = device if device is not None else torch.device("cpu")
         self.dist = None
         self._owns_group = False
+        self.timeout_s = float(timeout_s if timeout_s is not None else os.environ.get("RLS_DIST_TIMEOUT_S", self.DEFAULT_TIMEOUT_S))
         if self.world > 1 or launched:
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized():
@@ -49,7 +54,9 @@ class Ranks:
                 if backend is None:
                     backend = "nccl" if self.device.type == "cuda" else "gloo"
                 kw = {"device_id": self.device} if backend == "nccl" else {}
-                dist.init_process_group(backend, **kw)
+                # A rank that never arrives (a dead GPU, a child that failed before this line) must not hold the others for
+                # torch's default 10-30 minutes: the rendezvous, and every collective after it, gives up after `timeout_s`.
+                dist.init_process_group(backend, timeout=datetime.timedelta(seconds=self.timeout_s), **kw)
                 self._owns_group = True
             self.dist = dist
 

@@ -131,3 +131,78 @@ def test_default_block_is_the_three_configurations():
         assert a.workloads == "none" and a.workload == "skin" and a.log2_points == 27
     finally:
         sys.argv = sys_argv
+
+
+# ---- failure shape: a launch that cannot work says so in ONE line, fast, with a non-zero exit ----------
+def _run_bench(argv, env_extra=None, timeout=120):
+    import os
+    import subprocess
+    import time
+    env = dict(os.environ, **(env_extra or {}))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.perf_counter()
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), *argv], capture_output=True, text=True, env=env, timeout=timeout,
+                       cwd=str(ROOT))
+    return p, time.perf_counter() - t0
+
+
+def _error_lines(stdout):
+    out = []
+    for l in stdout.splitlines():
+        if l.startswith("{"):
+            d = json.loads(l)
+            if "error" in d:
+                out.append(d)
+    return out
+
+
+def test_more_ranks_than_gpus_fails_in_the_parent_before_spawning():
+    """`python bench.py --gpus 8` on a box with fewer GPUs (here: none, unless the suite runs on a GPU box): the parent
+    counts the devices BEFORE it spawns torchrun, prints one JSON error line and exits non-zero -- no child ever dies inside
+    torch.cuda.set_device, nothing waits for a rendezvous"""
+    import torch
+    have = torch.cuda.device_count()
+    p, took = _run_bench(["--gpus", str(have + 7), "--steps", "2", "--warmup", "1"])
+    assert p.returncode == 2, (p.returncode, p.stderr[-2000:])
+    errs = _error_lines(p.stdout)
+    assert len(errs) == 1 and errs[0]["world_size"] == have + 7 and errs[0]["bench"] == "bench.py", p.stdout[-2000:]
+    assert ("GPU(s) visible" in errs[0]["error"]) if have else ("no GPU visible" in errs[0]["error"])
+    assert "torch.distributed.run" not in p.stderr and "Traceback" not in p.stderr       # nothing was launched, nothing raised
+    assert json.loads(p.stdout.splitlines()[-1]) == errs[0]                              # the LAST line is the error line
+    assert took < 60
+
+
+def test_one_rank_without_a_gpu_says_so_in_one_line():
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    p, took = _run_bench(["--steps", "2", "--warmup", "1"])
+    assert p.returncode == 2 and took < 60
+    errs = _error_lines(p.stdout)
+    assert len(errs) == 1 and "no GPU visible" in errs[0]["error"] and errs[0]["rank"] == 0 and "Traceback" not in p.stderr
+
+
+def test_torchrun_with_more_ranks_than_gpus_leaves_before_the_rendezvous():
+    """the driver starts N > 1 itself (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`): every rank
+    sees LOCAL_WORLD_SIZE > device count and leaves at once, before init_process_group -- the job is down in seconds with one
+    error line, not after a rendezvous timeout"""
+    import os
+    import subprocess
+    import time
+    import torch
+    have = torch.cuda.device_count()
+    world = have + 2
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("RLS_DIST_BACKEND", None)
+    port = 29300 + os.getpid() % 150
+    t0 = time.perf_counter()
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", str(world), "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=300, cwd=str(ROOT))
+    took = time.perf_counter() - t0
+    assert p.returncode != 0 and took < 90, (p.returncode, took)
+    errs = _error_lines(p.stdout)
+    assert len(errs) == 1, p.stdout[-2000:]
+    assert errs[0]["world_size"] == world and ("GPU(s) visible" in errs[0]["error"] or "no GPU visible" in errs[0]["error"])

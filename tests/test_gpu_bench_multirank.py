@@ -168,6 +168,94 @@ def test_multi_rank_line_is_self_sufficient():
     assert "ranks_waiting" not in one["_detail"]["cpu_baseline"] and one["cpu_baseline"]["with_alloc"]["value"] > 0
 
 
+def _errors(stdout):
+    out = []
+    for l in stdout.splitlines():
+        if l.startswith("{"):
+            d = json.loads(l)
+            if "error" in d:
+                out.append(d)
+    return out
+
+
+@pytest.mark.gpu
+def test_more_ranks_than_gpus_under_rccl_fails_fast_and_readably():
+    """N = visible GPUs + 2 with backend nccl.  Bare (`python bench.py --gpus N`): the PARENT counts the
+    devices before spawning and exits 2 with one JSON error line, no torchrun.  Under torchrun (how the driver starts N > 1):
+    every rank leaves before the rendezvous, one error line, the job is down in seconds instead of dying in set_device or
+    waiting out a rendezvous."""
+    import time
+    import torch
+    have = torch.cuda.device_count()
+    world = have + 2
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("RLS_DIST_BACKEND", None)
+    base = [str(ROOT / "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--log2-points", "18", "--no-cpu-baseline"]
+    t0 = time.perf_counter()
+    p = subprocess.run([sys.executable, *base], capture_output=True, text=True, env=env, timeout=300, cwd=str(ROOT))
+    assert p.returncode == 2 and time.perf_counter() - t0 < 60, (p.returncode, p.stderr[-2000:])
+    errs = _errors(p.stdout)
+    assert len(errs) == 1 and errs[0]["gpus_visible"] == have and f"--gpus {world}" in errs[0]["error"], p.stdout[-1000:]
+    assert json.loads(p.stdout.splitlines()[-1]) == errs[0] and "Traceback" not in p.stderr
+    port = 29100 + os.getpid() % 150
+    t0 = time.perf_counter()
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), *base], capture_output=True, text=True, env=env, timeout=300,
+                       cwd=str(ROOT))
+    took = time.perf_counter() - t0
+    assert p.returncode != 0 and took < 90, (p.returncode, took)
+    errs = _errors(p.stdout)
+    assert len(errs) == 1 and errs[0]["gpus_visible"] == have and errs[0]["world_size"] == world, p.stdout[-1000:]
+    assert not any(l.startswith("{") and "value" in l for l in p.stdout.splitlines())          # no result line
+
+
+@pytest.mark.gpu
+def test_a_rank_that_raises_takes_the_job_down_inside_a_minute():
+    """rank 1 of 2 raises after the device gather while rank 0 goes on to the opening barrier.  The
+    failing rank prints one JSON line {"error", "rank"} and exits non-zero without running the process group's destructors;
+    torchrun stops rank 0; the job's exit code is non-zero and no result line is printed."""
+    import time
+    env = dict(os.environ, RLS_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", RLS_BENCH_FAIL_RANK="1")
+    port = 29250 + os.getpid() % 150
+    t0 = time.perf_counter()
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup",
+                        "1", "--log2-points", "20", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=300,
+                       cwd=str(ROOT))
+    took = time.perf_counter() - t0
+    assert p.returncode != 0, p.stdout[-2000:]
+    assert took < 60, took
+    errs = _errors(p.stdout)
+    # the rank that failed says why; rank 0 may add its own line when it sees the peer's connection close (a consequence, and
+    # it names itself) before torchrun stops it
+    cause = [e for e in errs if e["rank"] == 1]
+    assert len(cause) == 1 and cause[0]["world_size"] == 2 and "RLS_BENCH_FAIL_RANK" in cause[0]["error"], errs
+    assert all(e["rank"] in (0, 1) for e in errs) and len(errs) <= 2
+    assert not any(l.startswith("{") and '"value"' in l for l in p.stdout.splitlines())
+    # the same through the bare launch (parent -> torchrun child -> ranks): the parent returns the children's failure
+    t0 = time.perf_counter()
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--log2-points", "20",
+                        "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=300, cwd=str(ROOT))
+    assert p.returncode != 0 and time.perf_counter() - t0 < 60
+    assert 1 in [e["rank"] for e in _errors(p.stdout)]
+
+
+@pytest.mark.gpu
+def test_rendezvous_gives_up_after_the_timeout():
+    """a rank that never arrives: the others leave init_process_group after RLS_DIST_TIMEOUT_S (default 120 s) instead of
+    torch's 10-30 minutes.  One process that believes it is rank 0 of 2, nobody else comes."""
+    import time
+    env = dict(os.environ, RLS_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29450 + os.getpid() % 40), RANK="0",
+               WORLD_SIZE="2", LOCAL_RANK="0", LOCAL_WORLD_SIZE="2", RLS_DIST_TIMEOUT_S="8")
+    t0 = time.perf_counter()
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--log2-points", "16",
+                        "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=300, cwd=str(ROOT))
+    took = time.perf_counter() - t0
+    assert p.returncode != 0 and took < 60, (p.returncode, took)
+    errs = _errors(p.stdout)
+    assert len(errs) == 1 and errs[0]["rank"] == 0, p.stdout[-1500:]
+
+
 @pytest.mark.gpu
 def test_default_shape_with_cpu_baseline():
     """the default command's shape at small sizes: configs block (3 records, each with its own cpu_baseline) printed before

@@ -1,0 +1,180 @@
+"""CPU: the committed counter profiles are tied to the device code they were taken on.
+
+rlshaders_amd/codeid.py reads the gfx950 code objects out of the built library and hashes them (library / unit / kernel
+ids); the summarisers write those ids into profiles/*_{traffic,flops,clock,stalls}.json; bench.py quotes a counter record
+only beside the same device code and otherwise drops every counter-derived key and says `counter_source.stale`."""
+import importlib.util
+import json
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+KERNELS = {"ggx_reflect_refract": "ggx_kernel<5, 0, 1>", "sss_probe": "sss_kernel<3, 0, 0>", "skin": "skin_kernel<0, 1>",
+           "disney_integrate": "disney_integrate_kernel<1, 0>"}
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_module_pb", ROOT / "bench.py")
+    m = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(m)
+    finally:
+        sys.argv = argv
+    return m
+
+
+@pytest.fixture(scope="module")
+def code():
+    from rlshaders_amd import build
+    from rlshaders_amd.codeid import DeviceCode
+    return DeviceCode(build.build_library())
+
+
+def test_ids_of_the_built_library(code):
+    from rlshaders_amd import codeid
+    assert len(code.units) >= 12 and len(code.library_id) == 16
+    assert codeid.mangled_fragment("void (anonymous namespace)::ggx_kernel<5, 0, 1>(rlsh::GgxIO)") == "10ggx_kernelILi5ELi0ELi1EE"
+    assert codeid.mangled_fragment("skin_kernel<0, 1>") == "11skin_kernelILi0ELi1EE"
+    seen = set()
+    for k in KERNELS.values():
+        rec = code.record(k)
+        assert rec["library_id"] == code.library_id and rec["unit_id"] and rec["kernel_id"], rec
+        seen.add(rec["kernel_id"])
+    assert len(seen) == len(KERNELS)
+    # EXACT, FAST and the stamped diagnostic instantiation are three different kernels
+    ids = {code.kernel_id(k) for k in ("ggx_kernel<5, 0, 1>", "ggx_kernel<5, 1, 1>", "ggx_kernel_stamped<5, 0, 1>")}
+    assert len(ids) == 3 and None not in ids
+    assert code.unit_of_kernel("ggx_kernel<5, 0, 1>") == code.unit_of_kernel("ggx_kernel_stamped<5, 0, 1>")
+    assert code.unit_of_kernel("ggx_kernel<5, 0, 1>") != code.unit_of_kernel("ggx_kernel<5, 1, 1>")      # the FAST unit
+    assert code.kernel_id("no_such_kernel<1>") is None and code.unit_of_kernel("no_such_kernel<1>") is None
+
+
+def test_a_changed_byte_changes_the_ids(code, tmp_path):
+    """flip one bit inside the EXACT rlGgx kernel's instructions in a copy of the library: its kernel, unit and library ids
+    move, the other kernels' ids stay"""
+    from rlshaders_amd import build, codeid
+    data = bytearray(Path(build.LIB).read_bytes())
+    secs = codeid._sections(bytes(data))
+    fb_off, fb_size, _ = secs[".hip_fatbin"]
+    fb = bytes(data[fb_off:fb_off + fb_size])
+    # find the code object that holds the kernel and the kernel's first instruction bytes inside it
+    frag = codeid.mangled_fragment(KERNELS["ggx_reflect_refract"])
+    for elf in codeid.code_objects(fb):
+        table = codeid._section_table(elf)
+        s2 = {name: (off, size, typ) for name, typ, _a, off, size in table}
+        hit = [s for s in codeid._symtab(elf, s2) if s[1] == 2 and frag in s[0] and "stamped" not in s[0]]
+        if hit:
+            _n, _t, shndx, value, _size = hit[0]
+            _sn, _typ, addr, off, _ss = table[shndx]
+            where = fb.index(elf) + off + value - addr + 16
+            break
+    else:
+        pytest.fail("kernel not found")
+    data[fb_off + where] ^= 0x01
+    other = tmp_path / "librlshaders_amd_flipped.so"
+    other.write_bytes(bytes(data))
+    dc = codeid.DeviceCode(other)
+    k = KERNELS["ggx_reflect_refract"]
+    assert dc.library_id != code.library_id
+    assert dc.kernel_id(k) != code.kernel_id(k) and dc.unit_of_kernel(k) != code.unit_of_kernel(k)
+    for w in ("sss_probe", "skin", "disney_integrate"):
+        assert dc.kernel_id(KERNELS[w]) == code.kernel_id(KERNELS[w]) and dc.unit_of_kernel(KERNELS[w]) == code.unit_of_kernel(KERNELS[w])
+
+
+class _Wl:
+    name, bytes_per_point, samples_per_point, launches_per_step, bound = "ggx_reflect_refract", 124, 2, 1, "hbm"
+    kernel, survey_bytes, config, desc = "ggx_kernel<5, {m}, 1>", 120, 2, "synthetic"
+
+
+def _profiles(tmp_path, stamp):
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    base = {"workload": "ggx_reflect_refract", "math": "exact", "kernel": "ggx_kernel<5, 0, 1>", "code": stamp}
+    (prof / "t_ggx_reflect_refract_traffic.json").write_text(json.dumps(dict(base, points_per_launch=1 << 26, hbm_bytes_per_launch=8321638588)))
+    (prof / "t_ggx_reflect_refract_flops.json").write_text(json.dumps(dict(base, points_per_launch=1 << 26, flops_per_point=1500.0,
+                                                                            instructions_per_point={"SQ_INSTS_VALU": 1375.0, "SQ_INSTS_SALU": 367.0})))
+    (prof / "t_ggx_reflect_refract_clock.json").write_text(json.dumps(dict(base, effective_clock_ghz=1.9)))
+    (prof / "t_ggx_reflect_refract_stalls.json").write_text(json.dumps(dict(base, valu_port={"busy": 0.9675, "holding_two": 0.59, "holding_one": 0.37,
+                                                                                              "idle": 0.03, "instructions_issued_in_pairs": 0.79})))
+    return prof
+
+
+COUNTER_KEYS = ("traffic", "frac_counter_bytes", "issue_slot_frac", "valu_per_point", "salu_per_point")
+
+
+def test_matching_profile_is_used(code, tmp_path):
+    b = _bench()
+    b.ROOT = tmp_path
+    _profiles(tmp_path, code.record("ggx_kernel<5, 0, 1>"))
+    roof = b.roofline_record(_Wl, 1 << 26, 2.0, "exact", None)
+    assert roof["counter_source"]["stale"] is False and "stale_files" not in roof["counter_source"]
+    assert roof["traffic"] == 8321638588 and roof["valu_per_point"] == 1375.0 and roof["valu_busy_frac"] == 0.9675
+    assert roof["effective_clock_ghz"] == 1.9 and roof["issue_slot_frac_at_clock"] is not None
+    assert roof["code"]["library_id"] == code.library_id and roof["code"]["kernel_id"] == code.kernel_id("ggx_kernel<5, 0, 1>")
+    assert abs(roof["frac"] - 124 * (1 << 26) / 2.0e-3 / 8e12) < 1e-3                       # `frac` is live either way
+    head = b.headline({"metric": "m", "value": 1.0, "unit": "u", "n_gpus": 1, "steps": 1, "warmup": 1, "ms_per_step": 1.0,
+                       "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                       "config": {"workload": "w"}, "roofline": roof, "ranks": {}})
+    assert head["roofline"]["library_id"] == code.library_id and head["roofline"]["counters_stale"] is False
+
+
+@pytest.mark.parametrize("stamp", [None, {"library_id": "0" * 16, "unit_id": "1" * 16, "kernel_id": "2" * 16},
+                                   {"library_id": "0" * 16}])
+def test_stale_or_unstamped_profile_is_dropped(code, tmp_path, stamp):
+    """a record taken on other device code (or on nobody-knows-which) fills NO key of the live line; the line says so"""
+    b = _bench()
+    b.ROOT = tmp_path
+    _profiles(tmp_path, stamp)
+    roof = b.roofline_record(_Wl, 1 << 26, 2.0, "exact", None)
+    src = roof["counter_source"]
+    assert src["stale"] is True and len(src["stale_files"]) == 4 and src["traffic"] is None and src["instruction_mix"] is None
+    assert all(f["taken_on"] == (stamp or "unstamped") for f in src["stale_files"])
+    for k in COUNTER_KEYS:
+        assert roof.get(k) is None, k
+    for k in ("valu_busy_frac", "valu_port", "effective_clock_ghz", "issue_slot_frac_at_clock", "clock_profile"):
+        assert k not in roof, k
+    assert roof["frac"] > 0 and roof["achieved"] > 0 and roof["kernel_ms"] == 2.0            # what is measured live stays
+    head = b.headline({"metric": "m", "value": 1.0, "unit": "u", "n_gpus": 1, "steps": 1, "warmup": 1, "ms_per_step": 1.0,
+                       "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                       "config": {"workload": "w"}, "roofline": roof, "ranks": {}})
+    assert head["roofline"]["counters_stale"] is True and head["roofline"]["traffic"] is None
+
+
+def test_newest_matching_record_wins_over_a_newer_stale_one(code, tmp_path):
+    b = _bench()
+    b.ROOT = tmp_path
+    prof = _profiles(tmp_path, code.record("ggx_kernel<5, 0, 1>"))
+    newer = json.loads((prof / "t_ggx_reflect_refract_traffic.json").read_text())
+    newer["code"] = {"library_id": "f" * 16, "unit_id": "e" * 16, "kernel_id": "d" * 16}
+    newer["hbm_bytes_per_launch"] = 1
+    (prof / "u_ggx_reflect_refract_traffic.json").write_text(json.dumps(newer))           # sorts after t_*
+    roof = b.roofline_record(_Wl, 1 << 26, 2.0, "exact", None)
+    assert roof["traffic"] == 8321638588 and roof["counter_source"]["stale"] is False
+    assert roof["counter_source"]["traffic"] == "profiles/t_ggx_reflect_refract_traffic.json"
+
+
+def test_committed_profiles_of_the_baseline_kernels_describe_this_library(code):
+    """what DESIGN.md section 5 quotes must have been taken on the device code that ships: for each BASELINE kernel there is a
+    committed, stamped record of every kind whose kernel_id is the built library's"""
+    b = _bench()
+    missing = []
+    for w, k in KERNELS.items():
+        live = code.record(k)
+        for suffix, key in (("traffic", "hbm_bytes_per_launch"), ("flops", "flops_per_point"), ("clock", "effective_clock_ghz"),
+                            ("stalls", "valu_port")):
+            d = b.profile_record(w, "exact", suffix, key, live)
+            if d is None or d.get("stale"):
+                missing.append((w, suffix, (d or {}).get("file")))
+    assert not missing, missing
+
+
+def test_summarisers_copy_the_stamp_from_the_bench_line(tmp_path):
+    """tools/summarize_stalls.py: `code` of the session's bench line (computed on the GPU box) lands in the summary"""
+    import test_tools_stalls_summary as T
+    stamp = {"library_id": "a" * 16, "kernel": "ggx_kernel<5, 0, 1>", "unit_id": "b" * 16, "kernel_id": "c" * 16}
+    out = T.run_summary(tmp_path, code=stamp)
+    assert out["code"] == stamp
+    assert json.loads((tmp_path / "profiles" / "t_ggx_reflect_refract_stalls.json").read_text())["code"] == stamp

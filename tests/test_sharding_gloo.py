@@ -79,3 +79,22 @@ def test_ranks_reuses_an_existing_process_group(tmp_path):
         assert dist.is_initialized()
     finally:
         dist.destroy_process_group()
+
+
+def test_rendezvous_gives_up_after_the_timeout():
+    """a rank whose peer never arrives leaves init_process_group after Ranks.timeout_s (default 120 s,
+    RLS_DIST_TIMEOUT_S) instead of torch's 10-30 minutes -- a hung rank cannot burn the driver's half hour.  One process that
+    believes it is rank 0 of 2; nobody else comes."""
+    import time
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from rlshaders_amd.sharding import Ranks\n"
+            "r = Ranks(backend='gloo', launched=True)\n" % str(ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29950 + os.getpid() % 40), RANK="0", WORLD_SIZE="2",
+               LOCAL_RANK="0", RLS_DIST_TIMEOUT_S="5")
+    t0 = time.perf_counter()
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    took = time.perf_counter() - t0
+    assert p.returncode != 0 and 4 < took < 60, (p.returncode, took, p.stderr[-800:])
+    assert "imeout" in p.stderr or "timed out" in p.stderr, p.stderr[-800:]
+    from rlshaders_amd.sharding import Ranks
+    assert Ranks.DEFAULT_TIMEOUT_S == 120.0

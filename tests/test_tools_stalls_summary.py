@@ -25,7 +25,9 @@ def _write(path, rows):
             w.writerow([disp, disp, "Agent 2", 2, 1, 1, 1 << 26, 7, name, 256, 0, 0, 64, 0, 78, counter, float(value), t0, t1])
 
 
-def test_by_name_median_and_port_decomposition(tmp_path):
+def run_summary(tmp_path, code=None):
+    """synthetic pmc_stalls.sh session under tmp_path -> summarize_stalls.main's record (also used by
+    tests/test_profile_binding.py: `code` is the device-code stamp bench.py puts on the session's bench line)"""
     spec = importlib.util.spec_from_file_location("summarize_stalls", ROOT / "tools" / "summarize_stalls.py")
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
@@ -34,7 +36,8 @@ def test_by_name_median_and_port_decomposition(tmp_path):
     n = 1 << 26
     (d).mkdir(parents=True)
     (d / "bench.json").write_text(json.dumps({"record": "headline_detail", "config": {"math": "exact", "points_per_gpu": n},
-                                              "roofline": {"kernel": "ggx_kernel<5, 0, 1>", "kernel_ms": 2.0}}) + "\n")
+                                              "roofline": dict({"kernel": "ggx_kernel<5, 0, 1>", "kernel_ms": 2.0},
+                                                               **({"code": code} if code else {}))}) + "\n")
     # 1000 shader cycles per SE -> Q = 1000 / 4 * 1024 = 256 000 SIMD quad-cycles; the counter comes as 8 rows (one per XCD)
     rows = []
     for disp, scale in ((1, 5.0), (2, 1.0), (3, 1.0)):          # dispatch 1: a cold outlier the median drops
@@ -48,7 +51,12 @@ def test_by_name_median_and_port_decomposition(tmp_path):
                  (disp, EXACT, "SQ_INSTS_VALU", 380_000, 0, 1)]
     rows += [(7, FAST, "SQ_ACTIVE_INST_VALU", 9e9, 0, 1), (8, STAMPED, "SQ_ACTIVE_INST_VALU2", 9e9, 0, 1)]
     _write(d / "b" / "x" / "2_counter_collection.csv", rows)
-    out = mod.main(["summarize_stalls.py", "t", "ggx_reflect_refract"], root=str(tmp_path))
+    return mod.main(["summarize_stalls.py", "t", "ggx_reflect_refract"], root=str(tmp_path))
+
+
+def test_by_name_median_and_port_decomposition(tmp_path):
+    out = run_summary(tmp_path)
+    assert out["code"] is None                                             # a bench line without a stamp: the summary says so
     assert out["kernel"] == "ggx_kernel<5, 0, 1>" and out["dispatches_per_counter"]["SQ_CYCLES"] == 3
     v = out["valu_port"]
     assert v["simd_quad_cycles_per_launch"] == 256_000.0                   # the median dispatch (scale 1.0), its 8 rows added up

@@ -48,7 +48,10 @@ def main(argv=None, root=ROOT):
         raise SystemExit(f"no dispatch of {kernel} under {d}")
     # median over the dispatches of a pass (the first launches after idle run at another clock)
     mean = {c: sorted(v.values())[len(v) // 2] for c, v in vals.items()}
-    out = {"workload": w, "math": line["config"]["math"], "kernel": kernel, "points_per_launch": line["config"]["points_per_gpu"],
+    out = {"workload": w, "math": line["config"]["math"], "kernel": kernel,
+           # the device code these passes ran (ids computed by bench.py on the GPU box for the library it had loaded)
+           "code": line["roofline"].get("code"),
+           "points_per_launch": line["config"]["points_per_gpu"],
            "dispatches_per_counter": {c: len(v) for c, v in vals.items()},
            "other_kernels_counted": 0, "counters_per_launch": {c: round(v, 1) for c, v in sorted(mean.items())},
            "bench_kernel_ms_unprofiled": line["roofline"]["kernel_ms"],

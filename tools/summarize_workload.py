@@ -34,13 +34,13 @@ def pmc(dirname, sub):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
-def clock_record(src, dst, tag, workload, ksub, math):
+def clock_record(src, dst, tag, workload, ksub, math, code=None):
     """profiles/<tag>_<workload>_clock.json: the shader clock the kernel holds, two independent ways --
     (a) GRBM_GUI_ACTIVE / 8 / dispatch duration per dispatch of the exact kernel (rocprofv3 --pmc pass on a batch large enough
         for dispatches of >= 10 ms, where the quotient is within 3 % of the in-kernel clock: MI355X_MICROARCH.md, DVFS give-back);
     (b) the in-kernel stamps (s_memtime / s_memrealtime, stamped instantiation) after two seconds of back-to-back launches
         (bench.py --sustain-seconds 2).  `effective_clock_ghz` = (b) when there is one, else (a)."""
-    rec = {"workload": workload, "math": math, "kernel": ksub}
+    rec = {"workload": workload, "math": math, "kernel": ksub, "code": code}
     clocks, durs = [], []
     for f in newest(glob.glob(os.path.join(src, "clock_grbm", "**", "*counter_collection.csv"), recursive=True)):
         per = {}                                        # rows of one dispatch (one per XCD, if rocprofv3 splits them) add up
@@ -95,6 +95,11 @@ def main():
     if line is None:
         raise SystemExit(f"no bench line under {src}")
     ksub = line["roofline"]["kernel"]
+    # which binary the passes of this session ran: the ids bench.py computed ON THE GPU BOX for the library it had loaded
+    # (rlshaders_amd/codeid.py).  Every summary carries it; bench.py quotes a summary only beside the same device code.
+    code = line["roofline"].get("code")
+    if not code or not code.get("library_id"):
+        print("WARNING: the bench line carries no device-code id: these summaries will read as stale", file=sys.stderr)
     n = line["config"]["points_per_gpu"]
     math = line["config"]["math"]
     launches = line["roofline"].get("launches_per_step", 1)
@@ -113,7 +118,7 @@ def main():
     if "FETCH_SIZE" in fetch and "WRITE_SIZE" in write:
         rd, wr = fetch["FETCH_SIZE"] * 1024.0 * factor, write["WRITE_SIZE"] * 1024.0
         alg = line["roofline"]["algorithmic_bytes_per_launch"]
-        t = {"workload": workload, "math": math, "kernel": ksub, "points_per_launch": points_per_launch,
+        t = {"workload": workload, "math": math, "kernel": ksub, "code": code, "points_per_launch": points_per_launch,
              "hbm_bytes_per_launch": int(round(rd + wr)),
              "read": int(round(rd)), "write": int(round(wr)), "algorithmic_bytes_per_launch": alg,
              "ratio_to_algorithmic": round((rd + wr) / alg, 4), "fetch_size_factor": round(factor, 4),
@@ -121,7 +126,7 @@ def main():
                        "the factor measured on rls_checksum (known byte count) in the same session"}
         json.dump(t, open(os.path.join(dst, f"{tag}_{workload}_traffic.json"), "w"), indent=1)
         print("traffic", t["hbm_bytes_per_launch"], "ratio", t["ratio_to_algorithmic"])
-    clock_record(src, dst, tag, workload, ksub, math)
+    clock_record(src, dst, tag, workload, ksub, math, code)
     mix = {}
     for d in ("mix_a", "mix_b", "mix_c", "mix_d"):
         mix.update(pmc(os.path.join(src, d), ksub))
@@ -132,7 +137,7 @@ def main():
         flops = (g("SQ_INSTS_VALU_ADD_F32") + g("SQ_INSTS_VALU_MUL_F32") + 2 * g("SQ_INSTS_VALU_FMA_F32")
                  + g("SQ_INSTS_VALU_TRANS_F32") + g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64")
                  + 2 * g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_TRANS_F64"))
-        f = {"workload": workload, "math": math, "kernel": ksub, "points_per_launch": points_per_launch,
+        f = {"workload": workload, "math": math, "kernel": ksub, "code": code, "points_per_launch": points_per_launch,
              "flops_per_point": round(flops, 1),
              "instructions_per_point": per,
              "note": "wave-instructions per wave of 64 points = instructions per point (G = 1: one lane per point); flops = "

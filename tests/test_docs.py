@@ -15,14 +15,50 @@ def test_design_md_is_short_and_narrow():
         assert must.lower() in "\n".join(lines).lower(), must
 
 
+def _cited_profiles(text):
+    return {m.rstrip(".") for m in set(re.findall(r"`(?:profiles/)?(r0\d_[A-Za-z0-9_.*]+)`", text))}
+
+
 def test_named_profiles_exist():
-    text = "".join((ROOT / f).read_text(encoding="utf8") for f in ("DESIGN.md", "docs/experiments_r04.md", "docs/experiments_r05.md",
-                                                                 "THIRD_PARTY.md"))
+    """what DESIGN.md and THIRD_PARTY.md name is under profiles/ itself; the experiment diaries of earlier rounds may name files
+    that have since moved to profiles/archive/ (profiles/ holds what is cited, the rest is archived)"""
     missing = []
-    for m in set(re.findall(r"`(?:profiles/)?(r0\d_[A-Za-z0-9_.*]+)`", text)):
-        name = m.rstrip(".")
-        if not list((ROOT / "profiles").glob(name if "*" in name else name + "*")):
-            missing.append(name)
+    for docs, dirs in ((("DESIGN.md", "THIRD_PARTY.md"), ("profiles",)),
+                       (("docs/experiments_r04.md", "docs/experiments_r05.md"), ("profiles", "profiles/archive"))):
+        text = "".join((ROOT / f).read_text(encoding="utf8") for f in docs)
+        for name in _cited_profiles(text):
+            if not any(list((ROOT / d).glob(name if "*" in name else name + "*")) for d in dirs):
+                missing.append(name)
+    assert not missing, missing
+
+
+def test_profiles_directory_holds_what_is_cited():
+    """fewer than 120 files under profiles/; the archive is a directory of its own and bench.py never reads
+    it (profile_record globs profiles/*.json only)"""
+    top = [p for p in (ROOT / "profiles").iterdir() if p.is_file()]
+    assert len(top) < 120, len(top)
+    assert (ROOT / "profiles" / "archive").is_dir()
+    assert 'glob(f"*_{suffix}.json")' in (ROOT / "bench.py").read_text()
+
+
+def test_cited_scripts_exist():
+    """docs/experiments_r04.md cited tools/r04_session*.sh after the scripts had moved.  Every `tools/...` and
+    `docs/...` path the documents name exists (a path followed by `@ <commit>` names a file of that commit, not of the tree)."""
+    missing = []
+    for d in ("DESIGN.md", "README.md", "INTEGRATION.md", "THIRD_PARTY.md", "docs/experiments_r04.md", "docs/experiments_r05.md",
+              "docs/coverage.md", "docs/sessions/README.md", "profiles/README.md", "tools/README.md"):
+        text = (ROOT / d).read_text(encoding="utf8")
+        for m in re.finditer(r"`((?:tools|docs)/[A-Za-z0-9_./{},*-]+)`( @ `?[0-9a-f]{7})?", text):
+            path, at_commit = m.group(1).rstrip("."), m.group(2)
+            if at_commit:
+                continue
+            names = [path]
+            b = re.search(r"\{([^}]*)\}", path)
+            if b:                                        # docs/sessions/r05_session{1,2,3}.sh
+                names = [path[:b.start()] + alt + path[b.end():] for alt in b.group(1).split(",")]
+            for n in names:
+                if not (list(ROOT.glob(n)) if "*" in n else (ROOT / n).exists()):
+                    missing.append((d, n))
     assert not missing, missing
 
 

@@ -700,11 +700,13 @@ def error_line(message: str, rank, world: int, **more) -> None:
 
 
 def visible_gpus() -> int:
-    """GPUs this process could use.  torch.cuda.device_count() does not initialise the HIP runtime on this image, so the
-    parent may call it and still start children."""
+    """GPUs a rank could use, counted in a throwaway CHILD process: the parent of a bare `--gpus N` launch never imports torch
+    or touches the HIP runtime, so starting the ranks afterwards is an ordinary spawn from a GPU-less process whatever
+    torch.cuda.device_count() does inside (on this image it does not initialise the runtime; elsewhere it may)."""
     try:
-        import torch
-        return int(torch.cuda.device_count())
+        p = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True,
+                           text=True, timeout=300)
+        return int(p.stdout.strip().splitlines()[-1]) if p.returncode == 0 else 0
     except Exception:                                    # noqa: BLE001
         return 0
 
@@ -770,11 +772,11 @@ def run_rank(args, world: int):
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
     if have == 0 or (backend == "nccl" and local_world > have):
         # no GPU, or launched under torchrun with more ranks than devices: every rank leaves at once, before the rendezvous
-        # (no peer waits for anyone); local rank 0 says why, in one line
-        if local_rank == 0:
-            error_line("no GPU visible; the closures only run on the HIP path" if have == 0 else
-                       f"{local_world} ranks on this node but only {have} GPU(s) visible: one rank per GPU over RCCL needs "
-                       f"{local_world} devices", rank_env, world, gpus_visible=have)
+        # (no peer waits for anyone).  EVERY rank says why, in one line each: whichever exits first makes torchrun stop the
+        # others, so a line left to one designated rank can be lost.
+        error_line("no GPU visible; the closures only run on the HIP path" if have == 0 else
+                   f"{local_world} ranks on this node but only {have} GPU(s) visible: one rank per GPU over RCCL needs "
+                   f"{local_world} devices", rank_env, world, gpus_visible=have)
         sys.stdout.flush()
         os._exit(BAD_LAUNCH)
     device_index = local_rank % have if backend != "nccl" else local_rank

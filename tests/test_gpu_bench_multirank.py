@@ -182,7 +182,7 @@ def _errors(stdout):
 def test_more_ranks_than_gpus_under_rccl_fails_fast_and_readably():
     """N = visible GPUs + 2 with backend nccl.  Bare (`python bench.py --gpus N`): the PARENT counts the
     devices before spawning and exits 2 with one JSON error line, no torchrun.  Under torchrun (how the driver starts N > 1):
-    every rank leaves before the rendezvous, one error line, the job is down in seconds instead of dying in set_device or
+    every rank leaves before the rendezvous with its own error line (one reason), the job is down in seconds instead of dying in set_device or
     waiting out a rendezvous."""
     import time
     import torch
@@ -205,7 +205,9 @@ def test_more_ranks_than_gpus_under_rccl_fails_fast_and_readably():
     took = time.perf_counter() - t0
     assert p.returncode != 0 and took < 90, (p.returncode, took)
     errs = _errors(p.stdout)
-    assert len(errs) == 1 and errs[0]["gpus_visible"] == have and errs[0]["world_size"] == world, p.stdout[-1000:]
+    # every rank that reached the check says why (whichever exits first makes torchrun stop the rest): >= 1 line, one reason
+    assert 1 <= len(errs) <= world and len({e["error"] for e in errs}) == 1, p.stdout[-1000:]
+    assert errs[0]["gpus_visible"] == have and errs[0]["world_size"] == world
     assert not any(l.startswith("{") and "value" in l for l in p.stdout.splitlines())          # no result line
 
 

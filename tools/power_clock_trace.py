@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Board power and clocks while a BASELINE kernel runs back to back: is the clock the kernel holds (in-kernel stamps:
-profiles/r05_*_clock.json) the power limit at work?  For each workload: launch the kernel continuously for `--seconds` while a
+profiles/r06_*_clock.json) the power limit at work?  For each workload: launch the kernel continuously for `--seconds` while a
 thread samples the hwmon files of the device (power1_average / power1_cap, freq1_input = sclk) -- read-only sysfs, no
 privileges -- then read the in-kernel clock of the last launches (rls_diag_clock_stamps_*).
 usage: tools/power_clock_trace.py [--seconds 6] [--workloads ggx_reflect_refract,sss_probe,skin,disney_integrate] [--math exact]

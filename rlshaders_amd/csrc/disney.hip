@@ -11,14 +11,7 @@ namespace {
 
 using rlsh::DisneyIO;
 
-#ifndef RLS_DISNEY_RELOAD
-#define RLS_DISNEY_RELOAD 1
-#endif
-#if RLS_DISNEY_RELOAD
 #define RLS_DISNEY_ARGS(a0) reload_args(a0)
-#else
-#define RLS_DISNEY_ARGS(a0) (a0)
-#endif
 enum { OP_SAMPLE = rlsh::DOP_SAMPLE, OP_EVAL = rlsh::DOP_EVAL, OP_PDF = rlsh::DOP_PDF, OP_FUSED = rlsh::DOP_FUSED };
 
 // MODE (checked on the host): STREAMED_ALL every parameter is a per-point plane; UNIFORM_ALL every one is a single value for

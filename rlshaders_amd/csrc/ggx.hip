@@ -13,14 +13,7 @@ namespace {
 
 using namespace rlsh;   // GgxOp, GgxIO
 
-#ifndef RLS_GGX_RELOAD
-#define RLS_GGX_RELOAD 1
-#endif
-#if RLS_GGX_RELOAD
 #define RLS_GGX_ARGS(a0) reload_args(a0)
-#else
-#define RLS_GGX_ARGS(a0) (a0)
-#endif
 
 // MODE (checked on the host): STREAMED_ALL every closure parameter is a per-point plane (no stream-or-uniform tests in the
 // loop); UNIFORM_MATERIAL roughness, ior and anisotropic are single values for the batch (an Arnold parameter is a constant
@@ -72,7 +65,7 @@ __device__ __forceinline__ void ggx_body(const GgxIO &a0)
     for (int64_t base = tiles.first; base < tiles.end; base += tiles.step) {
         const Idx i = make_idx(base);
         if (i.full() >= a0.n) continue;
-        // RLS_GGX_RELOAD: plane pointers re-read from the kernarg segment where they are used (rls_internal.hpp, reload_args)
+        // plane pointers re-read from the kernarg segment where they are used (rls_internal.hpp, reload_args)
         const GgxIO a = RLS_GGX_ARGS(a0);
         Ggx g = load_closure<MODE>(a.c, i, um);
 
@@ -170,11 +163,7 @@ template <int OP>
 rls_status launch_kernel(rls_context *ctx, const GgxIO &io, const char *name)
 {
     const rls_ggx_closure &c = io.c;
-#ifdef RLS_NO_STREAMED   // experiment switch
-    const bool streamed = false;
-#else
     const bool streamed = !c.materials.id && c.KsColor.r && c.specularRoughness.v && c.ior.v && c.anisotropic.v;
-#endif
     const bool uniform = !c.materials.id && !c.specularRoughness.v && !c.ior.v && !c.anisotropic.v;       // specColor: either
     if constexpr (OP == OP_REFLECT_REFRACT) {      // BASELINE config 2 under rls_diag_clock_stamps_begin: the stamped instantiation
         if (unsigned long long *stamps = streamed ? rlsh::stamps_for_launch(ctx) : nullptr) {

@@ -127,10 +127,7 @@ RLS_DEV void stage_libm_tables() {}
 // x / C, C one of the compile-time constants checked in tools/micro/exact1.hip (3, 0.3333, 1 - 0.6666, 0.6666 - 0.3333)
 #define R_DIVC(x, C) rlm::div32_const((x), (C), 1.0f / (C))
 // ... for an x that is inside 2^-100 .. 2^100 and not zero by construction: no range test (say why at the call)
-#define R_DIVCW(x, C) (RLS_ND_DIVC_UNGUARDED ? rlm::div32_const_w((x), (C), 1.0f / (C)) : rlm::div32_const((x), (C), 1.0f / (C)))
-#ifndef RLS_ND_DIVC_UNGUARDED    // experiment switch
-#define RLS_ND_DIVC_UNGUARDED 1
-#endif
+#define R_DIVCW(x, C) rlm::div32_const_w((x), (C), 1.0f / (C))
 #define R_RCPHI(b) rlm::rcp32_hi(b)          // 1 / x for x that is 0, NaN or >= 2^-126 in magnitude by construction
 #define R_RCPG(b) rlm::rcp32_hi(b)           // of A^2 - 1: 0 or >= 2^-24 in magnitude (A^2 is near 1 or far from it), unbounded above
 #define R_SQRTH(x) rlm::sqrt32(x)
@@ -157,33 +154,15 @@ RLS_DEV void stage_libm_tables()
 #define R_EXP_IN_RANGE(x) rlm::exp32_in_range(x, s_libm_tables)
 #define R_LOG(x) rlm::log32(x, s_libm_tables)
 #define R_POW(x, y) rlm::pow32(x, y, s_libm_tables)
-#ifdef RLS_POW5_GENERAL   // experiment switch
-#define R_POW5(x) rlm::pow32(x, 5.0f, s_libm_tables)
-#else
 #define R_POW5(x) rlm::pow5_32(x, s_libm_tables)   // powf(x, 5.0f)
-#endif
 // t_sincos / t_tan: angles bounded by construction (results of atan2f / acosf, the concentric-disk mapping, the
 // in-kernel sampler) -- the forms without the |x| >= 120 branch (rls_libm.hpp).  t_sincos_any: angles computed from
 // caller-supplied random numbers (2 pi xi); full domain, so that even numbers outside [0, 1) give what the CPU gives.
 RLS_DEV void t_sincos(float x, float *s, float *c) { rlm::sincos32_v<false>(x, s, c); }
 RLS_DEV void t_sincos_any(float x, float *s, float *c) { rlm::sincos32_v<true>(x, s, c); }
-#ifdef RLS_ATAN_SELECTS   // experiment switch: range constants by selects instead of the LDS table
-RLS_DEV float t_atan2(float y, float x) { return rlm::atan2_32_v(y, x); }
-#elif defined(RLS_ANGLE_SELECTS)   // experiment switch: the exceptional arguments by selects instead of a branch
-RLS_DEV float t_atan2(float y, float x) { return rlm::atan2_32_t(y, x, s_libm_tables); }
-#else
 RLS_DEV float t_atan2(float y, float x) { return rlm::atan2_32_q(y, x, s_libm_tables); }
-#endif
-#ifdef RLS_ANGLE_SELECTS
-RLS_DEV float t_acos(float x) { return rlm::acos32_v(x); }
-#else
 RLS_DEV float t_acos(float x) { return rlm::acos32_q(x); }
-#endif
-#ifdef RLS_ANGLE_SELECTS
-RLS_DEV float t_tan(float x) { return rlm::tan32_v<false>(x); }
-#else
 RLS_DEV float t_tan(float x) { return rlm::tan32_q<false>(x); }
-#endif
 #endif
 
 
@@ -259,7 +238,7 @@ struct VndfView {
     float B, B2, G1, invB;  // tanf(theta) terms (valid when !nearNormal)
     bool nearNormal;        // theta < AI_EPSILON -> uniform slope sample
 #if !RLS_FAST
-    float yG1;              // RN(1 / G1) for the n^2-spp loops' A = 2 rx / G1 - 1 (RLS_LOOP_RECIP); 0: G1 outside div32_y's window
+    float yG1;              // RN(1 / G1) for the n^2-spp loops' A = 2 rx / G1 - 1 ; 0: G1 outside div32_y's window
 #endif
 };
 
@@ -267,9 +246,6 @@ struct VndfView {
 // so closures that share (wo, N, T) but differ in alpha (rlSkin's sheen and specular lobes) compute
 // it once.  EXACT: sphericalDirection(clamp(N.V), atan2f(V.V, U.V)) (src/rlGgx.cpp:68-72);
 // FAST: the dot products themselves.
-#ifndef RLS_FAST_VIEW_Z_AS_REFERENCE
-#define RLS_FAST_VIEW_Z_AS_REFERENCE 1
-#endif
 #if RLS_FAST
 RLS_DEV V3 vndf_local(V3 view, const Frame &fr)
 {
@@ -287,15 +263,11 @@ RLS_DEV VndfView vndf_view_from(V3 local, float ax, float ay)
     float sx = local.x * ax;
     float sy = local.y * ay;
     float h2 = sx * sx + sy * sy;
-#if RLS_FAST_VIEW_Z_AS_REFERENCE
     // cos(theta') of the stretched view decides between the closed-form slopes and the uniform fallback at 1 - 1e-4
     // (src/rlGgx.cpp:75-79), and the two give DIFFERENT (equally valid) samples: formed by AiV3Normalize's own sequence --
     // exact sqrt, correctly rounded reciprocal, product -- it rounds as the reference's does whenever the local view agrees
     // to a few ulp (z' moves by 1e-4 of what they move), so FAST takes the reference's side of the threshold
     float z = cz * rlm::rcp32_w(rlm::sqrt32(h2 + cz * cz));
-#else
-    float z = R_DIVH(cz, R_SQRTH(h2 + cz * cz));          // cos(theta') of the stretched view
-#endif
     float h = R_SQRTH(h2);
     bool flat = !(z < (1.0f - kEps));
     w.cosPhi = (flat || h2 == 0.0f) ? 1.0f : R_DIVH(sx, h);
@@ -399,9 +371,6 @@ RLS_DEV float slope_y_ratio(float u)
 // LOOP_RECIP (the n^2-spp loops, whose rx comes from the in-kernel sampler: zero or a multiple of 2^-24 below 1, possibly
 // divided by the lobe weight -- never in (0, 2^-75)): the caller has checked that w.yG1 != 0 in every active lane and the
 // quotient by the per-point G1 goes through its reciprocal (rlm::div32_y), the same correctly rounded value.
-#ifndef RLS_LOOP_RECIP
-#define RLS_LOOP_RECIP 1
-#endif
 template <bool LOOP_RECIP = false>
 RLS_DEV bool vndf_slope_closed(const VndfView &w, float rx, float ry, V2 &slope)
 {
@@ -461,7 +430,7 @@ RLS_DEV V3 vndf_microfacet(const VndfView &w, const Frame &fr, float rx, float r
 RLS_DEV void vndf_microfacet_pair(const VndfView &w1, const Frame &fr1, float rx1, float ry1,
                                   const VndfView &w2, const Frame &fr2, float rx2, float ry2, V3 &M1, V3 &M2)
 {
-#if RLS_FAST || defined(RLS_NO_PAIR_COMPACTION)
+#if RLS_FAST
     M1 = vndf_microfacet(w1, fr1, rx1, ry1);
     M2 = vndf_microfacet(w2, fr2, rx2, ry2);
 #else
@@ -508,13 +477,8 @@ RLS_DEV void vndf_microfacet_pair(const VndfView &w1, const Frame &fr1, float rx
 
 // A value every lane of the wavefront holds (computed from kernel arguments only) moved to a scalar register: it costs no
 // vector register across the tile loop and the branches on it are scalar branches
-#ifdef RLS_NO_WAVE_UNIFORM   // experiment switch: keep the values in vector registers
-RLS_DEV float wave_uniform(float x) { return x; }
-RLS_DEV int wave_uniform(int x) { return x; }
-#else
 RLS_DEV float wave_uniform(float x) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(x))); }
 RLS_DEV int wave_uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
-#endif
 
 // ---- rlGgx closure state, src/rlGgx.h:130-156 ---------------------------------------------------
 struct Ggx {
@@ -751,8 +715,8 @@ struct Disney {
     float gtr2Weight;             // sampleSpecularDirection: 1 / (clearcoat + 1), src/rlDisney.cpp:371
     float om;                     // 1 - metallic
 #if !RLS_FAST
-    float yax, yay;               // RN(1 / ax), RN(1 / ay) for D_GTR2Aniso's two quotients (RLS_DISNEY_D_RECIP); 0: outside div32_y's window
-    float yW, y1mW;               // RN(1 / gtr2Weight), RN(1 / (1 - gtr2Weight)) for the lobe pick's rescaled rx (RLS_LOOP_RECIP); 0: no reciprocal
+    float yax, yay;               // RN(1 / ax), RN(1 / ay) for D_GTR2Aniso's two quotients; 0: outside div32_y's window
+    float yW, y1mW;               // RN(1 / gtr2Weight), RN(1 / (1 - gtr2Weight)) for the lobe pick's rescaled rx; 0: no reciprocal
 #endif
 };
 
@@ -829,15 +793,12 @@ RLS_DEV float D_GTR1(const Disney &d, float mn2)
     return R_DIV((a2 - 1.0f) * kInvPi, den);
 }
 // src/rlDisney.cpp:561-568
-// RLS_DISNEY_D_RECIP (round 4): the two quotients by alpha_x, alpha_y -- per-point denominators that every sample of the n^2-spp
+// Round 4: the two quotients by alpha_x, alpha_y -- per-point denominators that every sample of the n^2-spp
 // loops divides by -- through their correctly rounded reciprocals (rlm::div32_y: five instructions each instead of the IEEE
 // sequence's fifteen fma-equivalents).  div32_y wants 2^-14 <= alpha <= 2^14 (d.yax != 0 says so) and a numerator that is
 // zero or in [2^-75, 2^40]: h.u, h.v of a unit half vector are; below 2^-75 the quotient's square is below 2^-122 beside
 // the other two terms' >= 1e-2, so its last bit cannot reach the sum; above 2^40, infinite or NaN (hostile inputs) the whole
 // wavefront takes the IEEE form -- one test for both quotients.
-#ifndef RLS_DISNEY_D_RECIP
-#define RLS_DISNEY_D_RECIP 1
-#endif
 RLS_DEV float D_GTR2Aniso(const Disney &d, V3 m, float mn2)
 {
     float hu = dot(m, d.fr.U);
@@ -845,7 +806,7 @@ RLS_DEV float D_GTR2Aniso(const Disney &d, V3 m, float mn2)
 #if !RLS_FAST
     float qu, qv;
     const bool plain = !(absf(hu) <= 0x1p40f && absf(hv) <= 0x1p40f) || d.yax == 0.0f;
-    if (__builtin_expect(!RLS_DISNEY_D_RECIP || __builtin_amdgcn_ballot_w64(plain) != 0ull, 0)) {
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(plain) != 0ull, 0)) {
         qu = R_DIV(hu, d.ax);
         qv = R_DIV(hv, d.ay);
     } else {
@@ -881,13 +842,13 @@ RLS_DEV void disney_prepare_material(Disney &d)
     d.om = 1.0f - d.metallic;
 #if !RLS_FAST
     // ax, ay = max(1e-2, r^2 / aspect), max(1e-2, r^2 aspect): inside div32_y's window [2^-14, 2^14] unless the roughness is absurd
-    const bool win = RLS_DISNEY_D_RECIP && d.ax <= 0x1p14f && d.ay <= 0x1p14f && d.ax >= 0x1p-14f && d.ay >= 0x1p-14f;
+    const bool win = d.ax <= 0x1p14f && d.ay <= 0x1p14f && d.ax >= 0x1p-14f && d.ay >= 0x1p-14f;
     d.yax = win ? rlm::rcp32_w(d.ax) : 0.0f;
     d.yay = win ? rlm::rcp32_w(d.ay) : 0.0f;
     // gtr2Weight = 1 / (clearcoat + 1) and its complement: in the window for every clearcoat in [2.5e-4, 4 x 16383] or so
     const float w1 = d.gtr2Weight, w2 = 1.0f - d.gtr2Weight;
-    d.yW = (RLS_LOOP_RECIP && w1 >= 0x1p-14f && w1 <= 0x1p14f) ? rlm::rcp32_w(w1) : 0.0f;
-    d.y1mW = (RLS_LOOP_RECIP && w2 >= 0x1p-14f && w2 <= 0x1p14f) ? rlm::rcp32_w(w2) : 0.0f;
+    d.yW = (w1 >= 0x1p-14f && w1 <= 0x1p14f) ? rlm::rcp32_w(w1) : 0.0f;
+    d.y1mW = (w2 >= 0x1p-14f && w2 <= 0x1p14f) ? rlm::rcp32_w(w2) : 0.0f;
 #endif
 }
 RLS_DEV void disney_prepare_view(Disney &d)
@@ -1228,18 +1189,6 @@ struct NdProfile {
 // distance -3.5 %, NDProfile alone -4 %, rlSkin's one-sample kernel +4.5 % unless its occupancy is pinned (skin.hip).  evalProfile alone, which the
 // probe-ray loops call per shaded hit (nd_profile: the reciprocals' quotients + one range test): integrateScatter -6 % more,
 // rlSkin's shader_evaluate -8 % more.
-#ifndef RLS_ND_PP_RANGE_ONCE
-#define RLS_ND_PP_RANGE_ONCE 1
-#endif
-#ifndef RLS_ND_PROFILE_WINDOWED     // evalProfile alone (the probe-ray loops call it per hit): reciprocals + one range test
-#define RLS_ND_PROFILE_WINDOWED 1
-#endif
-#ifndef RLS_ND_MAKE_RANGE_ONCE
-#define RLS_ND_MAKE_RANGE_ONCE 1
-#endif
-#ifndef RLS_ND_RECIP_D
-#define RLS_ND_RECIP_D 1        // experiment switch: 0 = the one-sample kernels divide by d_i the IEEE way (round 2)
-#endif
 template <bool RECIPROCALS = false>
 RLS_DEV NdProfile nd_make(float dx, float dy, float dz)
 {
@@ -1248,9 +1197,9 @@ RLS_DEV NdProfile nd_make(float dx, float dy, float dz)
     p.maxR = maxf(dx, maxf(dy, dz)) * 3.0f;
 #if !RLS_FAST
     // d_i itself (not max(d_i, AI_EPSILON)) is what setDistance divides by: inside the window the two are the same value
-    p.window = (RECIPROCALS || RLS_ND_RECIP_D) ? 1 : 0;
+    p.window = 1;
 #pragma unroll
-    for (int i = 0; (RECIPROCALS || RLS_ND_RECIP_D) && i < 3; i++) {
+    for (int i = 0; i < 3; i++) {
         p.dm[i] = maxf(p.d[i], kEps);
         p.ydm[i] = R_RCPW(p.dm[i]);                  // windowed below; outside it the reciprocals are not used
         if (!(p.d[i] >= 0x1p-13f && p.d[i] <= 0x1p14f)) p.window = 0;      // 2^-13 > AI_EPSILON: d_i == max(d_i, AI_EPSILON)
@@ -1262,12 +1211,12 @@ RLS_DEV NdProfile nd_make(float dx, float dy, float dz)
 #pragma unroll
         for (int i = 0; i < 3; i++) q[i] = rlm::div32_y(-p.maxR, p.d[i], p.ydm[i]);
     }
-    if (__builtin_expect(p.window != 0 && (!RLS_ND_MAKE_RANGE_ONCE || rlm::exp32_in_range_3(q[0], q[1], q[2])), 1)) {
+    if (__builtin_expect(p.window != 0 && rlm::exp32_in_range_3(q[0], q[1], q[2]), 1)) {
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-            p.c1[i] = 1.0f - (RLS_ND_MAKE_RANGE_ONCE ? R_EXP_IN_RANGE(q[i]) : R_EXP(q[i]));
+            p.c1[i] = 1.0f - R_EXP_IN_RANGE(q[i]);
             // (|q| is between 3 x 2^-13 / 2^14 and 3 x 2^14 / 2^-13 inside the window: the division by 3 needs no range test)
-            p.c2[i] = 1.0f - (RLS_ND_MAKE_RANGE_ONCE ? R_EXP_IN_RANGE(R_DIVCW(q[i], 3.0f)) : R_EXP(R_DIVCW(q[i], 3.0f)));
+            p.c2[i] = 1.0f - R_EXP_IN_RANGE(R_DIVCW(q[i], 3.0f));
         }
     } else
 #endif
@@ -1307,33 +1256,14 @@ RLS_DEV NdProfile nd_wave_uniform(NdProfile p)
     return p;
 }
 
-// RLS_ND_MERGE_RADIUS: experiment switch (one division and one logf of selected operands for getRadius's two arms).
-// Measured twice, rounds 2 and 3 (profiles/r03_nd_recip.txt): the rlSss probe 1.576 -> 1.643 ms, rlSkin 4.12 -> 4.17 --
-// slower, although it executes fewer instructions; integrateScatter -0.6 %.  Off.
-#ifndef RLS_ND_MERGE_RADIUS
-#define RLS_ND_MERGE_RADIUS 0
-#endif
-#ifndef RLS_ND_RADIUS_SELECTS     // experiment switch: getRadius's channel lottery by selects (measured: the rlSss probe +27 %)
-#define RLS_ND_RADIUS_SELECTS 0
-#endif
+// Tried and not kept (the code is in history at 4127ff2, switches RLS_ND_MERGE_RADIUS / RLS_ND_RADIUS_SELECTS): one division
+// and one logf of selected operands for getRadius's two arms -- measured twice, rounds 2 and 3: the rlSss probe 1.576 -> 1.643
+// ms, rlSkin 4.12 -> 4.17, slower although it executes fewer instructions; the channel lottery by selects: the probe +27 %.
 // selectDistLobe + getRadius, src/rlSss.h:30-42, src/rlSss.cpp:36-66
 RLS_DEV float nd_radius(const NdProfile &p, float rx)
 {
     if (p.maxR < kEps) return 0.0f;
     float d, w1, w2;
-#if RLS_ND_RADIUS_SELECTS
-    // the channel lottery without branches: the three arms differ in their constants and in the channel they read
-    {
-        const bool c0 = rx < 0.3333f, c2 = rx > 0.6666f;
-        const float lo = c0 ? 0.0f : c2 ? 0.6666f : 0.3333f;
-        const float C = c0 ? (0.3333f - 0.0f) : c2 ? (1.0f - 0.6666f) : (0.6666f - 0.3333f);
-        const float rC = c0 ? 1.0f / (0.3333f - 0.0f) : c2 ? 1.0f / (1.0f - 0.6666f) : 1.0f / (0.6666f - 0.3333f);
-        rx = clampf(rlm::div32_const(rx - lo, C, rC), 0.0f, 1.0f);
-        d = c0 ? p.d[0] : c2 ? p.d[2] : p.d[1];
-        w1 = c0 ? p.c1[0] : c2 ? p.c1[2] : p.c1[1];
-        w2 = c0 ? p.c2[0] : c2 ? p.c2[2] : p.c2[1];
-    }
-#else
     // LINEARSTEP(lo, hi, t) = CLAMP((t - lo) / (hi - lo), 0, 1) with constant bounds: division by a constant
     if (rx < 0.3333f) {
         rx = clampf(R_DIVC(rx - 0.0f, 0.3333f - 0.0f), 0.0f, 1.0f);
@@ -1345,18 +1275,9 @@ RLS_DEV float nd_radius(const NdProfile &p, float rx)
         rx = clampf(R_DIVC(rx - 0.3333f, 0.6666f - 0.3333f), 0.0f, 1.0f);
         d = p.d[1]; w1 = p.c1[1]; w2 = p.c2[1];
     }
-#endif
     if (d < kEps) return 0.0f;
     float w = R_DIV(w1, w1 + w2 * 3.0f);
     float r;
-#if RLS_ND_MERGE_RADIUS
-    // the two arms divide and take the logarithm of different operands; the lanes of a wavefront take both, so the operands
-    // are selected and ONE division and ONE logf serve either arm (each lane still computes exactly what its arm computes:
-    // rx - 0 and w - 0 are exact)
-    const bool tail = rx > w;
-    const float t = clampf(R_DIV(rx - (tail ? w : 0.0f), (tail ? 1.0f : w) - (tail ? w : 0.0f)), 0.0f, 1.0f);
-    r = R_LOG(1.0f - t * (tail ? w2 : w1)) * (tail ? -d * 3.0f : -d);
-#else
     if (rx > w) {
         rx = linearstep(w, 1.0f, rx);
         r = R_LOG(1.0f - rx * w2) * (-d * 3.0f);
@@ -1364,7 +1285,6 @@ RLS_DEV float nd_radius(const NdProfile &p, float rx)
         rx = linearstep(0.0f, w, rx);
         r = R_LOG(1.0f - rx * w1) * (-d);
     }
-#endif
     return r;
 }
 
@@ -1408,43 +1328,8 @@ RLS_DEV float nd_pdf(const NdProfile &p, float r)
 // getPdf at three radii (the 3-axis MIS pdf of a probe hit asks for them together): nd_pdf()'s tests -- the window, the radii's
 // range, expf's range, the sums' floor -- once for the three calls instead of once each; the same operations per radius and
 // channel, so the same bits, and any failing test sends all three through nd_pdf()
-#ifndef RLS_ND_PDF3_MERGED     // experiment switch
-#define RLS_ND_PDF3_MERGED 0
-#endif
 RLS_DEV void nd_pdf3(const NdProfile &p, float r0, float r1, float r2, float (&out)[3])
 {
-#if !RLS_FAST && RLS_ND_PDF3_MERGED
-    const float r[3] = { r0, r1, r2 };
-    if (__builtin_expect(!(p.maxR < kEps) && p.window == 2 && minf(r0, minf(r1, r2)) >= 0x1p-40f && maxf(r0, maxf(r1, r2)) <= 0x1p40f &&
-                         r0 == r0 && r1 == r1 && r2 == r2, 1)) {
-        float q[3][3];
-#pragma unroll
-        for (int j = 0; j < 3; j++)
-#pragma unroll
-            for (int i = 0; i < 3; i++) q[j][i] = rlm::div32_y(-r[j], p.dm[i], p.ydm[i]);
-        if (__builtin_expect(rlm::exp32_in_range_3(q[0][0], q[0][1], q[0][2]) && rlm::exp32_in_range_3(q[1][0], q[1][1], q[1][2]) &&
-                             rlm::exp32_in_range_3(q[2][0], q[2][1], q[2][2]), 1)) {
-            float s[3][3], lo = 1.0f;
-#pragma unroll
-            for (int j = 0; j < 3; j++)
-#pragma unroll
-                for (int i = 0; i < 3; i++) {
-                    s[j][i] = R_EXP_IN_RANGE(q[j][i]) + R_EXP_IN_RANGE(R_DIVCW(q[j][i], 3.0f));
-                    lo = minf(lo, s[j][i]);
-                }
-            if (__builtin_expect(lo >= 0x1p-60f, 1)) {
-#pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    float pdf = 0.0f;
-#pragma unroll
-                    for (int i = 0; i < 3; i++) pdf += rlm::div32_y(rlm::div32_y(s[j][i], p.dm[i], p.ydm[i]), p.cw[i], p.ycw[i]);
-                    out[j] = R_DIV(pdf, kTwoPi * r[j] * 3.0f);
-                }
-                return;
-            }
-        }
-    }
-#endif
     out[0] = nd_pdf(p, r0); out[1] = nd_pdf(p, r1); out[2] = nd_pdf(p, r2);
 }
 
@@ -1455,7 +1340,7 @@ RLS_DEV void nd_profile(const NdProfile &p, float r, float &R, float &G, float &
     if (r < kEps) { R = 1.0f; G = 1.0f; B = 1.0f; return; }
     float denom = 8.0f * kPi * r;
     float out[3];
-#if !RLS_FAST && RLS_ND_PROFILE_WINDOWED
+#if !RLS_FAST
     // inside the window of the per-point reciprocals (d_i >= 2^-13 > AI_EPSILON: the d_i < AI_EPSILON arm cannot occur) the three
     // quotients -r / d_i through them, and expf's range tests once for the six calls (|-r / (3 d_i)| <= |-r / d_i|)
     if (__builtin_expect(p.window != 0 && r <= 0x1p40f, 1)) {
@@ -1493,7 +1378,7 @@ RLS_DEV void nd_pdf_profile_t(const NdProfile &p, float r, float &pdf, float &R,
 #if !RLS_FAST
     // ONCE: expf's range tests once for the nine calls -- |q / 3| <= |q| and, d_i being its own max(d_i, AI_EPSILON) inside
     // the window, |-r / (3 d_i)| <= |q| as well: the three quotients bound all nine arguments.  Outside the range: the general form
-    constexpr bool ONCE = WINDOWED != 0 && RLS_ND_PP_RANGE_ONCE != 0;
+    constexpr bool ONCE = WINDOWED != 0;
     float qw[3] = { 0.0f, 0.0f, 0.0f };
     if (ONCE) {
 #pragma unroll
@@ -1566,21 +1451,12 @@ RLS_DEV Frame sss_frame(V3 Ns, V3 t, bool has_dPdu)
 }
 
 // getProbeRay, src/rlSss.h:487-533
-// RLS_PROBE_SELECTS: the axis lottery without branches.  The three linearstep() calls divide by 0.5 - 0, 0.75 - 0.5 and
-// 1 - 0.75 -- powers of two, so the quotient IS the product with 2 or 4, exactly -- and the three to_frame() calls differ in
-// which axes they read, so one call on selected axes (the middle one's sign moved into o.y: a (-u) = -(a u) exactly) gives
-// the same bits (the parity tests pass with it).  Measured (profiles/r03_exp_range_once.txt): nothing, +-0.3 % on every kernel
-// that draws probe rays -- an experiment switch, off.
-#ifndef RLS_PROBE_SELECTS
-#define RLS_PROBE_SELECTS 0
-#endif
+// Tried and not kept (history at 4127ff2, switch RLS_PROBE_SELECTS): the axis lottery without branches -- the three linearstep()
+// divisors are powers of two and the three to_frame() calls differ only in the axes they read, so one call on selected axes
+// gives the same bits; measured: nothing, +-0.3 % on every kernel that draws probe rays.
 RLS_DEV float sss_probe_ray(const NdProfile &p, const Frame &fr, float rx, float ry,
                             V3 &offset, V3 &dir, float &maxdist)
 {
-#if RLS_PROBE_SELECTS
-    const bool a0 = rx < 0.5f, a1 = rx < 0.75f;               // idx 0 | 2 | 3 of the reference
-    rx = clampf((rx - (a0 ? 0.0f : a1 ? 0.5f : 0.75f)) * (a0 ? 2.0f : 4.0f), 0.0f, 1.0f);
-#else
     int idx;
     if (rx < 0.5f) {
         idx = 0;
@@ -1592,7 +1468,6 @@ RLS_DEV float sss_probe_ray(const NdProfile &p, const Frame &fr, float rx, float
         idx = 3;
         rx = linearstep(0.75f, 1.0f, rx);
     }
-#endif
     float r = nd_radius(p, rx);
     float rmax = p.maxR;
     float phi = kTwoPi * ry;
@@ -1603,14 +1478,6 @@ RLS_DEV float sss_probe_ray(const NdProfile &p, const Frame &fr, float rx, float
     o.z = s * r;
     o.y = R_SQRT(rmax * rmax - r * r);
     maxdist = o.y * 2.0f;
-#if RLS_PROBE_SELECTS
-    // idx < 2: dir = -N, to_frame(o, U, N, V); idx 2: dir = U, to_frame(o, V, -U, N); idx 3: dir = V, to_frame(o, N, -V, U)
-    const V3 u = a0 ? fr.U : a1 ? fr.V : fr.N;
-    const V3 v = a0 ? fr.N : a1 ? fr.U : fr.V;                 // |middle axis|; its sign goes into o.y
-    const V3 w = a0 ? fr.V : a1 ? fr.N : fr.U;
-    dir = a0 ? -v : v;
-    offset = to_frame(mk(o.x, a0 ? o.y : -o.y, o.z), u, v, w);
-#else
     if (idx < 2) {
         dir = -fr.N;
         offset = to_frame(o, fr.U, -dir, fr.V);
@@ -1621,7 +1488,6 @@ RLS_DEV float sss_probe_ray(const NdProfile &p, const Frame &fr, float rx, float
         dir = fr.V;
         offset = to_frame(o, fr.N, -dir, fr.U);
     }
-#endif
     return r;
 }
 
@@ -1738,15 +1604,11 @@ RLS_DEV float hash_u01(uint32_t seed, uint64_t index, uint32_t stream)
 // ---- streaming loads / stores -------------------------------------------------------------------
 // Every plane is read or written exactly once per launch: non-temporal so the streams do not
 // evict each other from L2 / Infinity Cache.
-// Cache policy of the plane accesses.  Every plane is touched exactly once per launch, so both directions are non-temporal
-// (0).  Experiment switch (round 5, after the pointwise kernels turned out to run at the board's power cap -- a policy that
-// spares the caches' energy would come back as clock): 1 plain loads, 2 plain stores, 3 both plain.  Measured:
-// profiles/r05_mem_policy.txt.
-#ifndef RLS_MEM_POLICY
-#define RLS_MEM_POLICY 0
-#endif
-template <class P> RLS_DEV float ld_policy(P p) { return (RLS_MEM_POLICY & 1) ? *p : __builtin_nontemporal_load(p); }
-template <class P> RLS_DEV void st_policy(float v, P p) { if (RLS_MEM_POLICY & 2) *p = v; else __builtin_nontemporal_store(v, p); }
+// Cache policy of the plane accesses: every plane is touched exactly once per launch, so both directions are non-temporal.
+// Plain loads, plain stores and both were measured in round 5, after the pointwise kernels turned out to run at the board's
+// power cap (a policy that spares the caches' energy would come back as clock): profiles/r05_mem_policy.txt -- not kept.
+template <class P> RLS_DEV float ld_policy(P p) { return __builtin_nontemporal_load(p); }
+template <class P> RLS_DEV void st_policy(float v, P p) { __builtin_nontemporal_store(v, p); }
 RLS_DEV float ldg(const float *p, int64_t i) { return ld_policy(p + i); }
 RLS_DEV void stg(float *p, int64_t i, float v) { st_policy(v, p + i); }
 
@@ -1769,19 +1631,11 @@ RLS_DEV Idx make_idx(int64_t base)
     Idx i = { base, threadIdx.x, byte };
     return i;
 }
-#ifdef RLS_NO_SADDR   // experiment switch: 64-bit vector addressing
-typedef __attribute__((address_space(1))) float GFloat;
-RLS_DEV const GFloat *at(const float *p, Idx i) { return (const GFloat *)(p + i.full()); }
-RLS_DEV GFloat *at(float *p, Idx i) { return (GFloat *)(p + i.full()); }
-#else
 // plane pointer + tile offset: a wave-uniform sum, formed with scalar arithmetic and KEPT in a scalar register pair (the
 // empty asm) -- left alone, the optimiser re-associates it to (pointer + lane offset) + tile offset whenever the pointer
 // is loaded inside the loop (reload_args), which costs two 64-bit vector adds and two moves per access instead of none.
 // The pointer is cast to the global address space first: through the asm it would otherwise come back as a generic
 // pointer and the access as a flat_load / flat_store.
-#ifndef RLS_AT_SCALAR_BARRIER
-#define RLS_AT_SCALAR_BARRIER 1
-#endif
 // RLS_LOAD_RENEW: loads that sit in a later basic block than make_idx() (after a per-parameter stream-or-uniform branch,
 // after reload_args) renew the barrier on the lane offset like the stores do: one move instead of a 64-bit vector add
 #ifndef RLS_LOAD_RENEW
@@ -1792,20 +1646,15 @@ typedef __attribute__((address_space(1))) float GFloat;
 RLS_DEV const GFloat *at(const float *p, Idx i)
 {
     const GChar *q = (const GChar *)(p + i.base);
-#if RLS_AT_SCALAR_BARRIER
     asm("" : "+s"(q));
-#endif
     return (const GFloat *)(q + i.byte);
 }
 RLS_DEV GFloat *at(float *p, Idx i)
 {
     GChar *q = (GChar *)(p + i.base);
-#if RLS_AT_SCALAR_BARRIER
     asm("" : "+s"(q));
-#endif
     return (GFloat *)(q + i.byte);
 }
-#endif
 RLS_DEV float ldg(const float *p, Idx i)
 {
 #if RLS_LOAD_RENEW

@@ -254,7 +254,7 @@ inline hipError_t &pending_device_error()
 // -7.5 %, config 2 -1.0 %, rlSkin -1.3 %, reflect triple 0; the rlSss / NDProfile and rlDisney kernels LOSE 3-5 % (their
 // per-workgroup staging of the libm tables is paid per tile then) and keep the cap.
 #ifndef RLS_CAP_MULT
-#define RLS_CAP_MULT 16          // experiment switch: 1 = every kernel under the context's cap
+#define RLS_CAP_MULT 16          // tuning knob: 1 = every kernel under the context's cap
 #endif
 inline dim3 grid_for(const rls_context *ctx, int64_t n, int points_per_block = kBlock, int cap_mult = 1)
 {
@@ -352,11 +352,7 @@ struct TileRange { int64_t first, end, step; };
 RLS_DEV TileRange tile_range(int64_t n)
 {
     TileRange t;
-#ifdef RLS_NO_XCD_TILES   // experiment switch
-    if (false) {
-#else
     if (gridDim.x % 8u == 0u) {
-#endif
         const int64_t tiles = (n + rlsh::kBlock - 1) / rlsh::kBlock;
         const int64_t per_xcd = (tiles + 7) / 8;
         const int64_t x = blockIdx.x % 8u, b = blockIdx.x / 8u;
@@ -383,14 +379,11 @@ RLS_DEV TileRange tile_range(int64_t n)
 // spilled SGPRs, 4.44 -> 4.34 ms (-2.2 %); the rlSss probe 30 -> 0, 1.710 -> 1.686 ms (-1.4 %); the rlGgx kernels 52 -> 2:
 // +2.3 % when first measured at six waves per SIMD (2.054 -> 2.102 ms), but since those kernels run at eight waves (64
 // vector registers, where every spilled scalar costs a lane write) the reload is worth 7 %: 2.139 ms without it, 2.001 ms with
-// (profiles/r04_ggx_ab.txt, tools/ab.sh, two interleaved repetitions) -- ggx.hip uses it (RLS_GGX_RELOAD 1).
-#ifndef RLS_RELOAD_ARGS
-#define RLS_RELOAD_ARGS 1
-#endif
+// (profiles/r04_ggx_ab.txt, tools/ab.sh, two interleaved repetitions) -- every pointwise unit uses it.
 template <class IO>
 RLS_DEV IO reload_args(const IO &a)
 {
-#if RLS_RELOAD_ARGS && defined(__HIP_DEVICE_COMPILE__)     // (the host pass of the translation unit only parses this)
+#if defined(__HIP_DEVICE_COMPILE__)     // (the host pass of the translation unit only parses this)
     typedef const __attribute__((address_space(4))) IO *KP;
     KP p = (KP)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(p));

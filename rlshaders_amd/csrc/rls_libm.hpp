@@ -108,10 +108,8 @@ template <bool GUARDED = true>
 RLM_FN float sqrt32(float x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-#ifndef RLS_SQRT_NO_FALLBACK
     // |x| < 2^-96, x != 0 (negative subnormals included: v_sqrt_f32 would flush them to -0 instead of NaN)
     if (GUARDED && __builtin_expect((f2u(x) & 0x7fffffffu) - 1u < 0x0f800000u - 1u, 0)) return sqrtf(x);
-#endif
     float s = __builtin_amdgcn_sqrtf(x);
     const float sm = __uint_as_float(__float_as_uint(s) - 1u);
     const float sp = __uint_as_float(__float_as_uint(s) + 1u);
@@ -139,7 +137,7 @@ RLM_FN float sqrt32_1m(float t) { return sqrt32<false>(1.0f - t); }
 // rcp32: any argument -- subnormal or huge ones (two compares) take the IEEE sequence.
 RLM_FN float rcp32_w(float x)
 {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RLS_NO_FAST_RCP)
+#if defined(__HIP_DEVICE_COMPILE__)
     float r = __builtin_amdgcn_rcpf(x);
     const float e = __builtin_fmaf(-x, r, 1.0f);
     r = __builtin_fmaf(e, r, r);
@@ -150,7 +148,7 @@ RLM_FN float rcp32_w(float x)
 }
 RLM_FN float rcp32(float x)
 {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RLS_NO_FAST_RCP)
+#if defined(__HIP_DEVICE_COMPILE__)
     // +-subnormal (class bits 4 and 7), or beyond 2^126 (1/x subnormal; +-inf lands here too and is slow but right)
     if (__builtin_expect(__builtin_amdgcn_classf(x, 0x90) || __builtin_fabsf(x) > 0x1p126f, 0)) return 1.0f / x;
     return rcp32_w(x);
@@ -166,7 +164,7 @@ RLM_FN float rcp32(float x)
 // tools/libm_exhaustive.py runs atanf, acosf and tanf on all 2^32 arguments against the host libm.
 RLM_FN float div32_m(float a, float b)
 {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RLS_NO_FAST_RCP)
+#if defined(__HIP_DEVICE_COMPILE__)
     float y = __builtin_amdgcn_rcpf(b);
     const float e = __builtin_fmaf(-b, y, 1.0f);
     y = __builtin_fmaf(e, y, y);
@@ -185,7 +183,7 @@ RLM_FN float div32_m(float a, float b)
 // the same without the range test, for callers whose x is inside 2^-100 .. 2^100 by construction (and not zero)
 RLM_FN float div32_const_w(float x, float c, float rc)
 {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RLS_NO_FAST_RCP)
+#if defined(__HIP_DEVICE_COMPILE__)
     const float q0 = x * rc;
     const float r = __builtin_fmaf(-c, q0, x);
     return __builtin_fmaf(r, rc, q0);
@@ -196,7 +194,7 @@ RLM_FN float div32_const_w(float x, float c, float rc)
 }
 RLM_FN float div32_const(float x, float c, float rc)
 {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RLS_NO_FAST_RCP)
+#if defined(__HIP_DEVICE_COMPILE__)
     if (__builtin_expect(!(__builtin_fabsf(x) >= 0x1p-100f && __builtin_fabsf(x) <= 0x1p100f), 0)) return x / c;   // 0, NaN too
     const float q0 = x * rc;
     const float r = __builtin_fmaf(-c, q0, x);
@@ -210,7 +208,7 @@ RLM_FN float div32_const(float x, float c, float rc)
 // rcp32 for arguments that are 0, NaN or at least 2^-126 in magnitude by construction: only the upper end is tested
 RLM_FN float rcp32_hi(float x)
 {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RLS_NO_FAST_RCP)
+#if defined(__HIP_DEVICE_COMPILE__)
     if (__builtin_expect(!(__builtin_fabsf(x) <= 0x1p126f), 0)) return 1.0f / x;
     return rcp32_w(x);
 #else

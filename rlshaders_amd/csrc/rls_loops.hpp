@@ -19,14 +19,7 @@ namespace {
 // plane pointers re-read per point (reload_args) in the rlDisney n^2-spp kernel: 126 -> 24 spilled scalar registers, and no
 // time (73.06 / 72.90 ms with, 73.10 / 73.13 without): the spills sat outside the sample loop already.  Kept for the registers;
 // the other loop kernels were left alone.
-#ifndef RLS_INT_RELOAD
-#define RLS_INT_RELOAD 1
-#endif
-#if RLS_INT_RELOAD
 #define RLS_INT_ARGS(a) reload_args(a)
-#else
-#define RLS_INT_ARGS(a) (a)
-#endif
 #ifndef RLS_INT_WAVES
 #define RLS_INT_WAVES 4
 #endif
@@ -190,9 +183,9 @@ __device__ __forceinline__ void disney_spec_push(SlowLds<K> &L, int k, int &cnt,
     bool needU;
 #if !RLS_FAST
     // rx comes from the in-kernel sampler (a multiple of 2^-24 below 1) and the two denominators are per-point values: the
-    // rescaled rx and A = 2 rx' / G1 - 1 through their reciprocals (rlm::div32_y) unless some lane has none (RLS_LOOP_RECIP)
+    // rescaled rx and A = 2 rx' / G1 - 1 through their reciprocals (rlm::div32_y) unless some lane has none
     const float y = gtr2 ? d.yW : d.y1mW;
-    if (__builtin_expect(RLS_LOOP_RECIP && __builtin_amdgcn_ballot_w64(y == 0.0f || w.yG1 == 0.0f) == 0ull, 1)) {
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(y == 0.0f || w.yG1 == 0.0f) == 0ull, 1)) {
         rxp = rlm::div32_y(num, den, y);
         needU = vndf_slope_closed<true>(w, rxp, ry, slope);
     } else
@@ -235,7 +228,7 @@ __device__ __forceinline__ void ggx_vndf_push(SlowLds<K> &L, int k, int &cnt, bo
     V2 slope;
     bool needU;
 #if !RLS_FAST
-    if (__builtin_expect(RLS_LOOP_RECIP && __builtin_amdgcn_ballot_w64(w.yG1 == 0.0f) == 0ull, 1))
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(w.yG1 == 0.0f) == 0ull, 1))
         needU = vndf_slope_closed<true>(w, rx, ry, slope);       // rx from the in-kernel sampler: G1's reciprocal serves
     else
 #endif

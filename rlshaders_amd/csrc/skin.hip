@@ -56,18 +56,11 @@ __device__ __forceinline__ LobeOut ggx_lobe(V3 wo, V3 N, V3 T, V3 local, const G
 // hoisted roughness / ior / distance terms -- the colour-map case -- gains 1 % over STREAMED there and costs the all-uniform case
 // 6 %: 3.47 -> 3.73 ms.)
 enum { MIXED = 0, STREAMED_ALL = 1, UNIFORM_ALL = 2 };
-#ifndef RLS_ND_ONE_SAMPLE_RECIP     // experiment switch: see sss.hip
-#define RLS_ND_ONE_SAMPLE_RECIP 0
-#endif
-#ifndef RLS_SKIN_SGPR          // experiment switch: which hoisted values move to scalar registers (1 the lobes', 2 NDProfile)
-#define RLS_SKIN_SGPR 3
-#endif
-#ifndef RLS_SKIN_ND_RECIP      // experiment switch: all of getPdf's reciprocals hoisted as well
-#define RLS_SKIN_ND_RECIP 1
-#endif
+// (hoisted values -- the lobes' and NDProfile's -- all move to scalar registers, and the hoisted profile keeps all of getPdf's
+// reciprocals; the per-point profile of the streamed kernel keeps the three of d_i only, as in sss.hip)
 // Occupancy of the rlSkin kernel (waves per SIMD the register allocator must allow).  Left alone it takes 95 vector registers --
-// five waves, one register pair short of four: NDProfile's single range tests (rls_device.hpp, RLS_ND_MAKE_RANGE_ONCE /
-// RLS_ND_PP_RANGE_ONCE), which gain 2-7 % in the rlSss kernels, pushed it to 98-101 registers and four waves, +4.5 ... +5.6 %.
+// five waves, one register pair short of four: NDProfile's single range tests (rls_device.hpp, nd_make / nd_pdf_profile_t),
+// which gain 2-7 % in the rlSss kernels, pushed it to 98-101 registers and four waves, +4.5 ... +5.6 %.
 // Pinned at six waves (80 registers, 4 of them spilled: 20 B of scratch per lane) with those tests: 4.086 -> 3.997 ms (-2.2 %),
 // uniform parameters -0.8 %; at five -1.1 %, at seven +3.7 % (profiles/r03_exp_range_once.txt).
 #ifndef RLS_SKIN_WAVES
@@ -88,9 +81,9 @@ __device__ __forceinline__ void skin_body(const SkinIO &a0)
         um1 = ggx_material<true>(c.sheen_ior.u, c.sheen_roughness.u, 0.0f);
         um2 = ggx_material<true>(c.specular_ior.u, c.specular_roughness.u, 0.0f);
         const float mult = c.sss_dist_multiplier.u;                               // src/rlSkin.cpp:235-236
-        up = nd_make<RLS_SKIN_ND_RECIP != 0>(c.sss_scatter_dist[0].u * mult, c.sss_scatter_dist[1].u * mult, c.sss_scatter_dist[2].u * mult);
-        if (RLS_SKIN_SGPR & 1) { um1 = ggx_material_wave_uniform(um1); um2 = ggx_material_wave_uniform(um2); }
-        if (RLS_SKIN_SGPR & 2) up = nd_wave_uniform(up);
+        up = nd_make<true>(c.sss_scatter_dist[0].u * mult, c.sss_scatter_dist[1].u * mult, c.sss_scatter_dist[2].u * mult);
+        um1 = ggx_material_wave_uniform(um1); um2 = ggx_material_wave_uniform(um2);
+        up = nd_wave_uniform(up);
     }
     const TileRange tiles = tile_range(a0.n);
     for (int64_t base = tiles.first; base < tiles.end; base += tiles.step) {
@@ -123,7 +116,6 @@ __device__ __forceinline__ void skin_body(const SkinIO &a0)
         const bool sheenOn = sheenWeight > kEps, specOn = specWeight > kEps;          // src/rlSkin.cpp:191, 214
         const GgxMaterial m1 = UNIFORM ? um1 : ggx_material<true>(sheenIor, sheenRough, 0.0f);
         const GgxMaterial m2 = UNIFORM ? um2 : ggx_material<true>(specIor, specRough, 0.0f);
-#ifndef RLS_NO_PAIR_COMPACTION
         if (UNIFORM ? (sheenOn && specOn) : __builtin_amdgcn_ballot_w64(sheenOn && specOn) == ~0ull) {
             // every lane of the wavefront evaluates both lobes: their two microfacet samples share one pass of the
             // uniform-slope fallback (vndf_microfacet_pair)
@@ -137,7 +129,6 @@ __device__ __forceinline__ void skin_body(const SkinIO &a0)
             sheenFresnel = sh.F * sheenWeight;                              // :204 (one sample)
             specularFresnel = sp.F * specWeight;                            // :228
         } else
-#endif
         {
             if (sheenOn) {
                 sh = ggx_lobe(wo, N, T, local, m1, shr, shg, shb, rx0, ry0);
@@ -159,7 +150,7 @@ __device__ __forceinline__ void skin_body(const SkinIO &a0)
 
         float r = 0.0f, rpdf = 0.0f, R = 0.0f, G = 0.0f, B = 0.0f;
         if (!(sssWeight < kEps)) {                                          // :244
-            const NdProfile p = UNIFORM ? up : nd_make<RLS_ND_ONE_SAMPLE_RECIP != 0>(dx, dy, dz);
+            const NdProfile p = UNIFORM ? up : nd_make<false>(dx, dy, dz);
             Frame fr = sss_frame(N, T, true);                               // src/rlSss.h:151-154
             V3 off, dir;
             float maxdist;

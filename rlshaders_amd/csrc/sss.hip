@@ -23,9 +23,7 @@ enum { OP_ND = rlsh::SOP_ND, OP_ND_PDF = rlsh::SOP_ND_PDF, OP_ND_EVAL = rlsh::SO
 enum { OP_CAVITY = rlsh::MOP_CAVITY, OP_DIFFUSE_DIR = rlsh::MOP_DIFFUSE_DIR, OP_UTIL = rlsh::MOP_UTIL,
        OP_REFLECT_LUM = rlsh::MOP_REFLECT_LUM };
 
-#ifndef RLS_ND_ONE_SAMPLE_RECIP     // experiment switch: the one-sample kernels keep the reciprocals of c1 + 3 c2 as well
-#define RLS_ND_ONE_SAMPLE_RECIP 0
-#endif
+// (the one-sample kernels keep the reciprocals of d_i only: those of c1 + 3 c2 would serve one division each -- measured, not kept)
 // INDEXED: the parameters are per-material columns (rls_material_index); a specialisation, so that the kernels launched
 // without a table keep their code
 template <bool INDEXED, class I>
@@ -37,22 +35,21 @@ __device__ __forceinline__ NdProfile load_profile(const rls_sss_closure &c, I i)
     float dx = ldp(c.sss_scatter_dist[0], k) * m;
     float dy = ldp(c.sss_scatter_dist[1], k) * m;
     float dz = ldp(c.sss_scatter_dist[2], k) * m;
-    return nd_make<RLS_ND_ONE_SAMPLE_RECIP != 0>(dx, dy, dz);
+    return nd_make<false>(dx, dy, dz);
 }
 
 // UNIFORM: the scatter distance and its multiplier are one value for the batch (an Arnold parameter is a constant unless a
 // texture is linked to it): setDistance -- three divisions, six expf, with all of getPdf's reciprocals -- runs once per
 // thread ahead of the tile loop, the same values a per-point evaluation gives
-#ifndef RLS_SSS_UNIFORM_SGPR
-#define RLS_SSS_UNIFORM_SGPR 0
-#endif
 __device__ __forceinline__ NdProfile uniform_profile(const rls_sss_closure &c)
 {
     const float m = c.sss_dist_multiplier.u;
     const NdProfile p = nd_make<!RLS_FAST>(c.sss_scatter_dist[0].u * m, c.sss_scatter_dist[1].u * m, c.sss_scatter_dist[2].u * m);
     // measured (tools/ab.sh, probe ray at 2^26 points): 1.258 ms from scalar registers, 1.240 from vector registers -- these
     // kernels have the vector registers to spare and every use of a scalar operand beyond the first costs a move
-    return RLS_SSS_UNIFORM_SGPR ? nd_wave_uniform(p) : p;
+    // (an explicit copy: plain `return p;` makes the compiler order the same instructions differently; this form keeps the
+    // kernels byte-identical to the ones the committed counter profiles were taken on -- rlshaders_amd/codeid.py)
+    return NdProfile(p);
 }
 
 enum { PER_POINT = 0, UNIFORM_DISTANCE = 1, BY_REFERENCE = 2 };

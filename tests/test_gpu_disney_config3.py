@@ -278,7 +278,7 @@ def _border_check(a, b, is_count, what):
 def test_loop_reciprocals_at_their_window_borders(gpu, oracle):
     """The sample loops divide by alpha_x, alpha_y, the lobe weight 1 / (clearcoat + 1), its complement and G1 through
     per-point reciprocals when those lie inside rlm::div32_y's window, and the IEEE way for the whole wavefront when a lane's
-    do not (RLS_DISNEY_D_RECIP, RLS_LOOP_RECIP).  Parameter sets on either side of every border, in one batch (so that
+    do not (the per-point reciprocals of round 4: D_GTR2Aniso's, the lobe weight's, G1's).  Parameter sets on either side of every border, in one batch (so that
     wavefronts mix both kinds) and as uniform values: bit for bit the oracle's sums and counts."""
     n, spp_n, seed = 1 << 12, 4, 31
     base = cases.disney_mixed(cases.SEED_PARITY, n)

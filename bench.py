@@ -758,7 +758,31 @@ def main():
         os._exit(RANK_FAILED)
 
 
+DEADLINE_S = 1200.0         # RLS_BENCH_DEADLINE_S: a rank still running after this long gives up (the default run takes ~30 s)
+
+
+def start_deadline(rank: int, world: int):
+    """A rank that hangs where no collective's timeout can see it -- a launch that never completes, a wedged device, a host
+    call that blocks -- must not burn the caller's half hour: after DEADLINE_S a timer thread prints the one-line error and
+    leaves the process (HIP and torch calls release the GIL, so the timer fires while the main thread is stuck inside one)."""
+    import threading
+    limit = float(os.environ.get("RLS_BENCH_DEADLINE_S", DEADLINE_S))
+
+    def expire():
+        error_line(f"deadline: still running after {limit:g} s (RLS_BENCH_DEADLINE_S); giving up", rank, world)
+        sys.stdout.flush()
+        os._exit(RANK_FAILED)
+
+    timer = threading.Timer(limit, expire)
+    timer.daemon = True
+    timer.start()
+    return timer
+
+
 def run_rank(args, world: int):
+    deadline = start_deadline(int(os.environ.get("RANK", "0")), world)
+    if os.environ.get("RLS_BENCH_STALL_S"):                 # tests: a rank that hangs before it gets anywhere
+        time.sleep(float(os.environ["RLS_BENCH_STALL_S"]))
     import torch
     import rlshaders_amd as R
     from rlshaders_amd.sharding import Ranks
@@ -932,6 +956,7 @@ def run_rank(args, world: int):
         torch.cuda.empty_cache()
 
     ranks.close()
+    deadline.cancel()
     if rank == 0:
         emit(detail, records, args.records_file)
 

@@ -208,3 +208,12 @@ def test_torchrun_with_more_ranks_than_gpus_leaves_before_the_rendezvous():
     # all with the same reason
     assert 1 <= len(errs) <= world and len({e["error"] for e in errs}) == 1, p.stdout[-2000:]
     assert errs[0]["world_size"] == world and ("GPU(s) visible" in errs[0]["error"] or "no GPU visible" in errs[0]["error"])
+
+
+def test_a_rank_that_hangs_gives_up_at_the_deadline():
+    """a rank stuck where no collective's timeout can see it leaves after RLS_BENCH_DEADLINE_S (default 1200 s; the default run
+    takes ~30 s) with the one-line error and a non-zero exit, instead of burning the caller's half hour"""
+    p, took = _run_bench(["--steps", "2", "--warmup", "1"], {"RLS_BENCH_DEADLINE_S": "2", "RLS_BENCH_STALL_S": "60"})
+    assert p.returncode == 1 and took < 30, (p.returncode, took)
+    errs = _error_lines(p.stdout)
+    assert len(errs) == 1 and "deadline" in errs[0]["error"] and errs[0]["rank"] == 0

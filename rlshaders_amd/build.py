@@ -80,8 +80,12 @@ def build_library(force: bool = False, verbose: bool = False, variant: str = "",
             obj = objdir / (src.stem + suffix + ".o")
             objs.append(obj)
             if force or _stale(obj, [src, *HEADERS, Path(__file__)]):
-                jobs.append([hipcc, *HIPCC_FLAGS, *extra, f"-D{flag}", *[f"-D{d}" for d in defines], "-c", str(src),
-                             "-o", str(obj)])
+                # -cuid: clang names one symbol per unit `__hip_cuid_<hash>` and by default hashes the PATHS on its command line
+                # into it -- the same sources in another checkout or object directory then differ in that symbol's length now
+                # and again, which can move a code object's layout by a cache line (rlshaders_amd/codeid.py).  A fixed id per
+                # unit makes the device code a function of sources and flags alone.
+                jobs.append([hipcc, *HIPCC_FLAGS, *extra, f"-cuid=rlshaders_amd.{src.stem}{suffix}", f"-D{flag}",
+                             *[f"-D{d}" for d in defines], "-c", str(src), "-o", str(obj)])
 
     def run(cmd):
         if verbose:

@@ -23,7 +23,8 @@ instructions they produce.  One field of every kernel descriptor is left out: KE
 from the descriptor to the kernel's first instruction.  It is layout, not code, and it moves by a cache line with the
 length of the ``__hip_cuid_<hash>`` symbol clang derives from the PATHS on its command line (a 15-digit hash instead of a
 16-digit one shortens ``.dynstr`` by a byte): the same sources compiled into another object directory would otherwise read
-as other device code one time in a few.  Pure Python (struct + hashlib), no tool of the ROCm installation is run: bench.py
+as other device code now and again.  (Both builds of this repository pass a fixed `-cuid=` per unit since round 6, which removes
+the cause; leaving the field out keeps the ids stable for libraries built any other way.)  Pure Python (struct + hashlib), no tool of the ROCm installation is run: bench.py
 calls it on the GPU box for the library it has just loaded.
 """
 from __future__ import annotations

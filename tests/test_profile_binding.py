@@ -33,6 +33,20 @@ def code():
     return DeviceCode(build.build_library())
 
 
+# "EXACT kernels: frozen -- a change to these kernels from here on is a correctness change".  The freeze as
+# a test: the device code of the whole library (EXACT and FAST units) is the code rounds 5 and 6 measured and soaked.  A change
+# that moves this id is a kernel change: soak it (tools/parity_soak.py), take the counter passes again
+# (docs/sessions/r06_session1.sh) and only then update the id here.  (ROCm 7.2.0's hipcc, the image's compiler; host-only
+# changes, comments, link order and the object directory do not move it.)
+FROZEN_LIBRARY_ID = "aa4bc4c4290cc062"
+
+
+def test_the_device_code_is_the_frozen_one(code):
+    assert code.library_id == FROZEN_LIBRARY_ID, (code.library_id, "the kernels changed: see the comment above FROZEN_LIBRARY_ID")
+    recorded = json.loads((ROOT / "profiles" / "r06_library_id.json").read_text())          # what the GPU box ran in round 6
+    assert recorded["library_id"] == FROZEN_LIBRARY_ID and sorted(recorded["unit_ids"]) == sorted(u for u, _ in code.units)
+
+
 def test_ids_of_the_built_library(code):
     from rlshaders_amd import codeid
     assert len(code.units) >= 12 and len(code.library_id) == 16

@@ -695,8 +695,16 @@ def error_line(message: str, rank, world: int, **more) -> None:
     """One JSON line that says what went wrong and where -- on stdout, where the driver looks for the result line (a reader
     that parses the last line finds `error` instead of `value`), and on stderr."""
     line = json.dumps(dict({"error": message, "rank": rank, "world_size": world, "bench": "bench.py"}, **more))
-    print(line, file=sys.stderr, flush=True)
-    print(line, flush=True)
+    # several ranks may say this at the same moment into one pipe: each line goes out in ONE write (atomic below PIPE_BUF), so
+    # two ranks' lines cannot interleave whatever the buffering of sys.stdout is (print() under PYTHONUNBUFFERED writes the text
+    # and the newline separately)
+    data = (_short(line, 3500) + "\n").encode()
+    for stream, fd in ((sys.stderr, 2), (sys.stdout, 1)):
+        try:
+            stream.flush()
+            os.write(fd, data)
+        except OSError:
+            pass
 
 
 def visible_gpus() -> int:

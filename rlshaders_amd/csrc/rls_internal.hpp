@@ -328,6 +328,7 @@ inline bool ok_materials(const rls_material_index &m) { return m.id == nullptr |
 // to run (rls_diag_clock_stamps_begin not in force).  The slots are cleared on the launch stream first, so _read returns the
 // stamps of the LAST stamped launch only, whatever grid an earlier stamped launch of the same begin/end bracket used.  A
 // bracket and a graph recording exclude each other (context.hip), so a stamped launch is never baked into a graph.
+// (Should the clear fail, the product kernel runs and _read reports no stamps: a diagnostic never costs the caller its launch.)
 inline unsigned long long *stamps_for_launch(rls_context *ctx)
 {
     if (!ctx->stamps || ctx->capturing) return nullptr;

@@ -58,6 +58,7 @@ __device__ __forceinline__ LobeOut ggx_lobe(V3 wo, V3 N, V3 T, V3 local, const G
 enum { MIXED = 0, STREAMED_ALL = 1, UNIFORM_ALL = 2 };
 // (hoisted values -- the lobes' and NDProfile's -- all move to scalar registers, and the hoisted profile keeps all of getPdf's
 // reciprocals; the per-point profile of the streamed kernel keeps the three of d_i only, as in sss.hip)
+//
 // Occupancy of the rlSkin kernel (waves per SIMD the register allocator must allow).  Left alone it takes 95 vector registers --
 // five waves, one register pair short of four: NDProfile's single range tests (rls_device.hpp, nd_make / nd_pdf_profile_t),
 // which gain 2-7 % in the rlSss kernels, pushed it to 98-101 registers and four waves, +4.5 ... +5.6 %.

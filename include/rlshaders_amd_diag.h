@@ -4,7 +4,10 @@
  * Nothing here has a counterpart in shihchinw/rlShaders and nothing here is needed to replace its closure layer:
  * include/rlshaders_amd.h is the boundary a plugin binds.  These entry points exist for bench.py and for the profiling
  * scripts under tools/ (DESIGN.md sections 5 and 6); they are exported by the same library so that what is measured is
- * the library that ships.
+ * the library that ships.  A build with RLS_DIAGNOSTICS=0 (cmake -DRLS_DIAGNOSTICS=OFF; python -m rlshaders_amd.build
+ * --variant nodiag -DRLS_DIAGNOSTICS=0) leaves all of it out: that library exports the drop-in surface only, holds no
+ * diagnostic kernel, and its product kernels are the default build's up to address literals
+ * (tests/test_diagnostics_option.py).
  */
 #ifndef RLSHADERS_AMD_DIAG_H
 #define RLSHADERS_AMD_DIAG_H

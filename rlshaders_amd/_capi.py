@@ -304,7 +304,8 @@ def load() -> C.CDLL:
         try:
             fn = getattr(lib, name)
         except AttributeError:
-            missing.append(name)
+            if not name.startswith("rls_diag_"):       # a library built with RLS_DIAGNOSTICS=0 exports the drop-in surface only
+                missing.append(name)
             continue
         fn.restype = restype
         fn.argtypes = argtypes

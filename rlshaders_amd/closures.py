@@ -83,6 +83,8 @@ class Context:
     # ---- in-kernel clock stamps (rls_diag_clock_stamps_*; a measurement aid, not part of the closure surface) ----------
     def clock_stamps_begin(self) -> None:
         """From here to clock_stamps_end() the kernels of BASELINE configs 2-5 run as their stamped instantiation."""
+        if not hasattr(self.lib, "rls_diag_clock_stamps_begin"):
+            raise RlsError(5, "this library was built with RLS_DIAGNOSTICS=0: it carries no clock stamps")
         check(self.lib.rls_diag_clock_stamps_begin(self.handle))
 
     def clock_stamps_end(self) -> None:

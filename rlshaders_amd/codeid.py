@@ -138,6 +138,37 @@ def kernel_digests(elf: bytes) -> Dict[str, str]:
     return out
 
 
+def kernel_images(elf: bytes) -> Dict[str, Tuple[bytes, bytes]]:
+    """mangled kernel name -> (the kernel's instruction bytes, its descriptor without the entry offset) of one code object"""
+    table = _section_table(elf)
+    secs = {name: (off, size, typ) for name, typ, _a, off, size in table}
+    syms = _symtab(elf, secs)
+    kds = {s[0][:-3]: s for s in syms if s[0].endswith(".kd")}
+    out = {}
+    for s in syms:
+        if s[1] != 2 or s[0] not in kds:
+            continue
+        _sn, _typ, addr, off, _ss = table[s[2]]
+        k = kds[s[0]]
+        _kn, _kt, kaddr, koff, _ks = table[k[2]]
+        out[s[0]] = (elf[off + s[3] - addr:off + s[3] - addr + s[4]], _normalised_kd(elf[koff + k[3] - kaddr:koff + k[3] - kaddr + k[4]]))
+    return out
+
+
+def same_code_up_to_relocation(a: bytes, b: bytes) -> bool:
+    """Two images of one kernel from differently laid out code objects: equal, or of equal length with every differing dword
+    off by ONE common amount -- the PC-relative address literals of a kernel whose unit's constant data sits at another distance
+    (a hash cannot see through that; a pairwise comparison can)."""
+    if a == b:
+        return True
+    if len(a) != len(b) or len(a) % 4:
+        return False
+    n = len(a) // 4
+    wa, wb = struct.unpack(f"<{n}I", a), struct.unpack(f"<{n}I", b)
+    deltas = {(y - x) & 0xFFFFFFFF for x, y in zip(wa, wb) if x != y}
+    return len(deltas) == 1
+
+
 def fatbin(path) -> bytes:
     """the .hip_fatbin section of a host shared library or object"""
     data = Path(path).read_bytes()

@@ -264,6 +264,7 @@ rls_status rls_timer_elapsed_ms(rls_context *ctx, float *ms)
     return RLS_OK;
 }
 
+#if RLS_DIAGNOSTICS
 // ---- in-kernel clock stamps (diagnostic) -----------------------------------------------------
 // rls_internal.hpp, ClockStamp: while in force, rls_ggx_reflect_refract (all planes streamed), rls_sss_probe_ray
 // (per-point distances), rls_skin_sample_eval_pdf (all planes streamed) and rls_disney_integrate (one lane per point)
@@ -311,6 +312,7 @@ rls_status rls_diag_clock_stamps_end(rls_context *ctx)
     ctx->stamps = nullptr;
     return RLS_OK;
 }
+#endif
 
 // ---- launch graphs ---------------------------------------------------------------------------
 struct rls_graph {

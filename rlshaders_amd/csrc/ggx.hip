@@ -141,6 +141,7 @@ __global__ RLS_GGX_ATTR(OP) void ggx_kernel(GgxIO a0)
     ggx_body<OP, FAST_MATH, MODE>(a0);
 }
 
+#if RLS_DIAGNOSTICS
 template <int OP, int FAST_MATH, int MODE>
 __global__ RLS_GGX_ATTR(OP) void ggx_kernel_stamped(GgxIO a0, unsigned long long *stamps)
 {
@@ -149,6 +150,7 @@ __global__ RLS_GGX_ATTR(OP) void ggx_kernel_stamped(GgxIO a0, unsigned long long
     ggx_body<OP, FAST_MATH, MODE>(a0);
     cs.end(stamps);
 }
+#endif
 
 rls_status check_closure(const rls_ggx_closure *c)
 {
@@ -165,6 +167,7 @@ rls_status launch_kernel(rls_context *ctx, const GgxIO &io, const char *name)
     const rls_ggx_closure &c = io.c;
     const bool streamed = !c.materials.id && c.KsColor.r && c.specularRoughness.v && c.ior.v && c.anisotropic.v;
     const bool uniform = !c.materials.id && !c.specularRoughness.v && !c.ior.v && !c.anisotropic.v;       // specColor: either
+#if RLS_DIAGNOSTICS
     if constexpr (OP == OP_REFLECT_REFRACT) {      // BASELINE config 2 under rls_diag_clock_stamps_begin: the stamped instantiation
         if (unsigned long long *stamps = streamed ? rlsh::stamps_for_launch(ctx) : nullptr) {
             hipLaunchKernelGGL((ggx_kernel_stamped<OP, RLS_FAST, STREAMED_ALL>), rlsh::grid_for(ctx, io.n, rlsh::kBlock, RLS_CAP_MULT),
@@ -172,6 +175,7 @@ rls_status launch_kernel(rls_context *ctx, const GgxIO &io, const char *name)
             return rlsh::check_launch(name);
         }
     }
+#endif
     if (streamed)
         hipLaunchKernelGGL((ggx_kernel<OP, RLS_FAST, STREAMED_ALL>), rlsh::grid_for(ctx, io.n, rlsh::kBlock, RLS_CAP_MULT), dim3(rlsh::kBlock), 0, ctx->stream, io);
     else if (uniform)   // a thread that hoists wants many tiles to spread the hoisted work over (grid_for_hoisting)

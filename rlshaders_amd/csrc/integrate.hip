@@ -169,6 +169,7 @@ __global__ RLS_INT_ATTR void disney_integrate_kernel(DisneyIntIO a)
     disney_integrate_body<G, FAST_MATH>(a);
 }
 
+#if RLS_DIAGNOSTICS
 template <int G, int FAST_MATH = RLS_FAST>
 __global__ RLS_INT_ATTR void disney_integrate_kernel_stamped(DisneyIntIO a, unsigned long long *stamps)
 {
@@ -177,6 +178,7 @@ __global__ RLS_INT_ATTR void disney_integrate_kernel_stamped(DisneyIntIO a, unsi
     disney_integrate_body<G, FAST_MATH>(a);
     cs.end(stamps);
 }
+#endif
 
 template <int G, int FAST_MATH = RLS_FAST>
 __global__ RLS_INT_ATTR void ggx_refract_integrate_kernel(RefractIntIO a)
@@ -217,6 +219,7 @@ __global__ RLS_INT_ATTR void ggx_refract_integrate_kernel(RefractIntIO a)
     }
 }
 
+#if RLS_DIAGNOSTICS
 // BASELINE config 3 (one lane per point) under rls_diag_clock_stamps_begin: the stamped instantiation
 inline rls_status launch_disney_stamped(rls_context *ctx, const rlsh::DisneyIntIO &io, unsigned long long *stamps, const char *name)
 {
@@ -224,6 +227,7 @@ inline rls_status launch_disney_stamped(rls_context *ctx, const rlsh::DisneyIntI
                        io, stamps);
     return rlsh::check_launch(name);
 }
+#endif
 
 } // namespace
 
@@ -235,8 +239,10 @@ RLS_HIDDEN rls_status rls_fast_ggx_integrate(rls_context *ctx, int g, const rlsh
 }
 RLS_HIDDEN rls_status rls_fast_disney_integrate(rls_context *ctx, int g, const rlsh::DisneyIntIO *io)
 {
+#if RLS_DIAGNOSTICS
     if (unsigned long long *stamps = g == 1 ? rlsh::stamps_for_launch(ctx) : nullptr)
         return launch_disney_stamped(ctx, *io, stamps, "rls_disney_integrate[fast, stamped]");
+#endif
     return launch_g(ctx, disney_integrate_kernel<1>, disney_integrate_kernel<4>, disney_integrate_kernel<16>,
                     disney_integrate_kernel<64>, g, *io, "rls_disney_integrate[fast]");
 }
@@ -323,8 +329,10 @@ rls_status rls_disney_integrate(rls_context *ctx, int64_t n, const rls_disney_cl
     // streamed planes are sample-major: one lane per point keeps every store coalesced
     int g = io.streamed ? 1 : pick_group(ctx, n, io.spp);
     if (ctx->fast) return rls_fast_disney_integrate(ctx, g, &io);
+#if RLS_DIAGNOSTICS
     if (unsigned long long *stamps = g == 1 ? rlsh::stamps_for_launch(ctx) : nullptr)
         return launch_disney_stamped(ctx, io, stamps, "rls_disney_integrate[stamped]");
+#endif
     return launch_g(ctx, disney_integrate_kernel<1>, disney_integrate_kernel<4>, disney_integrate_kernel<16>,
                     disney_integrate_kernel<64>, g, io, "rls_disney_integrate");
 }

@@ -6,7 +6,16 @@
 #include <stdio.h>
 
 #include "../../include/rlshaders_amd.h"
+
+// RLS_DIAGNOSTICS (build option, default 1).  With 0 the library carries no measurement code at all: no `*_kernel_stamped`
+// instantiation in any code object, no rls_diag_* symbol, no stamp test on a launch path -- and the product kernels are the
+// same machine code either way, up to address literals (tests/test_diagnostics_option.py compares them).  bench.py's in-kernel clock needs 1.
+#ifndef RLS_DIAGNOSTICS
+#define RLS_DIAGNOSTICS 1
+#endif
+#if RLS_DIAGNOSTICS
 #include "../../include/rlshaders_amd_diag.h"
+#endif
 #include "rls_device.hpp"
 
 struct rls_context {
@@ -329,6 +338,7 @@ inline bool ok_materials(const rls_material_index &m) { return m.id == nullptr |
 // stamps of the LAST stamped launch only, whatever grid an earlier stamped launch of the same begin/end bracket used.  A
 // bracket and a graph recording exclude each other (context.hip), so a stamped launch is never baked into a graph.
 // (Should the clear fail, the product kernel runs and _read reports no stamps: a diagnostic never costs the caller its launch.)
+#if RLS_DIAGNOSTICS
 inline unsigned long long *stamps_for_launch(rls_context *ctx)
 {
     if (!ctx->stamps || ctx->capturing) return nullptr;
@@ -338,6 +348,7 @@ inline unsigned long long *stamps_for_launch(rls_context *ctx)
     }
     return ctx->stamps;
 }
+#endif
 
 } // namespace rlsh
 
@@ -400,6 +411,7 @@ RLS_DEV IO reload_args(const IO &a)
 // every workgroup reads the shader-clock counter (s_memtime: one tick per shader cycle) and the constant 100 MHz counter
 // (s_memrealtime) on entry and on exit; effective clock of that workgroup's lifetime = d(memtime) / d(memrealtime) x 100 MHz
 // (MI355X_MICROARCH.md, "DVFS give-back" item 6).  The stamps go to a buffer of their own; no output depends on them.
+#if RLS_DIAGNOSTICS
 template <int STAMP> struct ClockStamp {
     RLS_DEV void begin() {}
     RLS_DEV void end(unsigned long long *) {}
@@ -421,6 +433,7 @@ template <> struct ClockStamp<1> {
         }
     }
 };
+#endif
 
 RLS_DEV int64_t idx_full(int64_t i) { return i; }
 RLS_DEV int64_t idx_full(const Idx &i) { return i.full(); }

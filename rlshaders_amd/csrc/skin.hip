@@ -179,6 +179,7 @@ __global__ RLS_SKIN_ATTR void skin_kernel(SkinIO a0)
     skin_body<FAST_MATH, MODE>(a0);
 }
 
+#if RLS_DIAGNOSTICS
 template <int FAST_MATH, int MODE>
 __global__ RLS_SKIN_ATTR void skin_kernel_stamped(SkinIO a0, unsigned long long *stamps)
 {
@@ -187,6 +188,7 @@ __global__ RLS_SKIN_ATTR void skin_kernel_stamped(SkinIO a0, unsigned long long 
     skin_body<FAST_MATH, MODE>(a0);
     cs.end(stamps);
 }
+#endif
 
 rls_status launch_kernel(rls_context *ctx, const SkinIO &io, const char *name)
 {
@@ -201,10 +203,14 @@ rls_status launch_kernel(rls_context *ctx, const SkinIO &io, const char *name)
                          !c.specular_weight.v && !c.specular_roughness.v && !c.specular_ior.v && !c.sheen_color.r &&
                          !c.sheen_weight.v && !c.sheen_roughness.v && !c.sheen_ior.v;
     const dim3 grid = rlsh::grid_for(ctx, io.n, rlsh::kBlock, RLS_CAP_MULT);
-    unsigned long long *stamps = streamed ? rlsh::stamps_for_launch(ctx) : nullptr;
-    if (stamps)                       // BASELINE config 5 under rls_diag_clock_stamps_begin: the stamped instantiation
+#if RLS_DIAGNOSTICS
+    if (unsigned long long *stamps = streamed ? rlsh::stamps_for_launch(ctx) : nullptr) {
+        // BASELINE config 5 under rls_diag_clock_stamps_begin: the stamped instantiation
         hipLaunchKernelGGL((skin_kernel_stamped<RLS_FAST, STREAMED_ALL>), grid, dim3(rlsh::kBlock), 0, ctx->stream, io, stamps);
-    else if (streamed)
+        return rlsh::check_launch(name);
+    }
+#endif
+    if (streamed)
         hipLaunchKernelGGL((skin_kernel<RLS_FAST, STREAMED_ALL>), grid, dim3(rlsh::kBlock), 0, ctx->stream, io);
     else if (uniform)   // a thread that hoists wants many tiles to spread the hoisted work over (grid_for_hoisting)
         hipLaunchKernelGGL((skin_kernel<RLS_FAST, UNIFORM_ALL>), rlsh::grid_for_hoisting(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);

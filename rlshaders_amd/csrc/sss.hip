@@ -118,6 +118,7 @@ __global__ RLS_SSS_ATTR(MODE) void sss_kernel(SssIO a0)
     sss_body<OP, MODE, FAST_MATH>(a0);
 }
 
+#if RLS_DIAGNOSTICS
 template <int OP, int MODE, int FAST_MATH = RLS_FAST>
 __global__ RLS_SSS_ATTR(MODE) void sss_kernel_stamped(SssIO a0, unsigned long long *stamps)
 {
@@ -126,6 +127,7 @@ __global__ RLS_SSS_ATTR(MODE) void sss_kernel_stamped(SssIO a0, unsigned long lo
     sss_body<OP, MODE, FAST_MATH>(a0);
     cs.end(stamps);
 }
+#endif
 
 
 template <int OP, int FAST_MATH = RLS_FAST>
@@ -174,12 +176,14 @@ rls_status launch_kernel(rls_context *ctx, const SssIO &io, const char *name)
                          !c.sss_scatter_dist[2].v;
     // evalProfile alone uses nothing setDistance computes but maxR: no uniform specialisation of it
     constexpr bool kHoists = OP != OP_ND_EVAL;
+#if RLS_DIAGNOSTICS
     if constexpr (OP == OP_PROBE) {      // BASELINE config 4 under rls_diag_clock_stamps_begin: the stamped instantiation
         if (unsigned long long *stamps = (!c.materials.id && !(uniform && kHoists)) ? rlsh::stamps_for_launch(ctx) : nullptr) {
             hipLaunchKernelGGL((sss_kernel_stamped<OP, PER_POINT>), rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io, stamps);
             return rlsh::check_launch(name);
         }
     }
+#endif
     if (c.materials.id)
         hipLaunchKernelGGL((sss_kernel<OP, BY_REFERENCE>), rlsh::grid_for(ctx, io.n), dim3(rlsh::kBlock), 0, ctx->stream, io);
     else if (uniform && kHoists)

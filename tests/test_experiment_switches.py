@@ -38,7 +38,8 @@ def test_the_groups_cover_the_switches_in_the_sources():
     code-path switches comes back unnoticed"""
     import re
     structural = {"RLS_FAST", "RLS_BLOCK", "RLS_DEV", "RLS_HIDDEN", "RLS_GGX_WAVES", "RLS_SSS_WAVES", "RLS_DISNEY_WAVES",
-                  "RLS_HOIST_TILES_PER_THREAD", "RLS_HOIST_MIN_BLOCKS_PER_CU"}      # (the *_WAVES(OP) macros take an argument)
+                  "RLS_HOIST_TILES_PER_THREAD", "RLS_HOIST_MIN_BLOCKS_PER_CU",      # (the *_WAVES(OP) macros take an argument)
+                  "RLS_DIAGNOSTICS"}            # a build option with a test of its own (tests/test_diagnostics_option.py)
     found = set()
     for f in list(CSRC.glob("*.hip")) + list(CSRC.glob("*.hpp")):
         for m in re.finditer(r"^\s*#\s*(?:ifndef|ifdef|if|elif)\s+(?:!\s*)?(?:defined\s*\(\s*)?(RLS_[A-Z0-9_]+)", f.read_text(), re.M):

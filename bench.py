@@ -395,9 +395,12 @@ def code_matches(recorded: dict | None, live: dict) -> bool:
     """does a profile's `code` stamp describe the device code loaded now?"""
     if not recorded:
         return False                                      # an unstamped profile proves nothing about this binary
-    for key in ("kernel_id", "unit_id"):                  # the kernel's own bytes; else the code object that holds it
-        if recorded.get(key) and live.get(key):
-            return recorded[key] == live[key]
+    # the kernel's own code (when both ids follow the same definition: rlshaders_amd/codeid.py KERNEL_ID_SCHEME); else the code
+    # object that holds it
+    if recorded.get("kernel_id") and live.get("kernel_id") and recorded.get("kernel_id_scheme", 1) == live.get("kernel_id_scheme", 1):
+        return recorded["kernel_id"] == live["kernel_id"]
+    if recorded.get("unit_id") and live.get("unit_id"):
+        return recorded["unit_id"] == live["unit_id"]
     return bool(recorded.get("library_id")) and recorded.get("library_id") == live.get("library_id")
 
 

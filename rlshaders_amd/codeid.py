@@ -13,10 +13,14 @@ section (one clang offload bundle per translation unit) and hashes what the GPU 
   -> ``10ggx_kernelILi5ELi0ELi1EE``), so a profile taken by exact kernel name is tied to that kernel's unit and is not
   invalidated by a change to some other unit or to host code;
 * ``kernel_id(name)``: sha-256 over ONE kernel -- its instructions (the function's bytes in ``.text``; every device function
-  is inlined, the code objects hold no other FUNC symbol), its 64-byte kernel descriptor, and the unit's constant data
-  (``.rodata`` outside the descriptors, ``.data``).  Moving a kernel into another translation unit beside other kernels
-  keeps its kernel_id when the compiler emits the same bytes for it; any change to its instructions, registers, LDS or
-  constants changes it.
+  is inlined, the code objects hold no other FUNC symbol) with the PC-relative ADDRESS LITERALS blanked, its 64-byte kernel
+  descriptor, and the unit's constant data (``.rodata`` with the descriptors cut out -- here the libm tables -- and
+  ``.data``).  The literals are the two dwords behind ``s_add_u32`` / ``s_addc_u32 ... <literal>`` that follow an
+  ``s_getpc_b64``: the distance from the instruction to a constant, i.e. layout.  So a kernel keeps its kernel_id when it
+  moves to another translation unit, when a neighbour joins or leaves its unit (the diagnostic instantiations of
+  RLS_DIAGNOSTICS) or when the unit is laid out differently -- and loses it with any change to its instructions, registers,
+  LDS, scratch or constants.  (Round 6 first hashed the raw bytes: round 5's counter files of config 3, taken before
+  ``integrate.hip`` was split, then read as stale over four moved literals.)
 
 Host code, comments and link order do not enter; compiler flags and every header a kernel includes do, through the
 instructions they produce.  One field of every kernel descriptor is left out: KERNEL_CODE_ENTRY_BYTE_OFFSET, the distance
@@ -37,6 +41,7 @@ from pathlib import Path
 from typing import Dict, List, Optional, Tuple
 
 BUNDLE_MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+KERNEL_ID_SCHEME = 2        # 1: raw instruction bytes (first half of round 6); 2: address literals blanked, descriptors cut out of the constants
 HASHED_SECTIONS = (".text", ".rodata", ".data")
 
 
@@ -88,6 +93,28 @@ def _section_table(elf: bytes) -> List[Tuple[str, int, int, int, int]]:
     return [(strtab[n:strtab.index(b"\0", n)].decode(), typ, addr, off, size) for n, typ, _f, addr, off, size in raw]
 
 
+def _mask_pc_relative(code: bytes) -> bytes:
+    """the kernel's instruction bytes with the literals of `s_getpc_b64 sN` ... `s_add_u32 / s_addc_u32 sM, sM, <literal>`
+    sequences blanked (gfx9 encodings: SOP1 0xBE80_1C00 | sdst << 16; SOP2 op 0 / op 4 with SSRC1 = 0xFF, the literal marker;
+    the compiler may schedule a few instructions in between)"""
+    n = len(code) // 4
+    if n == 0 or len(code) % 4:
+        return code
+    w = list(struct.unpack(f"<{n}I", code))
+    for i in range(n):
+        if (w[i] & 0xFF80FFFF) != 0xBE801C00:                      # s_getpc_b64
+            continue
+        j, found = i + 1, 0
+        while j < min(n - 1, i + 12) and found < 2:
+            if (w[j] & 0xFF80FF00) in (0x8000FF00, 0x8200FF00):     # s_add_u32 / s_addc_u32 with a literal
+                w[j + 1] = 0
+                found += 1
+                j += 2
+            else:
+                j += 1
+    return struct.pack(f"<{n}I", *w)
+
+
 KD_SIZE = 64
 KD_ENTRY_OFFSET = slice(16, 24)         # amd_kernel_descriptor_t.kernel_code_entry_byte_offset (int64): layout, not code
 
@@ -113,19 +140,19 @@ def kernel_digests(elf: bytes) -> Dict[str, str]:
         return None if typ == 8 else elf[off + value - addr:off + value - addr + size]
 
     kds = {s[0][:-3]: s for s in syms if s[0].endswith(".kd")}
-    # the unit's constant data: .rodata with the kernel descriptors cut out, .data
+    # the unit's constant data: .rodata with the kernel descriptors CUT OUT (how many kernels share the unit does not enter), .data
     const = hashlib.sha256()
     for name in (".rodata", ".data"):
         idx = [k for k, s in enumerate(table) if s[0] == name]
         if not idx or table[idx[0]][1] == 8:
             continue
         _sn, _typ, addr, off, size = table[idx[0]]
-        blob = bytearray(elf[off:off + size])
-        for s in kds.values():
-            if s[2] == idx[0]:
-                lo = s[3] - addr
-                blob[lo:lo + s[4]] = b"\0" * s[4]
-        const.update(name.encode() + b"\0" + bytes(blob))
+        blob, keep, pos = elf[off:off + size], bytearray(), 0
+        for lo, sz in sorted((s[3] - addr, s[4]) for s in kds.values() if s[2] == idx[0]):
+            keep += blob[pos:lo]
+            pos = lo + sz
+        keep += blob[pos:]
+        const.update(name.encode() + b"\0" + bytes(keep))
     const = const.digest()
     out = {}
     for s in syms:
@@ -134,7 +161,8 @@ def kernel_digests(elf: bytes) -> Dict[str, str]:
         code, kd = body(s), body(kds[s[0]])
         if code is None or kd is None:
             continue
-        out[s[0]] = hashlib.sha256(struct.pack("<QQ", len(code), len(kd)) + code + _normalised_kd(kd) + const).hexdigest()[:16]
+        out[s[0]] = hashlib.sha256(struct.pack("<QQ", len(code), len(kd)) + _mask_pc_relative(code) + _normalised_kd(kd) +
+                                   const).hexdigest()[:16]
     return out
 
 
@@ -269,6 +297,7 @@ class DeviceCode:
             rec["kernel"] = kernel
             rec["unit_id"] = self.unit_of_kernel(kernel)
             rec["kernel_id"] = self.kernel_id(kernel)
+            rec["kernel_id_scheme"] = KERNEL_ID_SCHEME
         return rec
 
 

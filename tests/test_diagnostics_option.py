@@ -50,6 +50,10 @@ def test_no_measurement_kernel_and_the_same_product_kernels(libs):
         assert a[k][1] == b[k][1], k                                            # same descriptor: registers, LDS, scratch
         assert C.same_code_up_to_relocation(a[k][0], b[k][0]), k
     assert len(identical) >= 200 and len(relocated) <= 40, (len(identical), len(relocated))
+    # ... and by hash: every product kernel keeps its kernel_id (address literals blanked, descriptors cut out of the constants), so
+    # a counter profile stamped on the default build is accepted beside this library's kernels
+    da, db = C.DeviceCode(default), C.DeviceCode(nodiag)
+    assert all(da.kernels[k] == db.kernels[k] for k in db.kernels) and da.library_id != db.library_id
     # the four BASELINE kernels: present once each, same length, same descriptor, same instructions up to the relocation amount
     for name in ("ggx_kernel<5, 0, 1>", "sss_kernel<3, 0, 0>", "skin_kernel<0, 1>", "disney_integrate_kernel<1, 0>"):
         frag = C.mangled_fragment(name)

@@ -170,6 +170,32 @@ def test_newest_matching_record_wins_over_a_newer_stale_one(code, tmp_path):
     assert roof["counter_source"]["traffic"] == "profiles/t_ggx_reflect_refract_traffic.json"
 
 
+def test_kernel_ids_are_compared_within_one_scheme_only():
+    """the kernel_id definition was refined during round 6 (address literals blanked: KERNEL_ID_SCHEME 2).  A stamp written under
+    the first definition is not compared kernel id against kernel id -- it is held to its unit_id instead"""
+    b = _bench()
+    live = {"library_id": "L", "unit_id": "U", "kernel_id": "K2", "kernel_id_scheme": 2}
+    assert b.code_matches({"library_id": "L", "unit_id": "U", "kernel_id": "K1"}, live)                        # scheme 1, same unit
+    assert not b.code_matches({"library_id": "L", "unit_id": "V", "kernel_id": "K1"}, live)                    # scheme 1, other unit
+    assert b.code_matches({"library_id": "x", "unit_id": "V", "kernel_id": "K2", "kernel_id_scheme": 2}, live)  # the kernel moved units
+    assert not b.code_matches({"library_id": "L", "unit_id": "U", "kernel_id": "K3", "kernel_id_scheme": 2}, live)
+    assert not b.code_matches(None, live) and not b.code_matches({}, live)
+
+
+def test_a_kernel_keeps_its_id_when_its_unit_is_laid_out_differently():
+    """blank what is layout: two images of one kernel that differ in the literal behind `s_getpc_b64; s_add_u32 ..., lit;
+    s_addc_u32 ..., lit` hash alike; a differing dword anywhere else does not"""
+    import struct
+    from rlshaders_amd import codeid
+    getpc, add, addc, other = 0xBE801C00 | (4 << 16), 0x8004FF04, 0x8205FF05, 0x7E000280
+    a = struct.pack("<8I", other, getpc, add, 0x1000, addc, 0, other, other)
+    b = struct.pack("<8I", other, getpc, add, 0x1040, addc, 0, other, other)
+    c = struct.pack("<8I", other, getpc, add, 0x1000, addc, 0, other, other ^ 1)
+    d = struct.pack("<8I", other, other, add, 0x1040, addc, 0, other, other)            # no s_getpc_b64 in front: not an address
+    assert codeid._mask_pc_relative(a) == codeid._mask_pc_relative(b) != codeid._mask_pc_relative(c)
+    assert codeid._mask_pc_relative(d) == d
+
+
 def test_committed_profiles_of_the_baseline_kernels_describe_this_library(code):
     """what DESIGN.md section 5 quotes must have been taken on the device code that ships: for each BASELINE kernel there is a
     committed, stamped record of every kind whose kernel_id is the built library's"""

@@ -10,7 +10,8 @@ box for the library it has loaded and the summarisers (tools/summarize_workload.
 the bench line of the profiled session.  Older profiles carry none, and bench.py treats an unstamped profile as stale.  This
 tool supplies the stamp for them WITHOUT guessing: it checks out <commit> (the tree the passes ran on) into a scratch git
 worktree, builds the library there from clean (rlshaders_amd/build.py; hipcc cross-compiles gfx950 without a GPU), reads the
-ids out of that build (rlshaders_amd/codeid.py) and writes them into every profiles/<tag>_*_{traffic,flops,clock,stalls}.json
+ids out of that build (rlshaders_amd/codeid.py) and writes them into every <tag>_*_{traffic,flops,clock,stalls}.json under
+profiles/ and profiles/archive/
 together with how they were obtained.  The build is deterministic: the same sources and flags give the same code objects, so
 the ids are those of the library that ran.
 
@@ -54,7 +55,8 @@ def main():
         dc = DeviceCode(lib)
         done = []
         for suffix in suffixes:
-            for p in sorted((ROOT / "profiles").glob(f"{tag}_*_{suffix}.json")):
+            for p in sorted(list((ROOT / "profiles").glob(f"{tag}_*_{suffix}.json")) +
+                            list((ROOT / "profiles" / "archive").glob(f"{tag}_*_{suffix}.json"))):
                 d = json.loads(p.read_text())
                 kernel = d.get("kernel")
                 if not kernel:
@@ -64,9 +66,10 @@ def main():
                     raise SystemExit(f"{p.name}: kernel {kernel!r} is in no code object of the build of {commit}")
                 rec["stamped"] = (f"tools/stamp_profiles.py {tag} {commit}: ids of a clean build of commit {full[:12]} (the tree "
                                   "these passes ran on), not recorded at collection time")
-                if d.get("code") and {k: d["code"].get(k) for k in ("library_id", "unit_id", "kernel_id")} != \
-                        {k: rec.get(k) for k in ("library_id", "unit_id", "kernel_id")}:
-                    raise SystemExit(f"{p.name} already carries another stamp: {d['code']}")
+                # a stamp this tool wrote may be rewritten (the id definitions were refined during round 6); one recorded at
+                # collection time on the GPU box is never touched
+                if d.get("code") and not d["code"].get("stamped"):
+                    raise SystemExit(f"{p.name} carries a stamp recorded at collection time: {d['code']}")
                 # keep the key order readable: code right behind kernel
                 out = {}
                 for k, v in d.items():

@@ -57,7 +57,8 @@ def test_cited_scripts_exist():
             if b:                                        # docs/sessions/r05_session{1,2,3}.sh
                 names = [path[:b.start()] + alt + path[b.end():] for alt in b.group(1).split(",")]
             for n in names:
-                if not (list(ROOT.glob(n)) if "*" in n else (ROOT / n).exists()):
+                # (`tools/micro/valurate` names a micro-benchmark by its binary: built from tools/micro/valurate.hip, not tracked)
+                if not (list(ROOT.glob(n)) if "*" in n else ((ROOT / n).exists() or list(ROOT.glob(n + ".hip")))):
                     missing.append((d, n))
     assert not missing, missing
 

@@ -815,7 +815,6 @@ def run_rank(args, world: int):
         sys.stdout.flush()
         os._exit(BAD_LAUNCH)
     device_index = local_rank % have if backend != "nccl" else local_rank
-    torch.cuda.set_device(device_index)
 
     block = {"all": BLOCK_ALL, "configs": BLOCK_CONFIGS, "none": []}[args.workloads]
     if args.block_log2_points is not None:
@@ -849,6 +848,7 @@ def run_rank(args, world: int):
             if cb is not None:
                 cb["all_cpu_legs_seconds"] = round(cpu_seconds_total, 2)
 
+    torch.cuda.set_device(device_index)                    # (the first call that touches the HIP runtime: after the CPU legs)
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ        # under torchrun, also with one rank
     ranks = Ranks(backend=backend if (world > 1 or launched) else None,
                   device=torch.device("cuda", device_index) if backend == "nccl" else torch.device("cpu"),
